@@ -1,0 +1,263 @@
+"""Generate golden vectors by running the REAL reference code from /root/reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container only (the reference never
+travels to the GPU box); writes small data-only fixtures to tests/golden/*.pt:
+
+  g1_gumbel.pt     GumbelSampler.forward           (reference module, direct import)
+  g2_imle.pt       imle eval wrapper + IMLEScheme   (reference module, direct import)
+  g3_aimle.pt      aimle eval wrapper               (reference module, direct import)
+  g4_question.pt   QuestionEncoder + QuestionDecoder at reduced dims (direct import;
+                   the CLIP embedding module is a same-key token+position stand-in because
+                   the constructor would download weights, isubgvqa.py:119)
+  g5_mgat_*.pt     MGAT / MaskingGATv2Conv / MaskingModel / GlobalAttention /
+                   NodeMaskToEdgeMask / scatter attention: the reference's own glue code
+                   executed over oracle/pyg_standin.py (restated third-party primitives)
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_goldens
+No reference source text is written anywhere; fixtures hold tensors only.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+from . import pyg_standin  # noqa: E402
+from . import samplers as S  # noqa: E402
+
+
+def _noise_from_seed(seed: int, shape, scale: float = 1.0) -> torch.Tensor:
+    """The Gumbel draw the reference makes right after torch.manual_seed(seed)."""
+    torch.manual_seed(seed)
+    return S.uniform_to_gumbel(torch.rand(shape), 0.0, scale)
+
+
+def gen_samplers():
+    from ISubGVQA.sampling.methods.gumbel_scheme import GumbelSampler
+    from ISubGVQA.models.masking import get_imle_samplers, get_aimle_samplers
+
+    g1 = []
+    case = 0
+    for (B, Nmax, k) in [(1, 8, 2), (4, 16, 5), (32, 20, 5), (4, 64, 5), (2, 200, 5), (3, 4, 5), (5, 37, 2)]:
+        gen = torch.Generator().manual_seed(100 + case)
+        scores = torch.randn(B, Nmax, 1, generator=gen)
+        # zero-padded tails as to_dense_batch produces them (quirk Q1), gelu-like negatives included
+        for b in range(B):
+            n = int(torch.randint(1, Nmax + 1, (1,), generator=gen))
+            if b == 0:
+                n = Nmax
+            scores[b, n:] = 0.0
+        seed = 7000 + case
+        sampler = GumbelSampler(k=k, policy="edge_candid", train_ensemble=1, val_ensemble=1)
+        torch.manual_seed(seed)
+        out, _ = sampler(scores.clone(), train=False)
+        noise = _noise_from_seed(seed, (B, Nmax))
+        g1.append(dict(scores=scores, k=k, seed=seed, noise=noise, out=out.clone()))
+        case += 1
+    torch.save(g1, os.path.join(OUT, "g1_gumbel.pt"))
+
+    g2 = []
+    case = 0
+    for (B, Nmax, k) in [(1, 8, 2), (4, 16, 5), (8, 20, 5), (3, 4, 5), (3, 5, 5), (4, 12, 3)]:
+        gen = torch.Generator().manual_seed(200 + case)
+        scores = torch.randn(B, Nmax, 1, generator=gen)
+        for b in range(B):
+            n = int(torch.randint(1, Nmax + 1, (1,), generator=gen))
+            scores[b, n:] = 0.0
+        if B >= 3 and Nmax >= 8:
+            scores[1, 2] = scores[1, 5] = scores[1].max() - 0.0   # exact ties at the top
+            scores[2, :6] = 0.25                                   # ties that straddle the k-th value
+        _, val = get_imle_samplers(sample_k=k, device="cpu", nb_samples=1, alpha=1.0, beta=10.0, tau=1.0)
+        seed = 7100 + case
+        torch.manual_seed(seed)
+        out = val(scores.clone())
+        g2.append(dict(scores=scores, k=k, seed=seed, out=out[0].clone()))
+        case += 1
+    torch.save(g2, os.path.join(OUT, "g2_imle.pt"))
+
+    g3 = []
+    case = 0
+    for (B, Nmax, k, tau) in [(1, 8, 2, 1.0), (4, 16, 5, 1.0), (8, 20, 5, 1.0), (3, 4, 5, 1.0), (4, 33, 3, 0.5)]:
+        gen = torch.Generator().manual_seed(300 + case)
+        scores = torch.randn(B, Nmax, 1, generator=gen)
+        for b in range(B):
+            n = int(torch.randint(1, Nmax + 1, (1,), generator=gen))
+            scores[b, n:] = 0.0
+        _, val = get_aimle_samplers(sample_k=k, device="cpu", nb_samples=1, alpha=1.0, tau=tau)
+        seed = 7200 + case
+        torch.manual_seed(seed)
+        out = val(scores.clone())
+        noise = _noise_from_seed(seed, (B, 1, Nmax, 1), scale=0.3)
+        g3.append(dict(scores=scores, k=k, tau=tau, seed=seed, noise=noise, out=out.clone()))
+        case += 1
+    torch.save(g3, os.path.join(OUT, "g3_aimle.pt"))
+
+
+class _TextEmb(torch.nn.Module):
+    """Same parameter keys and arithmetic as CLIPTextEmbeddings (token + position lookup)."""
+
+    def __init__(self, vocab, dim, max_pos=77):
+        super().__init__()
+        self.token_embedding = torch.nn.Embedding(vocab, dim)
+        self.position_embedding = torch.nn.Embedding(max_pos, dim)
+
+    def forward(self, input_ids):
+        T = input_ids.size(1)
+        return self.token_embedding(input_ids) + self.position_embedding(torch.arange(T)).unsqueeze(0)
+
+
+def gen_question():
+    from ISubGVQA.models.question_encoder import QuestionEncoder
+    from ISubGVQA.models.question_decoder import QuestionDecoder
+
+    torch.manual_seed(11)
+    D, nhead, nhid, vocab = 32, 4, 64, 50
+    emb = _TextEmb(vocab, D)
+    enc = QuestionEncoder(text_vocab_embedding=emb, text_emb_dim=D, ninp=D, nhead=nhead, nhid=nhid,
+                          nlayers=2, dropout=0.1).eval()
+    dec = QuestionDecoder(n_instructions=4, ninp=D, nhead=nhead, nhid=nhid, nlayers=2, dropout=0.1).eval()
+    B, T = 5, 9
+    q = torch.randint(0, vocab, (B, T))
+    lens = torch.tensor([9, 4, 7, 1, 9])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).long()      # HF attention_mask: 1 = real token
+    with torch.no_grad():
+        e = enc(q, mask)
+        d = dec(e)
+    # pos_encoder.pe is a constructed-but-unused 5000-row buffer (question_encoder.py:33-34): not stored
+    sd = {"question_encoder." + k: v.clone() for k, v in enc.state_dict().items() if "pos_encoder" not in k}
+    sd.update({"program_decoder." + k: v.clone() for k, v in dec.state_dict().items()})
+    torch.save(dict(sd=sd, questions=q, mask=mask, nhead=nhead, enc_out=e, dec_out=d),
+               os.path.join(OUT, "g4_question.pt"))
+
+
+def _graphs(kind: str, gen):
+    """Tiny PyG-style batches.  Returns batch[N], edge_index[2,E] (unsorted, self-loops, duplicates)."""
+    if kind == "edgecases":
+        sizes = [3, 1, 5, 2]          # incl. a 1-node graph
+    elif kind == "b1":
+        sizes = [6]
+    else:
+        sizes = [int(torch.randint(2, 9, (1,), generator=gen)) for _ in range(6)]
+    batch, src, dst = [], [], []
+    off = 0
+    for g, n in enumerate(sizes):
+        batch += [g] * n
+        for v in range(n):            # self loop per node first (scene_graph.py:309-343)
+            if not (kind == "edgecases" and g == 2 and v == 4):   # node 4 of graph 2: isolated target
+                src.append(off + v); dst.append(off + v)
+        m = int(torch.randint(0, 2 * n + 1, (1,), generator=gen)) if n > 1 else 0
+        for _ in range(m):
+            a = int(torch.randint(0, n, (1,), generator=gen)); b = int(torch.randint(0, n, (1,), generator=gen))
+            if kind == "edgecases" and g == 2 and b == 4:
+                b = 0
+            src.append(off + a); dst.append(off + b)
+            if torch.rand(1, generator=gen) < 0.3:                # duplicate edge
+                src.append(off + a); dst.append(off + b)
+        off += n
+    ei = torch.tensor([src, dst], dtype=torch.long)
+    perm = torch.randperm(ei.size(1), generator=gen)              # edge order is arbitrary
+    return torch.tensor(batch, dtype=torch.long), ei[:, perm]
+
+
+def gen_mgat():
+    from ISubGVQA.models.mgat import MGAT
+    from ISubGVQA.models.att_pooling import GlobalAttention
+    from ISubGVQA.models.masking import get_imle_samplers, get_aimle_samplers
+    from ISubGVQA.sampling.node_edge_masks import NodeMaskToEdgeMask
+    from ISubGVQA.utils.scatter_scaled_dot_product import scatter_scaled_dot_product_attention
+
+    cases = [
+        dict(name="gumbel_c8", C=8, L=3, masks=[1.0, 1.0, 0.15], sampler="gumbel", k=2, kind="rand", interp=False),
+        dict(name="gumbel_edge", C=8, L=4, masks=[1.0, 0.15, 1.0, 0.15], sampler="gumbel", k=2, kind="edgecases", interp=False),
+        dict(name="imle_c16", C=16, L=4, masks=[1.0, 1.0, 1.0, 0.15], sampler="imle", k=3, kind="rand", interp=False),
+        dict(name="aimle_c12", C=12, L=2, masks=[0.15, 0.15], sampler="aimle", k=2, kind="rand", interp=True),
+        dict(name="gumbel_b1", C=8, L=2, masks=[1.0, 0.15], sampler="gumbel", k=3, kind="b1", interp=True),
+        dict(name="nomask_c20", C=20, L=2, masks=[1.0, 1.0], sampler="gumbel", k=2, kind="rand", interp=False),
+    ]
+    for ci, c in enumerate(cases):
+        gen = torch.Generator().manual_seed(500 + ci)
+        batch, ei = _graphs(c["kind"], gen)
+        N, E, B, C, L = batch.numel(), ei.size(1), int(batch.max()) + 1, c["C"], c["L"]
+        torch.manual_seed(40 + ci)
+        model = MGAT(channels=C, num_ins=L, heads=4, use_instr=True, masking_thresholds=c["masks"],
+                     use_topk=True, interpretable_mode=c["interp"], sampler_type=c["sampler"],
+                     sample_k=c["k"], nb_samples=1, alpha=1.0, beta=10.0, tau=1.0).eval()
+        pool = GlobalAttention(num_node_features=C, num_out_features=C).eval()
+        with torch.no_grad():        # make biases / norm params non-trivial
+            for n_, p_ in list(model.named_parameters()) + list(pool.named_parameters()):
+                if n_.endswith("bias") or "bns" in n_:
+                    p_.add_(0.1 * torch.randn(p_.shape, generator=gen))
+        for conv in model.convs:     # the factories hard-code device="cuda" (masking.py:97,106; quirk Q7)
+            if c["sampler"] == "imle":
+                conv.mask.sampler_train, conv.mask.sampler_val = get_imle_samplers(
+                    sample_k=c["k"], device="cpu", nb_samples=1, alpha=1.0, beta=10.0, tau=1.0)
+            elif c["sampler"] == "aimle":
+                conv.mask.sampler_train, conv.mask.sampler_val = get_aimle_samplers(
+                    sample_k=c["k"], device="cpu", nb_samples=1, alpha=1.0, tau=1.0)
+        x = torch.randn(N, C, generator=gen)
+        edge_attr = torch.randn(E, C, generator=gen)
+        instr = torch.randn(L, B, C, generator=gen)
+        glf = torch.randn(B, C, generator=gen)
+        seed = 9000 + ci
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            h, mask, _, _ = model(x=x, edge_index=ei, instr_vectors=instr, global_language_feats=glf,
+                                  edge_attr=edge_attr, batch=batch, return_masks=True)
+            emb, gate = pool(x=h, u=glf, batch=batch, size=None, return_mask=True, node_mask=mask)
+        # replay the RNG stream the masked layers consumed, in order
+        counts = torch.bincount(batch, minlength=B)
+        nmax = int(counts.max())
+        torch.manual_seed(seed)
+        noises = {}
+        for i, thr in enumerate(c["masks"]):
+            if thr != 1.0:
+                if c["sampler"] == "gumbel":
+                    noises[i] = S.uniform_to_gumbel(torch.rand(B, nmax))
+                else:
+                    noises[i] = S.uniform_to_gumbel(torch.rand(B, 1, nmax, 1), 0.0, 0.3)
+        # single conv layer (the last one) with its attention weights, for the kernel-level check
+        li = L - 1
+        torch.manual_seed(seed + 1)
+        with torch.no_grad():
+            conv_out, conv_mask, (_, alpha) = model.convs[li](
+                x=x, edge_index=ei, edge_attr=edge_attr, instruction=instr[li], batch=batch,
+                return_masks=True, return_attention_weights=True, imle_att=glf, all_instrs=instr)
+            att9 = scatter_scaled_dot_product_attention(instr[li], x, x, batch)
+            if conv_mask is not None:
+                em = NodeMaskToEdgeMask.apply(conv_mask, ei, torch.tensor(N))
+            else:
+                em = None
+        torch.manual_seed(seed + 1)
+        conv_noise = None
+        if c["masks"][li] != 1.0:
+            conv_noise = (S.uniform_to_gumbel(torch.rand(B, nmax)) if c["sampler"] == "gumbel"
+                          else S.uniform_to_gumbel(torch.rand(B, 1, nmax, 1), 0.0, 0.3))
+        # node_logits.* (512x2577) is never used in forward (mgat.py:98-102): not stored
+        sd = {"gat_seq." + k: v.clone() for k, v in model.state_dict().items() if "node_logits" not in k}
+        sd.update({"graph_global_attention_pooling." + k: v.clone() for k, v in pool.state_dict().items()})
+        torch.save(dict(cfg={k: c[k] for k in ("C", "L", "masks", "sampler", "k", "interp")}, sd=sd,
+                        x=x, edge_index=ei, edge_attr=edge_attr, batch=batch, instr=instr, glf=glf,
+                        noises=noises, h=h, mask=mask, pool_out=emb, pool_gate=gate,
+                        conv_layer=li, conv_noise=conv_noise, conv_out=conv_out, conv_mask=conv_mask,
+                        conv_alpha=alpha, conv_edge_mask=em, scatter_att=att9),
+                   os.path.join(OUT, f"g5_mgat_{c['name']}.pt"))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sys.dont_write_bytecode = True
+    pyg_standin.install()
+    sys.path.insert(0, REF)
+    gen_samplers()
+    gen_question()
+    gen_mgat()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
