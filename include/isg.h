@@ -1,0 +1,180 @@
+/*
+ * isg.h -- C ABI of libisg_hip.so: the MI355X (gfx950) kernels behind the ISubGVQA
+ * inference hot path (batched scene-graph message passing + discrete subgraph sampling).
+ *
+ * The reference (DigitalPhonetics/Intrinsic-Subgraph-Generation-for-VQA) has no FFI: its
+ * boundary is the Python nn.Module surface under ISubGVQA/models, and all sparse arithmetic
+ * is delegated to torch_geometric / torch_scatter kernels.  Each entry point below replaces
+ * one such delegated step; the comment above it cites the reference call site (file:line,
+ * relative to the reference root) whose arithmetic it reproduces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named *_host
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates,
+ *     frees or synchronises, so every call is hipGraph-capturable
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream)
+ *   - return value: ISG_OK (0) or a negative ISG_E* status; nothing throws across the ABI;
+ *     isg_status_string() names a status
+ *   - features are fp32 row-major; PyG index tensors (edge_index, batch) arrive as int64 and
+ *     are converted once by isg_graph_ptr / isg_csr_build into int32 plan arrays
+ *   - N nodes, E edges, B graphs of the batch; H heads, C channels per head; 4 | C required
+ */
+#ifndef ISG_H
+#define ISG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISG_ABI_VERSION 1
+
+#define ISG_OK 0
+#define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
+#define ISG_EUNSUPPORTED (-2) /* shape outside what the kernels are built for (see each fn) */
+#define ISG_ELAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch            */
+#define ISG_EWORKSPACE (-4)   /* workspace too small                                        */
+
+int isg_abi_version(void);
+const char *isg_status_string(int status);
+/* text of the last HIP error seen by a launch on this thread ("" if none) */
+const char *isg_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph plan (built once per PyG Batch, reused by every layer)
+ * ------------------------------------------------------------------------------------------- */
+
+/* ptr[b] = first node of graph b, ptr[B] = N, from the sorted PyG `batch` vector; nmax[0] = the
+ * largest node count of any graph.  Replaces `size = batch[-1].item()+1` and the counting inside
+ * to_dense_batch (ISubGVQA/models/masking.py:135,162; att_pooling.py:60).
+ * batch int64[N] (sorted ascending), ptr int32[B+1], nmax int32[1]. */
+int isg_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t *ptr, int32_t *nmax, void *stream);
+
+/* Bytes of workspace isg_csr_build needs. */
+size_t isg_csr_workspace_bytes(int64_t N, int64_t E);
+
+/* CSR by destination node of the COO `edge_index` int64[2,E] (row 0 = source j, row 1 = target i,
+ * flow source_to_target as in PyG MessagePassing; ISubGVQA/models/mgat_v2_conv.py:47,215).
+ * Within a destination segment edges keep ascending original edge id, so every segmented
+ * reduction accumulates in the order torch_scatter's CPU kernels do.
+ * rowptr int32[N+1]; eid int32[E] original edge id per CSR slot; src int32[E] source node per slot. */
+int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, int32_t *rowptr, int32_t *eid,
+                  int32_t *src, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Message passing
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[n,:] = gelu(x[n,:] * instr[batch[n],:])      ISubGVQA/models/mgat_v2_conv.py:156-157
+ * x,out fp32[N,C]; instr fp32[B,C]; batch int64[N].  out may alias x. */
+int isg_instr_gate(const float *x, const float *instr, const int64_t *batch, float *out, int64_t N,
+                   int32_t C, void *stream);
+
+/* edge_mask[e] = mask[src[e]] * mask[dst[e]]        ISubGVQA/sampling/node_edge_masks.py:7-10
+ * mask fp32[N]; edge_index int64[2,E]; out fp32[E]. */
+int isg_node_to_edge_mask(const float *node_mask, const int64_t *edge_index, int64_t E, float *out,
+                          void *stream);
+
+/* GATv2 message + softmax + aggregate: MaskingGATv2Conv.message and the PyG 'add' aggregation,
+ * ISubGVQA/models/mgat_v2_conv.py:243-279 (+ the bias add of :231-232 when bias != NULL).
+ *   s      = x_r[i] + x_l[j] + e_proj[e];  s *= m_e;  s = leaky_relu(s, slope);  s *= m_e
+ *   a[e,h] = <s[h,:], att[h,:]>
+ *   alpha  = exp(a - max_i) / (sum_i exp(a - max_i) + 1e-16)      (torch_geometric.utils.softmax)
+ *   out[i] = sum_e x_l[j] * alpha[e] * m_e  (+ bias)
+ * m_e = edge_mask[e] if given, else node_mask[j]*node_mask[i] if given, else 1.
+ * x_l,x_r fp32[N,H*C]; e_proj fp32[E,H*C] (ORIGINAL edge order); att fp32[H*C]; bias fp32[H*C]|NULL;
+ * rowptr/eid/src from isg_csr_build; out fp32[N,H*C]; alpha fp32[E,H] (ORIGINAL edge order).
+ * H in {1,2,4,8}; 4 | C; C/4 <= 8*(64/H).  Isolated targets get 0 (+bias). */
+int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
+                     const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                     const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
+                     int64_t E, int32_t H, int32_t C, float negative_slope, void *stream);
+
+/* out[i,:] = sum_{e: dst(e)=i} msg[e,:] / max(deg(i),1)       torch_scatter.scatter_mean at
+ * ISubGVQA/models/scene_graph_encoder.py:141.  msg fp32[E,C] (original edge order); out fp32[N,C]. */
+int isg_scatter_mean(const float *msg, const int32_t *rowptr, const int32_t *eid, float *out, int64_t N,
+                     int32_t C, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Node gate + discrete top-k samplers
+ * ------------------------------------------------------------------------------------------- */
+
+/* gate[n] = gelu( <xn[n,:], q[r(n),:]> / sqrt(C) )           ISubGVQA/models/masking.py:151-155
+ * r(n) = batch[batch[n]] when double_index != 0 (the reference indexes an already-gathered
+ * tensor again: mgat_v2_conv.py:167 + masking.py:152), else batch[n].
+ * xn fp32[N,C] (= node_nn(x)); q fp32[Bq,C] (= ques_nn(u)); gate fp32[N]. */
+int isg_node_gate(const float *xn, const float *q, const int64_t *batch, int32_t double_index, float *gate,
+                  int64_t N, int32_t C, void *stream);
+
+/* Row layout shared by the samplers.  Row b has `Nmax` slots:
+ *   ragged input  (ptr != NULL): slot j < n_b reads scores[ptr[b]+j], slots n_b..Nmax-1 are the
+ *                 0.0 pads of to_dense_batch (masking.py:162) and DO compete; outputs are written
+ *                 for j < n_b at out[ptr[b]+j]               (masking.py:170-176  `[mask]`)
+ *   dense input   (ptr == NULL): scores/out are [B,Nmax] row-major, all slots real.
+ * Nmax = *nmax_dev if nmax_dev != NULL else nmax_host; nmax_host must be >= the true Nmax (it sizes
+ * the launch); rows longer than 1024 slots are ISG_EUNSUPPORTED.
+ * noise: explicit fp32 noise laid out [B, nmax_host] (the reference draws [B,Nmax] for Gumbel,
+ * gumbel_scheme.py:65-69, and [B,1,Nmax,1] for I-MLE/AIMLE, wrapper.py:84-91, aimle.py:93-106 --
+ * the same memory layout), or NULL to generate it in-kernel with Philox4x32-10 keyed by
+ * (seed, b, j). */
+
+/* Relaxed Gumbel top-k with straight-through hard mask: GumbelSampler.forward, policy
+ * 'edge_candid', ISubGVQA/sampling/methods/gumbel_scheme.py:55-58,63-104.
+ *   flat = scores + g;  repeat min(k,Nmax) times { flat += log(max(1-onehot, FLT_MIN));
+ *   onehot = softmax(flat/tau); khot += onehot };  hard = top-k(khot);  out = (hard-khot)+khot
+ * khot_out (optional) fp32[B,Nmax_host-strided] receives khot for inspection. */
+int isg_topk_gumbel(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
+                    const int32_t *nmax_dev, const float *noise, uint64_t seed, int32_t k, float tau,
+                    float *out, float *khot_out, void *stream);
+
+/* Threshold top-k used by I-MLE / AIMLE at inference:  select_from_edge_candidates,
+ * ISubGVQA/sampling/methods/deterministic_scheme.py:36-43, applied to scores + noise*noise_scale
+ * (wrapper.py:93-100 with temperature 0 for I-MLE -> pass noise_scale = 0 and noise = NULL;
+ * aimle.py:109-117 with temperature tau for AIMLE).  out = (v >= k-th largest v) as 0/1;
+ * k >= Nmax -> all ones.  With noise == NULL and noise_scale != 0 the in-kernel draw is
+ * Gumbel(0, 0.3) (masking.py:236,273) times noise_scale. */
+int isg_topk_threshold(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
+                       const int32_t *nmax_dev, const float *noise, float noise_scale, uint64_t seed,
+                       int32_t k, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-graph attention / normalisation / pooling
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[n,:] = softmax_{n in g}( <query[g,:], key[n,:]> / sqrt(C) ) * value[n,:]
+ * ISubGVQA/utils/scatter_scaled_dot_product.py:6-15 (torch_scatter.scatter_softmax: no epsilon). */
+int isg_scatter_attention(const float *query, const float *key, const float *value, const int32_t *ptr,
+                          float *out, int64_t B, int32_t C, void *stream);
+
+/* PyG GraphNorm forward: y = w*(x - mean_g*ms)/sqrt(var_g+eps) + b, per graph and channel
+ * (ISubGVQA/models/mgat.py:93-95,171); eps is rounded to fp32 on the fp32 path, as `var + self.eps`
+ * does.  accumulate_fp64 != 0 does all arithmetic in double and rounds
+ * once at the end, as the reference does for the scene-graph encoder
+ * (ISubGVQA/models/scene_graph_encoder.py:99-102). */
+int isg_graph_norm(const float *x, const int32_t *ptr, const float *weight, const float *bias,
+                   const float *mean_scale, double eps, int32_t accumulate_fp64, float *out, int64_t B,
+                   int32_t C, void *stream);
+
+/* One MGAT layer tail, fused:  ISubGVQA/models/mgat.py:168-177
+ *   c = scatter_attention(ins, c, c);  c = GraphNorm(c);  h_out = c + h;  h_out *= node_mask (optional)
+ * ins fp32[B,C]; c,h,h_out fp32[N,C] (h_out may alias h); node_mask fp32[N]|NULL. */
+int isg_instr_attn_graphnorm_residual(const float *ins, const float *c, const float *h, const int32_t *ptr,
+                                      const float *weight, const float *bias, const float *mean_scale,
+                                      double eps, const float *node_mask, float *h_out, int64_t B, int32_t C,
+                                      void *stream);
+
+/* Question-conditioned softmax pooling: GlobalAttention.forward, ISubGVQA/models/att_pooling.py:63-73
+ *   x = xn * node_mask;  gate = softmax_g(<x, q[g]>/sqrt(C)) (+1e-16 in the denominator);
+ *   out[g,:] = sum_n gate[n] * x[n,:]
+ * xn fp32[N,C] (= node_nn(x)); q fp32[B,C] (= ques_nn(u)); node_mask fp32[N]|NULL;
+ * out fp32[B,C]; gate fp32[N]. */
+int isg_global_attn_pool(const float *xn, const float *q, const int32_t *ptr, const float *node_mask,
+                         float *out, float *gate, int64_t B, int32_t C, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISG_H */

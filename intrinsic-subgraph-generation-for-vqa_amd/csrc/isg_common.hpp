@@ -1,0 +1,109 @@
+// Shared device helpers for libisg_hip.so (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#include "../../include/isg.h"
+
+#define ISG_WAVE 64
+
+namespace isg {
+
+// ---- host-side launch bookkeeping -------------------------------------------------------------
+int check_launch();                 // hipGetLastError() -> ISG_OK / ISG_ELAUNCH (records the text)
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- cross-lane movement via DPP (no LDS traffic) --------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+// DPP controls: quad_perm[1,0,3,2]=0xB1, quad_perm[2,3,0,1]=0x4E, row_half_mirror=0x141, row_mirror=0x140
+#define ISG_DPP_XOR1 0xB1
+#define ISG_DPP_XOR2 0x4E
+#define ISG_DPP_HMIRROR 0x141
+#define ISG_DPP_MIRROR 0x140
+
+// Sum over aligned groups of G lanes (G in {8,16,32,64}); every lane of a group gets the group total.
+// The butterfly order is fixed, so the result is bitwise reproducible run to run.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_mov<ISG_DPP_XOR1>(v);
+  v += dpp_mov<ISG_DPP_XOR2>(v);
+  v += dpp_mov<ISG_DPP_HMIRROR>(v);
+  if (G >= 16) v += dpp_mov<ISG_DPP_MIRROR>(v);
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, dpp_mov<ISG_DPP_XOR1>(v));
+  v = fmaxf(v, dpp_mov<ISG_DPP_XOR2>(v));
+  v = fmaxf(v, dpp_mov<ISG_DPP_HMIRROR>(v));
+  if (G >= 16) v = fmaxf(v, dpp_mov<ISG_DPP_MIRROR>(v));
+  if (G >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  if (G >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// exact (erf) GELU, the torch.nn.functional.gelu default used everywhere in the reference
+__device__ __forceinline__ float gelu_exact(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---- Philox4x32-10 counter RNG (in-kernel noise when the caller passes none) ---------------------
+struct Philox {
+  static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  static __device__ __forceinline__ uint32_t draw(uint64_t seed, uint32_t a, uint32_t b) {
+    uint32_t c[4] = {a, b, 0x1571u, 0x9E37u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    return c[0];
+  }
+};
+
+// u in [0,1) with 24 random bits, then the reference's Uniform(tiny, 1-eps) -> Gumbel(loc, scale)
+// transform chain (torch.distributions.Gumbel; ISubGVQA/sampling/methods/gumbel_scheme.py:65-69).
+__device__ __forceinline__ float gumbel_from_bits(uint32_t bits, float loc, float scale) {
+  float u01 = (float)(bits >> 8) * (1.0f / 16777216.0f);
+  const float lo = FLT_MIN, hi = 1.0f - FLT_EPSILON;
+  float u = __fadd_rn(lo, __fmul_rn(u01, hi - lo));
+  float l1 = (float)log((double)u);
+  float l2 = (float)log((double)(-l1));
+  return __fsub_rn(loc, __fmul_rn(scale, l2));
+}
+
+}  // namespace isg

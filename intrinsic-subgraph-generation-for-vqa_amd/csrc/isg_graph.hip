@@ -1,0 +1,164 @@
+// Graph plan kernels: per-graph node ranges and the CSR-by-destination of a PyG COO edge_index.
+#include "isg_common.hpp"
+
+#include <string>
+
+namespace isg {
+
+static thread_local std::string g_last_error;
+
+int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return ISG_OK;
+  g_last_error = hipGetErrorString(e);
+  return ISG_ELAUNCH;
+}
+
+// ---- ptr / nmax -----------------------------------------------------------------------------------
+// batch is sorted ascending.  Node n owns the boundaries of every graph id in (batch[n-1], batch[n]];
+// the last node also closes all graphs above batch[N-1] (empty trailing graphs).
+__global__ void graph_ptr_kernel(const int64_t *__restrict__ batch, int N, int B, int *__restrict__ ptr) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int b = (int)batch[n];
+  int prev = n > 0 ? (int)batch[n - 1] : -1;
+  if (b >= B) b = B - 1;  // malformed input is clamped, never written out of bounds
+  for (int g = prev + 1; g <= b; ++g) ptr[g] = n;
+  if (n == N - 1)
+    for (int g = b + 1; g <= B; ++g) ptr[g] = N;
+}
+
+__global__ void graph_nmax_kernel(const int *__restrict__ ptr, int B, int *__restrict__ nmax) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  int v = 0;
+  if (g < B) v = ptr[g + 1] - ptr[g];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(nmax, v);
+}
+
+__global__ void fill_i32_kernel(int *__restrict__ p, int n, int v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---- CSR build ------------------------------------------------------------------------------------
+__global__ void csr_hist_kernel(const int64_t *__restrict__ dst, int E, int N, int *__restrict__ deg) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int d = (int)dst[e];
+  if (d >= 0 && d < N) atomicAdd(&deg[d], 1);
+}
+
+// Exclusive scan of deg[0..N) into rowptr[0..N], one 1024-thread block (N is ~1e5 per batch).
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int *__restrict__ deg, int N,
+                                                        int *__restrict__ rowptr) {
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  const int per = (N + 1023) / 1024;
+  const int beg = min(tid * per, N), end = min(beg + per, N);
+  int sum = 0;
+  for (int i = beg; i < end; ++i) sum += deg[i];
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the partials
+    int v = tid >= off ? s_part[tid - off] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - sum;
+  for (int i = beg; i < end; ++i) {
+    rowptr[i] = run;
+    run += deg[i];
+  }
+  if (tid == 1023) rowptr[N] = s_part[1023];
+}
+
+__global__ void csr_fill_kernel(const int64_t *__restrict__ dst, int E, int N, const int *__restrict__ rowptr,
+                                int *__restrict__ cursor, int *__restrict__ eid_tmp) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int d = (int)dst[e];
+  if (d < 0 || d >= N) return;
+  int slot = atomicAdd(&cursor[d], 1);
+  eid_tmp[rowptr[d] + slot] = e;
+}
+
+// The atomic fill leaves each segment in arrival order; rank every slot by its edge id inside its
+// segment so the final order is ascending edge id (= torch_scatter's CPU accumulation order).
+__global__ void csr_rank_kernel(const int64_t *__restrict__ edge_index, int E, int N,
+                                const int *__restrict__ rowptr, const int *__restrict__ eid_tmp,
+                                int *__restrict__ eid, int *__restrict__ src) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = rowptr[N];
+  if (t >= total) return;
+  int e = eid_tmp[t];
+  int d = (int)edge_index[(int64_t)E + e];
+  int rb = rowptr[d], re = rowptr[d + 1];
+  int rank = 0;
+  for (int u = rb; u < re; ++u) rank += (eid_tmp[u] < e) ? 1 : 0;
+  int s = (int)edge_index[e];
+  s = min(max(s, 0), N - 1);  // a malformed source id must never turn into an out-of-bounds row read
+  eid[rb + rank] = e;
+  src[rb + rank] = s;
+}
+
+}  // namespace isg
+
+using namespace isg;
+
+extern "C" int isg_abi_version(void) { return ISG_ABI_VERSION; }
+
+extern "C" const char *isg_status_string(int status) {
+  switch (status) {
+    case ISG_OK: return "ok";
+    case ISG_EINVAL: return "invalid argument";
+    case ISG_EUNSUPPORTED: return "unsupported shape";
+    case ISG_ELAUNCH: return "HIP launch failed";
+    case ISG_EWORKSPACE: return "workspace too small";
+    default: return "unknown status";
+  }
+}
+
+extern "C" const char *isg_last_hip_error(void) { return g_last_error.c_str(); }
+
+extern "C" int isg_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t *ptr, int32_t *nmax,
+                             void *stream) {
+  if (!ptr || !nmax || N < 0 || B < 0 || (N > 0 && !batch)) return ISG_EINVAL;
+  if (N >= (1ll << 31) || B >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  // graphs with no node at all (N == 0, or ids never written) must still read as empty ranges
+  fill_i32_kernel<<<(int)((B + 1 + 255) / 256), 256, 0, st>>>(ptr, (int)B + 1, 0);
+  fill_i32_kernel<<<1, 64, 0, st>>>(nmax, 1, 0);
+  if (N > 0 && B > 0) {
+    graph_ptr_kernel<<<(int)((N + 255) / 256), 256, 0, st>>>(batch, (int)N, (int)B, ptr);
+    graph_nmax_kernel<<<(int)((B + 255) / 256), 256, 0, st>>>(ptr, (int)B, nmax);
+  }
+  return check_launch();
+}
+
+extern "C" size_t isg_csr_workspace_bytes(int64_t N, int64_t E) {
+  if (N < 0 || E < 0) return 0;
+  return (size_t)(2 * (N + 1) + E) * sizeof(int32_t);
+}
+
+extern "C" int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, int32_t *rowptr, int32_t *eid,
+                             int32_t *src, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!rowptr || N < 0 || E < 0 || (E > 0 && (!edge_index || !eid || !src))) return ISG_EINVAL;
+  if (N >= (1ll << 31) || E >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < isg_csr_workspace_bytes(N, E)) return ISG_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  int *deg = (int *)workspace;            // N+1
+  int *cursor = deg + (N + 1);            // N+1
+  int *eid_tmp = cursor + (N + 1);        // E
+  const int n = (int)N, e = (int)E;
+  fill_i32_kernel<<<(2 * (n + 1) + 255) / 256, 256, 0, st>>>(deg, 2 * (n + 1), 0);
+  if (e > 0) csr_hist_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index + E, e, n, deg);
+  csr_scan_kernel<<<1, 1024, 0, st>>>(deg, n, rowptr);
+  if (e > 0) {
+    csr_fill_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index + E, e, n, rowptr, cursor, eid_tmp);
+    csr_rank_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index, e, n, rowptr, eid_tmp, eid, src);
+  }
+  return check_launch();
+}

@@ -1,0 +1,309 @@
+// GATv2 message passing with edge features over a CSR-by-destination plan, plus the small
+// gather/scatter companions of the layer (instruction gate, node->edge mask, scatter-mean).
+//
+// Work decomposition of the message-passing kernel (gfx950, wave = 64):
+//   * one workgroup (4 waves) owns MP_NPB consecutive destination nodes; their CSR segment
+//     (row pointers, source ids, original edge ids) is staged once into LDS with coalesced loads,
+//     so the per-edge loop has no dependent index loads from HBM
+//   * one wave owns one destination node at a time; the 64 lanes are split into H groups of
+//     G = 64/H lanes, group g = head g, lane l of a group owns float4 columns l, l+G, ... of that
+//     head -> every row access is H contiguous 16*G-byte pieces (256 B for H = 4)
+//   * per-head attention logits are a G-lane DPP butterfly (no LDS), kept in an LDS strip per
+//     wave (overflow for in-degree > MP_LCAP goes through the alpha output buffer)
+//   * softmax is the exact three-step form of torch_geometric.utils.softmax (max, exp-sum + 1e-16,
+//     divide) and the aggregation adds messages in ascending edge id, unfused mul+add, i.e. the
+//     summation order and roundings of the reference's CPU scatter
+#include "isg_common.hpp"
+
+namespace isg {
+
+constexpr int MP_WAVES = 4;
+constexpr int MP_NPB = 16;     // destination nodes per workgroup
+constexpr int MP_ECAP = 1024;  // CSR slots staged in LDS per workgroup (rest read from global)
+constexpr int MP_LCAP = 32;    // logits per wave kept in LDS (x H)
+
+struct MpArgs {
+  const float4 *x_l, *x_r, *e_proj, *att, *bias;
+  const int *rowptr, *eid, *src;
+  const float *node_mask, *edge_mask;
+  float4 *out;
+  float *alpha;
+  int N, C;
+  float slope;
+};
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+template <int H, int P>
+__global__ __launch_bounds__(MP_WAVES * 64) void gatv2_mp_kernel(MpArgs a) {
+  constexpr int G = 64 / H;
+  __shared__ int s_rowptr[MP_NPB + 1];
+  __shared__ int s_src[MP_ECAP];
+  __shared__ int s_eid[MP_ECAP];
+  __shared__ float s_logit[MP_WAVES][MP_LCAP * H];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * MP_NPB;
+  const int nn = min(MP_NPB, a.N - n0);
+  if (tid <= nn) s_rowptr[tid] = a.rowptr[n0 + tid];
+  __syncthreads();
+  const int e0 = s_rowptr[0];
+  const int ne = min(s_rowptr[nn] - e0, MP_ECAP);
+  for (int t = tid; t < ne; t += MP_WAVES * 64) {
+    s_src[t] = a.src[e0 + t];
+    s_eid[t] = a.eid[e0 + t];
+  }
+  __syncthreads();
+
+  const int g = lane / G, l = lane % G;
+  const int Q = a.C >> 2;   // float4 per head
+  const int R = H * Q;      // float4 per row
+  int off[P];
+  bool ok[P];
+  float4 att4[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int q = p * G + l;
+    ok[p] = q < Q;
+    off[p] = g * Q + (ok[p] ? q : 0);
+    att4[p] = ok[p] ? a.att[off[p]] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int mode = a.edge_mask ? 2 : (a.node_mask ? 1 : 0);
+  float *s_lg = s_logit[wave];
+
+  for (int k = wave; k < nn; k += MP_WAVES) {
+    const int i = n0 + k;
+    const int rb = s_rowptr[k], re = s_rowptr[k + 1];
+    float4 xr4[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) xr4[p] = ok[p] ? a.x_r[(size_t)i * R + off[p]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float mi = mode == 1 ? a.node_mask[i] : 1.f;
+
+    // ---- pass 1: logits a[e,h] and their per-head maximum --------------------------------------
+    float mx = -INFINITY;
+    for (int t = rb; t < re; ++t) {
+      const int rel = t - e0;
+      int j, e;
+      if (rel < MP_ECAP) { j = s_src[rel]; e = s_eid[rel]; } else { j = a.src[t]; e = a.eid[t]; }
+      float me = 1.f;
+      if (mode == 1) me = a.node_mask[j] * mi;
+      else if (mode == 2) me = a.edge_mask[e];
+      const float4 *xl = a.x_l + (size_t)j * R;
+      const float4 *ep = a.e_proj + (size_t)e * R;
+      float part = 0.f;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (ok[p]) {
+          float4 u = xl[off[p]], v = ep[off[p]], s;
+          s.x = (xr4[p].x + u.x) + v.x;
+          s.y = (xr4[p].y + u.y) + v.y;
+          s.z = (xr4[p].z + u.z) + v.z;
+          s.w = (xr4[p].w + u.w) + v.w;
+          if (mode != 0) { s.x *= me; s.y *= me; s.z *= me; s.w *= me; }
+          s.x = leaky(s.x, a.slope); s.y = leaky(s.y, a.slope); s.z = leaky(s.z, a.slope); s.w = leaky(s.w, a.slope);
+          if (mode != 0) { s.x *= me; s.y *= me; s.z *= me; s.w *= me; }
+          part += dot4(s, att4[p]);
+        }
+      }
+      const float logit = group_sum<G>(part);
+      mx = fmaxf(mx, logit);
+      const int slot = t - rb;
+      if (l == 0) {
+        if (slot < MP_LCAP) s_lg[slot * H + g] = logit;
+        else a.alpha[(size_t)e * H + g] = logit;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass 2: denominator, accumulated in edge order like the CPU scatter_sum ---------------
+    float den = 0.f;
+    for (int t = rb; t < re; ++t) {
+      const int slot = t - rb;
+      float lg;
+      if (slot < MP_LCAP) {
+        lg = s_lg[slot * H + g];
+      } else {
+        const int rel = t - e0;
+        const int e = rel < MP_ECAP ? s_eid[rel] : a.eid[t];
+        lg = l == 0 ? a.alpha[(size_t)e * H + g] : 0.f;   // read back by the lane that wrote it
+        lg = __shfl(lg, lane - l, 64);
+      }
+      den += expf(lg - mx);
+    }
+    den += 1e-16f;
+
+    // ---- pass 3: alpha out + weighted aggregation (unfused mul, add: the CPU's roundings) ------
+    float4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = rb; t < re; ++t) {
+      const int rel = t - e0;
+      int j, e;
+      if (rel < MP_ECAP) { j = s_src[rel]; e = s_eid[rel]; } else { j = a.src[t]; e = a.eid[t]; }
+      const int slot = t - rb;
+      float lg;
+      if (slot < MP_LCAP) {
+        lg = s_lg[slot * H + g];
+      } else {
+        lg = l == 0 ? a.alpha[(size_t)e * H + g] : 0.f;
+        lg = __shfl(lg, lane - l, 64);
+      }
+      const float w = expf(lg - mx) / den;
+      if (l == 0) a.alpha[(size_t)e * H + g] = w;
+      float wm = w;
+      if (mode == 1) wm = __fmul_rn(w, a.node_mask[j] * mi);
+      else if (mode == 2) wm = __fmul_rn(w, a.edge_mask[e]);
+      const float4 *xl = a.x_l + (size_t)j * R;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (ok[p]) {
+          float4 u = xl[off[p]];
+          acc[p].x = __fadd_rn(acc[p].x, __fmul_rn(u.x, wm));
+          acc[p].y = __fadd_rn(acc[p].y, __fmul_rn(u.y, wm));
+          acc[p].z = __fadd_rn(acc[p].z, __fmul_rn(u.z, wm));
+          acc[p].w = __fadd_rn(acc[p].w, __fmul_rn(u.w, wm));
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (ok[p]) {
+        float4 o = acc[p];
+        if (a.bias) {
+          float4 b = a.bias[off[p]];
+          o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+        }
+        a.out[(size_t)i * R + off[p]] = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int H>
+static int launch_mp(const MpArgs &a, hipStream_t st) {
+  constexpr int G = 64 / H;
+  const int Q = a.C >> 2;
+  const int P = (Q + G - 1) / G;
+  const int blocks = (a.N + MP_NPB - 1) / MP_NPB;
+  dim3 grid(blocks), block(MP_WAVES * 64);
+  switch (P) {
+    case 1: gatv2_mp_kernel<H, 1><<<grid, block, 0, st>>>(a); break;
+    case 2: gatv2_mp_kernel<H, 2><<<grid, block, 0, st>>>(a); break;
+    case 3: gatv2_mp_kernel<H, 3><<<grid, block, 0, st>>>(a); break;
+    case 4: gatv2_mp_kernel<H, 4><<<grid, block, 0, st>>>(a); break;
+    case 5: gatv2_mp_kernel<H, 5><<<grid, block, 0, st>>>(a); break;
+    case 6: gatv2_mp_kernel<H, 6><<<grid, block, 0, st>>>(a); break;
+    case 7: gatv2_mp_kernel<H, 7><<<grid, block, 0, st>>>(a); break;
+    case 8: gatv2_mp_kernel<H, 8><<<grid, block, 0, st>>>(a); break;
+    default: return ISG_EUNSUPPORTED;
+  }
+  return check_launch();
+}
+
+// ---- instruction gate: gelu(x * instr[batch]) ---------------------------------------------------
+__global__ void instr_gate_kernel(const float4 *__restrict__ x, const float4 *__restrict__ instr,
+                                  const int64_t *__restrict__ batch, float4 *__restrict__ out, int64_t total,
+                                  int Q) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int64_t n = idx / Q;
+  int q = (int)(idx - n * Q);
+  int64_t b = batch[n];
+  float4 v = x[idx], w = instr[b * Q + q];
+  v.x = gelu_exact(v.x * w.x);
+  v.y = gelu_exact(v.y * w.y);
+  v.z = gelu_exact(v.z * w.z);
+  v.w = gelu_exact(v.w * w.w);
+  out[idx] = v;
+}
+
+__global__ void node_to_edge_mask_kernel(const float *__restrict__ mask, const int64_t *__restrict__ ei, int64_t E,
+                                         float *__restrict__ out) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  out[e] = mask[ei[e]] * mask[ei[E + e]];
+}
+
+// ---- scatter-mean over the CSR plan: one wave per destination node --------------------------------
+__global__ __launch_bounds__(256) void scatter_mean_kernel(const float4 *__restrict__ msg, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ eid, float4 *__restrict__ out, int N,
+                                                           int Q) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int rb = rowptr[i], re = rowptr[i + 1];
+  const float cnt = (float)max(re - rb, 1);
+  for (int q = lane; q < Q; q += 64) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = rb; t < re; ++t) {
+      float4 v = msg[(size_t)eid[t] * Q + q];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt;
+    out[(size_t)i * Q + q] = acc;
+  }
+}
+
+}  // namespace isg
+
+using namespace isg;
+
+extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
+                                const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
+                                int64_t E, int32_t H, int32_t C, float negative_slope, void *stream) {
+  if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
+  if (N == 0) return ISG_OK;
+  if (!x_l || !x_r || !att || !rowptr || !out || (E > 0 && (!e_proj || !eid || !src || !alpha))) return ISG_EINVAL;
+  if ((C & 3) != 0 || N >= (1ll << 31) || E >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  MpArgs a;
+  a.x_l = (const float4 *)x_l; a.x_r = (const float4 *)x_r; a.e_proj = (const float4 *)e_proj;
+  a.att = (const float4 *)att; a.bias = (const float4 *)bias;
+  a.rowptr = rowptr; a.eid = eid; a.src = src;
+  a.node_mask = node_mask; a.edge_mask = edge_mask;
+  a.out = (float4 *)out; a.alpha = alpha;
+  a.N = (int)N; a.C = C; a.slope = negative_slope;
+  hipStream_t st = as_stream(stream);
+  switch (H) {
+    case 1: return launch_mp<1>(a, st);
+    case 2: return launch_mp<2>(a, st);
+    case 4: return launch_mp<4>(a, st);
+    case 8: return launch_mp<8>(a, st);
+    default: return ISG_EUNSUPPORTED;
+  }
+}
+
+extern "C" int isg_instr_gate(const float *x, const float *instr, const int64_t *batch, float *out, int64_t N,
+                              int32_t C, void *stream) {
+  if (N < 0 || C <= 0) return ISG_EINVAL;
+  if (N == 0) return ISG_OK;
+  if (!x || !instr || !batch || !out) return ISG_EINVAL;
+  if ((C & 3) != 0) return ISG_EUNSUPPORTED;
+  const int Q = C >> 2;
+  const int64_t total = N * Q;
+  if ((total + 255) / 256 >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  instr_gate_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(
+      (const float4 *)x, (const float4 *)instr, batch, (float4 *)out, total, Q);
+  return check_launch();
+}
+
+extern "C" int isg_node_to_edge_mask(const float *node_mask, const int64_t *edge_index, int64_t E, float *out,
+                                     void *stream) {
+  if (E < 0) return ISG_EINVAL;
+  if (E == 0) return ISG_OK;
+  if (!node_mask || !edge_index || !out) return ISG_EINVAL;
+  node_to_edge_mask_kernel<<<(unsigned)((E + 255) / 256), 256, 0, as_stream(stream)>>>(node_mask, edge_index, E, out);
+  return check_launch();
+}
+
+extern "C" int isg_scatter_mean(const float *msg, const int32_t *rowptr, const int32_t *eid, float *out, int64_t N,
+                                int32_t C, void *stream) {
+  if (N < 0 || C <= 0) return ISG_EINVAL;
+  if (N == 0) return ISG_OK;
+  if (!rowptr || !out) return ISG_EINVAL;
+  if ((C & 3) != 0 || N >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  scatter_mean_kernel<<<(unsigned)((N + 3) / 4), 256, 0, as_stream(stream)>>>(
+      (const float4 *)msg, rowptr, eid, (float4 *)out, (int)N, C >> 2);
+  return check_launch();
+}

@@ -1,0 +1,238 @@
+// Per-graph kernels of the MGAT layer tail and the read-out: instruction->node scatter-softmax
+// attention, GraphNorm, residual, and question-conditioned attention pooling.
+//
+// One workgroup owns one graph (its nodes are a contiguous row range [ptr[g], ptr[g+1])).
+//   phase A  waves stride over the graph's nodes; a wave computes one <query, key_n> dot product
+//            with a 64-lane DPP/shuffle butterfly and parks the scaled logit in LDS
+//   phase B  wave 0 turns the LDS strip into softmax weights (max, exp, ordered sum, divide)
+//   phase C  threads stride over channels; each walks the graph's nodes in order, so per-graph
+//            means / variances / pooled sums accumulate in node order with unfused mul+add --
+//            the order and roundings of the reference's CPU scatter kernels
+// Rows are re-read from L1/L2 in phase C (a 20-node x 128-channel graph is 10 KB).
+#include "isg_common.hpp"
+
+namespace isg {
+
+constexpr int GN_NCAP = 1024;  // nodes per graph the LDS strip holds (host rejects larger graphs)
+
+// phase A: s_a[k] = <q, key[nb+k] (* mask)> / denom
+__device__ __forceinline__ void phase_logits(const float4 *__restrict__ q4, const float4 *__restrict__ key4,
+                                             const float *__restrict__ node_mask, int nb, int n, int Q, float denom,
+                                             float *s_a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int k = wave; k < n; k += nw) {
+    const float4 *row = key4 + (size_t)(nb + k) * Q;
+    const float m = node_mask ? node_mask[nb + k] : 1.f;
+    float part = 0.f;
+    for (int c = lane; c < Q; c += 64) {
+      float4 v = row[c];
+      if (node_mask) { v.x = __fmul_rn(v.x, m); v.y = __fmul_rn(v.y, m); v.z = __fmul_rn(v.z, m); v.w = __fmul_rn(v.w, m); }
+      part += dot4(v, q4[c]);
+    }
+    const float dot = wave_sum(part);
+    if (lane == 0) s_a[k] = dot / denom;
+  }
+}
+
+// phase B (wave 0 only): s_a[k] <- exp(s_a[k]-max) / (sum + eps_add); the sum runs in node order.
+__device__ __forceinline__ void phase_softmax(int n, float eps_add, float *s_a) {
+  const int lane = threadIdx.x & 63;
+  float mx = -INFINITY;
+  for (int k = lane; k < n; k += 64) mx = fmaxf(mx, s_a[k]);
+  mx = wave_max(mx);
+  for (int k = lane; k < n; k += 64) s_a[k] = expf(s_a[k] - mx);
+  __builtin_amdgcn_wave_barrier();
+  float sum = 0.f;
+  if (n <= 128) {
+    for (int k = 0; k < n; ++k) sum += s_a[k];   // every lane walks the strip: LDS broadcast reads
+  } else {
+    const int per = (n + 63) / 64;
+    float part = 0.f;
+    for (int k = lane * per; k < min(n, (lane + 1) * per); ++k) part += s_a[k];
+    sum = wave_sum(part);
+  }
+  sum += eps_add;
+  __builtin_amdgcn_wave_barrier();
+  for (int k = lane; k < n; k += 64) s_a[k] = s_a[k] / sum;
+}
+
+// MODE 0: out = a_n * value_n                      (scatter_scaled_dot_product_attention)
+// MODE 1: out = GraphNorm(x)                        (x = key)
+// MODE 2: out = GraphNorm(a_n * value_n) + h  [* node_mask]   (fused MGAT layer tail)
+template <int MODE>
+__global__ __launch_bounds__(256) void graph_tail_kernel(const float *__restrict__ query, const float *__restrict__ key,
+                                                         const float *h, const int *__restrict__ ptr,
+                                                         const float *__restrict__ weight, const float *__restrict__ bias,
+                                                         const float *__restrict__ mean_scale, float eps,
+                                                         const float *__restrict__ node_mask, float *out,
+                                                         int C, float denom) {
+  __shared__ float s_a[GN_NCAP];
+  const int g = blockIdx.x;
+  const int nb = ptr[g];
+  const int n = MODE == 1 ? ptr[g + 1] - nb : min(ptr[g + 1] - nb, GN_NCAP);
+  if (n <= 0) return;
+  if (MODE != 1) {
+    phase_logits((const float4 *)(query + (size_t)g * C), (const float4 *)key, nullptr, nb, n, C >> 2, denom, s_a);
+    __syncthreads();
+    if (threadIdx.x < 64) phase_softmax(n, 0.f, s_a);
+    __syncthreads();
+  }
+  const float cnt = (float)n;
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const float *col = key + (size_t)nb * C + ch;
+    if (MODE == 0) {
+      for (int k = 0; k < n; ++k) out[(size_t)(nb + k) * C + ch] = __fmul_rn(s_a[k], col[(size_t)k * C]);
+      continue;
+    }
+    float sum = 0.f;
+    for (int k = 0; k < n; ++k) {
+      float v = col[(size_t)k * C];
+      if (MODE == 2) v = __fmul_rn(s_a[k], v);
+      sum = __fadd_rn(sum, v);
+    }
+    const float mean_ms = __fmul_rn(sum / cnt, mean_scale[ch]);
+    float sq = 0.f;
+    for (int k = 0; k < n; ++k) {
+      float v = col[(size_t)k * C];
+      if (MODE == 2) v = __fmul_rn(s_a[k], v);
+      const float o = __fsub_rn(v, mean_ms);
+      sq = __fadd_rn(sq, __fmul_rn(o, o));
+    }
+    const float stdv = sqrtf(__fadd_rn(sq / cnt, eps));
+    const float w = weight[ch], b = bias[ch];
+    for (int k = 0; k < n; ++k) {
+      float v = col[(size_t)k * C];
+      if (MODE == 2) v = __fmul_rn(s_a[k], v);
+      const float o = __fsub_rn(v, mean_ms);
+      float y = __fadd_rn(__fmul_rn(w, o) / stdv, b);
+      if (MODE == 2) {
+        y = __fadd_rn(y, h[(size_t)(nb + k) * C + ch]);
+        if (node_mask) y = __fmul_rn(node_mask[nb + k], y);
+      }
+      out[(size_t)(nb + k) * C + ch] = y;
+    }
+  }
+}
+
+// GraphNorm with every intermediate in double (scene_graph_encoder.py:99-102).
+__global__ __launch_bounds__(256) void graph_norm_f64_kernel(const float *__restrict__ x, const int *__restrict__ ptr,
+                                                             const float *__restrict__ weight, const float *__restrict__ bias,
+                                                             const float *__restrict__ mean_scale, double eps,
+                                                             float *__restrict__ out, int C) {
+  const int g = blockIdx.x;
+  const int nb = ptr[g];
+  const int n = ptr[g + 1] - nb;
+  if (n <= 0) return;
+  const double cnt = (double)n;
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const float *col = x + (size_t)nb * C + ch;
+    double sum = 0.0;
+    for (int k = 0; k < n; ++k) sum = __dadd_rn(sum, (double)col[(size_t)k * C]);
+    const double mean_ms = __dmul_rn(sum / cnt, (double)mean_scale[ch]);
+    double sq = 0.0;
+    for (int k = 0; k < n; ++k) {
+      const double o = __dsub_rn((double)col[(size_t)k * C], mean_ms);
+      sq = __dadd_rn(sq, __dmul_rn(o, o));
+    }
+    const double stdv = sqrt(__dadd_rn(sq / cnt, eps));
+    const double w = (double)weight[ch], b = (double)bias[ch];
+    for (int k = 0; k < n; ++k) {
+      const double o = __dsub_rn((double)col[(size_t)k * C], mean_ms);
+      out[(size_t)(nb + k) * C + ch] = (float)__dadd_rn(__dmul_rn(w, o) / stdv, b);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void global_attn_pool_kernel(const float *__restrict__ xn, const float *__restrict__ q,
+                                                               const int *__restrict__ ptr, const float *__restrict__ node_mask,
+                                                               float *__restrict__ out, float *__restrict__ gate, int C,
+                                                               float denom) {
+  __shared__ float s_a[GN_NCAP];
+  const int g = blockIdx.x;
+  const int nb = ptr[g];
+  const int n = min(ptr[g + 1] - nb, GN_NCAP);
+  if (n <= 0) {   // scatter_add leaves an empty graph's row at zero
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) out[(size_t)g * C + ch] = 0.f;
+    return;
+  }
+  phase_logits((const float4 *)(q + (size_t)g * C), (const float4 *)xn, node_mask, nb, n, C >> 2, denom, s_a);
+  __syncthreads();
+  if (threadIdx.x < 64) phase_softmax(n, 1e-16f, s_a);
+  __syncthreads();
+  for (int k = threadIdx.x; k < n; k += blockDim.x) gate[nb + k] = s_a[k];
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const float *col = xn + (size_t)nb * C + ch;
+    float sum = 0.f;
+    for (int k = 0; k < n; ++k) {
+      float v = col[(size_t)k * C];
+      if (node_mask) v = __fmul_rn(v, node_mask[nb + k]);
+      sum = __fadd_rn(sum, __fmul_rn(s_a[k], v));
+    }
+    out[(size_t)g * C + ch] = sum;
+  }
+}
+
+static int block_for(int C) { return C <= 64 ? 64 : (C <= 128 ? 128 : 256); }
+
+}  // namespace isg
+
+using namespace isg;
+
+static int check_bc(int64_t B, int32_t C) {
+  if (B < 0 || C <= 0) return ISG_EINVAL;
+  if ((C & 3) != 0 || B >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  return ISG_OK;
+}
+
+extern "C" int isg_scatter_attention(const float *query, const float *key, const float *value, const int32_t *ptr,
+                                     float *out, int64_t B, int32_t C, void *stream) {
+  int st = check_bc(B, C);
+  if (st != ISG_OK) return st;
+  if (B == 0) return ISG_OK;
+  if (!query || !key || !value || !ptr || !out) return ISG_EINVAL;
+  if (key != value) return ISG_EUNSUPPORTED;   // the reference only ever passes key == value (mgat.py:168-170)
+  graph_tail_kernel<0><<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(
+      query, key, nullptr, ptr, nullptr, nullptr, nullptr, 0.f, nullptr, out, C, (float)sqrt((double)C));
+  return check_launch();
+}
+
+extern "C" int isg_graph_norm(const float *x, const int32_t *ptr, const float *weight, const float *bias,
+                              const float *mean_scale, double eps, int32_t accumulate_fp64, float *out, int64_t B,
+                              int32_t C, void *stream) {
+  int st = check_bc(B, C);
+  if (st != ISG_OK) return st;
+  if (B == 0) return ISG_OK;
+  if (!x || !ptr || !weight || !bias || !mean_scale || !out) return ISG_EINVAL;
+  if (accumulate_fp64)
+    graph_norm_f64_kernel<<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(x, ptr, weight, bias, mean_scale, eps, out, C);
+  else
+    graph_tail_kernel<1><<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(
+        nullptr, x, nullptr, ptr, weight, bias, mean_scale, (float)eps, nullptr, out, C, 1.f);
+  return check_launch();
+}
+
+extern "C" int isg_instr_attn_graphnorm_residual(const float *ins, const float *c, const float *h, const int32_t *ptr,
+                                                 const float *weight, const float *bias, const float *mean_scale,
+                                                 double eps, const float *node_mask, float *h_out, int64_t B, int32_t C,
+                                                 void *stream) {
+  int st = check_bc(B, C);
+  if (st != ISG_OK) return st;
+  if (B == 0) return ISG_OK;
+  if (!ins || !c || !h || !ptr || !weight || !bias || !mean_scale || !h_out) return ISG_EINVAL;
+  // scatter_scaled_dot_product.py:11 divides by math.sqrt(C): a double rounded to fp32 by the tensor op
+  graph_tail_kernel<2><<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(
+      ins, c, h, ptr, weight, bias, mean_scale, (float)eps, node_mask, h_out, C, (float)sqrt((double)C));
+  return check_launch();
+}
+
+extern "C" int isg_global_attn_pool(const float *xn, const float *q, const int32_t *ptr, const float *node_mask,
+                                    float *out, float *gate, int64_t B, int32_t C, void *stream) {
+  int st = check_bc(B, C);
+  if (st != ISG_OK) return st;
+  if (B == 0) return ISG_OK;
+  if (!xn || !q || !ptr || !out || !gate) return ISG_EINVAL;
+  // att_pooling.py:68 divides by torch.sqrt(torch.tensor(C)): fp32 sqrt
+  global_attn_pool_kernel<<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(xn, q, ptr, node_mask, out, gate, C,
+                                                                              sqrtf((float)C));
+  return check_launch();
+}

@@ -1,0 +1,116 @@
+"""Top-level ISubGVQA module: the drop-in boundary.
+
+Reference behaviour: ISubGVQA.__init__/forward, ISubGVQA/models/isubgvqa.py:86-297 -- same constructor
+arguments (an ``args`` namespace plus the keyword flags), same forward signature, same 5-tuple result
+and the same state_dict key layout, so a reference checkpoint loads with
+strict=True.  Differences that do not change results: no CLIP download (weights arrive through the
+state_dict), no GQA/GloVe files, one GraphPlan per batch instead of per-layer index work, and an
+optional ``noises``/``seed`` pair to make the stochastic samplers reproducible across devices.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from .. import ops
+from .att_pooling import GlobalAttention
+from .mgat import MGAT
+from .scene_graph_encoder import SceneGraphEncoder
+from .text_encoder import CLIPTextEmbeddings, QuestionDecoder, QuestionEncoder
+
+NUM_ANSWERS = 1842   # isubgvqa.py:207
+
+
+class ISubGVQA(torch.nn.Module):
+    def __init__(self, args, use_imle=False, use_masking=True, use_instruction=True, use_mgat=False, mgat_masks=None,
+                 use_topk=False, interpretable_mode=True, concat_instr=False, embed_cat=True):
+        super().__init__()
+        self.args = args
+        self.n_train_steps = 0
+        self.n_valid_steps = 0
+        self.use_imle, self.use_instruction, self.use_masking = use_imle, use_instruction, use_masking
+        self.use_mgat, self.interpretable_mode = use_mgat, interpretable_mode
+        self.concat_instr, self.embed_cat = concat_instr, embed_cat
+        self.text_sampling = getattr(args, "text_sampling", False)
+        if self.text_sampling:
+            raise NotImplementedError("--text_sampling uses the SIMPLE sampler (SURVEY §8f row 4)")
+
+        self.general_hidden_dim = args.general_hidden_dim
+        self.scene_graph_encoder = SceneGraphEncoder(hidden_dim=self.general_hidden_dim,
+                                                     dist=getattr(args, "distributed", False),
+                                                     vocab_size=getattr(args, "sg_vocab_size", 2578))
+        self.text_emb_dim = 512
+        self.text_vocab_embedding = CLIPTextEmbeddings(getattr(args, "text_vocab_size", 49408), self.text_emb_dim, 77)
+        self.question_hidden_dim = self.general_hidden_dim
+        hidden_dim = 512
+        self.question_encoder = QuestionEncoder(text_vocab_embedding=self.text_vocab_embedding,
+                                                text_emb_dim=self.text_emb_dim, ninp=self.text_emb_dim, nhead=8,
+                                                nhid=4 * hidden_dim, nlayers=4, dropout=0.1)
+        self.program_decoder = QuestionDecoder(n_instructions=args.mgat_layers, ninp=self.text_emb_dim, nhead=8,
+                                               nhid=4 * hidden_dim, nlayers=3, dropout=0.1)
+        self.gat_seq = MGAT(channels=self.general_hidden_dim, num_ins=args.mgat_layers, use_instr=use_instruction,
+                            masking_thresholds=mgat_masks, use_topk=use_topk, interpretable_mode=interpretable_mode,
+                            concat_instr=concat_instr, use_all_instrs=getattr(args, "use_all_instrs", False),
+                            use_global_mask=getattr(args, "use_global_mask", False),
+                            node_classification=getattr(args, "node_classification", False),
+                            sampler_type=args.sampler_type, sample_k=args.sample_k,
+                            nb_samples=getattr(args, "nb_samples", 1), alpha=getattr(args, "alpha", 1.0),
+                            beta=getattr(args, "beta", 10.0), tau=getattr(args, "tau", 1.0))
+        self.graph_global_attention_pooling = GlobalAttention(num_node_features=self.question_hidden_dim,
+                                                              num_out_features=self.question_hidden_dim)
+        self.qsts_reduction = torch.nn.Sequential(
+            torch.nn.Linear(self.text_emb_dim * args.mgat_layers, self.question_hidden_dim), torch.nn.GELU())
+        self.instr_reduction = torch.nn.Sequential(
+            torch.nn.Linear(self.text_emb_dim, self.question_hidden_dim), torch.nn.GELU())
+        self.embedding = torch.nn.Sequential(torch.nn.Linear(self.question_hidden_dim * 3, 512), torch.nn.GELU(),
+                                             torch.nn.Dropout(p=0.2))
+        self.logit_fc = torch.nn.Linear(512, NUM_ANSWERS)
+
+    # -- pieces of forward that the benchmark also drives on their own -------------------------------
+    def language_features(self, questions: Tensor, qsts_att_mask: Tensor):
+        enc = self.question_encoder(questions, mask=qsts_att_mask)                       # :228
+        qst_feats = self.program_decoder(memory=enc)                                     # :243
+        # :244-246 -- a .view, not a permute: rows 4b..4b+3 of the flattened [n_ins*B, 512] (quirk Q4)
+        flat = qst_feats.contiguous().view(qst_feats.size(1), int(qst_feats.size(0)), qst_feats.size(2)).flatten(1)
+        glf = self.qsts_reduction(flat)                                                  # :247
+        instr = self.instr_reduction(qst_feats)                                          # :265
+        return glf, instr
+
+    def answer_graphs(self, x_encoded, edge_index, edge_attr_encoded, batch, instr_vectors, glf, plan,
+                      return_masks=True, noises=None, seed=None, explainer=False, explainer_stage=False,
+                      expl_bypass_x=False):
+        """MGAT -> pooling -> classifier (isubgvqa.py:267-292)."""
+        x_mgat, imle_mask, node_logits_layers, _ = self.gat_seq(
+            x=x_encoded, edge_index=edge_index, edge_attr=edge_attr_encoded, instr_vectors=instr_vectors[:4],
+            global_language_feats=glf, batch=batch, return_masks=return_masks, explainer=explainer,
+            explainer_stage=explainer_stage, expl_bypass_x=expl_bypass_x, plan=plan, noises=noises, seed=seed)
+        embed, gate = self.graph_global_attention_pooling(x=x_mgat, u=glf, batch=batch, size=None,
+                                                          return_mask=True, node_mask=imle_mask, plan=plan)
+        feats = self.embedding(torch.cat((embed, glf, embed * glf), dim=1))              # :288-291
+        return self.logit_fc(feats), imle_mask, gate, node_logits_layers                 # :292
+
+    def forward(self, node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask,
+                return_masks=False, explainer=False, explainer_stage=False, expl_bypass_x=False, scene_graphs=None,
+                noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
+                plan: Optional[ops.GraphPlan] = None):
+        if not return_masks:
+            # the reference unpacks two values from GlobalAttention.forward, which returns a bare tensor when
+            # return_mask=False (isubgvqa.py:280, att_pooling.py:75-77): return_masks=True is mandatory there
+            raise ValueError("return_masks=True is required (isubgvqa.py:280 unpacks (embed, gate))")
+        mask_text = None
+        glf, instr_vectors = self.language_features(questions, qsts_att_mask)
+        if explainer and explainer_stage > 0:                                            # :249-253
+            node_embeddings, expl_bypass_x = expl_bypass_x, node_embeddings.clone()
+        if plan is None:
+            plan = ops.GraphPlan.build(batch, edge_index, num_graphs=questions.size(0))
+        x_enc, e_enc = self.scene_graph_encoder(node_embeddings, edge_index=edge_index, edge_attr=edge_embeddings,
+                                                batch=batch, explainer=explainer, explainer_stage=explainer_stage,
+                                                gt_scene_graphs=scene_graphs, plan=plan)  # :255
+        logits, imle_mask, gate, node_logits_layers = self.answer_graphs(
+            x_enc, edge_index, e_enc, batch, instr_vectors, glf, plan, return_masks, noises, seed, explainer,
+            explainer_stage, expl_bypass_x)
+        if explainer:
+            return logits                                                                # :294-295
+        return logits, imle_mask, gate, node_logits_layers, mask_text                    # :297

@@ -1,0 +1,95 @@
+"""Stack of masked GATv2 layers with head projection, instruction attention, GraphNorm and residual.
+
+Reference behaviour: MGAT, ISubGVQA/models/mgat.py:8-184.  Per layer i:
+  conv_i (MaskingGATv2Conv)  ->  x_proj_i (Linear-GELU-Linear-GELU)  ->
+  scatter_scaled_dot_product_attention(ins_i, .)  ->  GraphNorm_i  ->  + h  [-> * mask]
+The last four steps after x_proj are one kernel (isg_instr_attn_graphnorm_residual).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from .. import ops
+from .layers import GraphNorm
+from .mgat_v2_conv import MaskingGATv2Conv
+
+
+class MGAT(torch.nn.Module):
+    def __init__(self, channels, num_ins, dropout=0.0, heads=4, use_instr=False, masking_thresholds=None,
+                 use_topk: bool = False, interpretable_mode: bool = True, concat_instr: bool = False,
+                 use_all_instrs: bool = False, use_global_mask: bool = False, node_classification: bool = False,
+                 sampler_type: str = None, sample_k: int = None, nb_samples: int = 1, alpha=1.0, beta=10.0, tau=1.0):
+        super().__init__()
+        if not use_instr:
+            raise NotImplementedError("use_instr=False leaves the reference without its layer lists (mgat.py:46-64)")
+        if num_ins > 4:
+            raise ValueError("the reference supports at most 4 instruction layers (mgat.py:47-53)")
+        self.masking_thresholds = masking_thresholds
+        self.use_global_mask = use_global_mask
+        self.node_classification = node_classification
+        self.heads, self.use_instr, self.use_topk = heads, use_instr, use_topk
+        self.interpretable_mode, self.use_all_instrs = interpretable_mode, use_all_instrs
+        self.in_channels = channels * 2 if concat_instr else channels
+
+        self.convs = torch.nn.ModuleList([
+            MaskingGATv2Conv(in_channels=self.in_channels, out_channels=channels, heads=heads, edge_dim=channels,
+                             masking_threshold=masking_thresholds[i], add_self_loops=False, use_instr=True,
+                             use_topk=use_topk, concat_instr=concat_instr, use_all_instrs=use_all_instrs,
+                             sampler_type=sampler_type, sample_k=sample_k, nb_samples=nb_samples, alpha=alpha,
+                             beta=beta, tau=tau)
+            for i in range(num_ins)])
+        self.x_proj = torch.nn.ModuleList([
+            torch.nn.Sequential(torch.nn.Linear(heads * channels, channels * int(heads / 2)), torch.nn.GELU(),
+                                torch.nn.Linear(channels * int(heads / 2), channels), torch.nn.GELU())
+            for _ in range(num_ins)])
+        self.bns = torch.nn.ModuleList([GraphNorm(channels) for _ in range(num_ins)])
+        self.dropout = dropout
+        # constructed by the reference, never used in forward (mgat.py:98-102); kept for checkpoint keys
+        self.node_logits = torch.nn.Sequential(torch.nn.Linear(channels, 512), torch.nn.GELU(),
+                                               torch.nn.Linear(512, 2577))
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+
+    def forward(self, x, edge_index, instr_vectors, global_language_feats, edge_attr, batch, return_masks=False,
+                explainer=False, explainer_stage=False, expl_bypass_x=False, plan: Optional[ops.GraphPlan] = None,
+                noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
+                return_attention: bool = False):
+        if plan is None:
+            plan = ops.GraphPlan.build(batch, edge_index, num_graphs=global_language_feats.size(0))
+        h = x.float().contiguous()
+        edge_attr = edge_attr.float().contiguous()
+        glf = global_language_feats.contiguous()
+        mask = None
+        global_mask = None
+        edge_attns = []
+        for i in range(len(self.convs)):
+            ins = instr_vectors[i].contiguous()
+            if explainer:
+                h = expl_bypass_x if (explainer_stage - 1) == i else h                   # :140-141
+            conv_res, mask, edge_att = self.convs[i](
+                x=h, edge_index=edge_index, edge_attr=edge_attr, instruction=ins, batch=batch,
+                return_masks=return_masks, return_attention_weights=True, imle_att=glf, all_instrs=instr_vectors,
+                plan=plan, noise=None if noises is None else noises.get(i),
+                seed=None if seed is None else seed + i)                                 # :144-154
+            if return_attention:
+                edge_attns.append(edge_att)
+            conv_res = self.x_proj[i](conv_res)                                          # :156
+            tail_mask = None
+            if self.use_global_mask:                                                     # :161-162,174-175
+                global_mask = mask if global_mask is None else mask * global_mask
+                tail_mask = global_mask
+            elif self.interpretable_mode and mask is not None:                           # :176-177
+                tail_mask = mask
+            bn = self.bns[i]
+            h = ops.mgat_layer_tail(ins, conv_res.contiguous(), h, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
+                                    node_mask=tail_mask)                                 # :168-177
+        if return_attention:
+            return h, mask, [], [], edge_attns
+        return h, mask, [], []

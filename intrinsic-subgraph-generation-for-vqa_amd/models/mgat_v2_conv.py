@@ -1,0 +1,113 @@
+"""GATv2 convolution with edge features, instruction gating and node->edge masking.
+
+Reference behaviour: MaskingGATv2Conv, ISubGVQA/models/mgat_v2_conv.py:18-285 (constructor keywords,
+forward signature and return tuples are kept; ``plan``/``noise``/``seed`` are optional extras).
+
+Device work per call:
+  isg_instr_gate                 x = gelu(x * instruction[batch])                       (:156-157)
+  MaskingModel (masked layers)   node gate + top-k sampler -> node mask [N,1]           (:161-168)
+  three dense projections        lin_l, lin_r (C -> H*C, +bias), lin_edge (no bias)     (:177,181,259)
+  isg_gatv2_mp_fwd               message + segment softmax + aggregate + bias, with the node->edge
+                                 mask product of NodeMaskToEdgeMask fused in            (:169-171,215-232,243-279)
+The reference stashes alpha on the module between message() and forward() (:223-224,274); here it
+is a local, so the module is re-entrant.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+from torch.nn import Parameter
+
+from .. import ops
+from ..sampling.node_edge_masks import NodeMaskToEdgeMask
+from .layers import GlorotLinear, glorot_
+from .masking import MaskingModel
+
+
+class MaskingGATv2Conv(torch.nn.Module):
+    def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int, heads: int = 1,
+                 concat: bool = True, negative_slope: float = 0.2, dropout: float = 0.0, add_self_loops: bool = True,
+                 edge_dim: Optional[int] = None, fill_value="mean", bias: bool = True, share_weights: bool = False,
+                 masking_threshold=None, use_instr: bool = False, use_topk: bool = False, concat_instr: bool = False,
+                 use_all_instrs: bool = False, sampler_type: str = None, sample_k: int = None, nb_samples: int = 1,
+                 alpha=1.0, beta=10.0, tau=1.0, **kwargs):
+        super().__init__()
+        if not isinstance(in_channels, int):
+            raise NotImplementedError("bipartite in_channels=(src, dst) is never used by ISubGVQA (mgat.py:58)")
+        if add_self_loops:
+            raise NotImplementedError("add_self_loops=True: MGAT passes False (mgat.py:63); scene graphs carry their "
+                                      "self-loops already (datasets/scene_graph.py:309-343)")
+        if not concat:
+            raise NotImplementedError("concat=False (head averaging) is never used by ISubGVQA")
+        if concat_instr or use_all_instrs:
+            raise NotImplementedError("concat_instr / use_all_instrs are off by default (arg_parser.py:102,108) and "
+                                      "outside this path")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
+        self.add_self_loops, self.edge_dim, self.fill_value = add_self_loops, edge_dim, fill_value
+        self.share_weights, self.use_instr = share_weights, use_instr
+        self.concat_instr, self.use_all_instrs = concat_instr, use_all_instrs
+
+        self.lin_l = GlorotLinear(in_channels, heads * out_channels, bias=bias)
+        self.lin_r = self.lin_l if share_weights else GlorotLinear(in_channels, heads * out_channels, bias=bias)
+        self.att = Parameter(torch.empty(1, heads, out_channels))
+        self.lin_edge = GlorotLinear(edge_dim, heads * out_channels, bias=False) if edge_dim is not None else None
+        if bias:
+            self.bias = Parameter(torch.empty(heads * out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.mask = MaskingModel(in_channels, out_channels, masking_threshold, use_topk=use_topk,
+                                 sampler_type=sampler_type, sample_k=sample_k, nb_samples=nb_samples, alpha=alpha,
+                                 beta=beta, tau=tau)
+        self.masking = NodeMaskToEdgeMask.apply
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+        if self.lin_edge is not None:
+            self.lin_edge.reset_parameters()
+        glorot_(self.att)
+        if self.bias is not None:
+            torch.nn.init.zeros_(self.bias)
+
+    def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, edge_attr: Optional[Tensor] = None,
+                instruction: Optional[Tensor] = None, imle_att: Optional[Tensor] = None,
+                return_attention_weights: bool = None, return_masks: bool = None, all_instrs=None,
+                plan: Optional[ops.GraphPlan] = None, noise: Optional[Tensor] = None, seed: Optional[int] = None,
+                e_proj: Optional[Tensor] = None):
+        H, C = self.heads, self.out_channels
+        if x.dim() != 2:
+            raise ValueError("x must be [N, C]")
+        if self.dropout != 0.0 and self.training:
+            raise NotImplementedError("attention dropout in training mode (forward-only path)")
+        if plan is None:
+            plan = ops.GraphPlan.build(batch, edge_index,
+                                       num_graphs=None if instruction is None else instruction.size(0))
+        x = x.float().contiguous()
+        if self.use_instr:
+            x = ops.instr_gate(x, instruction.contiguous(), batch)                       # :156-157
+
+        mask = None
+        if self.mask.masking_threshold != 1.0:                                           # :161
+            mask = self.mask(x, imle_att, batch, edge_index, use_all_instrs=False, plan=plan, noise=noise,
+                             seed=seed, u_is_per_graph=True)                              # :166-168
+
+        x_l = self.lin_l(x)                                                              # :177
+        x_r = x_l if self.share_weights else self.lin_r(x)                               # :181
+        if e_proj is None:
+            if edge_attr is None or self.lin_edge is None:
+                raise NotImplementedError("edge_attr=None: MGAT always passes edge features (mgat.py:147)")
+            if edge_attr.dim() == 1:
+                edge_attr = edge_attr.view(-1, 1)
+            e_proj = self.lin_edge(edge_attr)                                            # :259
+        out, alpha = ops.gatv2_mp(x_l, x_r, e_proj, self.att, plan, H, bias=self.bias, node_mask=mask,
+                                  negative_slope=self.negative_slope)                    # :215-232
+        if isinstance(return_attention_weights, bool):
+            return out, mask, (edge_index, alpha)                                        # :237
+        return out, mask                                                                 # :241
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"

@@ -1,0 +1,101 @@
+"""Scene-graph encoder: token-embedding sum + bbox MLP -> one MetaLayer round -> fp64 GraphNorm.
+
+Reference behaviour: SceneGraphEncoder.forward, ISubGVQA/models/scene_graph_encoder.py:53-104 with the
+EdgeModel / NodeModel of :108-143 (PyG MetaLayer: edge model first, node model on the NEW edge features).
+The reference constructor loads the GQA vocabulary and GloVe vectors from disk (:11-22); here the
+vocabulary size is a constructor argument and weights come from the checkpoint.
+
+Device work: embedding gathers and the MLPs are dense torch ops; the per-destination mean of edge
+messages is isg_scatter_mean over the batch's CSR plan (:141), and the float64 GraphNorm of :99-102 is
+isg_graph_norm(accumulate_fp64=1) -- same fp64 arithmetic, without the reference's device->host->device
+round trip through torch.DoubleTensor.
+`added_sym_edge` holds per-graph LOCAL edge indices that PyG concatenates without offset; they are
+applied to the global edge list as-is, exactly like the reference.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from .. import ops
+from .layers import GraphNorm
+
+SG_VOCAB_SIZE = 2578   # reconstruction of the reference's torchtext vocab over meta_info/* 
+
+
+class _EdgeModel(torch.nn.Module):
+    def __init__(self, nf, ef, hidden_dim):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.edge_mlp = torch.nn.Sequential(torch.nn.Linear(2 * nf + ef, hidden_dim), torch.nn.GELU(),
+                                            torch.nn.Linear(hidden_dim, hidden_dim))
+
+    def forward(self, src, dest, edge_attr, u=None, batch=None):
+        return self.edge_mlp(torch.cat([src, dest, edge_attr], 1))                       # :119-120
+
+
+class _NodeModel(torch.nn.Module):
+    def __init__(self, nf, hidden_dim):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.node_mlp_1 = torch.nn.Sequential(torch.nn.Linear(nf + hidden_dim, hidden_dim), torch.nn.GELU(),
+                                              torch.nn.Linear(hidden_dim, hidden_dim))
+        self.node_mlp_2 = torch.nn.Sequential(torch.nn.Linear(nf + hidden_dim, hidden_dim), torch.nn.GELU(),
+                                              torch.nn.Linear(hidden_dim, hidden_dim))
+
+    def forward(self, x, edge_index, edge_attr, plan: ops.GraphPlan):
+        row = edge_index[0]
+        out = self.node_mlp_1(torch.cat([x[row], edge_attr], dim=1))                     # :139-140
+        out = ops.scatter_mean(out.contiguous(), plan)                                   # :141
+        return self.node_mlp_2(torch.cat([x, out], dim=1))                               # :142-143
+
+
+class _MetaLayer(torch.nn.Module):
+    def __init__(self, edge_model, node_model):
+        super().__init__()
+        self.edge_model, self.node_model = edge_model, node_model
+
+    def forward(self, x, edge_index, edge_attr, plan):
+        row, col = edge_index[0], edge_index[1]
+        edge_attr = self.edge_model(x[row], x[col], edge_attr)
+        return self.node_model(x, edge_index, edge_attr, plan), edge_attr
+
+
+class SceneGraphEncoder(torch.nn.Module):
+    def __init__(self, hidden_dim, dist=False, vocab_size: int = SG_VOCAB_SIZE, pad_idx: Optional[int] = 1):
+        super().__init__()
+        self.hidden_dim, self.dist = hidden_dim, dist
+        self.sg_emb_dim = 300
+        self.sg_vocab_embedding = torch.nn.Embedding(vocab_size, self.sg_emb_dim, padding_idx=pad_idx)
+        self.scene_graph_encoding_layer = _MetaLayer(_EdgeModel(self.sg_emb_dim, self.sg_emb_dim, hidden_dim),
+                                                     _NodeModel(self.sg_emb_dim, hidden_dim))
+        self.graph_layer_norm = GraphNorm(self.sg_emb_dim)
+        bn = torch.nn.SyncBatchNorm if dist else torch.nn.BatchNorm1d
+        self.bbox_encoding = torch.nn.Sequential(bn(4), torch.nn.Linear(4, 16), torch.nn.GELU(),
+                                                 bn(16), torch.nn.Linear(16, 32), torch.nn.GELU())
+        self.feat_reduc = torch.nn.Sequential(bn(self.sg_emb_dim + 32),
+                                              torch.nn.Linear(self.sg_emb_dim + 32, self.sg_emb_dim), torch.nn.GELU())
+
+    def forward(self, x, edge_index, edge_attr, batch, explainer=False, explainer_stage=False, gt_scene_graphs=None,
+                plan: Optional[ops.GraphPlan] = None):
+        if self.training:
+            raise NotImplementedError("forward-only path: call model.eval() (BatchNorm uses running statistics)")
+        first = explainer and (explainer_stage == 0)
+        x_embed_sum = x if first else torch.sum(self.sg_vocab_embedding(x), dim=-2)      # :63-70
+        x_bbox = self.bbox_encoding(gt_scene_graphs.x_bbox.to(dtype=x_embed_sum.dtype))  # :72
+        x_embed_sum = self.feat_reduc(torch.cat((x_embed_sum, x_bbox), dim=1))           # :73-74
+        edge_embed = self.sg_vocab_embedding(edge_attr)                                  # :76
+        sym = gt_scene_graphs.added_sym_edge
+        if sym is not None and sym.numel() > 0:
+            edge_embed[sym, :] = edge_embed[sym, :] * -1                                 # :80
+        if plan is None:
+            plan = ops.GraphPlan.build(batch, edge_index)
+        x_enc, e_enc = self.scene_graph_encoding_layer(x_embed_sum, edge_index, edge_embed, plan)   # :91-97
+        gn = self.graph_layer_norm
+        if x_enc.size(1) != gn.in_channels:
+            raise RuntimeError(f"GraphNorm({gn.in_channels}) applied to {x_enc.size(1)} channels: the full model only "
+                               "works at general_hidden_dim=300 (scene_graph_encoder.py:33,101)")
+        x_enc = gn(x_enc, plan=plan, fp64=True)                                          # :99-102
+        return x_enc, e_enc

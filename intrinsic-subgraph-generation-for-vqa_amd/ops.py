@@ -1,0 +1,294 @@
+"""Tensor-level operators over the C ABI (include/isg.h): one Python function per kernel.
+
+PyTorch is plumbing here: it owns device memory and the stream; every operator validates its
+operands on the host (device, dtype, contiguity, shapes -- a wrong shape must never reach a
+kernel) and then hands raw pointers to libisg_hip.so on torch's current stream.  Forward only:
+operators refuse tensors that require grad while grad mode is on (SURVEY §8f-1 is a later row).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+MAX_NODES_PER_GRAPH = 1024   # LDS strip / sampler row capacity of the kernels
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: Optional[Tensor], name: str, dtype, shape=None, optional=False) -> int:
+    if t is None:
+        if optional:
+            return 0
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda:
+        raise _lib.IsgError(f"{name} must live on the GPU (got {t.device}); this path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if torch.is_grad_enabled() and t.requires_grad:
+        raise NotImplementedError(
+            f"{name} requires grad: the HIP path is forward-only (wrap the call in torch.no_grad()); "
+            "backward of the hot path is SURVEY §8(f) row 1")
+    return t.data_ptr()
+
+
+def _f32(t: Tensor) -> Tensor:
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# Graph plan
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class GraphPlan:
+    """What every layer needs to know about one PyG Batch, computed once on the device.
+
+    ptr[B+1] node range per graph, nmax (device scalar + host bound), CSR by destination
+    (rowptr[N+1], eid[E] original edge ids, src[E] source ids).  Replaces the reference's per-call
+    ``batch[-1].item()+1``, ``to_dense_batch`` counting and PyG's per-layer index handling
+    (masking.py:135,162; att_pooling.py:60; mgat_v2_conv.py:215).
+    """
+    N: int
+    E: int
+    B: int
+    ptr: Tensor
+    nmax_dev: Tensor
+    nmax: int
+    rowptr: Optional[Tensor] = None
+    eid: Optional[Tensor] = None
+    src: Optional[Tensor] = None
+
+    @staticmethod
+    def build(batch: Tensor, edge_index: Optional[Tensor] = None, num_graphs: Optional[int] = None,
+              max_nodes: Optional[int] = None) -> "GraphPlan":
+        lib = _lib.load()
+        _chk(batch, "batch", torch.int64)
+        N = batch.numel()
+        if num_graphs is None:
+            num_graphs = int(batch[-1].item()) + 1 if N > 0 else 0     # the reference's own sync (masking.py:135)
+        B = int(num_graphs)
+        dev = batch.device
+        ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        nmax_dev = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.isg_graph_ptr(batch.data_ptr(), N, B, ptr.data_ptr(), nmax_dev.data_ptr(), _stream()),
+                   "isg_graph_ptr")
+        plan = GraphPlan(N=N, E=0, B=B, ptr=ptr, nmax_dev=nmax_dev, nmax=0)
+        if edge_index is not None:
+            _chk(edge_index, "edge_index", torch.int64)
+            if edge_index.dim() != 2 or edge_index.size(0) != 2:
+                raise ValueError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
+            E = edge_index.size(1)
+            plan.E = E
+            plan.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+            plan.eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            plan.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            ws_bytes = lib.isg_csr_workspace_bytes(N, E)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.isg_csr_build(edge_index.data_ptr(), N, E, plan.rowptr.data_ptr(), plan.eid.data_ptr(),
+                                         plan.src.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "isg_csr_build")
+        if max_nodes is None:
+            max_nodes = int(nmax_dev.item())        # one D2H sync per batch (to_dense_batch syncs per layer)
+        plan.nmax = int(max_nodes)
+        if plan.nmax > MAX_NODES_PER_GRAPH:
+            raise _lib.IsgError(f"graphs with more than {MAX_NODES_PER_GRAPH} nodes are unsupported (got {plan.nmax})")
+        return plan
+
+    def require_csr(self) -> None:
+        if self.rowptr is None:
+            raise ValueError("this GraphPlan was built without edge_index")
+
+
+# ------------------------------------------------------------------------------------------------
+# Message passing
+# ------------------------------------------------------------------------------------------------
+def instr_gate(x: Tensor, instr: Tensor, batch: Tensor) -> Tensor:
+    """gelu(x * instr[batch])   (mgat_v2_conv.py:156-157)"""
+    lib = _lib.load()
+    N, C = x.shape
+    out = torch.empty_like(x)
+    _lib.check(lib.isg_instr_gate(_chk(x, "x", torch.float32), _chk(instr, "instr", torch.float32, (instr.size(0), C)),
+                                  _chk(batch, "batch", torch.int64, (N,)), out.data_ptr(), N, C, _stream()),
+               "isg_instr_gate")
+    return out
+
+
+def node_to_edge_mask(mask: Tensor, edge_index: Tensor) -> Tensor:
+    """mask[src] * mask[dst]   (sampling/node_edge_masks.py:7-10).  mask [N,1] or [N] -> [E,1] / [E]."""
+    lib = _lib.load()
+    E = edge_index.size(1)
+    flat = mask.reshape(-1)
+    out = torch.empty(E, dtype=torch.float32, device=mask.device)
+    _lib.check(lib.isg_node_to_edge_mask(_chk(flat, "mask", torch.float32), _chk(edge_index, "edge_index", torch.int64),
+                                         E, out.data_ptr(), _stream()), "isg_node_to_edge_mask")
+    return out.view(E, 1) if mask.dim() == 2 else out
+
+
+def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphPlan, heads: int,
+             bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
+             negative_slope: float = 0.2) -> Tuple[Tensor, Tensor]:
+    """MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:243-279).  Returns (out[N,H*C], alpha[E,H])."""
+    lib = _lib.load()
+    plan.require_csr()
+    N, HC = x_l.shape
+    H = int(heads)
+    C = HC // H
+    E = plan.E
+    if N != plan.N or H * C != HC:
+        raise ValueError(f"x_l {tuple(x_l.shape)} does not match plan N={plan.N} / heads={H}")
+    out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
+    alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+    _lib.check(lib.isg_gatv2_mp_fwd(
+        _chk(x_l, "x_l", torch.float32), _chk(x_r, "x_r", torch.float32, (N, HC)),
+        _chk(e_proj, "e_proj", torch.float32, (E, HC)), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+        _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+        plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
+        out.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope), _stream()), "isg_gatv2_mp_fwd")
+    return out, alpha
+
+
+def scatter_mean(msg: Tensor, plan: GraphPlan) -> Tensor:
+    """scatter_mean(msg, dst, dim_size=N)   (scene_graph_encoder.py:141)"""
+    lib = _lib.load()
+    plan.require_csr()
+    E, C = msg.shape
+    if E != plan.E:
+        raise ValueError(f"msg has {E} rows, plan has {plan.E} edges")
+    out = torch.empty(plan.N, C, dtype=torch.float32, device=msg.device)
+    _lib.check(lib.isg_scatter_mean(_chk(msg, "msg", torch.float32), plan.rowptr.data_ptr(), plan.eid.data_ptr(),
+                                    out.data_ptr(), plan.N, C, _stream()), "isg_scatter_mean")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Node gate + samplers
+# ------------------------------------------------------------------------------------------------
+def node_gate(xn: Tensor, q: Tensor, batch: Tensor, double_index: bool) -> Tensor:
+    """gelu(<xn_n, q[r(n)]>/sqrt(C)) -> [N,1]   (masking.py:151-155)"""
+    lib = _lib.load()
+    N, C = xn.shape
+    gate = torch.empty(N, 1, dtype=torch.float32, device=xn.device)
+    _lib.check(lib.isg_node_gate(_chk(xn, "xn", torch.float32), _chk(q, "q", torch.float32, (q.size(0), C)),
+                                 _chk(batch, "batch", torch.int64, (N,)), 1 if double_index else 0, gate.data_ptr(),
+                                 N, C, _stream()), "isg_node_gate")
+    return gate
+
+
+def _rows(scores: Tensor, plan: Optional[GraphPlan]):
+    """(ptr, B, nmax_host, nmax_dev, out) for the ragged (plan) or dense ([B,Nmax]) row layout."""
+    if plan is not None:
+        flat = scores.reshape(-1)
+        if flat.numel() != plan.N:
+            raise ValueError(f"scores has {flat.numel()} entries, plan has {plan.N} nodes")
+        return flat, plan.ptr.data_ptr(), plan.B, plan.nmax, plan.nmax_dev.data_ptr()
+    if scores.dim() != 2:
+        raise ValueError("dense scores must be [B, Nmax]")
+    if scores.size(1) > MAX_NODES_PER_GRAPH:
+        raise _lib.IsgError(f"rows longer than {MAX_NODES_PER_GRAPH} slots are unsupported")
+    return scores, 0, scores.size(0), scores.size(1), 0
+
+
+def _noise_ptr(noise: Optional[Tensor], B: int, nmax: int) -> int:
+    if noise is None:
+        return 0
+    if noise.numel() != B * nmax:
+        raise ValueError(f"noise must hold B*Nmax = {B}*{nmax} values, got {tuple(noise.shape)}")
+    return _chk(noise.reshape(B, nmax), "noise", torch.float32)
+
+
+def topk_gumbel(scores: Tensor, k: int, tau: float = 0.1, plan: Optional[GraphPlan] = None,
+                noise: Optional[Tensor] = None, seed: int = 0, return_khot: bool = False):
+    """Relaxed Gumbel top-k + straight-through hard mask (gumbel_scheme.py:55-104).
+
+    Ragged (plan given): scores [N] / [N,1] -> mask of the same shape (the dense-pad and the `[mask]`
+    un-pad of masking.py:162,176 are fused).  Dense: scores [B,Nmax] -> [B,Nmax].
+    """
+    lib = _lib.load()
+    flat, ptr, B, nmax, nmax_dev = _rows(scores, plan)
+    out = torch.empty_like(flat)
+    khot = torch.empty(B, nmax, dtype=torch.float32, device=scores.device) if return_khot else None
+    _lib.check(lib.isg_topk_gumbel(_chk(flat, "scores", torch.float32), ptr, B, nmax, nmax_dev,
+                                   _noise_ptr(noise, B, nmax), int(seed) & (2 ** 64 - 1), int(k), float(tau),
+                                   out.data_ptr(), 0 if khot is None else khot.data_ptr(), _stream()),
+               "isg_topk_gumbel")
+    out = out.view(scores.shape)
+    return (out, khot) if return_khot else out
+
+
+def topk_threshold(scores: Tensor, k: int, plan: Optional[GraphPlan] = None, noise: Optional[Tensor] = None,
+                   noise_scale: float = 0.0, seed: int = 0) -> Tensor:
+    """(scores + noise*noise_scale) >= k-th largest, per row (deterministic_scheme.py:36-43)."""
+    lib = _lib.load()
+    flat, ptr, B, nmax, nmax_dev = _rows(scores, plan)
+    out = torch.empty_like(flat)
+    _lib.check(lib.isg_topk_threshold(_chk(flat, "scores", torch.float32), ptr, B, nmax, nmax_dev,
+                                      _noise_ptr(noise, B, nmax), float(noise_scale), int(seed) & (2 ** 64 - 1), int(k),
+                                      out.data_ptr(), _stream()), "isg_topk_threshold")
+    return out.view(scores.shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# Per-graph attention / norm / pooling
+# ------------------------------------------------------------------------------------------------
+def scatter_attention(query: Tensor, key: Tensor, plan: GraphPlan) -> Tensor:
+    """softmax_g(<query_g, key_n>/sqrt(C)) * key_n   (utils/scatter_scaled_dot_product.py:6-15, key == value)"""
+    lib = _lib.load()
+    N, C = key.shape
+    out = torch.empty_like(key)
+    _lib.check(lib.isg_scatter_attention(_chk(query, "query", torch.float32, (plan.B, C)),
+                                         _chk(key, "key", torch.float32, (plan.N, C)), key.data_ptr(),
+                                         plan.ptr.data_ptr(), out.data_ptr(), plan.B, C, _stream()),
+               "isg_scatter_attention")
+    return out
+
+
+def graph_norm(x: Tensor, plan: GraphPlan, weight: Tensor, bias: Tensor, mean_scale: Tensor, eps: float = 1e-5,
+               fp64: bool = False) -> Tensor:
+    """PyG GraphNorm forward (mgat.py:171); fp64=True mirrors scene_graph_encoder.py:99-102."""
+    lib = _lib.load()
+    N, C = x.shape
+    out = torch.empty_like(x)
+    _lib.check(lib.isg_graph_norm(_chk(x, "x", torch.float32, (plan.N, C)), plan.ptr.data_ptr(),
+                                  _chk(weight, "weight", torch.float32, (C,)), _chk(bias, "bias", torch.float32, (C,)),
+                                  _chk(mean_scale, "mean_scale", torch.float32, (C,)), float(eps), 1 if fp64 else 0,
+                                  out.data_ptr(), plan.B, C, _stream()), "isg_graph_norm")
+    return out
+
+
+def mgat_layer_tail(ins: Tensor, c: Tensor, h: Tensor, plan: GraphPlan, weight: Tensor, bias: Tensor,
+                    mean_scale: Tensor, eps: float = 1e-5, node_mask: Optional[Tensor] = None) -> Tensor:
+    """scatter attention -> GraphNorm -> + h [-> * mask], fused (mgat.py:168-177)."""
+    lib = _lib.load()
+    N, C = c.shape
+    out = torch.empty_like(h)
+    _lib.check(lib.isg_instr_attn_graphnorm_residual(
+        _chk(ins, "ins", torch.float32, (plan.B, C)), _chk(c, "c", torch.float32, (plan.N, C)),
+        _chk(h, "h", torch.float32, (plan.N, C)), plan.ptr.data_ptr(), _chk(weight, "weight", torch.float32, (C,)),
+        _chk(bias, "bias", torch.float32, (C,)), _chk(mean_scale, "mean_scale", torch.float32, (C,)), float(eps),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        out.data_ptr(), plan.B, C, _stream()), "isg_instr_attn_graphnorm_residual")
+    return out
+
+
+def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional[Tensor] = None):
+    """GlobalAttention soft-max pooling (att_pooling.py:63-73).  Returns (out[B,C], gate[N,1])."""
+    lib = _lib.load()
+    N, C = xn.shape
+    out = torch.empty(plan.B, C, dtype=torch.float32, device=xn.device)
+    gate = torch.empty(N, 1, dtype=torch.float32, device=xn.device)
+    _lib.check(lib.isg_global_attn_pool(
+        _chk(xn, "xn", torch.float32, (plan.N, C)), _chk(q, "q", torch.float32, (plan.B, C)), plan.ptr.data_ptr(),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        out.data_ptr(), gate.data_ptr(), plan.B, C, _stream()), "isg_global_attn_pool")
+    return out, gate

@@ -1,0 +1,165 @@
+"""Synthetic GQA-shaped scene-graph batches and the BASELINE.json workload configurations.
+
+There is no GQA data in either container, so every measurement and most parity tests
+run on seeded synthetic batches with the layout `gqa_collate` produces (datasets/gqa.py:237-272;
+datasets/scene_graph.py:309-343): per graph one self-loop per node first, then directed relation
+edges, graphs concatenated PyG-style (edge ids of a graph are contiguous, `batch` sorted).
+
+`AnswerModel` = MGAT -> GlobalAttention -> classifier with ISubGVQA's own state_dict keys: the part of
+ISubGVQA.forward (isubgvqa.py:267-292) that BASELINE config 2 drives directly, because the full model
+only runs at C=300 (GraphNorm(300) in the scene-graph encoder).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+
+@dataclass
+class WorkloadConfig:
+    num_graphs: int = 4096
+    channels: int = 128
+    heads: int = 4
+    layers: int = 3
+    masks: Tuple[float, ...] = (1.0, 1.0, 0.15)
+    sampler: str = "gumbel"
+    sample_k: int = 5
+    nodes_dist: str = "normal"          # normal | uniform | pareto
+    nodes_mean: float = 20.0
+    nodes_std: float = 4.0
+    nodes_min: int = 4
+    nodes_max: int = 48
+    edges_per_graph: float = 50.0       # self-loops included
+    degree: str = "uniform"             # uniform | powerlaw (in-degree, cfg5)
+    interpretable_mode: bool = False
+    seed: int = 2345
+
+
+# BASELINE.json configs
+CFG1 = WorkloadConfig(num_graphs=32, channels=300, layers=4, masks=(1.0, 1.0, 1.0, 0.15), sampler="gumbel", sample_k=5,
+                      nodes_dist="uniform", nodes_min=2, nodes_max=16, edges_per_graph=0.0, seed=1234)
+CFG2 = WorkloadConfig()
+CFG4_PER_RANK = WorkloadConfig(seed=3456)
+CFG5 = WorkloadConfig(sampler="aimle", nodes_dist="pareto", nodes_min=8, nodes_max=200, edges_per_graph=0.0,
+                      degree="powerlaw", seed=4567)
+
+
+@dataclass
+class Workload:
+    x: Tensor            # [N, C] node features entering MGAT
+    edge_index: Tensor   # [2, E] int64, row 0 source, row 1 target
+    edge_attr: Tensor    # [E, C]
+    batch: Tensor        # [N] int64 sorted
+    instr: Tensor        # [L, B, C]
+    glf: Tensor          # [B, C]
+    num_graphs: int = 0
+    max_nodes: int = 0
+
+    def to(self, device) -> "Workload":
+        return Workload(self.x.to(device), self.edge_index.to(device), self.edge_attr.to(device), self.batch.to(device),
+                        self.instr.to(device), self.glf.to(device), self.num_graphs, self.max_nodes)
+
+
+def graph_sizes(cfg: WorkloadConfig, gen: torch.Generator) -> Tensor:
+    B = cfg.num_graphs
+    if cfg.nodes_dist == "uniform":
+        n = torch.randint(cfg.nodes_min, cfg.nodes_max + 1, (B,), generator=gen)
+    elif cfg.nodes_dist == "pareto":      # 8 + Pareto(alpha=1.5) clipped (cfg5)
+        u = torch.rand(B, generator=gen).clamp_min(1e-6)
+        n = (cfg.nodes_min + (u.pow(-1.0 / 1.5) - 1.0) * 8.0).round().long()
+    else:
+        n = (cfg.nodes_mean + cfg.nodes_std * torch.randn(B, generator=gen)).round().long()
+    return n.clamp(cfg.nodes_min, cfg.nodes_max)
+
+
+def make_topology(cfg: WorkloadConfig, gen: torch.Generator):
+    """batch[N], edge_index[2,E]: per graph its self-loops, then random directed pairs."""
+    n = graph_sizes(cfg, gen)
+    B = cfg.num_graphs
+    ptr = torch.zeros(B + 1, dtype=torch.long)
+    ptr[1:] = n.cumsum(0)
+    N = int(ptr[-1])
+    batch = torch.repeat_interleave(torch.arange(B), n)
+    if cfg.edges_per_graph > 0:
+        extra = (cfg.edges_per_graph - cfg.nodes_mean + 5.0 * torch.randn(B, generator=gen)).round().long().clamp_min(1)
+    elif cfg.degree == "powerlaw":
+        extra = (2.0 * n.float()).round().long()
+    else:                                 # cfg1: U{1..(32-n)} random pairs, <= 32 edges in total
+        hi = (32 - n).clamp_min(1)
+        extra = (torch.rand(B, generator=gen) * hi.float()).floor().long() + 1
+    M = int(extra.sum())
+    eg = torch.repeat_interleave(torch.arange(B), extra)          # graph of every extra edge
+    ng = n[eg].float()
+    src_loc = (torch.rand(M, generator=gen) * ng).floor().long()
+    if cfg.degree == "powerlaw":          # in-degree ~ power law (alpha = 2): a few hub targets per graph
+        u = torch.rand(M, generator=gen).clamp_min(1e-6)
+        dst_loc = ((u.pow(-1.0) - 1.0)).floor().long()
+        dst_loc = torch.minimum(dst_loc, (n[eg] - 1))
+    else:
+        dst_loc = (torch.rand(M, generator=gen) * ng).floor().long()
+    # interleave per graph: [self loops of g][extras of g]
+    loops = torch.arange(N)
+    key_loop = batch * 2
+    key_extra = eg * 2 + 1
+    src_all = torch.cat([loops, ptr[eg] + src_loc])
+    dst_all = torch.cat([loops, ptr[eg] + dst_loc])
+    order = torch.sort(torch.cat([key_loop, key_extra]), stable=True).indices
+    edge_index = torch.stack([src_all[order], dst_all[order]]).contiguous()
+    return batch, edge_index, int(n.max())
+
+
+def make_workload(cfg: WorkloadConfig) -> Workload:
+    gen = torch.Generator().manual_seed(cfg.seed)
+    batch, edge_index, nmax = make_topology(cfg, gen)
+    N, E, B, C, L = batch.numel(), edge_index.size(1), cfg.num_graphs, cfg.channels, cfg.layers
+    x = torch.randn(N, C, generator=gen)
+    edge_attr = torch.randn(E, C, generator=gen)
+    instr = torch.randn(L, B, C, generator=gen)
+    glf = torch.randn(B, C, generator=gen)
+    return Workload(x, edge_index, edge_attr, batch, instr, glf, B, nmax)
+
+
+class AnswerModel(torch.nn.Module):
+    """gat_seq + graph_global_attention_pooling + embedding + logit_fc, keyed like ISubGVQA."""
+
+    def __init__(self, channels: int, layers: int, masks, sampler: str, sample_k: int, heads: int = 4,
+                 interpretable_mode: bool = False, tau: float = 1.0, num_answers: int = 1842):
+        super().__init__()
+        from .models.att_pooling import GlobalAttention
+        from .models.mgat import MGAT
+        self.gat_seq = MGAT(channels=channels, num_ins=layers, heads=heads, use_instr=True,
+                            masking_thresholds=list(masks), use_topk=True, interpretable_mode=interpretable_mode,
+                            sampler_type=sampler, sample_k=sample_k, nb_samples=1, alpha=1.0, beta=10.0, tau=tau)
+        self.graph_global_attention_pooling = GlobalAttention(channels, channels)
+        self.embedding = torch.nn.Sequential(torch.nn.Linear(channels * 3, 512), torch.nn.GELU(),
+                                             torch.nn.Dropout(p=0.2))
+        self.logit_fc = torch.nn.Linear(512, num_answers)
+
+    def forward(self, wl: Workload, noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
+                plan=None, use_hints: bool = True):
+        from . import ops
+        if plan is None:
+            plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=wl.glf.size(0),
+                                       max_nodes=(wl.max_nodes or None) if use_hints else None)
+        h, mask, _, _ = self.gat_seq(x=wl.x, edge_index=wl.edge_index, edge_attr=wl.edge_attr,
+                                     instr_vectors=wl.instr[:4], global_language_feats=wl.glf, batch=wl.batch,
+                                     return_masks=True, plan=plan, noises=noises, seed=seed)
+        embed, gate = self.graph_global_attention_pooling(x=h, u=wl.glf, batch=wl.batch, size=None, return_mask=True,
+                                                          node_mask=mask, plan=plan)
+        feats = self.embedding(torch.cat((embed, wl.glf, embed * wl.glf), dim=1))
+        return self.logit_fc(feats), mask, gate
+
+
+def build_answer_model(cfg: WorkloadConfig, weight_seed: int = 0) -> AnswerModel:
+    torch.manual_seed(weight_seed)
+    m = AnswerModel(cfg.channels, cfg.layers, cfg.masks, cfg.sampler, cfg.sample_k, cfg.heads, cfg.interpretable_mode)
+    # GraphNorm / bias parameters start at their trivial values; perturb them so parity covers them
+    g = torch.Generator().manual_seed(weight_seed + 1)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if "bns" in name or name.endswith(".bias"):
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+    return m

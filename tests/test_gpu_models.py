@@ -1,0 +1,256 @@
+"""Module-level parity on a real MI355X: the drop-in modules against the reference-made goldens (G4, G5),
+against the CPU oracle on seeded synthetic batches, and size-independent properties at BASELINE sizes."""
+import argparse
+import glob
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4      # BASELINE.json north_star: answer logits within 1e-4 (fp32) of the CPU path
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X (run with -m gpu on the GPU box)"
+    return torch.device("cuda:0")
+
+
+G5 = sorted(glob.glob(os.path.join(GOLDEN, "g5_mgat_*.pt")))
+
+
+def _load_g5(path, dev):
+    from isubgvqa_amd.models import MGAT, GlobalAttention
+    g = torch.load(path, map_location="cpu", weights_only=False)
+    c = g["cfg"]
+    m = MGAT(channels=c["C"], num_ins=c["L"], heads=4, use_instr=True, masking_thresholds=c["masks"], use_topk=True,
+             interpretable_mode=c["interp"], sampler_type=c["sampler"], sample_k=c["k"])
+    m.load_state_dict({k[len("gat_seq."):]: v for k, v in g["sd"].items() if k.startswith("gat_seq.")}, strict=False)
+    p = GlobalAttention(c["C"], c["C"])
+    p.load_state_dict({k[len("graph_global_attention_pooling."):]: v for k, v in g["sd"].items()
+                       if k.startswith("graph_global_attention_pooling.")})
+    return g, m.to(dev).eval(), p.to(dev).eval()
+
+
+@pytest.mark.parametrize("path", G5, ids=[os.path.basename(p) for p in G5])
+def test_mgat_stack_and_pooling_match_reference_goldens(dev, path):
+    g, m, p = _load_g5(path, dev)
+    t = lambda k: g[k].to(dev)
+    noises = {i: n.to(dev) for i, n in g["noises"].items()}
+    with torch.no_grad():
+        h, mask, _, _ = m(x=t("x"), edge_index=t("edge_index"), instr_vectors=t("instr"),
+                          global_language_feats=t("glf"), edge_attr=t("edge_attr"), batch=t("batch"),
+                          return_masks=True, noises=noises)
+        emb, gate = p(x=h, u=t("glf"), batch=t("batch"), size=None, return_mask=True, node_mask=mask)
+    if g["mask"] is None:
+        assert mask is None
+    else:
+        assert torch.equal(mask.cpu() > 0.5, g["mask"] > 0.5), "top-k node mask indices differ from the reference"
+        assert torch.allclose(mask.cpu(), g["mask"], atol=2.5e-7, rtol=0)
+    assert torch.allclose(h.cpu(), g["h"], atol=2e-5, rtol=1e-5), (h.cpu() - g["h"]).abs().max()
+    assert torch.allclose(emb.cpu(), g["pool_out"], atol=2e-5, rtol=1e-5)
+    assert torch.allclose(gate.cpu(), g["pool_gate"], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("path", G5, ids=[os.path.basename(p) for p in G5])
+def test_single_conv_matches_reference_goldens(dev, path):
+    from isubgvqa_amd.sampling.node_edge_masks import NodeMaskToEdgeMask
+    from isubgvqa_amd.utils.scatter_scaled_dot_product import scatter_scaled_dot_product_attention
+    g, m, _ = _load_g5(path, dev)
+    li = g["conv_layer"]
+    t = lambda k: g[k].to(dev)
+    with torch.no_grad():
+        out, mask, (ei, alpha) = m.convs[li](
+            x=t("x"), edge_index=t("edge_index"), edge_attr=t("edge_attr"), instruction=t("instr")[li],
+            batch=t("batch"), return_masks=True, return_attention_weights=True, imle_att=t("glf"),
+            all_instrs=t("instr"), noise=None if g["conv_noise"] is None else g["conv_noise"].to(dev))
+        att9 = scatter_scaled_dot_product_attention(t("instr")[li], t("x"), t("x"), t("batch"))
+    assert torch.equal(ei.cpu(), g["edge_index"])
+    assert torch.allclose(out.cpu(), g["conv_out"], atol=1e-5, rtol=1e-5), (out.cpu() - g["conv_out"]).abs().max()
+    assert torch.allclose(alpha.cpu(), g["conv_alpha"], atol=1e-6, rtol=1e-5)
+    assert torch.allclose(att9.cpu(), g["scatter_att"], atol=1e-6, rtol=1e-5)
+    if g["conv_mask"] is not None:
+        assert torch.equal(mask.cpu() > 0.5, g["conv_mask"] > 0.5)
+        em = NodeMaskToEdgeMask.apply(g["conv_mask"].to(dev), t("edge_index"), None)
+        assert torch.equal(em.cpu(), g["conv_edge_mask"])
+
+
+def test_question_encoder_decoder_match_reference_goldens(dev):
+    from isubgvqa_amd.models import CLIPTextEmbeddings, QuestionDecoder, QuestionEncoder
+    g = load_golden("g4_question.pt")
+    enc = QuestionEncoder(CLIPTextEmbeddings(50, 32, 77), 32, 32, g["nhead"], 64, 2, 0.1)
+    enc.load_state_dict({k[len("question_encoder."):]: v for k, v in g["sd"].items()
+                         if k.startswith("question_encoder.")}, strict=False)
+    dec = QuestionDecoder(4, 32, g["nhead"], 64, 2, 0.1)
+    dec.load_state_dict({k[len("program_decoder."):]: v for k, v in g["sd"].items() if k.startswith("program_decoder.")})
+    enc, dec = enc.to(dev).eval(), dec.to(dev).eval()
+    with torch.no_grad():
+        e = enc(g["questions"].to(dev), g["mask"].to(dev))
+        d = dec(e)
+    assert torch.allclose(e.cpu(), g["enc_out"], atol=1e-5, rtol=1e-4), (e.cpu() - g["enc_out"]).abs().max()
+    assert torch.allclose(d.cpu(), g["dec_out"], atol=1e-5, rtol=1e-4), (d.cpu() - g["dec_out"]).abs().max()
+
+
+def _oracle_cfg(cfg):
+    from oracle import model as OM
+    return OM.PathConfig(heads=cfg.heads, masking_thresholds=list(cfg.masks), use_topk=True, sampler_type=cfg.sampler,
+                         sample_k=cfg.sample_k, interpretable_mode=cfg.interpretable_mode)
+
+
+def _noises(cfg, wl, seed):
+    from oracle import samplers as OS
+    gen = torch.Generator().manual_seed(seed)
+    out = {}
+    for i, thr in enumerate(cfg.masks):
+        if thr != 1.0:
+            if cfg.sampler == "gumbel":
+                out[i] = OS.uniform_to_gumbel(torch.rand(cfg.num_graphs, wl.max_nodes, generator=gen))
+            elif cfg.sampler == "aimle":
+                out[i] = OS.uniform_to_gumbel(torch.rand(cfg.num_graphs, 1, wl.max_nodes, 1, generator=gen), 0.0, 0.3)
+    return out
+
+
+def _run_both(cfg, dev, noise_seed=5):
+    from isubgvqa_amd import synthetic
+    from oracle import model as OM
+    wl = synthetic.make_workload(cfg)
+    model = synthetic.build_answer_model(cfg).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    noises = _noises(cfg, wl, noise_seed)
+    with torch.no_grad():
+        ref = OM.mgat_pool_classify(sd, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf,
+                                    _oracle_cfg(cfg), noises)
+        got = model.to(dev)(wl.to(dev), noises={i: n.to(dev) for i, n in noises.items()})
+    torch.cuda.synchronize()
+    return wl, ref, tuple(None if t is None else t.cpu() for t in got)
+
+
+@pytest.mark.parametrize("sampler", ["gumbel", "imle", "aimle"])
+def test_cfg1_cpu_config_logits_and_masks_match_oracle(dev, sampler):
+    """BASELINE configs[0]: 32 graphs (<=16 nodes, <=32 edges), C=300, 4 layers, masks [1,1,1,0.15], k=5."""
+    from isubgvqa_amd import synthetic
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG1.__dict__, "sampler": sampler})
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    assert torch.equal(gm > 0.5, rm > 0.5), "top-k mask indices must be bit-exact"
+    assert (gl - rl).abs().max() < LOGIT_TOL, (gl - rl).abs().max()
+    assert torch.allclose(gg, rg, atol=1e-5)
+
+
+def test_cfg2_full_size_logits_within_tolerance(dev):
+    """BASELINE configs[1] at full size: B=4096, ~20 nodes / ~50 edges, C=128, 3 layers, Gumbel k=5.
+    Masks are compared first; a graph whose mask differs (a near-tie in khot decided by the last ulp of the GEMM
+    feeding the gate) has unrelated logits, so logits are compared on graphs with identical masks and the number
+    of differing graphs is bounded."""
+    from isubgvqa_amd import synthetic
+    cfg = synthetic.CFG2
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    same_node = (gm > 0.5) == (rm > 0.5)
+    bad_graph = torch.zeros(cfg.num_graphs, dtype=torch.bool).index_put_((wl.batch[~same_node.view(-1)],),
+                                                                         torch.tensor(True))
+    n_bad = int(bad_graph.sum())
+    print(f"cfg2: graphs with a differing top-k mask: {n_bad}/{cfg.num_graphs}")
+    assert n_bad <= 2
+    ok = ~bad_graph
+    err = (gl[ok] - rl[ok]).abs().max().item()
+    print(f"cfg2: max |logit diff| = {err:.3e}")
+    assert err < LOGIT_TOL
+    assert torch.allclose(gg[ok[wl.batch]], rg[ok[wl.batch]], atol=1e-5)
+
+
+def test_cfg5_skewed_graphs_aimle(dev):
+    """BASELINE configs[4] shape (fp32 features here): 8-200 nodes, power-law in-degree, AIMLE k=5."""
+    from isubgvqa_amd import synthetic
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": 192, "channels": 64})
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    assert wl.max_nodes > 100
+    assert torch.equal(gm, rm)
+    assert (gl - rl).abs().max() < LOGIT_TOL, (gl - rl).abs().max()
+
+
+def test_interpretable_mode_masks_hidden_state(dev):
+    from isubgvqa_amd import synthetic
+    cfg = synthetic.WorkloadConfig(num_graphs=40, channels=32, layers=3, masks=(0.15, 1.0, 0.15), sampler="imle",
+                                   sample_k=3, nodes_mean=8, nodes_std=3, nodes_min=2, nodes_max=16,
+                                   edges_per_graph=20, interpretable_mode=True, seed=77)
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    assert torch.equal(gm, rm)
+    assert (gl - rl).abs().max() < LOGIT_TOL
+
+
+def test_results_are_per_graph_independent_without_sampling(dev):
+    """With no masked layer nothing couples graphs (quirks Q1/Q3 only enter through MaskingModel): running a
+    sub-batch alone must reproduce its rows of the full batch -- the property data-parallel sharding rests on."""
+    from isubgvqa_amd import synthetic
+    cfg = synthetic.WorkloadConfig(num_graphs=64, channels=64, layers=2, masks=(1.0, 1.0), seed=3)
+    wl = synthetic.make_workload(cfg)
+    model = synthetic.build_answer_model(cfg).to(dev).eval()
+    from isubgvqa_amd.distributed import shard_workload
+    with torch.no_grad():
+        full, _, _ = model(wl.to(dev))
+        parts = [model(shard_workload(wl, r, 4).to(dev))[0] for r in range(4)]
+    assert torch.allclose(torch.cat(parts), full, atol=1e-5)
+
+
+def _full_args(**kw):
+    d = dict(text_sampling=False, general_hidden_dim=300, distributed=False, mgat_layers=4, use_all_instrs=False,
+             use_global_mask=False, node_classification=False, sampler_type="imle", sample_k=5, nb_samples=1,
+             alpha=1.0, beta=10.0, tau=1.0, use_masking=True, use_instruction=1, use_mgat=True,
+             mgat_masks=[1.0, 1.0, 1.0, 0.15], use_topk=True, interpretable_mode=False, concat_instr=0, embed_cat=0,
+             device="cpu", text_vocab_size=512, sg_vocab_size=2578)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+@pytest.mark.parametrize("sampler", ["imle", "gumbel"])
+def test_full_isubgvqa_model_matches_oracle(dev, sampler):
+    """BASELINE configs[2] stand-in: GQA-shaped synthetic A0 tensors (token ids, bbox ints, un-offset added_sym_edge,
+    ragged questions with HF-style attention mask), full model at C=300, logits within 1e-4 of the CPU path."""
+    from isubgvqa_amd import synthetic
+    from isubgvqa_amd.models import build_model
+    from oracle import model as OM
+    torch.manual_seed(0)
+    args = _full_args(sampler_type=sampler)
+    model = build_model(args, None).eval()
+    gen = torch.Generator().manual_seed(21)
+    with torch.no_grad():   # non-trivial BatchNorm running statistics
+        for n_, b_ in model.named_buffers():
+            if n_.endswith("running_mean"):
+                b_.copy_(torch.randn(b_.shape, generator=gen) * 0.5)
+            if n_.endswith("running_var"):
+                b_.copy_(torch.rand(b_.shape, generator=gen) + 0.5)
+    cfg = synthetic.WorkloadConfig(num_graphs=12, nodes_dist="uniform", nodes_min=2, nodes_max=16, edges_per_graph=0.0,
+                                   seed=99)
+    batch, ei, nmax = synthetic.make_topology(cfg, gen)
+    N, E, B, T = batch.numel(), ei.size(1), 12, 11
+    x = torch.randint(0, 2578, (N, 4), generator=gen)
+    x[:, 1:][torch.rand(N, 3, generator=gen) < 0.5] = 1
+    edge_attr = torch.randint(0, 2578, (E,), generator=gen)
+    x_bbox = torch.randint(0, 640, (N, 4), generator=gen)
+    sym = torch.randint(0, 10, (20,), generator=gen)                 # per-graph local ids, concatenated un-offset
+    q = torch.randint(0, 512, (B, T), generator=gen)
+    lens = torch.randint(6, T + 1, (B,), generator=gen)
+    qmask = (torch.arange(T)[None] < lens[:, None]).long()
+    sg = argparse.Namespace(x_bbox=x_bbox, added_sym_edge=sym)
+    noises = None
+    if sampler == "gumbel":
+        from oracle import samplers as OS
+        noises = {3: OS.uniform_to_gumbel(torch.rand(B, nmax, generator=gen))}
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ocfg = OM.PathConfig(heads=4, masking_thresholds=[1.0, 1.0, 1.0, 0.15], sampler_type=sampler, sample_k=5)
+    with torch.no_grad():
+        rl, rm, rg, _, _ = OM.isubgvqa_forward(sd, x, ei, edge_attr, batch, q, qmask, x_bbox, sym, ocfg, noises)
+        model = model.to(dev)
+        sgd = argparse.Namespace(x_bbox=x_bbox.to(dev), added_sym_edge=sym.to(dev))
+        gl, gm, gg, extra, mt = model(x.to(dev), ei.to(dev), edge_attr.to(dev), batch.to(dev), q.to(dev),
+                                      qmask.to(dev), return_masks=True, scene_graphs=sgd,
+                                      noises=None if noises is None else {k: v.to(dev) for k, v in noises.items()})
+    assert extra == [] and mt is None and gl.shape == (B, 1842)
+    assert torch.equal(gm.cpu() > 0.5, rm > 0.5)
+    err = (gl.cpu() - rl).abs().max().item()
+    print(f"full model ({sampler}): max |logit diff| = {err:.3e}")
+    assert err < LOGIT_TOL
+    assert torch.allclose(gg.cpu(), rg, atol=1e-5)

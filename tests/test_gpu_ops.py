@@ -1,0 +1,303 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against the CPU oracle
+(oracle/primitives.py, oracle/samplers.py, oracle/model.py) and the reference-made goldens."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X (run with -m gpu on the GPU box)"
+    from isubgvqa_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand_graphs(gen, sizes, extra_per_node=2.0, hub=None):
+    batch, src, dst = [], [], []
+    off = 0
+    for g, n in enumerate(sizes):
+        batch += [g] * n
+        src += list(range(off, off + n)); dst += list(range(off, off + n))
+        m = int(extra_per_node * n)
+        if m and n > 0:
+            s = torch.randint(0, n, (m,), generator=gen) + off
+            d = torch.randint(0, n, (m,), generator=gen) + off
+            src += s.tolist(); dst += d.tolist()
+        if hub is not None and g == hub[0] and n > 0:        # many edges into one target
+            s = torch.randint(0, n, (hub[1],), generator=gen) + off
+            src += s.tolist(); dst += [off] * hub[1]
+        off += n
+    ei = torch.tensor([src, dst], dtype=torch.long)
+    perm = torch.randperm(ei.size(1), generator=gen)
+    return torch.tensor(batch, dtype=torch.long), ei[:, perm].contiguous()
+
+
+# --------------------------------------------------------------------------------------------- plan
+def test_graph_plan_ptr_nmax_and_csr(dev):
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    sizes = [3, 1, 7, 0, 5, 64, 2]                      # incl. an empty graph in the middle
+    batch, ei = _rand_graphs(gen, sizes, hub=(5, 100))
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    ptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32)
+    assert torch.equal(plan.ptr.cpu(), ptr)
+    assert plan.nmax == 64 and int(plan.nmax_dev.item()) == 64
+    N, E = batch.numel(), ei.size(1)
+    # stable sort by destination == ascending edge id inside every segment
+    order = torch.sort(ei[1], stable=True).indices
+    deg = torch.bincount(ei[1], minlength=N)
+    rowptr = torch.zeros(N + 1, dtype=torch.long)
+    rowptr[1:] = deg.cumsum(0)
+    assert torch.equal(plan.rowptr.cpu().long(), rowptr)
+    assert torch.equal(plan.eid.cpu().long()[:E], order)
+    assert torch.equal(plan.src.cpu().long()[:E], ei[0][order])
+    # trailing empty graphs and the hint path (no sync)
+    plan2 = ops.GraphPlan.build(batch.to(dev), None, num_graphs=len(sizes) + 2, max_nodes=64)
+    assert plan2.ptr.cpu().tolist()[-3:] == [N, N, N]
+
+
+def test_graph_plan_empty_batch(dev):
+    from isubgvqa_amd import ops
+    plan = ops.GraphPlan.build(torch.zeros(0, dtype=torch.long, device=dev),
+                               torch.zeros(2, 0, dtype=torch.long, device=dev), num_graphs=0)
+    assert plan.N == 0 and plan.B == 0 and plan.nmax == 0
+
+
+# ------------------------------------------------------------------------------------ message passing
+MP_CASES = [
+    # H, C, sizes, extra, hub, mask
+    (4, 8, [3, 1, 5, 2], 2.0, None, None),
+    (4, 8, [3, 1, 5, 2], 2.0, None, "node"),
+    (4, 128, [20, 17, 33, 4, 9], 1.5, None, "edge"),
+    (4, 300, [12, 20, 7], 1.5, None, "node"),          # reference default width: 75 float4 per head, 5 passes
+    (1, 64, [9, 30], 2.0, None, None),
+    (2, 36, [9, 30], 2.0, None, "node"),
+    (8, 16, [9, 30], 2.0, None, "edge"),
+    (4, 32, [40, 6], 1.0, (0, 200), "node"),           # in-degree 200+: logits overflow the LDS strip
+    (4, 16, [40, 6], 1.0, (0, 1500), None),            # >1024 CSR slots in one workgroup's chunk
+    (4, 512, [6, 3], 2.0, None, None),                 # widest supported head (P = 8)
+]
+
+
+@pytest.mark.parametrize("H,C,sizes,extra,hub,mask", MP_CASES)
+def test_gatv2_message_passing_matches_oracle(dev, H, C, sizes, extra, hub, mask):
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(H * 1000 + C)
+    batch, ei = _rand_graphs(gen, sizes, extra, hub)
+    N, E = batch.numel(), ei.size(1)
+    x_l, x_r = torch.randn(N, H * C, generator=gen), torch.randn(N, H * C, generator=gen)
+    e_proj = torch.randn(E, H * C, generator=gen)
+    att = torch.randn(1, H, C, generator=gen)
+    bias = torch.randn(H * C, generator=gen)
+    nm = em = None
+    if mask == "node":
+        nm = (torch.rand(N, 1, generator=gen) > 0.4).float()
+        nm[torch.rand(N, 1, generator=gen) > 0.9] = 0.99999994      # straight-through values are not exactly 1
+        em = OM.node_mask_to_edge_mask(nm, ei)
+    elif mask == "edge":
+        em = (torch.rand(E, 1, generator=gen) > 0.4).float()
+    ref_out, ref_alpha = OM.gatv2_message_passing(x_l.view(N, H, C), x_r.view(N, H, C), e_proj.view(E, H, C), att, ei,
+                                                  em, 0.2)
+    ref_out = ref_out.view(N, H * C) + bias
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    out, alpha = ops.gatv2_mp(x_l.to(dev), x_r.to(dev), e_proj.to(dev), att.to(dev), plan, H, bias=bias.to(dev),
+                              node_mask=None if mask != "node" else nm.to(dev),
+                              edge_mask=None if mask != "edge" else em.to(dev))
+    torch.cuda.synchronize()
+    assert torch.allclose(alpha.cpu(), ref_alpha, atol=2e-6, rtol=1e-5), (alpha.cpu() - ref_alpha).abs().max()
+    assert torch.allclose(out.cpu(), ref_out, atol=2e-5, rtol=1e-5), (out.cpu() - ref_out).abs().max()
+    if mask is None:   # softmax rows sum to one per (target, head)
+        s = torch.zeros(N, H).index_add_(0, ei[1], alpha.cpu())
+        has = torch.bincount(ei[1], minlength=N) > 0
+        assert torch.allclose(s[has], torch.ones_like(s[has]), atol=1e-5)
+
+
+def test_message_passing_is_equivariant_to_edge_order(dev):
+    """Permuting the edge list permutes alpha and leaves the node output unchanged (CSR keeps edge-id order, so
+    the aggregation order changes: equality is to rounding, not bitwise)."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    batch, ei = _rand_graphs(gen, [25, 14, 31], 2.0)
+    N, E, H, C = batch.numel(), ei.size(1), 4, 32
+    x_l, x_r = torch.randn(N, H * C, generator=gen).to(dev), torch.randn(N, H * C, generator=gen).to(dev)
+    e_proj = torch.randn(E, H * C, generator=gen).to(dev)
+    att = torch.randn(1, H, C, generator=gen).to(dev)
+    perm = torch.randperm(E, generator=gen).to(dev)
+    p1 = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=3)
+    p2 = ops.GraphPlan.build(batch.to(dev), ei.to(dev)[:, perm].contiguous(), num_graphs=3)
+    o1, a1 = ops.gatv2_mp(x_l, x_r, e_proj, att, p1, H)
+    o2, a2 = ops.gatv2_mp(x_l, x_r, e_proj[perm].contiguous(), att, p2, H)
+    assert torch.allclose(a1[perm], a2, atol=1e-6)
+    assert torch.allclose(o1, o2, atol=1e-5)
+    # and the kernel is run-to-run deterministic (fixed summation order, no atomics in the data path)
+    o3, a3 = ops.gatv2_mp(x_l, x_r, e_proj, att, p1, H)
+    assert torch.equal(o1, o3) and torch.equal(a1, a3)
+
+
+def test_unsupported_shapes_are_refused_not_launched(dev):
+    from isubgvqa_amd import _lib, ops
+    plan = ops.GraphPlan.build(torch.zeros(2, dtype=torch.long, device=dev),
+                               torch.zeros(2, 1, dtype=torch.long, device=dev), num_graphs=1)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(_lib.IsgError):       # C not a multiple of 4
+        ops.gatv2_mp(z(2, 12), z(2, 12), z(1, 12), z(1, 4, 3), plan, 4)
+    with pytest.raises(_lib.IsgError):       # heads not in {1,2,4,8}
+        ops.gatv2_mp(z(2, 12), z(2, 12), z(1, 12), z(1, 3, 4), plan, 3)
+    with pytest.raises(ValueError):          # wrong operand shape never reaches the kernel
+        ops.gatv2_mp(z(2, 16), z(3, 16), z(1, 16), z(1, 4, 4), plan, 4)
+
+
+def test_small_gather_scatter_ops(dev):
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    from oracle import primitives as P
+    gen = torch.Generator().manual_seed(9)
+    batch, ei = _rand_graphs(gen, [5, 1, 12, 30], 2.0)
+    N, E, C, B = batch.numel(), ei.size(1), 20, 4
+    x, instr = torch.randn(N, C, generator=gen), torch.randn(B, C, generator=gen)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+    got = ops.instr_gate(x.to(dev), instr.to(dev), batch.to(dev)).cpu()
+    assert torch.allclose(got, P.gelu(x * instr[batch]), atol=1e-6)
+    nm = (torch.rand(N, 1, generator=gen) > 0.5).float()
+    assert torch.equal(ops.node_to_edge_mask(nm.to(dev), ei.to(dev)).cpu(), OM.node_mask_to_edge_mask(nm, ei))
+    msg = torch.randn(E, C, generator=gen)
+    assert torch.equal(ops.scatter_mean(msg.to(dev), plan).cpu(), P.scatter_mean(msg, ei[1], N))
+    # node gate with the reference's double indexing (quirk Q3)
+    xn, q = torch.randn(N, C, generator=gen), torch.randn(B, C, generator=gen)
+    for dbl in (False, True):
+        idx = batch[batch] if dbl else batch
+        ref = P.gelu((xn * q[idx]).sum(-1, keepdim=True) / torch.sqrt(torch.tensor(C)))
+        got = ops.node_gate(xn.to(dev), q.to(dev), batch.to(dev), dbl).cpu()
+        assert torch.allclose(got, ref, atol=1e-6), (got - ref).abs().max()
+
+
+# ------------------------------------------------------------------------------------------ samplers
+def test_gumbel_sampler_matches_reference_goldens_bit_exact(dev):
+    from isubgvqa_amd.sampling.methods.gumbel_scheme import GumbelSampler
+    for c in load_golden("g1_gumbel.pt"):
+        s = GumbelSampler(k=c["k"], policy="edge_candid", train_ensemble=1, val_ensemble=1)
+        out, aux = s(c["scores"].to(dev), train=False, noise=c["noise"].to(dev))
+        assert aux is None and out.shape == c["out"].shape
+        got, ref = out.cpu(), c["out"]
+        assert torch.equal(got > 0.5, ref > 0.5), "selected top-k indices differ from the reference"
+        assert torch.allclose(got, ref, atol=2.5e-7, rtol=0)          # straight-through values: (hard-khot)+khot
+
+
+def test_gumbel_khot_close_to_oracle(dev):
+    from isubgvqa_amd import ops
+    from oracle import samplers as OS
+    c = load_golden("g1_gumbel.pt")[2]
+    B, nmax, _ = c["scores"].shape
+    _, khot = ops.topk_gumbel(c["scores"].view(B, nmax).to(dev), c["k"], 0.1, noise=c["noise"].to(dev),
+                              return_khot=True)
+    _, ref_khot, _ = OS.gumbel_relaxed_topk(c["scores"], c["k"], c["noise"])
+    assert torch.allclose(khot.cpu(), ref_khot, atol=1e-6, rtol=1e-5)
+
+
+def test_imle_and_aimle_samplers_match_reference_goldens(dev):
+    from isubgvqa_amd.models.masking import get_aimle_samplers, get_imle_samplers
+    for c in load_golden("g2_imle.pt"):
+        _, val = get_imle_samplers(sample_k=c["k"], device=dev)
+        out, aux = val(c["scores"].to(dev))
+        assert aux is None and torch.equal(out.cpu(), c["out"])
+    for c in load_golden("g3_aimle.pt"):
+        _, val = get_aimle_samplers(sample_k=c["k"], device=dev, tau=c["tau"])
+        out = val(c["scores"].to(dev), noise=c["noise"].to(dev))
+        assert torch.equal(out.cpu(), c["out"])
+
+
+@pytest.mark.parametrize("sampler", ["gumbel", "imle", "aimle"])
+@pytest.mark.parametrize("sizes", [[3, 1, 5, 2], [20, 64, 7, 1, 33], [130, 5], [200, 90, 257]])
+def test_ragged_samplers_match_oracle_with_competing_pads(dev, sampler, sizes):
+    """to_dense_batch pad (0.0) + sampler + un-pad, fused, against the oracle's explicit three steps (quirk Q1)."""
+    from isubgvqa_amd import ops
+    from oracle import primitives as P
+    from oracle import samplers as OS
+    gen = torch.Generator().manual_seed(len(sizes) * 17 + sizes[0])
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    N, B, nmax, k = batch.numel(), len(sizes), max(sizes), 5
+    gate = torch.nn.functional.gelu(torch.randn(N, 1, generator=gen))
+    plan = ops.GraphPlan.build(batch.to(dev), None, num_graphs=B)
+    dense, m = P.to_dense_batch(gate, batch)
+    if sampler == "gumbel":
+        noise = OS.uniform_to_gumbel(torch.rand(B, nmax, generator=gen))
+        ref = OS.gumbel_relaxed_topk(dense, k, noise)[0].squeeze(0)[m]
+        got = ops.topk_gumbel(gate.to(dev), k, 0.1, plan=plan, noise=noise.to(dev)).cpu()
+        assert torch.equal(got > 0.5, ref > 0.5)
+        assert torch.allclose(got, ref, atol=2.5e-7, rtol=0)
+    elif sampler == "imle":
+        ref = OS.imle_eval(dense, k).squeeze(0)[m]
+        got = ops.topk_threshold(gate.to(dev), k, plan=plan).cpu()
+        assert torch.equal(got, ref)
+    else:
+        noise = OS.uniform_to_gumbel(torch.rand(B, 1, nmax, 1, generator=gen), 0.0, 0.3)
+        ref = OS.aimle_eval(dense, k, noise, 1.0)[m]
+        got = ops.topk_threshold(gate.to(dev), k, plan=plan, noise=noise.to(dev), noise_scale=1.0).cpu()
+        assert torch.equal(got, ref)
+
+
+def test_in_kernel_philox_noise_is_seeded_and_gumbel_distributed(dev):
+    from isubgvqa_amd import ops
+    scores = torch.zeros(2048, 64, device=dev)
+    a = ops.topk_gumbel(scores, 5, 0.1, seed=123)
+    b = ops.topk_gumbel(scores, 5, 0.1, seed=123)
+    c = ops.topk_gumbel(scores, 5, 0.1, seed=124)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    sel = (a > 0.5).float()
+    assert torch.all(sel.sum(1) == 5)
+    freq = sel.mean(0)                       # equal scores -> every slot equally likely (5/64)
+    assert (freq - 5 / 64).abs().max() < 0.03
+    t = ops.topk_threshold(scores, 5, noise_scale=1.0, seed=9)
+    assert torch.all(t.sum(1) == 5)
+
+
+# ----------------------------------------------------------------------- per-graph attention / norm / pool
+@pytest.mark.parametrize("C,sizes", [(8, [3, 1, 5, 2]), (128, [20, 33, 4, 48]), (300, [12, 1, 150]), (20, [260, 3])])
+def test_per_graph_kernels_match_oracle(dev, C, sizes):
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    from oracle import primitives as P
+    gen = torch.Generator().manual_seed(C + len(sizes))
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    N, B = batch.numel(), len(sizes)
+    plan = ops.GraphPlan.build(batch.to(dev), None, num_graphs=B)
+    ins, c, h = torch.randn(B, C, generator=gen), torch.randn(N, C, generator=gen), torch.randn(N, C, generator=gen)
+    w, b, ms = torch.randn(C, generator=gen), torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+    nm = (torch.rand(N, 1, generator=gen) > 0.5).float()
+
+    ref_att = OM.scatter_scaled_dot_product_attention(ins, c, c, batch, B)
+    got_att = ops.scatter_attention(ins.to(dev), c.to(dev), plan).cpu()
+    assert torch.allclose(got_att, ref_att, atol=1e-6, rtol=1e-5)
+
+    ref_gn = P.graph_norm(c, batch, w, b, ms, 1e-5, B)
+    got_gn = ops.graph_norm(c.to(dev), plan, w.to(dev), b.to(dev), ms.to(dev)).cpu()
+    assert torch.allclose(got_gn, ref_gn, atol=1e-5, rtol=1e-5), (got_gn - ref_gn).abs().max()
+
+    ref64 = P.graph_norm(c.double(), batch, w, b, ms, 1e-5, B).float()
+    got64 = ops.graph_norm(c.to(dev), plan, w.to(dev), b.to(dev), ms.to(dev), fp64=True).cpu()
+    assert torch.allclose(got64, ref64, atol=1e-6, rtol=1e-6)
+
+    for mask in (None, nm):
+        ref_tail = P.graph_norm(ref_att, batch, w, b, ms, 1e-5, B) + h
+        if mask is not None:
+            ref_tail = mask * ref_tail
+        got_tail = ops.mgat_layer_tail(ins.to(dev), c.to(dev), h.to(dev), plan, w.to(dev), b.to(dev), ms.to(dev),
+                                       node_mask=None if mask is None else mask.to(dev)).cpu()
+        assert torch.allclose(got_tail, ref_tail, atol=2e-5, rtol=1e-5), (got_tail - ref_tail).abs().max()
+
+    # pooling: x' = xn*mask; softmax (+1e-16); scatter-add
+    q = torch.randn(B, C, generator=gen)
+    for mask in (None, nm):
+        x = c if mask is None else c * mask
+        gate = P.pyg_softmax((x * q[batch]).sum(-1, keepdim=True) / torch.sqrt(torch.tensor(C)), batch, B)
+        ref_out = P.scatter_sum(gate * x, batch, B)
+        out, g = ops.global_attn_pool(c.to(dev), q.to(dev), plan, None if mask is None else mask.to(dev))
+        assert torch.allclose(g.cpu(), gate, atol=1e-6, rtol=1e-5)
+        assert torch.allclose(out.cpu(), ref_out, atol=1e-5, rtol=1e-5)

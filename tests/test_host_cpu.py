@@ -1,0 +1,169 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every declared symbol,
+the modules keep the reference's state_dict layout, the product path refuses to run on the CPU."""
+import argparse
+import glob
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_golden
+
+
+def test_library_exports_every_symbol_in_header():
+    import __graft_entry__ as ge
+    ge.build()
+    from isubgvqa_amd import _lib
+    header = open(os.path.join(ROOT, "include", "isg.h")).read()
+    declared = set(re.findall(r"\b(isg_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.isg_abi_version() == 1
+    assert lib.isg_status_string(-2) == b"unsupported shape"
+    assert lib.isg_csr_workspace_bytes(10, 7) == (2 * 11 + 7) * 4
+
+
+def test_product_path_fails_loudly_on_cpu_tensors():
+    from isubgvqa_amd import _lib, ops
+    with pytest.raises(_lib.IsgError):
+        ops.instr_gate(torch.zeros(4, 8), torch.zeros(2, 8), torch.zeros(4, dtype=torch.long))
+    with pytest.raises(_lib.IsgError):
+        ops.GraphPlan.build(torch.zeros(4, dtype=torch.long), num_graphs=1, max_nodes=4)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "intrinsic-subgraph-generation-for-vqa_amd")
+    for path in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), path
+        assert "/root/reference" not in src, path
+
+
+G5 = sorted(glob.glob(os.path.join(GOLDEN, "g5_mgat_*.pt")))
+
+
+@pytest.mark.parametrize("path", G5, ids=[os.path.basename(p) for p in G5])
+def test_mgat_and_pooling_accept_reference_state_dict(path):
+    from isubgvqa_amd.models import MGAT, GlobalAttention
+    g = torch.load(path, map_location="cpu", weights_only=False)
+    c = g["cfg"]
+    m = MGAT(channels=c["C"], num_ins=c["L"], heads=4, use_instr=True, masking_thresholds=c["masks"], use_topk=True,
+             interpretable_mode=c["interp"], sampler_type=c["sampler"], sample_k=c["k"])
+    sd = {k[len("gat_seq."):]: v for k, v in g["sd"].items() if k.startswith("gat_seq.")}
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith("node_logits.") for k in res.missing_keys), res.missing_keys   # dropped from the fixture
+    p = GlobalAttention(c["C"], c["C"])
+    p.load_state_dict({k[len("graph_global_attention_pooling."):]: v for k, v in g["sd"].items()
+                       if k.startswith("graph_global_attention_pooling.")}, strict=True)
+
+
+def test_question_modules_accept_reference_state_dict():
+    from isubgvqa_amd.models import CLIPTextEmbeddings, QuestionDecoder, QuestionEncoder
+    g = load_golden("g4_question.pt")
+    enc = QuestionEncoder(CLIPTextEmbeddings(50, 32, 77), 32, 32, g["nhead"], 64, 2, 0.1)
+    res = enc.load_state_dict({k[len("question_encoder."):]: v for k, v in g["sd"].items()
+                               if k.startswith("question_encoder.")}, strict=False)
+    assert not res.unexpected_keys and res.missing_keys == ["pos_encoder.pe"], res
+    dec = QuestionDecoder(4, 32, g["nhead"], 64, 2, 0.1)
+    dec.load_state_dict({k[len("program_decoder."):]: v for k, v in g["sd"].items()
+                         if k.startswith("program_decoder.")}, strict=True)
+
+
+def _args(**kw):
+    d = dict(text_sampling=False, general_hidden_dim=300, distributed=False, mgat_layers=4, use_all_instrs=False,
+             use_global_mask=False, node_classification=False, sampler_type="imle", sample_k=5, nb_samples=1,
+             alpha=1.0, beta=10.0, tau=1.0, use_masking=True, use_instruction=1, use_mgat=True,
+             mgat_masks=[1.0, 1.0, 1.0, 0.15], use_topk=True, interpretable_mode=False, concat_instr=0, embed_cat=0,
+             device="cpu", text_vocab_size=64, sg_vocab_size=40)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_isubgvqa_state_dict_layout_matches_appendix_c():
+    from isubgvqa_amd.models import build_model
+    m = build_model(_args(), None)
+    sd = m.state_dict()
+    C, H = 300, 4
+    expect = {
+        "scene_graph_encoder.sg_vocab_embedding.weight": (40, 300),
+        "scene_graph_encoder.scene_graph_encoding_layer.edge_model.edge_mlp.0.weight": (C, 900),
+        "scene_graph_encoder.scene_graph_encoding_layer.node_model.node_mlp_1.0.weight": (C, 600),
+        "scene_graph_encoder.scene_graph_encoding_layer.node_model.node_mlp_2.2.weight": (C, C),
+        "scene_graph_encoder.graph_layer_norm.mean_scale": (300,),
+        "scene_graph_encoder.bbox_encoding.0.running_mean": (4,),
+        "scene_graph_encoder.bbox_encoding.4.weight": (32, 16),
+        "scene_graph_encoder.feat_reduc.1.weight": (300, 332),
+        "text_vocab_embedding.token_embedding.weight": (64, 512),
+        "question_encoder.text_vocab_embedding.position_embedding.weight": (77, 512),
+        "question_encoder.emb_proj.weight": (512, 512),
+        "question_encoder.pos_encoder.pe": (5000, 1, 512),
+        "question_encoder.transformer_encoder.layers.3.self_attn.in_proj_weight": (1536, 512),
+        "question_encoder.transformer_encoder.layers.0.linear1.weight": (2048, 512),
+        "question_encoder.transformer_encoder.norm.weight": (512,),
+        "program_decoder.query_embed.weight": (4, 512),
+        "program_decoder.coarse_decoder.layers.2.multihead_attn.out_proj.weight": (512, 512),
+        "program_decoder.coarse_decoder.layers.0.norm3.bias": (512,),
+        "gat_seq.convs.3.att": (1, H, C),
+        "gat_seq.convs.0.bias": (H * C,),
+        "gat_seq.convs.0.lin_l.weight": (H * C, C),
+        "gat_seq.convs.0.lin_r.bias": (H * C,),
+        "gat_seq.convs.0.lin_edge.weight": (H * C, C),
+        "gat_seq.convs.0.mask.gate_nn.2.weight": (1, C),
+        "gat_seq.convs.0.mask.node_nn.0.weight": (C, C),
+        "gat_seq.convs.0.mask.ques_nn.0.bias": (C,),
+        "gat_seq.convs.0.mask.gate_top.select.weight": (1, C),
+        "gat_seq.x_proj.1.0.weight": (H * C // 2, H * C),
+        "gat_seq.x_proj.1.2.weight": (C, H * C // 2),
+        "gat_seq.bns.2.mean_scale": (C,),
+        "gat_seq.node_logits.2.weight": (2577, 512),
+        "graph_global_attention_pooling.gate_nn.2.weight": (1, C),
+        "graph_global_attention_pooling.node_nn.2.weight": (C, C),
+        "graph_global_attention_pooling.ques_nn.0.weight": (C, C),
+        "qsts_reduction.0.weight": (C, 2048),
+        "instr_reduction.0.weight": (C, 512),
+        "embedding.0.weight": (512, 3 * C),
+        "logit_fc.weight": (1842, 512),
+    }
+    for k, shp in expect.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == shp, (k, tuple(sd[k].shape))
+    assert "gat_seq.convs.0.lin_edge.bias" not in sd
+    # the CLIP embedding module is shared, so its tensors appear under both prefixes (isubgvqa.py:120,126-127)
+    assert sd["text_vocab_embedding.token_embedding.weight"].data_ptr() == \
+        sd["question_encoder.text_vocab_embedding.token_embedding.weight"].data_ptr()
+    # a DDP checkpoint carries a "module." prefix (train_loop.py:89): stripping it must load strictly
+    ddp = {"module." + k: v for k, v in sd.items()}
+    m2 = build_model(_args(), None)
+    m2.load_state_dict({k[len("module."):]: v for k, v in ddp.items()}, strict=True)
+
+
+def test_forward_requires_return_masks_like_the_reference():
+    from isubgvqa_amd.models import build_model
+    m = build_model(_args(), None).eval()
+    with pytest.raises(ValueError):
+        m(None, None, None, None, None, None, return_masks=False)
+
+
+def test_synthetic_cfg2_shapes():
+    from isubgvqa_amd import synthetic
+    cfg = synthetic.WorkloadConfig(num_graphs=512)
+    wl = synthetic.make_workload(cfg)
+    N, E = wl.x.size(0), wl.edge_index.size(1)
+    assert 18.0 < N / 512 < 22.0 and 45.0 < E / 512 < 55.0
+    assert torch.equal(wl.batch, wl.batch.sort().values)
+    b = wl.batch
+    assert torch.equal(b[wl.edge_index[0]], b[wl.edge_index[1]])          # edges stay inside their graph
+    assert wl.edge_index.min() >= 0 and wl.edge_index.max() < N
+    n = torch.bincount(b)
+    assert n.min() >= 4 and n.max() <= 48 and wl.max_nodes == int(n.max())
+    # every node has its self-loop
+    loops = wl.edge_index[0] == wl.edge_index[1]
+    assert torch.unique(wl.edge_index[0][loops]).numel() == N
+    wl5 = synthetic.make_workload(synthetic.WorkloadConfig(num_graphs=256, nodes_dist="pareto", nodes_min=8,
+                                                           nodes_max=200, edges_per_graph=0.0, degree="powerlaw"))
+    deg = torch.bincount(wl5.edge_index[1], minlength=wl5.x.size(0))
+    assert deg.max() > 8 * deg.float().mean()                            # hubs exist
