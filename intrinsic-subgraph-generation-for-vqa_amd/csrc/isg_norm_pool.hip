@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256) void graph_tail_kernel(const float *__restrict
   const float cnt = (float)n;
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const float *col = key + (size_t)nb * C + ch;
-    if (MODE == 0) {
-      for (int k = 0; k < n; ++k) out[(size_t)(nb + k) * C + ch] = __fmul_rn(s_a[k], col[(size_t)k * C]);
+    if (MODE == 0) {   // h carries `value` here
+      const float *val = h + (size_t)nb * C + ch;
+      for (int k = 0; k < n; ++k) out[(size_t)(nb + k) * C + ch] = __fmul_rn(s_a[k], val[(size_t)k * C]);
       continue;
     }
     float sum = 0.f;
@@ -190,9 +191,8 @@ extern "C" int isg_scatter_attention(const float *query, const float *key, const
   if (st != ISG_OK) return st;
   if (B == 0) return ISG_OK;
   if (!query || !key || !value || !ptr || !out) return ISG_EINVAL;
-  if (key != value) return ISG_EUNSUPPORTED;   // the reference only ever passes key == value (mgat.py:168-170)
   graph_tail_kernel<0><<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(
-      query, key, nullptr, ptr, nullptr, nullptr, nullptr, 0.f, nullptr, out, C, (float)sqrt((double)C));
+      query, key, value, ptr, nullptr, nullptr, nullptr, 0.f, nullptr, out, C, (float)sqrt((double)C));
   return check_launch();
 }
 

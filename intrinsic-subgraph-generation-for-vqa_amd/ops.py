@@ -18,6 +18,27 @@ from . import _lib
 MAX_NODES_PER_GRAPH = 1024   # LDS strip / sampler row capacity of the kernels
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around every launch of one named kernel (bench.py uses it for the
+    message-passing kernel).  Events are recorded on the stream the kernel is launched on."""
+
+    def __init__(self):
+        self.pairs = []
+        self.meta = []
+
+    def bracket(self, info):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.append((start, end))
+        self.meta.append(info)
+        return start, end
+
+    def durations_ms(self):
+        return [s.elapsed_time(e) for s, e in self.pairs]
+
+
+MP_TIMER: Optional[KernelTimer] = None   # set by bench.py around its timed region
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -147,6 +168,10 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         raise ValueError(f"x_l {tuple(x_l.shape)} does not match plan N={plan.N} / heads={H}")
     out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+    timer = MP_TIMER
+    if timer is not None:
+        ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None})
+        ev0.record()
     _lib.check(lib.isg_gatv2_mp_fwd(
         _chk(x_l, "x_l", torch.float32), _chk(x_r, "x_r", torch.float32, (N, HC)),
         _chk(e_proj, "e_proj", torch.float32, (E, HC)), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
@@ -155,7 +180,15 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
         _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
         out.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope), _stream()), "isg_gatv2_mp_fwd")
+    if timer is not None:
+        ev1.record()
     return out, alpha
+
+
+def mp_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool, feat_bytes: int = 4) -> int:
+    """bytes_mp = s*(3*N*HC + E*HC) + 4*E*H + 16*E (+4*E if edge-masked)."""
+    HC = H * C
+    return feat_bytes * (3 * N * HC + E * HC) + 4 * E * H + 16 * E + (4 * E if masked else 0)
 
 
 def scatter_mean(msg: Tensor, plan: GraphPlan) -> Tensor:
@@ -241,13 +274,16 @@ def topk_threshold(scores: Tensor, k: int, plan: Optional[GraphPlan] = None, noi
 # ------------------------------------------------------------------------------------------------
 # Per-graph attention / norm / pooling
 # ------------------------------------------------------------------------------------------------
-def scatter_attention(query: Tensor, key: Tensor, plan: GraphPlan) -> Tensor:
-    """softmax_g(<query_g, key_n>/sqrt(C)) * key_n   (utils/scatter_scaled_dot_product.py:6-15, key == value)"""
+def scatter_attention(query: Tensor, key: Tensor, plan: GraphPlan, value: Optional[Tensor] = None) -> Tensor:
+    """softmax_g(<query_g, key_n>/sqrt(C)) * value_n   (utils/scatter_scaled_dot_product.py:6-15)"""
     lib = _lib.load()
     N, C = key.shape
-    out = torch.empty_like(key)
+    if value is None:
+        value = key
+    out = torch.empty_like(value)
     _lib.check(lib.isg_scatter_attention(_chk(query, "query", torch.float32, (plan.B, C)),
-                                         _chk(key, "key", torch.float32, (plan.N, C)), key.data_ptr(),
+                                         _chk(key, "key", torch.float32, (plan.N, C)),
+                                         _chk(value, "value", torch.float32, (plan.N, C)),
                                          plan.ptr.data_ptr(), out.data_ptr(), plan.B, C, _stream()),
                "isg_scatter_attention")
     return out

@@ -15,8 +15,6 @@ from .. import ops
 
 def scatter_scaled_dot_product_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                                          batch: torch.Tensor, plan: Optional[ops.GraphPlan] = None) -> torch.Tensor:
-    if value is not key and (value.data_ptr() != key.data_ptr() or value.shape != key.shape):
-        raise NotImplementedError("key and value must be the same tensor (the only use: mgat.py:168-170)")
     if plan is None:
         plan = ops.GraphPlan.build(batch, None, num_graphs=query.size(0))
-    return ops.scatter_attention(query.contiguous(), key.contiguous(), plan)
+    return ops.scatter_attention(query.contiguous(), key.contiguous(), plan, value.contiguous())
