@@ -29,9 +29,13 @@ def graph_ranges(nodes_per_graph: Tensor, edges_per_graph: Optional[Tensor], wor
     total = float(cost[-1]) if B else 0.0
     cuts = [0]
     for r in range(1, world):
-        cuts.append(int(torch.searchsorted(cost, torch.tensor(total * r / world, dtype=torch.double))))
+        target = total * r / world
+        i = int(torch.searchsorted(cost, torch.tensor(target, dtype=torch.double)))   # graph holding the target
+        below = float(cost[i - 1]) if i > 0 else 0.0
+        above = float(cost[i]) if i < B else total
+        c = i if (target - below) <= (above - target) else i + 1                       # nearer boundary
+        cuts.append(min(max(c, cuts[-1]), B))
     cuts.append(B)
-    cuts = [max(cuts[i], cuts[i - 1]) if i else 0 for i in range(len(cuts))]
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
