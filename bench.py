@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-sample-graphs", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-hints", action="store_true", help="let the plan read Nmax back from the device (one sync)")
+    ap.add_argument("--mp-kernel", choices=["graph", "chunk"], default="graph")
     return ap.parse_args()
 
 
@@ -108,6 +109,7 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
 
+    ops.MP_KERNEL = args.mp_kernel
     cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": args.graphs,
                                       "seed": synthetic.CFG2.seed + rank})
     wl = synthetic.make_workload(cfg).to(dev)
@@ -166,7 +168,7 @@ def main():
                        "layers": cfg.layers, "sampler": "gumbel(in-kernel Philox noise)", "k": cfg.sample_k,
                        "parallelism": f"dp{world} (graphs sharded, RCCL all-gather of logits)" if world > 1 else "dp1",
                        "launch": "eager"},
-            "roofline": {"bound": "hbm", "kernel": "gatv2_mp_kernel<4,2> (isg_gatv2_mp_fwd)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": ("gatv2_mp_graph_kernel<2,1>" if args.mp_kernel == "graph" else "gatv2_mp_kernel<4,2>") + " (isg_gatv2_mp_fwd)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
                          "traffic": load_traffic(N, E), "algorithmic_bytes_per_launch": int(mp_bytes),

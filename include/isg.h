@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 1
+#define ISG_ABI_VERSION 2
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -87,11 +87,15 @@ int isg_node_to_edge_mask(const float *node_mask, const int64_t *edge_index, int
  * m_e = edge_mask[e] if given, else node_mask[j]*node_mask[i] if given, else 1.
  * x_l,x_r fp32[N,H*C]; e_proj fp32[E,H*C] (ORIGINAL edge order); att fp32[H*C]; bias fp32[H*C]|NULL;
  * rowptr/eid/src from isg_csr_build; out fp32[N,H*C]; alpha fp32[E,H] (ORIGINAL edge order).
- * H in {1,2,4,8}; 4 | C; C/4 <= 8*(64/H).  Isolated targets get 0 (+bias). */
+ * H in {1,2,4,8}; 4 | C; C/4 <= 8*(64/H).  Isolated targets get 0 (+bias).
+ * graph_ptr (optional, int32[B+1] from isg_graph_ptr) with nmax_host > 0 selects the per-graph kernel that
+ * keeps a graph's x_l rows in LDS (x_l, x_r, out touch HBM once per row); results are identical to the
+ * node-chunk kernel used when graph_ptr == NULL. */
 int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
                      const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
                      const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
-                     int64_t E, int32_t H, int32_t C, float negative_slope, void *stream);
+                     int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
+                     int64_t B, int32_t nmax_host, void *stream);
 
 /* out[i,:] = sum_{e: dst(e)=i} msg[e,:] / max(deg(i),1)       torch_scatter.scatter_mean at
  * ISubGVQA/models/scene_graph_encoder.py:141.  msg fp32[E,C] (original edge order); out fp32[N,C]. */

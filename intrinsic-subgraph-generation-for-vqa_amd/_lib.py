@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -25,7 +25,8 @@ SIGNATURES = {
     "isg_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "isg_instr_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_to_edge_mask": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
-    "isg_gatv2_mp_fwd": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "isg_gatv2_mp_fwd": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_int64,
+                                 c_int32, c_void_p]),
     "isg_scatter_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_topk_gumbel": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_int32,

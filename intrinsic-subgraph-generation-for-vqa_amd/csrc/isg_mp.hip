@@ -13,26 +13,13 @@
 //   * softmax is the exact three-step form of torch_geometric.utils.softmax (max, exp-sum + 1e-16,
 //     divide) and the aggregation adds messages in ascending edge id, unfused mul+add, i.e. the
 //     summation order and roundings of the reference's CPU scatter
-#include "isg_common.hpp"
+#include "isg_mp.hpp"
+
+#include <stdlib.h>
+
+#define ISG_MP_DEFAULT_FLAGS 0
 
 namespace isg {
-
-constexpr int MP_WAVES = 4;
-constexpr int MP_NPB = 16;     // destination nodes per workgroup
-constexpr int MP_ECAP = 1024;  // CSR slots staged in LDS per workgroup (rest read from global)
-constexpr int MP_LCAP = 32;    // logits per wave kept in LDS (x H)
-
-struct MpArgs {
-  const float4 *x_l, *x_r, *e_proj, *att, *bias;
-  const int *rowptr, *eid, *src;
-  const float *node_mask, *edge_mask;
-  float4 *out;
-  float *alpha;
-  int N, C;
-  float slope;
-};
-
-__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 template <int H, int P>
 __global__ __launch_bounds__(MP_WAVES * 64) void gatv2_mp_kernel(MpArgs a) {
@@ -43,7 +30,16 @@ __global__ __launch_bounds__(MP_WAVES * 64) void gatv2_mp_kernel(MpArgs a) {
   __shared__ float s_logit[MP_WAVES][MP_LCAP * H];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * MP_NPB;
+  // XCD-aware chunk order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+  // contiguous range of node chunks -- the two chunks a graph straddles then hit the same L2
+  int chunk = blockIdx.x;
+  if (a.flags & 2) {
+    const int cpx = gridDim.x >> 3;
+    chunk = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    if (chunk >= a.nchunks) return;
+  }
+  const bool nt = a.flags & 1;
+  const int n0 = chunk * MP_NPB;
   const int nn = min(MP_NPB, a.N - n0);
   if (tid <= nn) s_rowptr[tid] = a.rowptr[n0 + tid];
   __syncthreads();
@@ -94,7 +90,7 @@ __global__ __launch_bounds__(MP_WAVES * 64) void gatv2_mp_kernel(MpArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         if (ok[p]) {
-          float4 u = xl[off[p]], v = ep[off[p]], s;
+          float4 u = xl[off[p]], v = ld_stream(ep + off[p], nt), s;
           s.x = (xr4[p].x + u.x) + v.x;
           s.y = (xr4[p].y + u.y) + v.y;
           s.z = (xr4[p].z + u.z) + v.z;
@@ -173,7 +169,7 @@ __global__ __launch_bounds__(MP_WAVES * 64) void gatv2_mp_kernel(MpArgs a) {
           float4 b = a.bias[off[p]];
           o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
         }
-        a.out[(size_t)i * R + off[p]] = o;
+        st_stream(a.out + (size_t)i * R + off[p], o, nt);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -186,16 +182,19 @@ static int launch_mp(const MpArgs &a, hipStream_t st) {
   const int Q = a.C >> 2;
   const int P = (Q + G - 1) / G;
   const int blocks = (a.N + MP_NPB - 1) / MP_NPB;
-  dim3 grid(blocks), block(MP_WAVES * 64);
+  MpArgs b = a;
+  b.nchunks = blocks;
+  const int gridx = (b.flags & 2) ? ((blocks + 7) / 8) * 8 : blocks;
+  dim3 grid(gridx), block(MP_WAVES * 64);
   switch (P) {
-    case 1: gatv2_mp_kernel<H, 1><<<grid, block, 0, st>>>(a); break;
-    case 2: gatv2_mp_kernel<H, 2><<<grid, block, 0, st>>>(a); break;
-    case 3: gatv2_mp_kernel<H, 3><<<grid, block, 0, st>>>(a); break;
-    case 4: gatv2_mp_kernel<H, 4><<<grid, block, 0, st>>>(a); break;
-    case 5: gatv2_mp_kernel<H, 5><<<grid, block, 0, st>>>(a); break;
-    case 6: gatv2_mp_kernel<H, 6><<<grid, block, 0, st>>>(a); break;
-    case 7: gatv2_mp_kernel<H, 7><<<grid, block, 0, st>>>(a); break;
-    case 8: gatv2_mp_kernel<H, 8><<<grid, block, 0, st>>>(a); break;
+    case 1: gatv2_mp_kernel<H, 1><<<grid, block, 0, st>>>(b); break;
+    case 2: gatv2_mp_kernel<H, 2><<<grid, block, 0, st>>>(b); break;
+    case 3: gatv2_mp_kernel<H, 3><<<grid, block, 0, st>>>(b); break;
+    case 4: gatv2_mp_kernel<H, 4><<<grid, block, 0, st>>>(b); break;
+    case 5: gatv2_mp_kernel<H, 5><<<grid, block, 0, st>>>(b); break;
+    case 6: gatv2_mp_kernel<H, 6><<<grid, block, 0, st>>>(b); break;
+    case 7: gatv2_mp_kernel<H, 7><<<grid, block, 0, st>>>(b); break;
+    case 8: gatv2_mp_kernel<H, 8><<<grid, block, 0, st>>>(b); break;
     default: return ISG_EUNSUPPORTED;
   }
   return check_launch();
@@ -252,7 +251,8 @@ using namespace isg;
 extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
                                 const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
                                 const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
-                                int64_t E, int32_t H, int32_t C, float negative_slope, void *stream) {
+                                int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
+                                int64_t B, int32_t nmax_host, void *stream) {
   if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
   if (N == 0) return ISG_OK;
   if (!x_l || !x_r || !att || !rowptr || !out || (E > 0 && (!e_proj || !eid || !src || !alpha))) return ISG_EINVAL;
@@ -263,8 +263,18 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
   a.rowptr = rowptr; a.eid = eid; a.src = src;
   a.node_mask = node_mask; a.edge_mask = edge_mask;
   a.out = (float4 *)out; a.alpha = alpha;
-  a.N = (int)N; a.C = C; a.slope = negative_slope;
+  a.N = (int)N; a.C = C; a.H = H; a.slope = negative_slope;
+  a.graph_ptr = graph_ptr; a.B = (int)B; a.lrows = 0;
+  {
+    const char *f = getenv("ISG_MP_FLAGS");   // experiment switch; default = tuned setting
+    a.flags = f ? atoi(f) : ISG_MP_DEFAULT_FLAGS;
+  }
+  a.nchunks = 0;
   hipStream_t st = as_stream(stream);
+  if (graph_ptr && B > 0 && B < (1ll << 31) && nmax_host > 0) {
+    int rc = launch_mp_graph(a, nmax_host, st);
+    if (rc != ISG_EUNSUPPORTED) return rc;   // shapes without a per-graph instantiation use the node-chunk kernel
+  }
   switch (H) {
     case 1: return launch_mp<1>(a, st);
     case 2: return launch_mp<2>(a, st);

@@ -154,9 +154,12 @@ def node_to_edge_mask(mask: Tensor, edge_index: Tensor) -> Tensor:
     return out.view(E, 1) if mask.dim() == 2 else out
 
 
+MP_KERNEL = "graph"    # "graph": per-graph LDS-resident kernel; "chunk": node-chunk kernel (A/B switch for bench/tests)
+
+
 def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphPlan, heads: int,
              bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
-             negative_slope: float = 0.2) -> Tuple[Tensor, Tensor]:
+             negative_slope: float = 0.2, kernel: Optional[str] = None) -> Tuple[Tensor, Tensor]:
     """MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:243-279).  Returns (out[N,H*C], alpha[E,H])."""
     lib = _lib.load()
     plan.require_csr()
@@ -168,6 +171,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         raise ValueError(f"x_l {tuple(x_l.shape)} does not match plan N={plan.N} / heads={H}")
     out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+    use_graph = (kernel or MP_KERNEL) == "graph" and plan.B > 0 and plan.nmax > 0
     timer = MP_TIMER
     if timer is not None:
         ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None})
@@ -179,7 +183,8 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
         _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
-        out.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope), _stream()), "isg_gatv2_mp_fwd")
+        out.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope),
+        plan.ptr.data_ptr() if use_graph else 0, plan.B, plan.nmax if use_graph else 0, _stream()), "isg_gatv2_mp_fwd")
     if timer is not None:
         ev1.record()
     return out, alpha

@@ -82,11 +82,13 @@ MP_CASES = [
     (4, 32, [40, 6], 1.0, (0, 200), "node"),           # in-degree 200+: logits overflow the LDS strip
     (4, 16, [40, 6], 1.0, (0, 1500), None),            # >1024 CSR slots in one workgroup's chunk
     (4, 512, [6, 3], 2.0, None, None),                 # widest supported head (P = 8)
+    (4, 128, [70, 3, 45], 1.5, None, "node"),          # graphs larger than the LDS window (rows read from global)
 ]
 
 
+@pytest.mark.parametrize("kernel", ["graph", "chunk"])
 @pytest.mark.parametrize("H,C,sizes,extra,hub,mask", MP_CASES)
-def test_gatv2_message_passing_matches_oracle(dev, H, C, sizes, extra, hub, mask):
+def test_gatv2_message_passing_matches_oracle(dev, H, C, sizes, extra, hub, mask, kernel):
     from isubgvqa_amd import ops
     from oracle import model as OM
     gen = torch.Generator().manual_seed(H * 1000 + C)
@@ -109,7 +111,7 @@ def test_gatv2_message_passing_matches_oracle(dev, H, C, sizes, extra, hub, mask
     plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
     out, alpha = ops.gatv2_mp(x_l.to(dev), x_r.to(dev), e_proj.to(dev), att.to(dev), plan, H, bias=bias.to(dev),
                               node_mask=None if mask != "node" else nm.to(dev),
-                              edge_mask=None if mask != "edge" else em.to(dev))
+                              edge_mask=None if mask != "edge" else em.to(dev), kernel=kernel)
     torch.cuda.synchronize()
     assert torch.allclose(alpha.cpu(), ref_alpha, atol=2e-6, rtol=1e-5), (alpha.cpu() - ref_alpha).abs().max()
     assert torch.allclose(out.cpu(), ref_out, atol=2e-5, rtol=1e-5), (out.cpu() - ref_out).abs().max()
@@ -139,6 +141,9 @@ def test_message_passing_is_equivariant_to_edge_order(dev):
     # and the kernel is run-to-run deterministic (fixed summation order, no atomics in the data path)
     o3, a3 = ops.gatv2_mp(x_l, x_r, e_proj, att, p1, H)
     assert torch.equal(o1, o3) and torch.equal(a1, a3)
+    # the per-graph (LDS-resident) and node-chunk kernels do the same arithmetic in the same order
+    o4, a4 = ops.gatv2_mp(x_l, x_r, e_proj, att, p1, H, kernel="chunk")
+    assert torch.equal(o1, o4) and torch.equal(a1, a4)
 
 
 def test_unsupported_shapes_are_refused_not_launched(dev):
@@ -148,8 +153,8 @@ def test_unsupported_shapes_are_refused_not_launched(dev):
     z = lambda *s: torch.zeros(*s, device=dev)
     with pytest.raises(_lib.IsgError):       # C not a multiple of 4
         ops.gatv2_mp(z(2, 12), z(2, 12), z(1, 12), z(1, 4, 3), plan, 4)
-    with pytest.raises(_lib.IsgError):       # heads not in {1,2,4,8}
-        ops.gatv2_mp(z(2, 12), z(2, 12), z(1, 12), z(1, 3, 4), plan, 3)
+    with pytest.raises(_lib.IsgError):       # node-chunk kernel: heads not in {1,2,4,8}
+        ops.gatv2_mp(z(2, 12), z(2, 12), z(1, 12), z(1, 3, 4), plan, 3, kernel="chunk")
     with pytest.raises(ValueError):          # wrong operand shape never reaches the kernel
         ops.gatv2_mp(z(2, 16), z(3, 16), z(1, 16), z(1, 4, 4), plan, 4)
 

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Run only the message-passing kernel on the BASELINE configs[1] batch (for rocprofv3 --pmc passes), plus a
+known-size float4 copy used to calibrate FETCH_SIZE / WRITE_SIZE on gfx950 (MI355X_MICROARCH.md §HBM).
+
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/profile_mp.py
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 tools/profile_mp.py
+then  python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/rNN_mp_traffic.json
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from isubgvqa_amd import ops, synthetic
+
+graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+ops.MP_KERNEL = sys.argv[3] if len(sys.argv) > 3 else "graph"
+dev = torch.device("cuda:0")
+cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs})
+wl = synthetic.make_workload(cfg).to(dev)
+N, E, H, C = wl.x.size(0), wl.edge_index.size(1), cfg.heads, cfg.channels
+plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=graphs, max_nodes=wl.max_nodes)
+g = torch.Generator(device=dev).manual_seed(0)
+x_l = torch.randn(N, H * C, device=dev, generator=g)
+x_r = torch.randn(N, H * C, device=dev, generator=g)
+e_proj = torch.randn(E, H * C, device=dev, generator=g)
+att = torch.randn(1, H, C, device=dev, generator=g)
+bias = torch.randn(H * C, device=dev, generator=g)
+mask = (torch.rand(N, 1, device=dev, generator=g) > 0.7).float()
+big = torch.randn(1 << 28, device=dev, generator=g)            # 1 GiB: larger than the 256 MiB Infinity Cache
+dst = torch.empty_like(big)
+torch.cuda.synchronize()
+for _ in range(reps):
+    ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias)
+for _ in range(reps):
+    ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias, node_mask=mask)
+for _ in range(3):
+    dst.copy_(big)                                              # calibration: reads 1 GiB, writes 1 GiB
+torch.cuda.synchronize()
+print(f"N={N} E={E} H={H} C={C} bytes_unmasked={ops.mp_algorithmic_bytes(N, E, H, C, False)} "
+      f"bytes_masked={ops.mp_algorithmic_bytes(N, E, H, C, True)} copy_bytes={big.numel() * 4}")
