@@ -53,6 +53,11 @@ const char *isg_last_hip_error(void);
  * batch int64[N] (sorted ascending), ptr int32[B+1], nmax int32[1]. */
 int isg_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t *ptr, int32_t *nmax, void *stream);
 
+/* eptr[g] = rowptr[ptr[g]] for g = 0..B: the CSR-slot range of graph g when its nodes are contiguous and its edges
+ * stay inside it (PyG Batch layout).  Lets the per-graph message-passing kernel read a graph's node range and edge
+ * range in one round of loads.  ptr int32[B+1], rowptr int32[N+1], eptr int32[B+1]. */
+int isg_graph_edge_ptr(const int32_t *ptr, const int32_t *rowptr, int64_t B, int32_t *eptr, void *stream);
+
 /* Bytes of workspace isg_csr_build needs. */
 size_t isg_csr_workspace_bytes(int64_t N, int64_t E);
 
@@ -60,9 +65,10 @@ size_t isg_csr_workspace_bytes(int64_t N, int64_t E);
  * flow source_to_target as in PyG MessagePassing; ISubGVQA/models/mgat_v2_conv.py:47,215).
  * Within a destination segment edges keep ascending original edge id, so every segmented
  * reduction accumulates in the order torch_scatter's CPU kernels do.
- * rowptr int32[N+1]; eid int32[E] original edge id per CSR slot; src int32[E] source node per slot. */
+ * rowptr int32[N+1]; eid int32[E] original edge id per CSR slot; src int32[E] source node per slot;
+ * dst int32[E] (optional, may be NULL) destination node per slot, used by the per-graph message-passing kernel. */
 int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, int32_t *rowptr, int32_t *eid,
-                  int32_t *src, void *workspace, size_t workspace_bytes, void *stream);
+                  int32_t *src, int32_t *dst, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Message passing
@@ -88,14 +94,14 @@ int isg_node_to_edge_mask(const float *node_mask, const int64_t *edge_index, int
  * x_l,x_r fp32[N,H*C]; e_proj fp32[E,H*C] (ORIGINAL edge order); att fp32[H*C]; bias fp32[H*C]|NULL;
  * rowptr/eid/src from isg_csr_build; out fp32[N,H*C]; alpha fp32[E,H] (ORIGINAL edge order).
  * H in {1,2,4,8}; 4 | C; C/4 <= 8*(64/H).  Isolated targets get 0 (+bias).
- * graph_ptr (optional, int32[B+1] from isg_graph_ptr) with nmax_host > 0 selects the per-graph kernel that
- * keeps a graph's x_l rows in LDS (x_l, x_r, out touch HBM once per row); results are identical to the
- * node-chunk kernel used when graph_ptr == NULL. */
+ * graph_ptr (optional, int32[B+1] from isg_graph_ptr) together with graph_eptr (isg_graph_edge_ptr), dst (int32[E]
+ * from isg_csr_build) and nmax_host > 0 selects the per-graph kernel that keeps a graph's x_l rows in LDS (x_l, x_r, out touch HBM once
+ * per row); results are identical to the node-chunk kernel used when graph_ptr == NULL. */
 int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
                      const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
                      const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
                      int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
-                     int64_t B, int32_t nmax_host, void *stream);
+                     const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host, void *stream);
 
 /* out[i,:] = sum_{e: dst(e)=i} msg[e,:] / max(deg(i),1)       torch_scatter.scatter_mean at
  * ISubGVQA/models/scene_graph_encoder.py:141.  msg fp32[E,C] (original edge order); out fp32[N,C]. */

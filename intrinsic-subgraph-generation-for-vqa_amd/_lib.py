@@ -22,11 +22,13 @@ SIGNATURES = {
     "isg_last_hip_error": (c_char_p, []),
     "isg_graph_ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "isg_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "isg_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "isg_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                              c_void_p]),
     "isg_instr_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_to_edge_mask": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
-    "isg_gatv2_mp_fwd": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_int64,
-                                 c_int32, c_void_p]),
+    "isg_gatv2_mp_fwd": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_int64, c_int32, c_void_p]),
+    "isg_graph_edge_ptr": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "isg_scatter_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_topk_gumbel": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_int32,

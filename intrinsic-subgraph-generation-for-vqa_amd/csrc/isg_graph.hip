@@ -42,6 +42,12 @@ __global__ void fill_i32_kernel(int *__restrict__ p, int n, int v) {
   if (i < n) p[i] = v;
 }
 
+__global__ void graph_eptr_kernel(const int *__restrict__ ptr, const int *__restrict__ rowptr, int B,
+                                  int *__restrict__ eptr) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= B) eptr[g] = rowptr[ptr[g]];
+}
+
 // ---- CSR build ------------------------------------------------------------------------------------
 __global__ void csr_hist_kernel(const int64_t *__restrict__ dst, int E, int N, int *__restrict__ deg) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,7 +95,7 @@ __global__ void csr_fill_kernel(const int64_t *__restrict__ dst, int E, int N, c
 // segment so the final order is ascending edge id (= torch_scatter's CPU accumulation order).
 __global__ void csr_rank_kernel(const int64_t *__restrict__ edge_index, int E, int N,
                                 const int *__restrict__ rowptr, const int *__restrict__ eid_tmp,
-                                int *__restrict__ eid, int *__restrict__ src) {
+                                int *__restrict__ eid, int *__restrict__ src, int *__restrict__ dst) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int total = rowptr[N];
   if (t >= total) return;
@@ -102,6 +108,7 @@ __global__ void csr_rank_kernel(const int64_t *__restrict__ edge_index, int E, i
   s = min(max(s, 0), N - 1);  // a malformed source id must never turn into an out-of-bounds row read
   eid[rb + rank] = e;
   src[rb + rank] = s;
+  if (dst) dst[rb + rank] = d;
 }
 
 }  // namespace isg
@@ -144,7 +151,7 @@ extern "C" size_t isg_csr_workspace_bytes(int64_t N, int64_t E) {
 }
 
 extern "C" int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, int32_t *rowptr, int32_t *eid,
-                             int32_t *src, void *workspace, size_t workspace_bytes, void *stream) {
+                             int32_t *src, int32_t *dst, void *workspace, size_t workspace_bytes, void *stream) {
   if (!rowptr || N < 0 || E < 0 || (E > 0 && (!edge_index || !eid || !src))) return ISG_EINVAL;
   if (N >= (1ll << 31) || E >= (1ll << 31)) return ISG_EUNSUPPORTED;
   if (!workspace || workspace_bytes < isg_csr_workspace_bytes(N, E)) return ISG_EWORKSPACE;
@@ -158,7 +165,14 @@ extern "C" int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, in
   csr_scan_kernel<<<1, 1024, 0, st>>>(deg, n, rowptr);
   if (e > 0) {
     csr_fill_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index + E, e, n, rowptr, cursor, eid_tmp);
-    csr_rank_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index, e, n, rowptr, eid_tmp, eid, src);
+    csr_rank_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index, e, n, rowptr, eid_tmp, eid, src, dst);
   }
+  return check_launch();
+}
+
+extern "C" int isg_graph_edge_ptr(const int32_t *ptr, const int32_t *rowptr, int64_t B, int32_t *eptr, void *stream) {
+  if (B < 0 || !ptr || !rowptr || !eptr) return ISG_EINVAL;
+  if (B >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  graph_eptr_kernel<<<(unsigned)((B + 1 + 255) / 256), 256, 0, as_stream(stream)>>>(ptr, rowptr, (int)B, eptr);
   return check_launch();
 }

@@ -17,7 +17,7 @@
 
 #include <stdlib.h>
 
-#define ISG_MP_DEFAULT_FLAGS 0
+#define ISG_MP_DEFAULT_FLAGS 1
 
 namespace isg {
 
@@ -252,7 +252,8 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
                                 const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
                                 const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
                                 int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
-                                int64_t B, int32_t nmax_host, void *stream) {
+                                const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
+                                void *stream) {
   if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
   if (N == 0) return ISG_OK;
   if (!x_l || !x_r || !att || !rowptr || !out || (E > 0 && (!e_proj || !eid || !src || !alpha))) return ISG_EINVAL;
@@ -264,14 +265,14 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
   a.node_mask = node_mask; a.edge_mask = edge_mask;
   a.out = (float4 *)out; a.alpha = alpha;
   a.N = (int)N; a.C = C; a.H = H; a.slope = negative_slope;
-  a.graph_ptr = graph_ptr; a.B = (int)B; a.lrows = 0;
+  a.graph_ptr = graph_ptr; a.graph_eptr = graph_eptr; a.dst = dst; a.B = (int)B; a.lrows = 0;
   {
     const char *f = getenv("ISG_MP_FLAGS");   // experiment switch; default = tuned setting
     a.flags = f ? atoi(f) : ISG_MP_DEFAULT_FLAGS;
   }
   a.nchunks = 0;
   hipStream_t st = as_stream(stream);
-  if (graph_ptr && B > 0 && B < (1ll << 31) && nmax_host > 0) {
+  if (graph_ptr && graph_eptr && (dst || E == 0) && B > 0 && B < (1ll << 31) && nmax_host > 0) {
     int rc = launch_mp_graph(a, nmax_host, st);
     if (rc != ISG_EUNSUPPORTED) return rc;   // shapes without a per-graph instantiation use the node-chunk kernel
   }

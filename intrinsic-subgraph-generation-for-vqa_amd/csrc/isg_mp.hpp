@@ -18,7 +18,7 @@ struct MpArgs {
   float *alpha;
   int N, C, H;
   float slope;
-  const int *graph_ptr;   // per-graph kernel only
+  const int *graph_ptr, *graph_eptr, *dst;   // per-graph kernel only
   int B, lrows;           // graphs; x_l rows of a graph kept in LDS
   int flags;              // bit0: non-temporal e_proj loads / out stores; bit1: XCD-aware chunk mapping
   int nchunks;

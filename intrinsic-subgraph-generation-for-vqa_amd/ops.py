@@ -88,6 +88,8 @@ class GraphPlan:
     rowptr: Optional[Tensor] = None
     eid: Optional[Tensor] = None
     src: Optional[Tensor] = None
+    dst: Optional[Tensor] = None
+    eptr: Optional[Tensor] = None
 
     @staticmethod
     def build(batch: Tensor, edge_index: Optional[Tensor] = None, num_graphs: Optional[int] = None,
@@ -113,10 +115,15 @@ class GraphPlan:
             plan.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
             plan.eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
             plan.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            plan.dst = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
             ws_bytes = lib.isg_csr_workspace_bytes(N, E)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.isg_csr_build(edge_index.data_ptr(), N, E, plan.rowptr.data_ptr(), plan.eid.data_ptr(),
-                                         plan.src.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "isg_csr_build")
+                                         plan.src.data_ptr(), plan.dst.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+                       "isg_csr_build")
+            plan.eptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+            _lib.check(lib.isg_graph_edge_ptr(ptr.data_ptr(), plan.rowptr.data_ptr(), B, plan.eptr.data_ptr(), _stream()),
+                       "isg_graph_edge_ptr")
         if max_nodes is None:
             max_nodes = int(nmax_dev.item())        # one D2H sync per batch (to_dense_batch syncs per layer)
         plan.nmax = int(max_nodes)
@@ -184,7 +191,9 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
         _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
         out.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope),
-        plan.ptr.data_ptr() if use_graph else 0, plan.B, plan.nmax if use_graph else 0, _stream()), "isg_gatv2_mp_fwd")
+        plan.ptr.data_ptr() if use_graph else 0, plan.eptr.data_ptr() if use_graph else 0,
+        plan.dst.data_ptr() if use_graph else 0, plan.B,
+        plan.nmax if use_graph else 0, _stream()), "isg_gatv2_mp_fwd")
     if timer is not None:
         ev1.record()
     return out, alpha

@@ -57,6 +57,7 @@ def test_graph_plan_ptr_nmax_and_csr(dev):
     assert torch.equal(plan.rowptr.cpu().long(), rowptr)
     assert torch.equal(plan.eid.cpu().long()[:E], order)
     assert torch.equal(plan.src.cpu().long()[:E], ei[0][order])
+    assert torch.equal(plan.dst.cpu().long()[:E], ei[1][order])
     # trailing empty graphs and the hint path (no sync)
     plan2 = ops.GraphPlan.build(batch.to(dev), None, num_graphs=len(sizes) + 2, max_nodes=64)
     assert plan2.ptr.cpu().tolist()[-3:] == [N, N, N]
