@@ -76,14 +76,15 @@ def cpu_baseline(cfg, sample_graphs: int, seconds: float):
                       f"{threads} threads of {os.cpu_count()} logical cores"}
 
 
-def load_traffic(N: int, E: int):
-    """HBM bytes per message-passing launch from the committed PMC summary (profiles/*_mp_traffic.json), if its
-    shape matches this run; None otherwise."""
+def load_traffic(N: int, E: int, kernel: str):
+    """HBM bytes per message-passing launch from the committed PMC summary (profiles/*_mp_traffic.json, made by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), if kernel and batch shape match
+    this run; None otherwise."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*mp_traffic.json")), reverse=True):
         try:
             t = json.load(open(path))
-            if t.get("N") == N and t.get("E") == E:
+            if t.get("N") == N and t.get("E") == E and (("graph" in t.get("kernel", "")) == (kernel == "graph")):
                 return t.get("hbm_bytes_per_launch")
         except Exception:
             pass
@@ -171,7 +172,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": ("gatv2_mp_graph_kernel<2,1>" if args.mp_kernel == "graph" else "gatv2_mp_kernel<4,2>") + " (isg_gatv2_mp_fwd)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
-                         "traffic": load_traffic(N, E), "algorithmic_bytes_per_launch": int(mp_bytes),
+                         "traffic": load_traffic(N, E, args.mp_kernel), "algorithmic_bytes_per_launch": int(mp_bytes),
                          "avg_launch_us": round(mp_ms * 1e3, 2), "launches_timed": len(durs)},
         }
         if world == 1 and not args.no_cpu_baseline:

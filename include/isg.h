@@ -55,8 +55,10 @@ int isg_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t *ptr, int3
 
 /* eptr[g] = rowptr[ptr[g]] for g = 0..B: the CSR-slot range of graph g when its nodes are contiguous and its edges
  * stay inside it (PyG Batch layout).  Lets the per-graph message-passing kernel read a graph's node range and edge
- * range in one round of loads.  ptr int32[B+1], rowptr int32[N+1], eptr int32[B+1]. */
-int isg_graph_edge_ptr(const int32_t *ptr, const int32_t *rowptr, int64_t B, int32_t *eptr, void *stream);
+ * range in one round of loads.  ptr int32[B+1], rowptr int32[N+1], eptr int32[B+1]; emax int32[1] (optional)
+ * receives the largest edge count of any graph. */
+int isg_graph_edge_ptr(const int32_t *ptr, const int32_t *rowptr, int64_t B, int32_t *eptr, int32_t *emax,
+                       void *stream);
 
 /* Bytes of workspace isg_csr_build needs. */
 size_t isg_csr_workspace_bytes(int64_t N, int64_t E);
@@ -95,13 +97,17 @@ int isg_node_to_edge_mask(const float *node_mask, const int64_t *edge_index, int
  * rowptr/eid/src from isg_csr_build; out fp32[N,H*C]; alpha fp32[E,H] (ORIGINAL edge order).
  * H in {1,2,4,8}; 4 | C; C/4 <= 8*(64/H).  Isolated targets get 0 (+bias).
  * graph_ptr (optional, int32[B+1] from isg_graph_ptr) together with graph_eptr (isg_graph_edge_ptr), dst (int32[E]
- * from isg_csr_build) and nmax_host > 0 selects the per-graph kernel that keeps a graph's x_l rows in LDS (x_l, x_r, out touch HBM once
- * per row); results are identical to the node-chunk kernel used when graph_ptr == NULL. */
+ * from isg_csr_build) and host bounds nmax_host / emax_host (max nodes / edges of any graph, > 0) selects the
+ * per-graph kernel that keeps a graph's x_l rows in LDS (x_l, x_r, out touch HBM once per row).  It requires the
+ * PyG batch layout (a graph's nodes contiguous, edges inside their graph) and is used only when every graph fits its
+ * LDS tables (<= 64 nodes, <= 256 edges, rows within 64 KB); otherwise, or with graph_ptr == NULL, the node-chunk
+ * kernel runs.  Both compute the same function (alpha to ~1e-6 relative: hardware exp2/rcp in the per-graph form). */
 int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
                      const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
                      const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
                      int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
-                     const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host, void *stream);
+                     const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
+                     int32_t emax_host, void *stream);
 
 /* out[i,:] = sum_{e: dst(e)=i} msg[e,:] / max(deg(i),1)       torch_scatter.scatter_mean at
  * ISubGVQA/models/scene_graph_encoder.py:141.  msg fp32[E,C] (original edge order); out fp32[N,C]. */

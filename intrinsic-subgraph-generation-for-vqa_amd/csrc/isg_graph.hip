@@ -43,9 +43,17 @@ __global__ void fill_i32_kernel(int *__restrict__ p, int n, int v) {
 }
 
 __global__ void graph_eptr_kernel(const int *__restrict__ ptr, const int *__restrict__ rowptr, int B,
-                                  int *__restrict__ eptr) {
+                                  int *__restrict__ eptr, int *__restrict__ emax) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g <= B) eptr[g] = rowptr[ptr[g]];
+  int cnt = 0;
+  if (g <= B) {
+    const int lo = rowptr[ptr[g]];
+    eptr[g] = lo;
+    if (g < B) cnt = rowptr[ptr[g + 1]] - lo;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, __shfl_xor(cnt, off, 64));
+  if (emax && (threadIdx.x & 63) == 0 && cnt > 0) atomicMax(emax, cnt);
 }
 
 // ---- CSR build ------------------------------------------------------------------------------------
@@ -170,9 +178,12 @@ extern "C" int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, in
   return check_launch();
 }
 
-extern "C" int isg_graph_edge_ptr(const int32_t *ptr, const int32_t *rowptr, int64_t B, int32_t *eptr, void *stream) {
+extern "C" int isg_graph_edge_ptr(const int32_t *ptr, const int32_t *rowptr, int64_t B, int32_t *eptr, int32_t *emax,
+                                  void *stream) {
   if (B < 0 || !ptr || !rowptr || !eptr) return ISG_EINVAL;
   if (B >= (1ll << 31)) return ISG_EUNSUPPORTED;
-  graph_eptr_kernel<<<(unsigned)((B + 1 + 255) / 256), 256, 0, as_stream(stream)>>>(ptr, rowptr, (int)B, eptr);
+  hipStream_t st = as_stream(stream);
+  if (emax) fill_i32_kernel<<<1, 64, 0, st>>>(emax, 1, 0);
+  graph_eptr_kernel<<<(unsigned)((B + 1 + 255) / 256), 256, 0, st>>>(ptr, rowptr, (int)B, eptr, emax);
   return check_launch();
 }

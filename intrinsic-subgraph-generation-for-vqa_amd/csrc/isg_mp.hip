@@ -253,7 +253,7 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
                                 const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
                                 int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
                                 const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
-                                void *stream) {
+                                int32_t emax_host, void *stream) {
   if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
   if (N == 0) return ISG_OK;
   if (!x_l || !x_r || !att || !rowptr || !out || (E > 0 && (!e_proj || !eid || !src || !alpha))) return ISG_EINVAL;
@@ -273,7 +273,7 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
   a.nchunks = 0;
   hipStream_t st = as_stream(stream);
   if (graph_ptr && graph_eptr && (dst || E == 0) && B > 0 && B < (1ll << 31) && nmax_host > 0) {
-    int rc = launch_mp_graph(a, nmax_host, st);
+    int rc = launch_mp_graph(a, nmax_host, emax_host, st);
     if (rc != ISG_EUNSUPPORTED) return rc;   // shapes without a per-graph instantiation use the node-chunk kernel
   }
   switch (H) {

@@ -42,6 +42,6 @@ __device__ __forceinline__ void st_stream(float4 *p, const float4 &v, bool nt) {
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // isg_mp_graph.hip: returns ISG_EUNSUPPORTED when the shape has no per-graph instantiation
-int launch_mp_graph(MpArgs a, int nmax_host, hipStream_t st);
+int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st);
 
 }  // namespace isg

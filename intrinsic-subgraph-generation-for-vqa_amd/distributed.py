@@ -53,7 +53,8 @@ def shard_workload(wl: Workload, rank: int, world: int, balance: bool = False) -
     return Workload(x=wl.x[n_lo:n_hi].contiguous(), edge_index=(wl.edge_index[:, emask] - n_lo).contiguous(),
                     edge_attr=wl.edge_attr[emask].contiguous(), batch=(wl.batch[n_lo:n_hi] - lo).contiguous(),
                     instr=wl.instr[:, lo:hi].contiguous(), glf=wl.glf[lo:hi].contiguous(), num_graphs=hi - lo,
-                    max_nodes=int(npg[lo:hi].max()) if hi > lo else 0)
+                    max_nodes=int(npg[lo:hi].max()) if hi > lo else 0,
+                    max_edges=int(epg[lo:hi].max()) if hi > lo else 0)
 
 
 def all_gather_logits(logits: Tensor, out: Optional[Tensor] = None, group=None) -> Tensor:

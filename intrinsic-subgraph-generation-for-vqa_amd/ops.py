@@ -85,6 +85,7 @@ class GraphPlan:
     ptr: Tensor
     nmax_dev: Tensor
     nmax: int
+    emax: int = 0
     rowptr: Optional[Tensor] = None
     eid: Optional[Tensor] = None
     src: Optional[Tensor] = None
@@ -93,7 +94,7 @@ class GraphPlan:
 
     @staticmethod
     def build(batch: Tensor, edge_index: Optional[Tensor] = None, num_graphs: Optional[int] = None,
-              max_nodes: Optional[int] = None) -> "GraphPlan":
+              max_nodes: Optional[int] = None, max_edges: Optional[int] = None) -> "GraphPlan":
         lib = _lib.load()
         _chk(batch, "batch", torch.int64)
         N = batch.numel()
@@ -102,7 +103,8 @@ class GraphPlan:
         B = int(num_graphs)
         dev = batch.device
         ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
-        nmax_dev = torch.empty(1, dtype=torch.int32, device=dev)
+        bounds = torch.zeros(2, dtype=torch.int32, device=dev)     # [max nodes per graph, max edges per graph]
+        nmax_dev = bounds[:1]
         _lib.check(lib.isg_graph_ptr(batch.data_ptr(), N, B, ptr.data_ptr(), nmax_dev.data_ptr(), _stream()),
                    "isg_graph_ptr")
         plan = GraphPlan(N=N, E=0, B=B, ptr=ptr, nmax_dev=nmax_dev, nmax=0)
@@ -122,11 +124,14 @@ class GraphPlan:
                                          plan.src.data_ptr(), plan.dst.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
                        "isg_csr_build")
             plan.eptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
-            _lib.check(lib.isg_graph_edge_ptr(ptr.data_ptr(), plan.rowptr.data_ptr(), B, plan.eptr.data_ptr(), _stream()),
-                       "isg_graph_edge_ptr")
-        if max_nodes is None:
-            max_nodes = int(nmax_dev.item())        # one D2H sync per batch (to_dense_batch syncs per layer)
+            _lib.check(lib.isg_graph_edge_ptr(ptr.data_ptr(), plan.rowptr.data_ptr(), B, plan.eptr.data_ptr(),
+                                              bounds[1:].data_ptr(), _stream()), "isg_graph_edge_ptr")
+        if max_nodes is None or (edge_index is not None and max_edges is None):
+            got = bounds.tolist()                   # one D2H sync per batch (to_dense_batch syncs per layer)
+            max_nodes = got[0] if max_nodes is None else max_nodes
+            max_edges = got[1] if max_edges is None else max_edges
         plan.nmax = int(max_nodes)
+        plan.emax = int(max_edges or 0)
         if plan.nmax > MAX_NODES_PER_GRAPH:
             raise _lib.IsgError(f"graphs with more than {MAX_NODES_PER_GRAPH} nodes are unsupported (got {plan.nmax})")
         return plan
@@ -193,7 +198,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         out.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope),
         plan.ptr.data_ptr() if use_graph else 0, plan.eptr.data_ptr() if use_graph else 0,
         plan.dst.data_ptr() if use_graph else 0, plan.B,
-        plan.nmax if use_graph else 0, _stream()), "isg_gatv2_mp_fwd")
+        plan.nmax if use_graph else 0, plan.emax if use_graph else 0, _stream()), "isg_gatv2_mp_fwd")
     if timer is not None:
         ev1.record()
     return out, alpha

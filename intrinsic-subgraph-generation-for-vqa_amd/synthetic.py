@@ -57,10 +57,11 @@ class Workload:
     glf: Tensor          # [B, C]
     num_graphs: int = 0
     max_nodes: int = 0
+    max_edges: int = 0
 
     def to(self, device) -> "Workload":
         return Workload(self.x.to(device), self.edge_index.to(device), self.edge_attr.to(device), self.batch.to(device),
-                        self.instr.to(device), self.glf.to(device), self.num_graphs, self.max_nodes)
+                        self.instr.to(device), self.glf.to(device), self.num_graphs, self.max_nodes, self.max_edges)
 
 
 def graph_sizes(cfg: WorkloadConfig, gen: torch.Generator) -> Tensor:
@@ -119,7 +120,8 @@ def make_workload(cfg: WorkloadConfig) -> Workload:
     edge_attr = torch.randn(E, C, generator=gen)
     instr = torch.randn(L, B, C, generator=gen)
     glf = torch.randn(B, C, generator=gen)
-    return Workload(x, edge_index, edge_attr, batch, instr, glf, B, nmax)
+    emax = int(torch.bincount(batch[edge_index[1]], minlength=B).max())
+    return Workload(x, edge_index, edge_attr, batch, instr, glf, B, nmax, emax)
 
 
 class AnswerModel(torch.nn.Module):
@@ -143,7 +145,8 @@ class AnswerModel(torch.nn.Module):
         from . import ops
         if plan is None:
             plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=wl.glf.size(0),
-                                       max_nodes=(wl.max_nodes or None) if use_hints else None)
+                                       max_nodes=(wl.max_nodes or None) if use_hints else None,
+                                       max_edges=(wl.max_edges or None) if use_hints else None)
         h, mask, _, _ = self.gat_seq(x=wl.x, edge_index=wl.edge_index, edge_attr=wl.edge_attr,
                                      instr_vectors=wl.instr[:4], global_language_feats=wl.glf, batch=wl.batch,
                                      return_masks=True, plan=plan, noises=noises, seed=seed)

@@ -142,9 +142,10 @@ def test_message_passing_is_equivariant_to_edge_order(dev):
     # and the kernel is run-to-run deterministic (fixed summation order, no atomics in the data path)
     o3, a3 = ops.gatv2_mp(x_l, x_r, e_proj, att, p1, H)
     assert torch.equal(o1, o3) and torch.equal(a1, a3)
-    # the per-graph (LDS-resident) and node-chunk kernels do the same arithmetic in the same order
+    # the per-graph (LDS-resident) and node-chunk kernels compute the same function in the same summation order;
+    # they differ only in exp / reciprocal (hardware v_exp_f32 / v_rcp_f32 vs libm-accurate forms): ~1e-6 relative
     o4, a4 = ops.gatv2_mp(x_l, x_r, e_proj, att, p1, H, kernel="chunk")
-    assert torch.equal(o1, o4) and torch.equal(a1, a4)
+    assert torch.allclose(a1, a4, atol=2e-6, rtol=1e-5) and torch.allclose(o1, o4, atol=2e-5, rtol=1e-5)
 
 
 def test_unsupported_shapes_are_refused_not_launched(dev):

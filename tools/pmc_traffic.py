@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_mp.py into the per-launch HBM traffic
+of the message-passing kernel, corrected as MI355X_MICROARCH.md §HBM prescribes for gfx950:
+  * both counters are in KiB;
+  * FETCH_SIZE tallies the 128-B requests of wide (16 B/lane) streaming reads at 64 B -> multiply by 2; the factor is
+    re-derived here from the known-size copy in the same run (1 GiB read, 1 GiB written);
+  * WRITE_SIZE is exact for 16 B/lane stores (checked against the same copy).
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [kernel-substring]"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def load(d, counter):
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
+    rows = list(csv.DictReader(open(f[0])))
+    out = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] == counter:
+            out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch_dir, write_dir, out_path = sys.argv[1:4]
+    kern = sys.argv[4] if len(sys.argv) > 4 else "gatv2_mp"
+    fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    copy_f = [v for k, vs in fetch.items() if "copyBuffer" in k for v in vs]
+    copy_w = [v for k, vs in write.items() if "copyBuffer" in k for v in vs]
+    gib_kib = 1 << 20
+    f_scale = gib_kib / (sum(copy_f) / len(copy_f))          # expected 2.0 on gfx950
+    w_scale = gib_kib / (sum(copy_w) / len(copy_w))          # expected 1.0
+    kf = [v for k, vs in fetch.items() if kern in k for v in vs]
+    kw = [v for k, vs in write.items() if kern in k for v in vs]
+    name = [k for k in fetch if kern in k][0]
+    half = len(kf) // 2                                      # profile_mp.py: first half unmasked, second half masked
+    log = open(glob.glob(f"{fetch_dir}/../*fetch*.log")[0]).read() if glob.glob(f"{fetch_dir}/../*fetch*.log") else ""
+    m = re.search(r"N=(\d+) E=(\d+) H=(\d+) C=(\d+) bytes_unmasked=(\d+) bytes_masked=(\d+)", log)
+    res = {
+        "kernel": name.split("(")[0],
+        "fetch_kib_raw": sum(kf[:half]) / half, "write_kib_raw": sum(kw[:half]) / half,
+        "fetch_scale_from_copy": round(f_scale, 4), "write_scale_from_copy": round(w_scale, 4),
+        "hbm_bytes_per_launch": int((sum(kf[:half]) / half * f_scale + sum(kw[:half]) / half * w_scale) * 1024),
+        "hbm_bytes_per_launch_masked": int((sum(kf[half:]) / (len(kf) - half) * f_scale +
+                                            sum(kw[half:]) / (len(kw) - half) * w_scale) * 1024),
+    }
+    if m:
+        res.update(N=int(m.group(1)), E=int(m.group(2)), H=int(m.group(3)), C=int(m.group(4)),
+                   algorithmic_bytes=int(m.group(5)), algorithmic_bytes_masked=int(m.group(6)))
+        res["traffic_over_algorithmic"] = round(res["hbm_bytes_per_launch"] / res["algorithmic_bytes"], 3)
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs})
 wl = synthetic.make_workload(cfg).to(dev)
 N, E, H, C = wl.x.size(0), wl.edge_index.size(1), cfg.heads, cfg.channels
-plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=graphs, max_nodes=wl.max_nodes)
+plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=graphs, max_nodes=wl.max_nodes, max_edges=wl.max_edges)
 g = torch.Generator(device=dev).manual_seed(0)
 x_l = torch.randn(N, H * C, device=dev, generator=g)
 x_r = torch.randn(N, H * C, device=dev, generator=g)
