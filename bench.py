@@ -41,12 +41,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads for the CPU baseline (capped at the host's)")
     ap.add_argument("--no-hints", action="store_true", help="let the plan read Nmax back from the device (one sync)")
     ap.add_argument("--mp-kernel", choices=["graph", "chunk"], default="graph")
+    ap.add_argument("--gemm", choices=["bf16x6", "torch"], default="bf16x6")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sample_graphs: int, seconds: float):
+def cpu_baseline(cfg, sample_graphs: int, seconds: float, threads: int):
     """Oracle (kind 'port') on the host cores: same workload distribution, `sample_graphs` graphs per pass."""
     import torch
     from isubgvqa_amd import synthetic
@@ -61,7 +63,8 @@ def cpu_baseline(cfg, sample_graphs: int, seconds: float):
     gen = torch.Generator().manual_seed(1)
     noises = {i: OS.uniform_to_gumbel(torch.rand(sample_graphs, wl.max_nodes, generator=gen))
               for i, t in enumerate(scfg.masks) if t != 1.0}
-    threads = torch.get_num_threads()
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)       # many-core hosts: small graph ops slow down past a few dozen threads
     with torch.no_grad():
         OM.mgat_pool_classify(sd, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, ocfg, noises)
         t0 = time.perf_counter()
@@ -105,12 +108,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the product path has no CPU fallback"
+    # ISG_BENCH_SINGLE_DEVICE=1 + ISG_BENCH_BACKEND=gloo: rehearse the N>1 code path with every rank on cuda:0
+    # (a one-GPU box cannot form an RCCL communicator with two ranks on one device)
+    if os.environ.get("ISG_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("ISG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     ops.MP_KERNEL = args.mp_kernel
+    ops.GEMM_BACKEND = args.gemm
     cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": args.graphs,
                                       "seed": synthetic.CFG2.seed + rank})
     wl = synthetic.make_workload(cfg).to(dev)
@@ -168,7 +180,7 @@ def main():
                        "nodes_per_gpu": N, "edges_per_gpu": E, "channels": cfg.channels, "heads": cfg.heads,
                        "layers": cfg.layers, "sampler": "gumbel(in-kernel Philox noise)", "k": cfg.sample_k,
                        "parallelism": f"dp{world} (graphs sharded, RCCL all-gather of logits)" if world > 1 else "dp1",
-                       "launch": "eager"},
+                       "launch": "eager", "dense": ("isg_linear_bf16x6 (fp32 via 3-way bf16 split on MFMA)" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
             "roofline": {"bound": "hbm", "kernel": ("gatv2_mp_graph_kernel<2,1>" if args.mp_kernel == "graph" else "gatv2_mp_kernel<4,2>") + " (isg_gatv2_mp_fwd)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
@@ -176,7 +188,7 @@ def main():
                          "avg_launch_us": round(mp_ms * 1e3, 2), "launches_timed": len(durs)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_graphs, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_graphs, args.cpu_seconds, args.cpu_threads)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

@@ -190,6 +190,24 @@ int isg_instr_attn_graphnorm_residual(const float *ins, const float *c, const fl
 int isg_global_attn_pool(const float *xn, const float *q, const int32_t *ptr, const float *node_mask,
                          float *out, float *gate, int64_t B, int32_t C, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense projections (fp32 accuracy on the bf16 matrix cores)
+ * ------------------------------------------------------------------------------------------- */
+
+/* planes[q][row][Kp] (q = 0..2, Kp = K rounded up to 32, zero padded, bf16 bit patterns) with
+ * w[row][k] = planes[0] + planes[1] + planes[2] exactly: each plane is the bf16 rounding of what the previous ones
+ * left.  Weights are static, so this runs once per weight.  w fp32[rows,K]; planes uint16[3*rows*Kp]. */
+int isg_split_bf16x3(const float *w, int64_t rows, int32_t K, uint16_t *planes, void *stream);
+
+/* d[M,N] = act(a[M,K] @ W[N,K]^T + bias):  torch.nn.Linear / PyG Linear (+ the GELU that follows it) as used by
+ * ISubGVQA/models/mgat_v2_conv.py:177,181,259, mgat.py:156, masking.py:137,152, att_pooling.py:62,66.
+ * a fp32 with row stride lda; w_planes from isg_split_bf16x3; bias fp32[N] or NULL; d fp32 with row stride ldd;
+ * act 0 = none, 1 = exact (erf) GELU.  Products are formed from the three bf16 planes of both operands (six MFMA
+ * terms, fp32 accumulate): fp32-level accuracy (rel. rms ~1e-7) at bf16 matrix-core speed.
+ * Requires 4 | K, 4 | lda, a 16-byte aligned. */
+int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const float *bias, float *d, int64_t M, int32_t N,
+                      int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

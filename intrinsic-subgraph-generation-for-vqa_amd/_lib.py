@@ -40,6 +40,9 @@ SIGNATURES = {
                                c_int64, c_int32, c_void_p]),
     "isg_instr_attn_graphnorm_residual": (c_int, [c_void_p] * 7 + [c_double, c_void_p, c_void_p, c_int64, c_int32,
                                                                   c_void_p]),
+    "isg_split_bf16x3": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "isg_linear_bf16x6": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                  c_int32, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

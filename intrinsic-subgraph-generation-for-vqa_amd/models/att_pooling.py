@@ -37,8 +37,8 @@ class GlobalAttention(torch.nn.Module):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         if plan is None:
             plan = ops.GraphPlan.build(batch, None, num_graphs=u.size(0) if size is None else size)
-        xn = self.node_nn(x)                                                             # :62
-        q = self.ques_nn(u)                                                              # :66
+        xn = ops.mlp(self.node_nn, x)                                                    # :62
+        q = ops.mlp(self.ques_nn, u)                                                     # :66
         out, gate = ops.global_attn_pool(xn.contiguous(), q.contiguous(), plan, node_mask)   # :63-73
         if return_mask:
             return out, gate

@@ -66,8 +66,8 @@ class MaskingModel(torch.nn.Module):
         """masking.py:137,151-155 -> [N,1].  ``u_is_per_graph``: u is [B,C] and the caller would have passed
         u[batch]; the reference then indexes ques_nn(u[batch]) with batch AGAIN (quirk Q3), which equals
         ques_nn(u)[batch[batch]] row for row -- computed here without the N-row GEMM."""
-        xn = self.node_nn(x)
-        q = self.ques_nn(u)
+        xn = ops.mlp(self.node_nn, x)
+        q = ops.mlp(self.ques_nn, u)
         return ops.node_gate(xn.contiguous(), q.contiguous(), batch, double_index=u_is_per_graph)
 
     def forward(self, x, u, batch, edge_index, size=None, use_all_instrs=True, plan: Optional[ops.GraphPlan] = None,

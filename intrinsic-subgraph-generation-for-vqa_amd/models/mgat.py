@@ -80,7 +80,7 @@ class MGAT(torch.nn.Module):
                 seed=None if seed is None else seed + i)                                 # :144-154
             if return_attention:
                 edge_attns.append(edge_att)
-            conv_res = self.x_proj[i](conv_res)                                          # :156
+            conv_res = ops.mlp(self.x_proj[i], conv_res)                                 # :156 (Linear+GELU fused)
             tail_mask = None
             if self.use_global_mask:                                                     # :161-162,174-175
                 global_mask = mask if global_mask is None else mask * global_mask

@@ -95,14 +95,14 @@ class MaskingGATv2Conv(torch.nn.Module):
             mask = self.mask(x, imle_att, batch, edge_index, use_all_instrs=False, plan=plan, noise=noise,
                              seed=seed, u_is_per_graph=True)                              # :166-168
 
-        x_l = self.lin_l(x)                                                              # :177
-        x_r = x_l if self.share_weights else self.lin_r(x)                               # :181
+        x_l = ops.linear(x, self.lin_l.weight, self.lin_l.bias)                          # :177
+        x_r = x_l if self.share_weights else ops.linear(x, self.lin_r.weight, self.lin_r.bias)   # :181
         if e_proj is None:
             if edge_attr is None or self.lin_edge is None:
                 raise NotImplementedError("edge_attr=None: MGAT always passes edge features (mgat.py:147)")
             if edge_attr.dim() == 1:
                 edge_attr = edge_attr.view(-1, 1)
-            e_proj = self.lin_edge(edge_attr)                                            # :259
+            e_proj = ops.linear(edge_attr.float().contiguous(), self.lin_edge.weight, None)   # :259
         out, alpha = ops.gatv2_mp(x_l, x_r, e_proj, self.att, plan, H, bias=self.bias, node_mask=mask,
                                   negative_slope=self.negative_slope)                    # :215-232
         if isinstance(return_attention_weights, bool):

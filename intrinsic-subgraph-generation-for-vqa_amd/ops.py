@@ -347,3 +347,59 @@ def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
         out.data_ptr(), gate.data_ptr(), plan.B, C, _stream()), "isg_global_attn_pool")
     return out, gate
+
+
+# ------------------------------------------------------------------------------------------------
+# Dense projections: fp32 accuracy on the bf16 matrix cores (csrc/isg_gemm.hip)
+# ------------------------------------------------------------------------------------------------
+GEMM_BACKEND = "bf16x6"      # "bf16x6": isg_linear_bf16x6; "torch": hipBLASLt fp32 through torch (A/B switch)
+_PLANES = {}                 # id(weight) -> (version, data_ptr, planes): static weights are split once
+
+
+def _weight_planes(weight: Tensor) -> Tensor:
+    key = id(weight)
+    hit = _PLANES.get(key)
+    if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
+        return hit[2]
+    lib = _lib.load()
+    N, K = weight.shape
+    Kp = (K + 31) // 32 * 32
+    planes = torch.empty(3 * N * Kp, dtype=torch.int16, device=weight.device)
+    w = weight.detach()
+    _lib.check(lib.isg_split_bf16x3(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(), _stream()),
+               "isg_split_bf16x3")
+    _PLANES[key] = (weight._version, weight.data_ptr(), planes)
+    return planes
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
+    """act(x @ weight^T + bias), x [M,K] fp32, weight [N,K] (torch Linear layout).  Uses the bf16x6 matrix-core kernel
+    when the shape allows it, hipBLASLt through torch otherwise (K not a multiple of 4)."""
+    M, K = x.shape
+    N = weight.size(0)
+    if GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or M == 0:
+        y = torch.nn.functional.linear(x, weight, bias)
+        return torch.nn.functional.gelu(y) if gelu else y
+    lib = _lib.load()
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    planes = _weight_planes(weight)
+    _lib.check(lib.isg_linear_bf16x6(_chk(x, "x", torch.float32), planes.data_ptr(),
+                                     _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
+                                     out.data_ptr(), M, N, K, K, N, 1 if gelu else 0, _stream()), "isg_linear_bf16x6")
+    return out
+
+
+def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:
+    """Run an nn.Sequential of Linear / GELU / Dropout(eval) modules with every Linear(+GELU) pair as one launch."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Linear) or (hasattr(m, "weight") and hasattr(m, "bias") and m.weight.dim() == 2):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.GELU) and mods[i + 1].approximate == "none"
+            x = linear(x.contiguous(), m.weight, m.bias, gelu=fuse)
+            i += 2 if fuse else 1
+        else:
+            x = m(x)
+            i += 1
+    return x

@@ -152,8 +152,9 @@ class AnswerModel(torch.nn.Module):
                                      return_masks=True, plan=plan, noises=noises, seed=seed)
         embed, gate = self.graph_global_attention_pooling(x=h, u=wl.glf, batch=wl.batch, size=None, return_mask=True,
                                                           node_mask=mask, plan=plan)
-        feats = self.embedding(torch.cat((embed, wl.glf, embed * wl.glf), dim=1))
-        return self.logit_fc(feats), mask, gate
+        from . import ops as _ops
+        feats = _ops.mlp(self.embedding, torch.cat((embed, wl.glf, embed * wl.glf), dim=1))
+        return _ops.linear(feats, self.logit_fc.weight, self.logit_fc.bias), mask, gate
 
 
 def build_answer_model(cfg: WorkloadConfig, weight_seed: int = 0) -> AnswerModel:

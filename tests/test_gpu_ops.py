@@ -308,3 +308,42 @@ def test_per_graph_kernels_match_oracle(dev, C, sizes):
         out, g = ops.global_attn_pool(c.to(dev), q.to(dev), plan, None if mask is None else mask.to(dev))
         assert torch.allclose(g.cpu(), gate, atol=1e-6, rtol=1e-5)
         assert torch.allclose(out.cpu(), ref_out, atol=1e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------- dense projections
+@pytest.mark.parametrize("M,K,N,bias,gelu", [
+    (1000, 128, 512, True, False),      # lin_l / lin_r / lin_edge shape (C=128, H=4)
+    (777, 512, 256, True, True),        # x_proj.0 + GELU, M not a multiple of the 128-row tile
+    (513, 256, 128, True, True),        # x_proj.2
+    (300, 300, 1200, False, False),     # reference width: K = 300 (tail k-tile), N = 1200 (tail n-tile), no bias
+    (129, 1200, 600, True, True),
+    (64, 600, 300, True, False),        # N = 300: not a multiple of 32
+    (5, 384, 512, True, True),          # classifier input width 3C
+    (1, 4, 8, True, False),
+])
+def test_linear_bf16x6_has_fp32_accuracy(dev, M, K, N, bias, gelu):
+    """isg_linear_bf16x6 against an fp64 reference: the 3-way bf16 split must not cost accuracy relative to an fp32 GEMM."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / math.sqrt(K)
+    b = torch.randn(N, generator=gen) if bias else None
+    ref = x.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    wd = w.to(dev)
+    got = ops.linear(x.to(dev), wd, None if b is None else b.to(dev), gelu=gelu).cpu().double()
+    f32 = torch.nn.functional.linear(x, w, b)
+    if gelu:
+        f32 = torch.nn.functional.gelu(f32)
+    err = (got - ref).abs().max().item()
+    err32 = (f32.double() - ref).abs().max().item()
+    assert got.shape == (M, N)
+    assert err <= max(6.0 * err32, 2e-6), (err, err32)     # fp32 accumulation over K in one chain (MFMA) vs blocked
+    # weights are split once and cached; an in-place update must invalidate the cache
+    with torch.no_grad():
+        wd.mul_(2.0)
+    got2 = ops.linear(x.to(dev), wd, None, gelu=False).cpu().double()
+    assert torch.allclose(got2, 2.0 * (x.double() @ w.double().t()), atol=1e-5, rtol=1e-6)
