@@ -7,13 +7,15 @@
 // drop only terms below 2^-24 of the result: fp32-level accuracy (measured rel. rms 1.2e-7 against fp64, vs 2.9e-7 for a
 // plain fp32 GEMM) at 6/16 of the f32-MFMA time.  Each bf16 x bf16 product is exact in the MFMA's fp32 accumulator.
 //
-//   tile    128 x 128 per workgroup (4 waves, 2 x 2; a wave owns 64 x 64 = 2 x 2 MFMA tiles of 32x32), BK = 32
+//   tile    128 x 128 per workgroup (8 waves, 4 x 2; a wave owns 32 x 64 = 1 x 2 MFMA tiles of 32x32), BK = 32;
+//           2 workgroups per CU -> 4 waves per SIMD whose split / LDS / MFMA phases interleave
 //   A       fp32 in HBM, loaded as float4, split into its three bf16 planes in registers (v_cvt_pk_bf16_f32 = RNE),
 //           written to LDS; W is static, so its planes are split once (isg_split_bf16x3) and streamed as bf16
 //   LDS     [plane][row][32 + 8 pad] bf16: 80-byte rows keep the 16-byte fragment reads (ds_read_b128) conflict-free
 //   MFMA    v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8*(l>>5)..+7] and W[n = l&31][same k]; 6 per
 //           (tile, k-step), small terms first
-//   pipeline single LDS buffer + register prefetch: the next tile's global loads are in flight during the 48 MFMAs
+//   pipeline single LDS buffer + TWO register images: a tile's global loads are issued two k-steps ahead and get two
+//           MFMA phases (2 x 24 MFMAs per wave, x 4 waves per SIMD) to land
 //   epilogue acc (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) -> + bias -> optional exact GELU -> 128-byte
 //           row segments
 #include "isg_common.hpp"
@@ -54,107 +56,108 @@ __global__ void split_bf16x3_kernel(const float *__restrict__ w, int rows, int K
 }
 
 template <int ACT>   // 0 none, 1 exact GELU
-__global__ __launch_bounds__(256) void linear_bf16x6_kernel(const float *__restrict__ A, const __bf16 *__restrict__ Wp,
+__global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__restrict__ A, const __bf16 *__restrict__ Wp,
                                                             const float *__restrict__ bias, float *__restrict__ D, int M,
                                                             int N, int K, int Kp, int lda, int ldd) {
   __shared__ __attribute__((aligned(16))) __bf16 sA[3][GM_BM][GM_LD];
   __shared__ __attribute__((aligned(16))) __bf16 sB[3][GM_BN][GM_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave & 3, wn = wave >> 2;
   const int n0 = blockIdx.x * GM_BN, m0 = blockIdx.y * GM_BM;
   const int64_t plane_stride = (int64_t)N * Kp;
 
-  f32x16 acc[2][2];
+  f32x16 acc[1][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 1; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4];     // next A tile: 4 float4 per thread
-  bf16x8 rb[3][2];  // next W tile: 2 x 16 B per plane per thread
+  // two register images (tiles t+1 and t+2): a tile's global loads get two MFMA phases to land
+  float4 ra0[2], ra1[2];        // A: 2 float4 per thread per tile
+  bf16x8 rb0[3], rb1[3];        // W: 16 B per plane per thread per tile
 
   // next tile -> registers (global loads only; the LDS image is written below, in one place, so that every LDS access
   // stays a direct __shared__ access)
-#define GM_LOAD_TILE(k0)                                                                                       \
+#define GM_LOAD_TILE(RA, RB, k0)                                                                                    \
   {                                                                                                            \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                            \
-      const int i = tid + 256 * u;                                                                             \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                            \
+      const int i = tid + 512 * u;                                                                             \
       const int row = i >> 3, c4 = i & 7;                                                                      \
       /* never a conditional load (the compiler would wait for it at once): clamp the address, mask at store time */ \
       const int gr = min(m0 + row, M - 1), gk = min((k0) + c4 * 4, K - 4);                                     \
-      ra[u] = *reinterpret_cast<const float4 *>(A + (int64_t)gr * lda + gk);                                   \
+      RA[u] = *reinterpret_cast<const float4 *>(A + (int64_t)gr * lda + gk);                                   \
     }                                                                                                          \
-    _Pragma("unroll") for (int v = 0; v < 2; ++v) {                                                            \
-      const int j = tid + 256 * v;                                                                             \
-      const int row = j >> 2, c8 = j & 3;                                                                      \
+    {                                                                                                          \
+      const int row = tid >> 2, c8 = tid & 3;                                                                  \
       const int gn = min(n0 + row, N - 1);   /* rows past N repeat the last row; their columns are never stored */ \
       _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                            \
-        rb[q][v] = *reinterpret_cast<const bf16x8 *>(Wp + q * plane_stride + (int64_t)gn * Kp + (k0) + c8 * 8); \
+        RB[q] = *reinterpret_cast<const bf16x8 *>(Wp + q * plane_stride + (int64_t)gn * Kp + (k0) + c8 * 8);   \
     }                                                                                                          \
   }
 
   const int nk = Kp / GM_BK;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
-  GM_LOAD_TILE(0)
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt > 0) __syncthreads();   // everyone is done reading the previous tile
-    // registers -> LDS: split the fp32 A values into their three bf16 planes, copy the W planes
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = tid + 256 * u;
-      const int row = i >> 3, c4 = i & 7;
-      if (m0 + row >= M || kt * GM_BK + c4 * 4 >= K) ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);   // tile tails
-      bf16x4 p0, p1, p2;
-      __bf16 t0, t1, t2;
-      split3(ra[u].x, t0, t1, t2); p0[0] = t0; p1[0] = t1; p2[0] = t2;
-      split3(ra[u].y, t0, t1, t2); p0[1] = t0; p1[1] = t1; p2[1] = t2;
-      split3(ra[u].z, t0, t1, t2); p0[2] = t0; p1[2] = t1; p2[2] = t2;
-      split3(ra[u].w, t0, t1, t2); p0[3] = t0; p1[3] = t1; p2[3] = t2;
-      *reinterpret_cast<bf16x4 *>(&sA[0][row][c4 * 4]) = p0;
-      *reinterpret_cast<bf16x4 *>(&sA[1][row][c4 * 4]) = p1;
-      *reinterpret_cast<bf16x4 *>(&sA[2][row][c4 * 4]) = p2;
-    }
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int j = tid + 256 * v;
-      const int row = j >> 2, c8 = j & 3;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8 *>(&sB[q][row][c8 * 8]) = rb[q][v];
-    }
-    __syncthreads();
-    if (kt + 1 < nk) GM_LOAD_TILE((kt + 1) * GM_BK)   // in flight during the 48 MFMAs below
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          a[i][q] = *reinterpret_cast<const bf16x8 *>(&sA[q][wm * 64 + i * 32 + fr][ks * 16 + fk]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          b[j][q] = *reinterpret_cast<const bf16x8 *>(&sB[q][wn * 64 + j * 32 + fr][ks * 16 + fk]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
-    }
+  // Row-blocks walk K from different starting tiles (wrapping): with a power-of-two row stride every workgroup would
+  // otherwise touch the same 128-byte column of its rows at the same moment, i.e. the same few HBM channels
+  // ("partition camping").  Only the order of the fp32 accumulation changes, deterministically per row-block.
+  const int kshift = (int)(blockIdx.y % (unsigned)nk);
+#define GM_KT(t) ((((t) + kshift) >= nk ? (t) + kshift - nk : (t) + kshift))
+#define GM_STEP(RA, RB, kt)                                                                                    \
+  {                                                                                                            \
+    if ((kt) > 0) __syncthreads(); /* everyone is done reading the previous tile */                            \
+    /* registers -> LDS: split the fp32 A values into their three bf16 planes, copy the W planes */            \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                            \
+      const int i = tid + 512 * u;                                                                             \
+      const int row = i >> 3, c4 = i & 7;                                                                      \
+      if (m0 + row >= M || GM_KT(kt) * GM_BK + c4 * 4 >= K) RA[u] = make_float4(0.f, 0.f, 0.f, 0.f);           \
+      bf16x4 p0, p1, p2;                                                                                       \
+      __bf16 t0, t1, t2;                                                                                       \
+      split3(RA[u].x, t0, t1, t2); p0[0] = t0; p1[0] = t1; p2[0] = t2;                                         \
+      split3(RA[u].y, t0, t1, t2); p0[1] = t0; p1[1] = t1; p2[1] = t2;                                         \
+      split3(RA[u].z, t0, t1, t2); p0[2] = t0; p1[2] = t1; p2[2] = t2;                                         \
+      split3(RA[u].w, t0, t1, t2); p0[3] = t0; p1[3] = t1; p2[3] = t2;                                         \
+      *reinterpret_cast<bf16x4 *>(&sA[0][row][c4 * 4]) = p0;                                                   \
+      *reinterpret_cast<bf16x4 *>(&sA[1][row][c4 * 4]) = p1;                                                   \
+      *reinterpret_cast<bf16x4 *>(&sA[2][row][c4 * 4]) = p2;                                                   \
+    }                                                                                                          \
+    {                                                                                                          \
+      const int row = tid >> 2, c8 = tid & 3;                                                                  \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8 *>(&sB[q][row][c8 * 8]) = RB[q];  \
+    }                                                                                                          \
+    __syncthreads();                                                                                           \
+    if ((kt) + 2 < nk) GM_LOAD_TILE(RA, RB, GM_KT((kt) + 2) * GM_BK) /* lands two MFMA phases from now */      \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
+      bf16x8 a[3], b[2][3];                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                            \
+        a[q] = *reinterpret_cast<const bf16x8 *>(&sA[q][wm * 32 + fr][ks * 16 + fk]);                          \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                          \
+          b[j][q] = *reinterpret_cast<const bf16x8 *>(&sB[q][wn * 64 + j * 32 + fr][ks * 16 + fk]);            \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+        f32x16 c = acc[0][j];                                                                                  \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], c, 0, 0, 0);                                \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], c, 0, 0, 0);                                \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], c, 0, 0, 0);                                \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], c, 0, 0, 0);                                \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], c, 0, 0, 0);                                \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], c, 0, 0, 0);                                \
+        acc[0][j] = c;                                                                                         \
+      }                                                                                                        \
+    }                                                                                                          \
   }
+
+  GM_LOAD_TILE(ra0, rb0, GM_KT(0) * GM_BK)
+  if (nk > 1) GM_LOAD_TILE(ra1, rb1, GM_KT(1) * GM_BK)
+  for (int kt = 0; kt < nk; kt += 2) {
+    GM_STEP(ra0, rb0, kt)
+    if (kt + 1 < nk) GM_STEP(ra1, rb1, kt + 1)
+  }
+#undef GM_STEP
 #undef GM_LOAD_TILE
+#undef GM_KT
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
   const int h = lane >> 5;
@@ -163,10 +166,10 @@ __global__ __launch_bounds__(256) void linear_bf16x6_kernel(const float *__restr
     const int col = n0 + wn * 64 + j * 32 + fr;
     const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 1; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = m0 + wm * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < M && col < N) {
           float v = acc[i][j][r] + bv;
           if (ACT == 1) v = gelu_exact(v);
@@ -203,7 +206,7 @@ extern "C" int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const
   const int Kp = (K + GM_BK - 1) / GM_BK * GM_BK;
   const long long mt = (M + GM_BM - 1) / GM_BM;
   if (mt > 65535) return ISG_EUNSUPPORTED;
-  dim3 grid((unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)mt), block(256);
+  dim3 grid((unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)mt), block(512);
   const __bf16 *wp = reinterpret_cast<const __bf16 *>(w_planes);
   if (act == 1)
     linear_bf16x6_kernel<1><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd);
