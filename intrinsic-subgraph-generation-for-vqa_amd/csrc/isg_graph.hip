@@ -64,29 +64,71 @@ __global__ void csr_hist_kernel(const int64_t *__restrict__ dst, int E, int N, i
   if (d >= 0 && d < N) atomicAdd(&deg[d], 1);
 }
 
-// Exclusive scan of deg[0..N) into rowptr[0..N], one 1024-thread block (N is ~1e5 per batch).
-__global__ __launch_bounds__(1024) void csr_scan_kernel(const int *__restrict__ deg, int N,
-                                                        int *__restrict__ rowptr) {
-  __shared__ int s_part[1024];
-  const int tid = threadIdx.x;
-  const int per = (N + 1023) / 1024;
-  const int beg = min(tid * per, N), end = min(beg + per, N);
-  int sum = 0;
-  for (int i = beg; i < end; ++i) sum += deg[i];
-  s_part[tid] = sum;
+// Exclusive scan of deg[0..N) into rowptr[0..N] in three small launches: per-chunk sums (1024 elements per
+// workgroup), a one-workgroup scan of the chunk sums, per-chunk exclusive scan + offset.
+constexpr int SCAN_CHUNK = 1024;
+
+__device__ __forceinline__ int block_inclusive_scan_256(int v, int *s_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  if (lane == 63) s_wave[wave] = v;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the partials
-    int v = tid >= off ? s_part[tid - off] : 0;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
-  }
-  int run = s_part[tid] - sum;
+  int add = 0;
+  for (int w = 0; w < wave; ++w) add += s_wave[w];
+  __syncthreads();
+  return v + add;
+}
+
+__global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const int *__restrict__ deg, int N, int *__restrict__ sums) {
+  __shared__ int s_wave[4];
+  const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+  int v = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (base + u < N) v += deg[base + u];
+  const int inc = block_inclusive_scan_256(v, s_wave);
+  if (threadIdx.x == 255) sums[blockIdx.x] = inc;
+}
+
+// one workgroup: exclusive scan of up to 256*per chunk sums, in place; total -> *total_out
+__global__ __launch_bounds__(256) void scan_sums_kernel(int *__restrict__ sums, int nchunks, int *__restrict__ total_out) {
+  __shared__ int s_wave[4];
+  const int per = (nchunks + 255) / 256;
+  const int beg = min((int)threadIdx.x * per, nchunks), end = min(beg + per, nchunks);
+  int v = 0;
+  for (int i = beg; i < end; ++i) v += sums[i];
+  const int inc = block_inclusive_scan_256(v, s_wave);
+  int run = inc - v;
   for (int i = beg; i < end; ++i) {
-    rowptr[i] = run;
-    run += deg[i];
+    const int t = sums[i];
+    sums[i] = run;
+    run += t;
   }
-  if (tid == 1023) rowptr[N] = s_part[1023];
+  if (threadIdx.x == 255) *total_out = inc;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int *__restrict__ deg, const int *__restrict__ sums, int N,
+                                                         int *__restrict__ rowptr) {
+  __shared__ int s_wave[4];
+  const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+  int d[4];
+  int v = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    d[u] = base + u < N ? deg[base + u] : 0;
+    v += d[u];
+  }
+  const int inc = block_inclusive_scan_256(v, s_wave);
+  int run = sums[blockIdx.x] + inc - v;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (base + u < N) rowptr[base + u] = run;
+    run += d[u];
+  }
 }
 
 __global__ void csr_fill_kernel(const int64_t *__restrict__ dst, int E, int N, const int *__restrict__ rowptr,
@@ -155,7 +197,7 @@ extern "C" int isg_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t
 
 extern "C" size_t isg_csr_workspace_bytes(int64_t N, int64_t E) {
   if (N < 0 || E < 0) return 0;
-  return (size_t)(2 * (N + 1) + E) * sizeof(int32_t);
+  return (size_t)(2 * (N + 1) + E + (N + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * sizeof(int32_t);
 }
 
 extern "C" int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, int32_t *rowptr, int32_t *eid,
@@ -167,10 +209,15 @@ extern "C" int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, in
   int *deg = (int *)workspace;            // N+1
   int *cursor = deg + (N + 1);            // N+1
   int *eid_tmp = cursor + (N + 1);        // E
+  int *chunk_sums = eid_tmp + E;          // ceil(N / SCAN_CHUNK) + 1
   const int n = (int)N, e = (int)E;
   fill_i32_kernel<<<(2 * (n + 1) + 255) / 256, 256, 0, st>>>(deg, 2 * (n + 1), 0);
   if (e > 0) csr_hist_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index + E, e, n, deg);
-  csr_scan_kernel<<<1, 1024, 0, st>>>(deg, n, rowptr);
+  const int nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  if (nchunks > 256 * 4096) return ISG_EUNSUPPORTED;
+  if (nchunks > 0) scan_chunk_sums_kernel<<<nchunks, 256, 0, st>>>(deg, n, chunk_sums);
+  scan_sums_kernel<<<1, 256, 0, st>>>(chunk_sums, nchunks, rowptr + n);      // rowptr[N] = number of valid edges
+  if (nchunks > 0) scan_apply_kernel<<<nchunks, 256, 0, st>>>(deg, chunk_sums, n, rowptr);
   if (e > 0) {
     csr_fill_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index + E, e, n, rowptr, cursor, eid_tmp);
     csr_rank_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index, e, n, rowptr, eid_tmp, eid, src, dst);

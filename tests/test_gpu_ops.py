@@ -347,3 +347,21 @@ def test_linear_bf16x6_has_fp32_accuracy(dev, M, K, N, bias, gelu):
         wd.mul_(2.0)
     got2 = ops.linear(x.to(dev), wd, None, gelu=False).cpu().double()
     assert torch.allclose(got2, 2.0 * (x.double() @ w.double().t()), atol=1e-5, rtol=1e-6)
+
+
+def test_csr_build_large_batch_scan(dev):
+    """More than 256 scan chunks (N > 262144): every level of the three-launch scan is exercised."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    N, E = 300_017, 700_003
+    dst = torch.randint(0, N, (E,), generator=gen)
+    src = torch.randint(0, N, (E,), generator=gen)
+    ei = torch.stack([src, dst])
+    batch = torch.arange(N) // 37
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=int(batch[-1]) + 1)
+    rowptr = torch.zeros(N + 1, dtype=torch.long)
+    rowptr[1:] = torch.bincount(dst, minlength=N).cumsum(0)
+    assert torch.equal(plan.rowptr.cpu().long(), rowptr)
+    order = torch.sort(dst, stable=True).indices
+    assert torch.equal(plan.eid.cpu().long(), order)
+    assert plan.nmax == 37

@@ -23,7 +23,7 @@ def test_library_exports_every_symbol_in_header():
         assert hasattr(lib, name)
     assert lib.isg_abi_version() == 2
     assert lib.isg_status_string(-2) == b"unsupported shape"
-    assert lib.isg_csr_workspace_bytes(10, 7) == (2 * 11 + 7) * 4
+    assert lib.isg_csr_workspace_bytes(10, 7) == (2 * 11 + 7 + 2) * 4
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
@@ -167,3 +167,23 @@ def test_synthetic_cfg2_shapes():
                                                            nodes_max=200, edges_per_graph=0.0, degree="powerlaw"))
     deg = torch.bincount(wl5.edge_index[1], minlength=wl5.x.size(0))
     assert deg.max() > 8 * deg.float().mean()                            # hubs exist
+
+
+def test_reference_checkpoint_reader_roundtrip(tmp_path):
+    """A checkpoint in the reference's layout (train_loop.py:84-130: DDP 'module.' prefix, pickled Namespace) loads
+    strictly into the drop-in model."""
+    from isubgvqa_amd.checkpoint import load_model, read_checkpoint
+    from isubgvqa_amd.models import build_model
+    torch.manual_seed(3)
+    src = build_model(_args(sampler_type="gumbel"), None)
+    args = _args(sampler_type="gumbel")
+    del args.nb_samples                                   # an older Namespace without this flag
+    path = os.path.join(tmp_path, "checkpoint.pth")
+    torch.save({"model": {"module." + k: v for k, v in src.state_dict().items()}, "optimizer": {"state": {}},
+                "lr_scheduler": {}, "epoch": 7, "args": args}, path)
+    sd, got_args, rest = read_checkpoint(path)
+    assert rest["epoch"] == 7 and got_args.nb_samples == 1 and not any(k.startswith("module.") for k in sd)
+    model, _, _ = load_model(path, device="cpu")
+    assert not model.training
+    for k, v in src.state_dict().items():
+        assert torch.equal(model.state_dict()[k], v), k
