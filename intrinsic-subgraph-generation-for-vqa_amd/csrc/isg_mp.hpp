@@ -17,6 +17,8 @@ struct MpArgs {
   float4 *out;
   float *alpha;
   int N, C, H;
+  int ldl4, ldr4;         // row stride of x_l / x_r in float4 (H*C/4 when dense; larger when they are column
+                          // slices of one fused [N, 2*H*C] projection)
   float slope;
   const int *graph_ptr, *graph_eptr, *dst;   // per-graph kernel only
   int B, lrows;           // graphs; x_l rows of a graph kept in LDS

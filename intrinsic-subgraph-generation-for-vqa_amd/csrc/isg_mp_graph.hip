@@ -22,9 +22,10 @@
 // (phases add up instead of overlapping, SIMDs ~95 % busy).  Hence: every wave-uniform value (slot record, row
 // bases) is forced into SGPRs with readfirstlane, row addresses are scalar base + 32-bit lane offset, the CSR slot
 // is one 16-byte LDS record, exp/reciprocal are the hardware instructions, and there is no fallback code in this
-// kernel: it only runs when EVERY graph of the batch fits the LDS tables (host-checked from the plan's
-// max nodes / max edges per graph); other batches use the node-chunk kernel.  A source id outside its graph
-// (never produced by PyG batching) is clamped into the staged window instead of faulting.
+// kernel: it only runs when EVERY graph of the batch fits the CSR tables (host-checked from the plan's max nodes /
+// max edges per graph); other batches use the node-chunk kernel.  The x_l window holds as many rows as fit 40 KB per
+// workgroup; rows of a larger graph are read from global memory under a wave-uniform branch.  A source id outside
+// its graph (never produced by PyG batching) is clamped into the graph instead of faulting.
 #include "isg_mp.hpp"
 
 #include <stdlib.h>
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
     if (tid <= n) v_rp = a.rowptr[nb + tid] - e0;
     if (tid < ne) {
       const int s = a.src[e0 + tid], e = a.eid[e0 + tid], d = a.dst[e0 + tid];
-      rec.x = min(max(s - nb, 0), rows - 1);   // a source outside the staged window is clamped, never out of bounds
+      rec.x = min(max(s - nb, 0), n - 1);      // a source outside its graph is clamped into it, never out of bounds
       rec.y = e;
       rec.z = d - nb;
       if (MASKED) {
@@ -90,10 +91,10 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
       for (int c = lane; c < RQ; c += 64) {
         float4 v0, v1, v2, v3;
         const int r1 = r0 + GK_WAVES, r2 = r0 + 2 * GK_WAVES, r3 = r0 + 3 * GK_WAVES;
-        v0 = a.x_l[(size_t)(nb + r0) * R + hoff + c];
-        if (r1 < rows) v1 = a.x_l[(size_t)(nb + r1) * R + hoff + c];
-        if (r2 < rows) v2 = a.x_l[(size_t)(nb + r2) * R + hoff + c];
-        if (r3 < rows) v3 = a.x_l[(size_t)(nb + r3) * R + hoff + c];
+        v0 = a.x_l[(size_t)(nb + r0) * a.ldl4 + hoff + c];
+        if (r1 < rows) v1 = a.x_l[(size_t)(nb + r1) * a.ldl4 + hoff + c];
+        if (r2 < rows) v2 = a.x_l[(size_t)(nb + r2) * a.ldl4 + hoff + c];
+        if (r3 < rows) v3 = a.x_l[(size_t)(nb + r3) * a.ldl4 + hoff + c];
         s_xl[r0 * RQ + c] = v0;
         if (r1 < rows) s_xl[r1 * RQ + c] = v1;
         if (r2 < rows) s_xl[r2 * RQ + c] = v2;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
         jl[u] = uni(rec.x);
         me[u] = unif(__int_as_float(rec.w));
         const float4 *ep = a.e_proj + (size_t)uni(rec.y) * R + hoff;
-        const float4 *xr = a.x_r + (size_t)(nb + uni(rec.z)) * R + hoff;
+        const float4 *xr = a.x_r + (size_t)(nb + uni(rec.z)) * a.ldr4 + hoff;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (ok[p]) {
@@ -145,12 +146,17 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
 #pragma unroll
       for (int u = 0; u < GK_U; ++u) {
         const int t = tb + u;
-        const float4 *xl_s = s_xl + jl[u] * RQ;
+        // rows of a graph larger than the LDS window (rare: the window is sized for 4 workgroups per CU) come
+        // from global memory; LDS read from a clamped row first, override under a wave-uniform branch
+        const bool in_lds = jl[u] < rows;
+        const float4 *xl_s = s_xl + (in_lds ? jl[u] : 0) * RQ;
         float part = 0.f;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (ok[p]) {
-            const float4 v = epv[u][p], r4 = xrv[u][p], w4 = xl_s[off[p]];
+            const float4 v = epv[u][p], r4 = xrv[u][p];
+            float4 w4 = xl_s[off[p]];
+            if (!in_lds) w4 = a.x_l[(size_t)(nb + jl[u]) * a.ldl4 + hoff + off[p]];
             float4 s;
             s.x = (r4.x + w4.x) + v.x;
             s.y = (r4.y + w4.y) + v.y;
@@ -190,11 +196,14 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
         const float w = __builtin_amdgcn_exp2f((s_lg[t * HS + grp] - mx) * 1.4426950408889634f) * rden;
         if (l == 0) a.alpha[(size_t)uni(rec.y) * a.H + hd] = w;
         const float wm = MASKED ? __fmul_rn(w, unif(__int_as_float(rec.w))) : w;
-        const float4 *xl_s = s_xl + uni(rec.x) * RQ;
+        const int jl = uni(rec.x);
+        const bool in_lds = jl < rows;
+        const float4 *xl_s = s_xl + (in_lds ? jl : 0) * RQ;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (ok[p]) {
-            const float4 u4 = xl_s[off[p]];
+            float4 u4 = xl_s[off[p]];
+            if (!in_lds) u4 = a.x_l[(size_t)(nb + jl) * a.ldl4 + hoff + off[p]];
             acc[p].x = __fadd_rn(acc[p].x, __fmul_rn(u4.x, wm));
             acc[p].y = __fadd_rn(acc[p].y, __fmul_rn(u4.y, wm));
             acc[p].z = __fadd_rn(acc[p].z, __fmul_rn(u4.z, wm));
@@ -249,9 +258,14 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   if (P > 2) return ISG_EUNSUPPORTED;
   const size_t row_bytes = (size_t)HS * a.C * 4;
   const size_t static_bytes = GK_ECAP * 16 + (size_t)GK_ECAP * HS * 4 + (GK_NCAP + 4) * 4;
-  const size_t dyn = (size_t)nmax_host * row_bytes;       // every row of every graph is staged
-  if (static_bytes + dyn > 64 * 1024) return ISG_EUNSUPPORTED;   // keep at least 2 workgroups per CU
-  a.lrows = nmax_host;
+  // LDS window: as many rows as fit 40 KB per workgroup (4 workgroups = 32 waves per CU), never more than the
+  // largest graph needs; rows beyond the window are read from global memory
+  const char *kb = getenv("ISG_MP_LDS_KB");
+  const size_t budget = (size_t)(kb ? atoi(kb) : 40) * 1024;
+  if (budget < static_bytes + 8 * row_bytes) return ISG_EUNSUPPORTED;
+  a.lrows = (int)((budget - static_bytes) / row_bytes);
+  if (a.lrows > nmax_host) a.lrows = nmax_host;
+  const size_t dyn = (size_t)a.lrows * row_bytes;
 #define ISG_GK(hs, p) if (HS == hs && P == p) return launch_one<hs, p>(a, dyn, st)
   ISG_GK(1, 1); ISG_GK(1, 2);
   ISG_GK(2, 1); ISG_GK(2, 2);

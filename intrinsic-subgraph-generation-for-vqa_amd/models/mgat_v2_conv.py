@@ -95,8 +95,10 @@ class MaskingGATv2Conv(torch.nn.Module):
             mask = self.mask(x, imle_att, batch, edge_index, use_all_instrs=False, plan=plan, noise=noise,
                              seed=seed, u_is_per_graph=True)                              # :166-168
 
-        x_l = ops.linear(x, self.lin_l.weight, self.lin_l.bias)                          # :177
-        x_r = x_l if self.share_weights else ops.linear(x, self.lin_r.weight, self.lin_r.bias)   # :181
+        if self.share_weights:
+            x_l = x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias)                # :177-179
+        else:   # lin_l and lin_r share their input: one [N, 2*H*C] projection, x_l / x_r are its column halves
+            x_l, x_r = ops.linear_fused(x, (self.lin_l, self.lin_r))                     # :177,181
         if e_proj is None:
             if edge_attr is None or self.lin_edge is None:
                 raise NotImplementedError("edge_attr=None: MGAT always passes edge features (mgat.py:147)")

@@ -63,6 +63,17 @@ def _chk(t: Optional[Tensor], name: str, dtype, shape=None, optional=False) -> i
     return t.data_ptr()
 
 
+def _chk_rows(t: Tensor, name: str) -> int:
+    """Like _chk for a 2-D fp32 tensor whose rows may be strided (columns contiguous, 16-byte aligned rows)."""
+    if not t.is_cuda:
+        raise _lib.IsgError(f"{name} must live on the GPU (got {t.device}); this path has no CPU fallback")
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or (t.stride(0) & 3) or (t.data_ptr() & 15):
+        raise ValueError(f"{name}: expected fp32 [rows, cols] with contiguous columns and 16-byte aligned rows")
+    if torch.is_grad_enabled() and t.requires_grad:
+        raise NotImplementedError(f"{name} requires grad: the HIP path is forward-only")
+    return t.data_ptr()
+
+
 def _f32(t: Tensor) -> Tensor:
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
@@ -181,6 +192,10 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
     E = plan.E
     if N != plan.N or H * C != HC:
         raise ValueError(f"x_l {tuple(x_l.shape)} does not match plan N={plan.N} / heads={H}")
+    # x_l / x_r may be column slices of one fused [N, 2*H*C] projection: rows strided, columns contiguous
+    ld_l, ld_r = x_l.stride(0), x_r.stride(0)
+    if x_l.stride(1) != 1 or x_r.stride(1) != 1 or tuple(x_r.shape) != (N, HC):
+        raise ValueError("x_l / x_r must be [N, H*C] with contiguous columns")
     out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     use_graph = (kernel or MP_KERNEL) == "graph" and plan.B > 0 and plan.nmax > 0
@@ -189,7 +204,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None})
         ev0.record()
     _lib.check(lib.isg_gatv2_mp_fwd(
-        _chk(x_l, "x_l", torch.float32), _chk(x_r, "x_r", torch.float32, (N, HC)),
+        _chk_rows(x_l, "x_l"), _chk_rows(x_r, "x_r"),
         _chk(e_proj, "e_proj", torch.float32, (E, HC)), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
         _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
         plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
@@ -198,7 +213,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         out.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope),
         plan.ptr.data_ptr() if use_graph else 0, plan.eptr.data_ptr() if use_graph else 0,
         plan.dst.data_ptr() if use_graph else 0, plan.B,
-        plan.nmax if use_graph else 0, plan.emax if use_graph else 0, _stream()), "isg_gatv2_mp_fwd")
+        plan.nmax if use_graph else 0, plan.emax if use_graph else 0, ld_l, ld_r, _stream()), "isg_gatv2_mp_fwd")
     if timer is not None:
         ev1.record()
     return out, alpha
@@ -403,3 +418,28 @@ def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:
             x = m(x)
             i += 1
     return x
+
+
+_CAT = {}   # (ids of the weights) -> (versions, concatenated weight, concatenated bias)
+
+
+def linear_fused(x: Tensor, layers) -> Tuple[Tensor, ...]:
+    """Several Linear layers that share their input as ONE projection (weights concatenated along the output dim, cached);
+    returns one column-slice view of the fused output per layer (row stride = total width)."""
+    key = tuple(id(m.weight) for m in layers)
+    ver = tuple((m.weight._version, m.weight.data_ptr(), None if m.bias is None else m.bias._version) for m in layers)
+    hit = _CAT.get(key)
+    if hit is None or hit[0] != ver:
+        w = torch.cat([m.weight.detach() for m in layers], dim=0).contiguous()
+        has_b = any(m.bias is not None for m in layers)
+        b = torch.cat([m.bias.detach() if m.bias is not None else torch.zeros(m.weight.size(0), device=w.device)
+                       for m in layers]) if has_b else None
+        hit = (ver, w, b)
+        _CAT[key] = hit
+    y = linear(x, hit[1], hit[2])
+    outs, o = [], 0
+    for m in layers:
+        n = m.weight.size(0)
+        outs.append(y[:, o:o + n])
+        o += n
+    return tuple(outs)

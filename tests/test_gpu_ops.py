@@ -83,7 +83,9 @@ MP_CASES = [
     (4, 32, [40, 6], 1.0, (0, 200), "node"),           # in-degree 200+: logits overflow the LDS strip
     (4, 16, [40, 6], 1.0, (0, 1500), None),            # >1024 CSR slots in one workgroup's chunk
     (4, 512, [6, 3], 2.0, None, None),                 # widest supported head (P = 8)
-    (4, 128, [70, 3, 45], 1.5, None, "node"),          # graphs larger than the LDS window (rows read from global)
+    (4, 128, [70, 3, 45], 1.5, None, "node"),          # a graph beyond the per-graph kernel's tables -> node-chunk kernel
+    (4, 128, [50, 3, 60], 1.5, None, "node"),          # per-graph kernel, graphs larger than its 33-row LDS window
+    (4, 128, [50, 3, 60], 1.5, None, None),
 ]
 
 
