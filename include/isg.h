@@ -95,8 +95,9 @@ int isg_node_to_edge_mask(const float *node_mask, const int64_t *edge_index, int
  * m_e = edge_mask[e] if given, else node_mask[j]*node_mask[i] if given, else 1.
  * x_l,x_r fp32[N,H*C]; e_proj fp32[E,H*C] (ORIGINAL edge order); att fp32[H*C]; bias fp32[H*C]|NULL;
  * rowptr/eid/src from isg_csr_build; out fp32[N,H*C]; alpha fp32[E,H] (ORIGINAL edge order).
- * ld_l / ld_r: row stride of x_l / x_r in floats (0 = dense H*C); lets both be column slices of one fused
- * [N, 2*H*C] projection (lin_l and lin_r share their input).
+ * ld_l / ld_r / ld_e: row stride of x_l / x_r / e_proj in floats (0 = dense H*C); lets x_l and x_r be column slices
+ * of one fused [N, 2*H*C] projection (lin_l and lin_r share their input) and e_proj a slice of one [E, L*H*C]
+ * projection (every layer's lin_edge reads the same edge_attr, mgat.py:144-148).
  * H in {1,2,4,8}; 4 | C; C/4 <= 8*(64/H).  Isolated targets get 0 (+bias).
  * graph_ptr (optional, int32[B+1] from isg_graph_ptr) together with graph_eptr (isg_graph_edge_ptr), dst (int32[E]
  * from isg_csr_build) and host bounds nmax_host / emax_host (max nodes / edges of any graph, > 0) selects the
@@ -109,7 +110,7 @@ int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, co
                      const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
                      int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
                      const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
-                     int32_t emax_host, int32_t ld_l, int32_t ld_r, void *stream);
+                     int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e, void *stream);
 
 /* out[i,:] = sum_{e: dst(e)=i} msg[e,:] / max(deg(i),1)       torch_scatter.scatter_mean at
  * ISubGVQA/models/scene_graph_encoder.py:141.  msg fp32[E,C] (original edge order); out fp32[N,C]. */

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(MP_WAVES * 64) void gatv2_mp_kernel(MpArgs a) {
       if (mode == 1) me = a.node_mask[j] * mi;
       else if (mode == 2) me = a.edge_mask[e];
       const float4 *xl = a.x_l + (size_t)j * a.ldl4;
-      const float4 *ep = a.e_proj + (size_t)e * R;
+      const float4 *ep = a.e_proj + (size_t)e * a.lde4;
       float part = 0.f;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -253,15 +253,16 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
                                 const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
                                 int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
                                 const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
-                                int32_t emax_host, int32_t ld_l, int32_t ld_r, void *stream) {
+                                int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e, void *stream) {
   if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
   if (N == 0) return ISG_OK;
   if (!x_l || !x_r || !att || !rowptr || !out || (E > 0 && (!e_proj || !eid || !src || !alpha))) return ISG_EINVAL;
   if ((C & 3) != 0 || N >= (1ll << 31) || E >= (1ll << 31)) return ISG_EUNSUPPORTED;
   if (ld_l == 0) ld_l = H * C;
   if (ld_r == 0) ld_r = H * C;
-  if (ld_l < H * C || ld_r < H * C) return ISG_EINVAL;
-  if ((ld_l & 3) != 0 || (ld_r & 3) != 0) return ISG_EUNSUPPORTED;
+  if (ld_e == 0) ld_e = H * C;
+  if (ld_l < H * C || ld_r < H * C || ld_e < H * C) return ISG_EINVAL;
+  if ((ld_l & 3) != 0 || (ld_r & 3) != 0 || (ld_e & 3) != 0) return ISG_EUNSUPPORTED;
   MpArgs a;
   a.x_l = (const float4 *)x_l; a.x_r = (const float4 *)x_r; a.e_proj = (const float4 *)e_proj;
   a.att = (const float4 *)att; a.bias = (const float4 *)bias;
@@ -269,7 +270,7 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
   a.node_mask = node_mask; a.edge_mask = edge_mask;
   a.out = (float4 *)out; a.alpha = alpha;
   a.N = (int)N; a.C = C; a.H = H; a.slope = negative_slope;
-  a.ldl4 = ld_l >> 2; a.ldr4 = ld_r >> 2;
+  a.ldl4 = ld_l >> 2; a.ldr4 = ld_r >> 2; a.lde4 = ld_e >> 2;
   a.graph_ptr = graph_ptr; a.graph_eptr = graph_eptr; a.dst = dst; a.B = (int)B; a.lrows = 0;
   {
     const char *f = getenv("ISG_MP_FLAGS");   // experiment switch; default = tuned setting

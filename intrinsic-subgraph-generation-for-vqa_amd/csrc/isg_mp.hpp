@@ -17,6 +17,8 @@ struct MpArgs {
   float4 *out;
   float *alpha;
   int N, C, H;
+  int lde4;               // row stride of e_proj in float4 (H*C/4 when dense; L*H*C/4 when the layers' lin_edge
+                          // projections are one fused [E, L*H*C] GEMM)
   int ldl4, ldr4;         // row stride of x_l / x_r in float4 (H*C/4 when dense; larger when they are column
                           // slices of one fused [N, 2*H*C] projection)
   float slope;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
         const int4 rec = s_tab[t];
         jl[u] = uni(rec.x);
         me[u] = unif(__int_as_float(rec.w));
-        const float4 *ep = a.e_proj + (size_t)uni(rec.y) * R + hoff;
+        const float4 *ep = a.e_proj + (size_t)uni(rec.y) * a.lde4 + hoff;
         const float4 *xr = a.x_r + (size_t)(nb + uni(rec.z)) * a.ldr4 + hoff;
 #pragma unroll
         for (int p = 0; p < P; ++p) {

@@ -69,6 +69,8 @@ class MGAT(torch.nn.Module):
         mask = None
         global_mask = None
         edge_attns = []
+        # (Batching the layers' lin_edge projections into one [E, L*H*C] GEMM was measured: it saves ~60 us of GEMM time
+        #  per step and costs the same in the message-passing kernel, whose e_proj rows are then L*H*C*4 bytes apart.)
         for i in range(len(self.convs)):
             ins = instr_vectors[i].contiguous()
             if explainer:

@@ -193,9 +193,9 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
     if N != plan.N or H * C != HC:
         raise ValueError(f"x_l {tuple(x_l.shape)} does not match plan N={plan.N} / heads={H}")
     # x_l / x_r may be column slices of one fused [N, 2*H*C] projection: rows strided, columns contiguous
-    ld_l, ld_r = x_l.stride(0), x_r.stride(0)
-    if x_l.stride(1) != 1 or x_r.stride(1) != 1 or tuple(x_r.shape) != (N, HC):
-        raise ValueError("x_l / x_r must be [N, H*C] with contiguous columns")
+    ld_l, ld_r, ld_e = x_l.stride(0), x_r.stride(0), (e_proj.stride(0) if E > 0 else HC)
+    if x_l.stride(1) != 1 or x_r.stride(1) != 1 or tuple(x_r.shape) != (N, HC) or tuple(e_proj.shape) != (E, HC):
+        raise ValueError("x_l / x_r must be [N, H*C] and e_proj [E, H*C], columns contiguous")
     out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     use_graph = (kernel or MP_KERNEL) == "graph" and plan.B > 0 and plan.nmax > 0
@@ -205,7 +205,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         ev0.record()
     _lib.check(lib.isg_gatv2_mp_fwd(
         _chk_rows(x_l, "x_l"), _chk_rows(x_r, "x_r"),
-        _chk(e_proj, "e_proj", torch.float32, (E, HC)), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+        _chk_rows(e_proj, "e_proj") if E > 0 else 0, _chk(att.reshape(-1), "att", torch.float32, (HC,)),
         _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
         plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
@@ -213,7 +213,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         out.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope),
         plan.ptr.data_ptr() if use_graph else 0, plan.eptr.data_ptr() if use_graph else 0,
         plan.dst.data_ptr() if use_graph else 0, plan.B,
-        plan.nmax if use_graph else 0, plan.emax if use_graph else 0, ld_l, ld_r, _stream()), "isg_gatv2_mp_fwd")
+        plan.nmax if use_graph else 0, plan.emax if use_graph else 0, ld_l, ld_r, ld_e, _stream()), "isg_gatv2_mp_fwd")
     if timer is not None:
         ev1.record()
     return out, alpha
