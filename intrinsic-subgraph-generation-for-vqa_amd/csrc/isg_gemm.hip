@@ -16,8 +16,8 @@
 //           (tile, k-step), small terms first
 //   pipeline single LDS buffer + TWO register images: a tile's global loads are issued two k-steps ahead and get two
 //           MFMA phases (2 x 24 MFMAs per wave, x 4 waves per SIMD) to land
-//   epilogue acc (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) -> + bias -> optional exact GELU -> 128-byte
-//           row segments
+//   epilogue acc (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) -> + bias -> optional exact GELU -> transposed
+//           through a per-wave LDS patch -> 16-byte-per-lane row stores
 #include "isg_common.hpp"
 
 namespace isg {
@@ -159,24 +159,44 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
 #undef GM_LOAD_TILE
 #undef GM_KT
 
-  // ---- epilogue ----------------------------------------------------------------------------------------------------
+  // ---- epilogue: + bias, optional GELU, then each 32x32 accumulator tile goes through a private LDS patch so that the
+  //      global stores are 16 bytes per lane along a row (4 store instructions per tile instead of 16 dword stores) ----
+  __syncthreads();   // every wave is done with the operand tiles: the LDS is free
+  float *patch = reinterpret_cast<float *>(&sA[0][0][0]) + wave * (32 * 36);   // [32][32 + 4 pad] floats per wave
   const int h = lane >> 5;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + fr;
+    const int colb = n0 + wn * 64 + j * 32;
+    const int col = colb + fr;
     const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 1; ++i) {
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[0][j][r] + bv;
+      if (ACT == 1) v = gelu_exact(v);
+      patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + fr] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int rowb = m0 + wm * 32;
+    const bool vec_ok = (ldd & 3) == 0 && colb + 32 <= N && (reinterpret_cast<uintptr_t>(D) & 15) == 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < M && col < N) {
-          float v = acc[i][j][r] + bv;
-          if (ACT == 1) v = gelu_exact(v);
-          D[(int64_t)row * ldd + col] = v;
+    for (int q = 0; q < 4; ++q) {
+      const int idx = q * 64 + lane;
+      const int rr = idx >> 3, c4 = idx & 7;
+      const float4 v = *reinterpret_cast<const float4 *>(&patch[rr * 36 + c4 * 4]);
+      const int row = rowb + rr;
+      if (row < M) {
+        float *dst = D + (int64_t)row * ldd + colb + c4 * 4;
+        if (vec_ok) {
+          *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+          if (colb + c4 * 4 + 0 < N) dst[0] = v.x;
+          if (colb + c4 * 4 + 1 < N) dst[1] = v.y;
+          if (colb + c4 * 4 + 2 < N) dst[2] = v.z;
+          if (colb + c4 * 4 + 3 < N) dst[3] = v.w;
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
