@@ -20,6 +20,8 @@
 //           through a per-wave LDS patch -> 16-byte-per-lane row stores
 #include "isg_common.hpp"
 
+#include <stdlib.h>
+
 namespace isg {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -32,6 +34,11 @@ constexpr int GM_LD = GM_BK + 8;   // bf16 elements per LDS row (80 bytes)
 __device__ __forceinline__ float bf16_to_f32(__bf16 v) {
   return __uint_as_float(((unsigned)__builtin_bit_cast(unsigned short, v)) << 16);
 }
+
+// keep a value alive without using it (ablation builds only)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void keep(const float4 &v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+__device__ __forceinline__ void keep(const bf16x8 &v) { asm volatile("" ::"v"(__builtin_bit_cast(i32x4, v))); }
 
 // x -> (x1, x2, x3), xk = bf16(remainder)
 __device__ __forceinline__ void split3(float x, __bf16 &p1, __bf16 &p2, __bf16 &p3) {
@@ -55,7 +62,9 @@ __global__ void split_bf16x3_kernel(const float *__restrict__ w, int rows, int K
   planes[2 * total + idx] = p3;
 }
 
-template <int ACT>   // 0 none, 1 exact GELU
+// DBG: compile-time ablation switches for profiling (outputs wrong unless 0): 1 no MFMA, 2 no fragment reads,
+// 4 no split / LDS stores, 8 no in-loop global loads, 16 no epilogue stores
+template <int ACT, int DBG>   // ACT: 0 none, 1 exact GELU
 __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__restrict__ A, const __bf16 *__restrict__ Wp,
                                                             const float *__restrict__ bias, float *__restrict__ D, int M,
                                                             int N, int K, int Kp, int lda, int ldd) {
@@ -109,7 +118,11 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
   {                                                                                                            \
     if ((kt) > 0) __syncthreads(); /* everyone is done reading the previous tile */                            \
     /* registers -> LDS: split the fp32 A values into their three bf16 planes, copy the W planes */            \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                            \
+    if constexpr (DBG & 4) {                                                                                   \
+      keep(RA[0]);                                                                                             \
+      keep(RA[1]);                                                                                             \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) keep(RB[q]);                                               \
+    } else _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                     \
       const int i = tid + 512 * u;                                                                             \
       const int row = i >> 3, c4 = i & 7;                                                                      \
       if (m0 + row >= M || GM_KT(kt) * GM_BK + c4 * 4 >= K) RA[u] = make_float4(0.f, 0.f, 0.f, 0.f);           \
@@ -123,20 +136,27 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
       *reinterpret_cast<bf16x4 *>(&sA[1][row][c4 * 4]) = p1;                                                   \
       *reinterpret_cast<bf16x4 *>(&sA[2][row][c4 * 4]) = p2;                                                   \
     }                                                                                                          \
-    {                                                                                                          \
+    if constexpr (!(DBG & 4)) {                                                                                \
       const int row = tid >> 2, c8 = tid & 3;                                                                  \
       _Pragma("unroll") for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8 *>(&sB[q][row][c8 * 8]) = RB[q];  \
     }                                                                                                          \
     __syncthreads();                                                                                           \
-    if ((kt) + 2 < nk) GM_LOAD_TILE(RA, RB, GM_KT((kt) + 2) * GM_BK) /* lands two MFMA phases from now */      \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
+    if constexpr (!(DBG & 8))                                                                                  \
+      if ((kt) + 2 < nk) GM_LOAD_TILE(RA, RB, GM_KT((kt) + 2) * GM_BK) /* lands two MFMA phases from now */    \
+    if constexpr (!(DBG & 2)) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                               \
       bf16x8 a[3], b[2][3];                                                                                    \
       _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                            \
         a[q] = *reinterpret_cast<const bf16x8 *>(&sA[q][wm * 32 + fr][ks * 16 + fk]);                          \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
         _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                          \
           b[j][q] = *reinterpret_cast<const bf16x8 *>(&sB[q][wn * 64 + j * 32 + fr][ks * 16 + fk]);            \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+      if constexpr (DBG & 1) {                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                        \
+          keep(a[q]);                                                                                          \
+          keep(b[0][q]);                                                                                       \
+          keep(b[1][q]);                                                                                       \
+        }                                                                                                      \
+      } else _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
         f32x16 c = acc[0][j];                                                                                  \
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], c, 0, 0, 0);                                \
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], c, 0, 0, 0);                                \
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
       const int rr = idx >> 3, c4 = idx & 7;
       const float4 v = *reinterpret_cast<const float4 *>(&patch[rr * 36 + c4 * 4]);
       const int row = rowb + rr;
-      if (row < M) {
+      if ((DBG & 16) ? (row < 0) : (row < M)) {
         float *dst = D + (int64_t)row * ldd + colb + c4 * 4;
         if (vec_ok) {
           *reinterpret_cast<float4 *>(dst) = v;
@@ -228,9 +248,16 @@ extern "C" int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const
   if (mt > 65535) return ISG_EUNSUPPORTED;
   dim3 grid((unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)mt), block(512);
   const __bf16 *wp = reinterpret_cast<const __bf16 *>(w_planes);
+#ifdef ISG_GEMM_ABLATION   // profiling build only (tools/build_ablation.sh): select a compile-time ablated variant by env
+  const char *dv = getenv("ISG_GEMM_DBG");
+  const int dbg = dv ? atoi(dv) : 0;
+#define ISG_DBG_CASE(v) if (dbg == v) { linear_bf16x6_kernel<0, v><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd); return check_launch(); }
+  ISG_DBG_CASE(1) ISG_DBG_CASE(3) ISG_DBG_CASE(7) ISG_DBG_CASE(15) ISG_DBG_CASE(16) ISG_DBG_CASE(31) ISG_DBG_CASE(8) ISG_DBG_CASE(4)
+#undef ISG_DBG_CASE
+#endif
   if (act == 1)
-    linear_bf16x6_kernel<1><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd);
+    linear_bf16x6_kernel<1, 0><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd);
   else
-    linear_bf16x6_kernel<0><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd);
+    linear_bf16x6_kernel<0, 0><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd);
   return check_launch();
 }
