@@ -103,7 +103,7 @@ int isg_node_to_edge_mask(const float *node_mask, const int64_t *edge_index, int
  * from isg_csr_build) and host bounds nmax_host / emax_host (max nodes / edges of any graph, > 0) selects the
  * per-graph kernel that keeps a graph's x_l rows in LDS (x_l, x_r, out touch HBM once per row).  It requires the
  * PyG batch layout (a graph's nodes contiguous, edges inside their graph) and is used only when every graph fits its
- * LDS tables (<= 64 nodes, <= 256 edges, rows within 64 KB); otherwise, or with graph_ptr == NULL, the node-chunk
+ * LDS tables (<= 256 nodes, <= 1024 edges per graph); otherwise, or with graph_ptr == NULL, the node-chunk
  * kernel runs.  Both compute the same function (alpha to ~1e-6 relative: hardware exp2/rcp in the per-graph form). */
 int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
                      const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,

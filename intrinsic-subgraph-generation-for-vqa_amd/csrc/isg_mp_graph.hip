@@ -23,7 +23,8 @@
 // bases) is forced into SGPRs with readfirstlane, row addresses are scalar base + 32-bit lane offset, the CSR slot
 // is one 16-byte LDS record, exp/reciprocal are the hardware instructions, and there is no fallback code in this
 // kernel: it only runs when EVERY graph of the batch fits the CSR tables (host-checked from the plan's max nodes /
-// max edges per graph); other batches use the node-chunk kernel.  The x_l window holds as many rows as fit 40 KB per
+// max edges per graph; two table sizes are instantiated: 64 nodes / 256 edges and 256 nodes / 1024 edges); other
+// batches use the node-chunk kernel.  The x_l window holds as many rows as fit 40 KB per
 // workgroup; rows of a larger graph are read from global memory under a wave-uniform branch.  A source id outside
 // its graph (never produced by PyG batching) is clamped into the graph instead of faulting.
 #include "isg_mp.hpp"
@@ -34,8 +35,10 @@ namespace isg {
 
 constexpr int GK_WAVES = 8;
 constexpr int GK_THREADS = GK_WAVES * 64;
-constexpr int GK_NCAP = 64;    // nodes per graph this kernel accepts
-constexpr int GK_ECAP = 256;   // CSR slots per graph this kernel accepts
+// table sizes (nodes, CSR slots per graph) of the two instantiations: scene-graph sized batches, and skewed batches
+// with hubs (BASELINE configs[4]: up to 200 nodes); the small one leaves more LDS for x_l rows
+constexpr int GK_NCAP_S = 64, GK_ECAP_S = 256;
+constexpr int GK_NCAP_L = 256, GK_ECAP_L = 1024;
 constexpr int GK_U = 4;        // slots a wave has in flight in phase B
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -43,7 +46,7 @@ __device__ __forceinline__ float unif(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
-template <int HS, int P, bool MASKED, bool EXACT>
+template <int HS, int P, bool MASKED, bool EXACT, int GK_NCAP, int GK_ECAP>
 __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
   constexpr int G = 64 / HS;
   extern __shared__ __attribute__((aligned(16))) float4 s_xl[];   // [lrows][HS*Q]
@@ -69,19 +72,25 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
 
   // ---- phase A: stage (loads first, LDS stores after) ------------------------------------------------------------
   {
-    int4 rec = make_int4(0, 0, 0, __float_as_int(1.f));
+    constexpr int RECS = (GK_ECAP + GK_THREADS - 1) / GK_THREADS;   // CSR records per thread
+    int4 rec[RECS];
     int v_rp = 0;
     if (tid <= n) v_rp = a.rowptr[nb + tid] - e0;
-    if (tid < ne) {
-      const int s = a.src[e0 + tid], e = a.eid[e0 + tid], d = a.dst[e0 + tid];
-      rec.x = min(max(s - nb, 0), n - 1);      // a source outside its graph is clamped into it, never out of bounds
-      rec.y = e;
-      rec.z = d - nb;
-      if (MASKED) {
-        float me;
-        if (a.edge_mask) me = a.edge_mask[e];
-        else me = a.node_mask[s] * a.node_mask[d];      // NodeMaskToEdgeMask, fused
-        rec.w = __float_as_int(me);
+#pragma unroll
+    for (int k = 0; k < RECS; ++k) {
+      const int t = tid + k * GK_THREADS;
+      rec[k] = make_int4(0, 0, 0, __float_as_int(1.f));
+      if (t < ne) {
+        const int s = a.src[e0 + t], e = a.eid[e0 + t], d = a.dst[e0 + t];
+        rec[k].x = min(max(s - nb, 0), n - 1);   // a source outside its graph is clamped into it, never out of bounds
+        rec[k].y = e;
+        rec[k].z = d - nb;
+        if (MASKED) {
+          float me;
+          if (a.edge_mask) me = a.edge_mask[e];
+          else me = a.node_mask[s] * a.node_mask[d];    // NodeMaskToEdgeMask, fused
+          rec[k].w = __float_as_int(me);
+        }
       }
     }
     // x_l slice: wave w copies rows w, w+8, ...; a lane covers columns lane, lane+64, ... of the slice
@@ -102,7 +111,9 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
       }
     }
     if (tid <= n) s_rowptr[tid] = v_rp;
-    if (tid < ne) s_tab[tid] = rec;
+#pragma unroll
+    for (int k = 0; k < RECS; ++k)
+      if (tid + k * GK_THREADS < ne) s_tab[tid + k * GK_THREADS] = rec[k];
   }
   __syncthreads();
 
@@ -227,38 +238,13 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
   }
 }
 
-template <int HS, int P>
-static int launch_one(const MpArgs &a, size_t dyn, hipStream_t st) {
+template <int HS, int P, int NC, int EC>
+static int launch_sized(MpArgs a, int nmax_host, hipStream_t st) {
   const long long items = (long long)a.B * (a.H / HS);
   if (items >= (1ll << 31)) return ISG_EUNSUPPORTED;
-  dim3 grid((unsigned)items), block(GK_THREADS);
-  const bool masked = a.node_mask || a.edge_mask;
-  const bool exact = (a.C >> 2) == (64 / HS) * P;
-  if (masked) {
-    if (exact) gatv2_mp_graph_kernel<HS, P, true, true><<<grid, block, dyn, st>>>(a);
-    else gatv2_mp_graph_kernel<HS, P, true, false><<<grid, block, dyn, st>>>(a);
-  } else {
-    if (exact) gatv2_mp_graph_kernel<HS, P, false, true><<<grid, block, dyn, st>>>(a);
-    else gatv2_mp_graph_kernel<HS, P, false, false><<<grid, block, dyn, st>>>(a);
-  }
-  return check_launch();
-}
-
-// Runs only when every graph of the batch fits the kernel's LDS tables; ISG_EUNSUPPORTED otherwise (the caller
-// then uses the node-chunk kernel).
-int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
-  const int Q = a.C >> 2;
-  if (nmax_host <= 0 || nmax_host > GK_NCAP || emax_host < 0 || emax_host > GK_ECAP) return ISG_EUNSUPPORTED;
-  // heads per workgroup: the largest HS | H with a row slice of at most 1280 bytes (at least one head)
-  int HS = 1;
-  for (int hs = 8; hs >= 1; hs >>= 1)
-    if (a.H % hs == 0 && hs * a.C * 4 <= 1280) { HS = hs; break; }
-  const int G = 64 / HS;
-  const int P = (Q + G - 1) / G;
-  if (P > 2) return ISG_EUNSUPPORTED;
   const size_t row_bytes = (size_t)HS * a.C * 4;
-  const size_t static_bytes = GK_ECAP * 16 + (size_t)GK_ECAP * HS * 4 + (GK_NCAP + 4) * 4;
-  // LDS window: as many rows as fit 40 KB per workgroup (4 workgroups = 32 waves per CU), never more than the
+  const size_t static_bytes = (size_t)EC * 16 + (size_t)EC * HS * 4 + (NC + 4) * 4;
+  // LDS window: as many x_l rows as fit 40 KB per workgroup (4 workgroups = 32 waves per CU), never more than the
   // largest graph needs; rows beyond the window are read from global memory
   const char *kb = getenv("ISG_MP_LDS_KB");
   const size_t budget = (size_t)(kb ? atoi(kb) : 40) * 1024;
@@ -266,7 +252,38 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   a.lrows = (int)((budget - static_bytes) / row_bytes);
   if (a.lrows > nmax_host) a.lrows = nmax_host;
   const size_t dyn = (size_t)a.lrows * row_bytes;
-#define ISG_GK(hs, p) if (HS == hs && P == p) return launch_one<hs, p>(a, dyn, st)
+  dim3 grid((unsigned)items), block(GK_THREADS);
+  const bool masked = a.node_mask || a.edge_mask;
+  const bool exact = (a.C >> 2) == (64 / HS) * P;
+  if (masked) {
+    if (exact) gatv2_mp_graph_kernel<HS, P, true, true, NC, EC><<<grid, block, dyn, st>>>(a);
+    else gatv2_mp_graph_kernel<HS, P, true, false, NC, EC><<<grid, block, dyn, st>>>(a);
+  } else {
+    if (exact) gatv2_mp_graph_kernel<HS, P, false, true, NC, EC><<<grid, block, dyn, st>>>(a);
+    else gatv2_mp_graph_kernel<HS, P, false, false, NC, EC><<<grid, block, dyn, st>>>(a);
+  }
+  return check_launch();
+}
+
+template <int HS, int P>
+static int launch_one(const MpArgs &a, int nmax_host, int emax_host, hipStream_t st) {
+  if (nmax_host <= GK_NCAP_S && emax_host <= GK_ECAP_S) return launch_sized<HS, P, GK_NCAP_S, GK_ECAP_S>(a, nmax_host, st);
+  return launch_sized<HS, P, GK_NCAP_L, GK_ECAP_L>(a, nmax_host, st);
+}
+
+// Runs only when every graph of the batch fits the kernel's LDS tables; ISG_EUNSUPPORTED otherwise (the caller
+// then uses the node-chunk kernel).
+int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
+  const int Q = a.C >> 2;
+  if (nmax_host <= 0 || nmax_host > GK_NCAP_L || emax_host < 0 || emax_host > GK_ECAP_L) return ISG_EUNSUPPORTED;
+  // heads per workgroup: the largest HS | H with a row slice of at most 1280 bytes (at least one head)
+  int HS = 1;
+  for (int hs = 8; hs >= 1; hs >>= 1)
+    if (a.H % hs == 0 && hs * a.C * 4 <= 1280) { HS = hs; break; }
+  const int G = 64 / HS;
+  const int P = (Q + G - 1) / G;
+  if (P > 2) return ISG_EUNSUPPORTED;
+#define ISG_GK(hs, p) if (HS == hs && P == p) return launch_one<hs, p>(a, nmax_host, emax_host, st)
   ISG_GK(1, 1); ISG_GK(1, 2);
   ISG_GK(2, 1); ISG_GK(2, 2);
   ISG_GK(4, 1); ISG_GK(4, 2);
