@@ -57,17 +57,21 @@ def shard_workload(wl: Workload, rank: int, world: int, balance: bool = False) -
                     max_edges=int(epg[lo:hi].max()) if hi > lo else 0)
 
 
-def all_gather_logits(logits: Tensor, out: Optional[Tensor] = None, group=None) -> Tensor:
-    """[B_local, A] on every rank -> [world*B_local, A] (equal shard sizes) via all_gather_into_tensor."""
+def all_gather_logits(logits: Tensor, out: Optional[Tensor] = None, group=None, async_op: bool = False):
+    """[B_local, A] on every rank -> [world*B_local, A] (equal shard sizes) via all_gather_into_tensor.
+
+    async_op=True returns (out, work): the collective runs on the communicator's own stream behind the producer of
+    `logits`, so the next batch's kernels overlap it; call work.wait() before reading `out` or reusing either buffer
+    (keep `logits` referenced until then)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return logits
+        return (logits, None) if async_op else logits
     world = dist.get_world_size(group)
     if out is None:
         out = torch.empty((world * logits.size(0),) + tuple(logits.shape[1:]), dtype=logits.dtype,
                           device=logits.device)
-    dist.all_gather_into_tensor(out, logits.contiguous(), group=group)
-    return out
+    work = dist.all_gather_into_tensor(out, logits.contiguous(), group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def all_gather_logits_ragged(logits: Tensor, group=None) -> Tensor:
