@@ -194,6 +194,35 @@ int isg_global_attn_pool(const float *xn, const float *q, const int32_t *ptr, co
                          float *out, float *gate, int64_t B, int32_t C, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Backward (training of the hot path)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Backward of isg_gatv2_mp_fwd with respect to x_l, x_r, e_proj, att and (optionally) the edge mask.  Dense rows only
+ * (ld = H*C).  alpha is the forward's attention output; grad_out fp32[N,H*C] is d out (the bias gradient is its column
+ * sum, left to the caller).  rowptr/eid/src: CSR by destination; rowptr_s/eid_s/dst_s: CSR by source, i.e.
+ * isg_csr_build on the flipped edge_index (its `src` output is then the destination per slot).
+ * d_att_partial fp32[ceil(N/16), H*C]: per-workgroup partial sums, d att = their column sum (fixed order, no atomics).
+ * d_edge_mask fp32[E] or NULL.  The gradient flowing into alpha is not supported. */
+int isg_gatv2_mp_bwd(const float *x_l, const float *x_r, const float *e_proj, const float *att, const float *alpha,
+                     const float *grad_out, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                     const int32_t *rowptr_s, const int32_t *eid_s, const int32_t *dst_s, const float *node_mask,
+                     const float *edge_mask, float *d_x_l, float *d_x_r, float *d_e_proj, float *d_att_partial,
+                     float *d_edge_mask, int64_t N, int64_t E, int32_t H, int32_t C, float negative_slope, void *stream);
+
+/* Straight-through backward of isg_topk_gumbel (gumbel_scheme.py:83-90): d_out is the gradient of the mask in the
+ * forward's layout (ragged [N] with ptr, dense [B,nmax] without), d_scores the gradient of the scores, same layout.
+ * scores / noise / seed / k / tau must be the forward's.  ISG_EUNSUPPORTED when k * row length exceeds the 64 KB LDS
+ * history (k * nmax_slots > 4096). */
+int isg_topk_gumbel_bwd(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
+                        const int32_t *nmax_dev, const float *noise, uint64_t seed, int32_t k, float tau,
+                        const float *d_out, float *d_scores, void *stream);
+
+/* NodeMaskToEdgeMask.backward, ISubGVQA/sampling/node_edge_masks.py:13-19: d_node_mask[i] = sum over edges INTO i of
+ * d_edge_mask[e] (the reference's rule: destination only, no product rule).  CSR by destination. */
+int isg_node_to_edge_mask_bwd(const float *d_edge_mask, const int32_t *rowptr, const int32_t *eid, float *d_node_mask,
+                              int64_t N, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense projections (fp32 accuracy on the bf16 matrix cores)
  * ------------------------------------------------------------------------------------------- */
 

@@ -40,6 +40,10 @@ SIGNATURES = {
                                c_int64, c_int32, c_void_p]),
     "isg_instr_attn_graphnorm_residual": (c_int, [c_void_p] * 7 + [c_double, c_void_p, c_void_p, c_int64, c_int32,
                                                                   c_void_p]),
+    "isg_topk_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_int32,
+                                    c_float, c_void_p, c_void_p, c_void_p]),
+    "isg_gatv2_mp_bwd": (c_int, [c_void_p] * 19 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "isg_node_to_edge_mask_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "isg_split_bf16x3": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "isg_linear_bf16x6": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                   c_int32, c_void_p]),

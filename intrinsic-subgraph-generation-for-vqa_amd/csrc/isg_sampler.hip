@@ -174,6 +174,83 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(RowArgs a) {
   }
 }
 
+// Backward of the relaxed top-k (straight-through: d khot = d out, gumbel_scheme.py:83-90).  The forward recurrence
+//   s_0 = scores + g;  p_i = softmax(s_i / tau);  s_{i+1} = s_i + log(max(1 - p_i, tiny));  khot = sum_i p_i
+// is replayed with the forward kernel's arithmetic, p_i kept in LDS ([k][SLOTS*64] per wave), then walked backwards:
+//   dp_i = G - ds_{i+1} / (1 - p_i)   (0 where the max() clamps),   ds_i = ds_{i+1} + p_i (dp_i - <dp_i, p_i>) / tau.
+template <int SLOTS>
+__global__ __launch_bounds__(256) void topk_gumbel_bwd_kernel(RowArgs a, const float *__restrict__ d_out,
+                                                              float *__restrict__ d_scores) {
+  extern __shared__ float s_hist[];
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const int nmax = min(a.nmax_dev ? a.nmax_dev[0] : a.nmax_host, SLOTS * 64);
+  const int base = a.ptr ? a.ptr[b] : b * nmax;
+  const int n = a.ptr ? a.ptr[b + 1] - base : nmax;
+  const int local_k = min(a.k, nmax);
+  float *hist = s_hist + (size_t)(threadIdx.x >> 6) * a.k * SLOTS * 64;
+
+  float flat[SLOTS], onehot[SLOTS], G[SLOTS], ds[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int j = s * 64 + lane;
+    float v = -INFINITY;
+    if (j < nmax) {
+      const float sc = j < n ? a.scores[base + j] : 0.f;
+      const float g = a.noise ? a.noise[(size_t)b * a.nmax_host + j]
+                              : gumbel_from_bits(Philox::draw(a.seed, (uint32_t)b, (uint32_t)j), 0.f, 1.f);
+      v = sc + g;
+    }
+    flat[s] = v;
+    onehot[s] = 0.f;
+    G[s] = (j < n && j < nmax) ? d_out[base + j] : 0.f;
+    ds[s] = 0.f;
+  }
+  for (int it = 0; it < local_k; ++it) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const float km = fmaxf(1.0f - onehot[s], FLT_MIN);
+      flat[s] = flat[s] + (float)log((double)km);
+      mx = fmaxf(mx, flat[s] / a.tau);
+    }
+    mx = wave_max(mx);
+    float ex[SLOTS];
+    double sum = 0.0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      ex[s] = (float)exp((double)(flat[s] / a.tau - mx));
+      sum += (double)ex[s];
+    }
+    const float den = (float)wave_sum_f64(sum);
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      onehot[s] = ex[s] / den;
+      hist[(it * SLOTS + s) * 64 + lane] = onehot[s];
+    }
+  }
+  for (int it = local_k - 1; it >= 0; --it) {
+    float p[SLOTS], dp[SLOTS];
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      p[s] = hist[(it * SLOTS + s) * 64 + lane];
+      const float om = 1.0f - p[s];
+      dp[s] = G[s] - (om > FLT_MIN ? ds[s] / om : 0.f);
+      part += dp[s] * p[s];
+    }
+    const float dot = wave_sum(part);
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) ds[s] += p[s] * (dp[s] - dot) / a.tau;
+  }
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int j = s * 64 + lane;
+    if (j < n && j < nmax) d_scores[base + j] = ds[s];
+  }
+}
+
 static int pick_slots(int nmax_host) {
   if (nmax_host <= 64) return 1;
   if (nmax_host <= 128) return 2;
@@ -243,6 +320,30 @@ extern "C" int isg_topk_threshold(const float *scores, const int32_t *ptr, int64
     case 8: topk_threshold_kernel<8><<<grid, block, 0, s>>>(a); break;
     case 16: topk_threshold_kernel<16><<<grid, block, 0, s>>>(a); break;
     default: return ISG_EUNSUPPORTED;
+  }
+  return check_launch();
+}
+
+extern "C" int isg_topk_gumbel_bwd(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
+                                   const int32_t *nmax_dev, const float *noise, uint64_t seed, int32_t k, float tau,
+                                   const float *d_out, float *d_scores, void *stream) {
+  int st = check_rows(scores, B, nmax_host, k, d_scores);
+  if (st != ISG_OK) return st;
+  if (B == 0 || nmax_host == 0) return ISG_OK;
+  if (!(tau > 0.f) || !d_out) return ISG_EINVAL;
+  const int slots = pick_slots(nmax_host);
+  if (slots == 0) return ISG_EUNSUPPORTED;
+  const size_t lds = (size_t)4 * k * slots * 64 * sizeof(float);
+  if (lds > 64 * 1024) return ISG_EUNSUPPORTED;   // k * row length beyond the LDS history
+  RowArgs a{scores, ptr, nmax_dev, noise, nullptr, nullptr, (int)B, nmax_host, k, tau, 0.f, seed};
+  dim3 grid((unsigned)((B + 3) / 4)), block(256);
+  hipStream_t s = as_stream(stream);
+  switch (slots) {
+    case 1: topk_gumbel_bwd_kernel<1><<<grid, block, lds, s>>>(a, d_out, d_scores); break;
+    case 2: topk_gumbel_bwd_kernel<2><<<grid, block, lds, s>>>(a, d_out, d_scores); break;
+    case 4: topk_gumbel_bwd_kernel<4><<<grid, block, lds, s>>>(a, d_out, d_scores); break;
+    case 8: topk_gumbel_bwd_kernel<8><<<grid, block, lds, s>>>(a, d_out, d_scores); break;
+    case 16: topk_gumbel_bwd_kernel<16><<<grid, block, lds, s>>>(a, d_out, d_scores); break;
   }
   return check_launch();
 }

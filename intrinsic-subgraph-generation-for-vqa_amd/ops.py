@@ -102,6 +102,26 @@ class GraphPlan:
     src: Optional[Tensor] = None
     dst: Optional[Tensor] = None
     eptr: Optional[Tensor] = None
+    edge_index: Optional[Tensor] = None      # kept for the lazily built CSR by source (backward only)
+    _by_src: Optional[Tuple[Tensor, Tensor, Tensor]] = None
+
+    def source_csr(self) -> Tuple[Tensor, Tensor, Tensor]:
+        """(rowptr_s[N+1], eid_s[E], dst_s[E]): out-edges of every node in edge-id order.  Only the backward of the
+        message passing needs it (d x_l is a scatter by source), so it is built on first use."""
+        self.require_csr()
+        if self._by_src is None:
+            lib = _lib.load()
+            dev = self.rowptr.device
+            flipped = self.edge_index.flip(0).contiguous()
+            rowptr_s = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
+            eid_s = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
+            dst_s = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
+            ws_bytes = lib.isg_csr_workspace_bytes(self.N, self.E)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.isg_csr_build(flipped.data_ptr(), self.N, self.E, rowptr_s.data_ptr(), eid_s.data_ptr(),
+                                         dst_s.data_ptr(), 0, ws.data_ptr(), ws_bytes, _stream()), "isg_csr_build")
+            self._by_src = (rowptr_s, eid_s, dst_s)
+        return self._by_src
 
     @staticmethod
     def build(batch: Tensor, edge_index: Optional[Tensor] = None, num_graphs: Optional[int] = None,
@@ -125,6 +145,7 @@ class GraphPlan:
                 raise ValueError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
             E = edge_index.size(1)
             plan.E = E
+            plan.edge_index = edge_index
             plan.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
             plan.eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
             plan.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
@@ -217,6 +238,54 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
     if timer is not None:
         ev1.record()
     return out, alpha
+
+
+def gatv2_mp_backward(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, alpha: Tensor, grad_out: Tensor,
+                      plan: GraphPlan, heads: int, node_mask: Optional[Tensor] = None,
+                      edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_mask_grad: bool = False):
+    """Backward of gatv2_mp: (d_x_l, d_x_r, d_e_proj, d_att[H*C], d_bias[H*C], d_edge_mask[E] or None).
+
+    No reference counterpart file: the reference relies on autograd through PyG's propagate
+    (mgat_v2_conv.py:215-279); the formulas are derived in csrc/isg_mp_bwd.hip.
+    """
+    lib = _lib.load()
+    plan.require_csr()
+    N, HC = x_l.shape
+    H = int(heads)
+    C = HC // H
+    E = plan.E
+    dev = x_l.device
+    x_l, x_r, e_proj, grad_out = x_l.contiguous(), x_r.contiguous(), e_proj.contiguous(), grad_out.contiguous()
+    rowptr_s, eid_s, dst_s = plan.source_csr()
+    d_x_l = torch.empty(N, HC, dtype=torch.float32, device=dev)
+    d_x_r = torch.empty(N, HC, dtype=torch.float32, device=dev)
+    d_e = torch.empty(E, HC, dtype=torch.float32, device=dev)
+    blocks = (N + 15) // 16
+    part = torch.empty(blocks, HC, dtype=torch.float32, device=dev)
+    d_m = torch.empty(E, dtype=torch.float32, device=dev) if want_mask_grad else None
+    _lib.check(lib.isg_gatv2_mp_bwd(
+        _chk(x_l, "x_l", torch.float32, (N, HC)), _chk(x_r, "x_r", torch.float32, (N, HC)),
+        _chk(e_proj, "e_proj", torch.float32, (E, HC)) if E > 0 else 0,
+        _chk(att.reshape(-1), "att", torch.float32, (HC,)), _chk(alpha, "alpha", torch.float32, (E, H)) if E > 0 else 0,
+        _chk(grad_out, "grad_out", torch.float32, (N, HC)),
+        plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
+        rowptr_s.data_ptr(), eid_s.data_ptr(), dst_s.data_ptr(),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
+        d_x_l.data_ptr(), d_x_r.data_ptr(), d_e.data_ptr(), part.data_ptr(), 0 if d_m is None else d_m.data_ptr(),
+        N, E, H, C, float(negative_slope), _stream()), "isg_gatv2_mp_bwd")
+    return d_x_l, d_x_r, d_e, part.sum(0), grad_out.sum(0), d_m
+
+
+def node_to_edge_mask_backward(d_edge_mask: Tensor, plan: GraphPlan) -> Tensor:
+    """NodeMaskToEdgeMask.backward (sampling/node_edge_masks.py:13-19): scatter to the destination only."""
+    lib = _lib.load()
+    plan.require_csr()
+    out = torch.empty(plan.N, dtype=torch.float32, device=d_edge_mask.device)
+    _lib.check(lib.isg_node_to_edge_mask_bwd(_chk(d_edge_mask.reshape(-1), "d_edge_mask", torch.float32, (plan.E,)),
+                                             plan.rowptr.data_ptr(), plan.eid.data_ptr(), out.data_ptr(), plan.N,
+                                             _stream()), "isg_node_to_edge_mask_bwd")
+    return out
 
 
 def mp_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool, feat_bytes: int = 4) -> int:

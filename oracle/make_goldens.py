@@ -13,6 +13,11 @@ travels to the GPU box); writes small data-only fixtures to tests/golden/*.pt:
                    NodeMaskToEdgeMask / scatter attention: the reference's own glue code
                    executed over oracle/pyg_standin.py (restated third-party primitives)
 
+  g6_sampler_grads.pt  training-mode samplers (GumbelSampler train=True straight-through; imle / aimle train wrappers
+                   with their second MAP solve and the adaptive-beta state) -- forward outputs and input gradients
+  g7_train_*.pt    MGAT + GlobalAttention in train() mode (dropout patched to identity), loss gradients for every
+                   parameter and input, through the reference's custom backward rules
+
 Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_goldens
 No reference source text is written anywhere; fixtures hold tensors only.
 """
@@ -247,6 +252,163 @@ def gen_mgat():
                    os.path.join(OUT, f"g5_mgat_{c['name']}.pt"))
 
 
+def _padded_scores(B, Nmax, gen):
+    scores = torch.randn(B, Nmax, 1, generator=gen)
+    lens = []
+    for b in range(B):
+        n = int(torch.randint(1, Nmax + 1, (1,), generator=gen))
+        if b == 0:
+            n = Nmax
+        scores[b, n:] = 0.0
+        lens.append(n)
+    return scores, torch.tensor(lens)
+
+
+def gen_sampler_grads():
+    """Training-mode samplers: outputs and gradients w.r.t. the dense scores for a random upstream gradient that is
+    zero on the padded slots (what the `[mask]` gather of masking.py:170-176 sends back)."""
+    from ISubGVQA.sampling.methods.gumbel_scheme import GumbelSampler
+    from ISubGVQA.sampling.methods.aimle import aimle
+    from ISubGVQA.sampling.methods.imle_scheme import IMLEScheme
+    from ISubGVQA.sampling.methods.noise import GumbelDistribution
+    from ISubGVQA.sampling.methods.target_aimle import AdaptiveTargetDistribution
+    from ISubGVQA.models.masking import get_imle_samplers
+
+    out = dict(gumbel=[], imle=[], aimle=[])
+    for ci, (B, Nmax, k) in enumerate([(1, 8, 2), (4, 16, 5), (16, 20, 5), (3, 4, 5), (2, 130, 3)]):
+        gen = torch.Generator().manual_seed(600 + ci)
+        scores, lens = _padded_scores(B, Nmax, gen)
+        w = torch.randn(B, Nmax, 1, generator=gen) * (torch.arange(Nmax)[None, :, None] < lens[:, None, None])
+        seed = 7600 + ci
+        sampler = GumbelSampler(k=k, policy="edge_candid", train_ensemble=1, val_ensemble=1)
+        th = scores.clone().requires_grad_(True)
+        torch.manual_seed(seed)
+        res, _ = sampler(th, train=True)
+        (res.squeeze(0) * w).sum().backward()
+        out["gumbel"].append(dict(scores=scores, lens=lens, k=k, w=w, noise=_noise_from_seed(seed, (B, Nmax)),
+                                  out=res.detach().clone(), grad=th.grad.clone()))
+    for ci, (B, Nmax, k, beta) in enumerate([(1, 8, 2, 10.0), (4, 16, 5, 10.0), (16, 20, 5, 10.0), (3, 4, 5, 10.0),
+                                             (6, 40, 3, 2.5)]):
+        gen = torch.Generator().manual_seed(650 + ci)
+        scores, lens = _padded_scores(B, Nmax, gen)
+        w = 0.2 * torch.randn(B, Nmax, 1, generator=gen) * (torch.arange(Nmax)[None, :, None] < lens[:, None, None])
+        seed = 7650 + ci
+        train, _ = get_imle_samplers(sample_k=k, device="cpu", nb_samples=1, alpha=1.0, beta=beta, tau=1.0)
+        th = scores.clone().requires_grad_(True)
+        torch.manual_seed(seed)
+        res = train(th)[0]
+        (res.squeeze(0) * w).sum().backward()
+        out["imle"].append(dict(scores=scores, lens=lens, k=k, beta=beta, w=w,
+                                noise=_noise_from_seed(seed, (B, 1, Nmax, 1), 0.3),
+                                out=res.detach().clone(), grad=th.grad.clone()))
+    for ci, (B, Nmax, k, beta0, tau) in enumerate([(4, 16, 5, 0.0, 1.0), (8, 20, 5, 3.0, 1.0), (3, 12, 2, 0.7, 0.5)]):
+        gen = torch.Generator().manual_seed(680 + ci)
+        scheduler = IMLEScheme("edge_candid", k, 1, 1)
+        target = AdaptiveTargetDistribution(initial_alpha=1.0, initial_beta=beta0)
+
+        @aimle(target_distribution=target, noise_distribution=GumbelDistribution(0.0, 0.3, "cpu"), nb_samples=1,
+               theta_noise_temperature=tau, target_noise_temperature=tau, symmetric_perturbation=True)
+        def train(logits):
+            return scheduler.torch_sample_scheme(logits)
+
+        steps = []
+        for st in range(4):      # the adaptive beta is state carried from one backward to the next
+            scores, lens = _padded_scores(B, Nmax, gen)
+            w = torch.randn(B, Nmax, 1, generator=gen) * (torch.arange(Nmax)[None, :, None] < lens[:, None, None])
+            seed = 7680 + 10 * ci + st
+            th = scores.clone().requires_grad_(True)
+            torch.manual_seed(seed)
+            res = train(th)
+            (res * w).sum().backward()
+            steps.append(dict(scores=scores, lens=lens, w=w, noise=_noise_from_seed(seed, (B, 1, Nmax, 1), 0.3),
+                              out=res.detach().clone(), grad=th.grad.clone(), beta_after=float(target.beta),
+                              grad_norm_after=float(target.grad_norm)))
+        out["aimle"].append(dict(k=k, beta0=beta0, tau=tau, steps=steps))
+    torch.save(out, os.path.join(OUT, "g6_sampler_grads.pt"))
+
+
+def gen_mgat_train():
+    """MGAT + GlobalAttention in train() mode.  The gate dropout (masking.py:159) is patched to identity for the run --
+    its mask is RNG-private -- everything else is the reference's training graph incl. its custom backward rules."""
+    from unittest import mock
+    import torch.nn.functional as F
+    from ISubGVQA.models.mgat import MGAT
+    from ISubGVQA.models.att_pooling import GlobalAttention
+    from ISubGVQA.models.masking import get_imle_samplers
+    from ISubGVQA.sampling.methods.aimle import aimle
+    from ISubGVQA.sampling.methods.imle_scheme import IMLEScheme
+    from ISubGVQA.sampling.methods.noise import GumbelDistribution
+    from ISubGVQA.sampling.methods.target_aimle import AdaptiveTargetDistribution
+
+    cases = [
+        dict(name="gumbel_c8", C=8, L=3, masks=[1.0, 0.15, 0.15], sampler="gumbel", k=2, kind="rand", interp=False),
+        dict(name="imle_c16", C=16, L=3, masks=[0.15, 1.0, 0.15], sampler="imle", k=3, kind="rand", interp=True, beta=10.0),
+        dict(name="aimle_c12", C=12, L=2, masks=[0.15, 0.15], sampler="aimle", k=2, kind="edgecases", interp=True, beta=4.0),
+        dict(name="nomask_c20", C=20, L=2, masks=[1.0, 1.0], sampler="gumbel", k=2, kind="rand", interp=False),
+    ]
+    for ci, c in enumerate(cases):
+        gen = torch.Generator().manual_seed(800 + ci)
+        batch, ei = _graphs(c["kind"], gen)
+        N, E, B, C, L = batch.numel(), ei.size(1), int(batch.max()) + 1, c["C"], c["L"]
+        torch.manual_seed(70 + ci)
+        model = MGAT(channels=C, num_ins=L, heads=4, use_instr=True, masking_thresholds=c["masks"], use_topk=True,
+                     interpretable_mode=c["interp"], sampler_type=c["sampler"], sample_k=c["k"], nb_samples=1,
+                     alpha=1.0, beta=c.get("beta", 10.0), tau=1.0).train()
+        pool = GlobalAttention(num_node_features=C, num_out_features=C).train()
+        with torch.no_grad():
+            for n_, p_ in list(model.named_parameters()) + list(pool.named_parameters()):
+                if n_.endswith("bias") or "bns" in n_:
+                    p_.add_(0.1 * torch.randn(p_.shape, generator=gen))
+        targets = {}
+        for li, conv in enumerate(model.convs):
+            if c["sampler"] == "imle":
+                conv.mask.sampler_train, conv.mask.sampler_val = get_imle_samplers(
+                    sample_k=c["k"], device="cpu", nb_samples=1, alpha=1.0, beta=c["beta"], tau=1.0)
+            elif c["sampler"] == "aimle":
+                scheduler = IMLEScheme("edge_candid", c["k"], 1, 1)
+                targets[li] = AdaptiveTargetDistribution(initial_alpha=1.0, initial_beta=c["beta"])
+                conv.mask.sampler_train = aimle(
+                    scheduler.torch_sample_scheme, target_distribution=targets[li],
+                    noise_distribution=GumbelDistribution(0.0, 0.3, "cpu"), nb_samples=1, theta_noise_temperature=1.0,
+                    target_noise_temperature=1.0, symmetric_perturbation=True)
+        x = torch.randn(N, C, generator=gen).requires_grad_(True)
+        edge_attr = torch.randn(E, C, generator=gen).requires_grad_(True)
+        instr = torch.randn(L, B, C, generator=gen).requires_grad_(True)
+        glf = torch.randn(B, C, generator=gen).requires_grad_(True)
+        w_h = torch.randn(N, C, generator=gen)
+        w_e = torch.randn(B, C, generator=gen)
+        seed = 9500 + ci
+        torch.manual_seed(seed)
+        with mock.patch.object(F, "dropout", lambda t, p=0.5, training=True, inplace=False: t):
+            h, mask, _, _ = model(x=x, edge_index=ei, instr_vectors=instr, global_language_feats=glf,
+                                  edge_attr=edge_attr, batch=batch, return_masks=True)
+            emb, gate = pool(x=h, u=glf, batch=batch, size=None, return_mask=True, node_mask=mask)
+            loss = (h * w_h).sum() + (emb * w_e).sum()
+            loss.backward()
+        counts = torch.bincount(batch, minlength=B)
+        nmax = int(counts.max())
+        torch.manual_seed(seed)
+        noises = {}
+        for i, thr in enumerate(c["masks"]):
+            if thr != 1.0:
+                noises[i] = (S.uniform_to_gumbel(torch.rand(B, nmax)) if c["sampler"] == "gumbel"
+                             else S.uniform_to_gumbel(torch.rand(B, 1, nmax, 1), 0.0, 0.3))
+        sd = {"gat_seq." + k: v.detach().clone() for k, v in model.state_dict().items() if "node_logits" not in k}
+        sd.update({"graph_global_attention_pooling." + k: v.detach().clone() for k, v in pool.state_dict().items()})
+        grads = {"gat_seq." + k: p_.grad.clone() for k, p_ in model.named_parameters() if p_.grad is not None}
+        grads.update({"graph_global_attention_pooling." + k: p_.grad.clone() for k, p_ in pool.named_parameters()
+                      if p_.grad is not None})
+        torch.save(dict(cfg={k: c[k] for k in ("C", "L", "masks", "sampler", "k", "interp")}, beta=c.get("beta", 10.0),
+                        sd=sd, x=x.detach(), edge_index=ei, edge_attr=edge_attr.detach(), batch=batch,
+                        instr=instr.detach(), glf=glf.detach(), noises=noises, w_h=w_h, w_e=w_e,
+                        h=h.detach(), mask=None if mask is None else mask.detach(), pool_out=emb.detach(),
+                        loss=loss.detach(), grads=grads,
+                        grad_x=x.grad.clone(), grad_edge_attr=edge_attr.grad.clone(), grad_instr=instr.grad.clone(),
+                        grad_glf=glf.grad.clone(),
+                        aimle_beta_after={li: float(t.beta) for li, t in targets.items()}),
+                   os.path.join(OUT, f"g7_train_{c['name']}.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.dont_write_bytecode = True
@@ -255,6 +417,8 @@ def main():
     gen_samplers()
     gen_question()
     gen_mgat()
+    gen_sampler_grads()
+    gen_mgat_train()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

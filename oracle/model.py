@@ -40,6 +40,11 @@ class PathConfig:
     gumbel_tau: float = 0.1               # GumbelSampler default (gumbel_scheme.py:15)
     interpretable_mode: bool = False
     use_global_mask: bool = False
+    # training mode: train samplers + custom backward rules; dropout is NOT modelled (treated as p=0)
+    training: bool = False
+    imle_alpha: float = 1.0
+    imle_beta: float = 10.0
+    aimle_states: Optional[dict] = None   # layer prefix -> samplers.AimleTargetState (stateful, one per conv)
     graphnorm_eps: float = 1e-5
     nhead_text: int = 8
 
@@ -53,7 +58,24 @@ def linear(sd: Mapping[str, Tensor], p: str, x: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------
 # A8  NodeMaskToEdgeMask.forward (sampling/node_edge_masks.py:7-10)
 # ---------------------------------------------------------------------------
+class _NodeMaskToEdgeMaskFn(torch.autograd.Function):
+    """The reference's custom rule (node_edge_masks.py:13-19): the edge-mask gradient goes to the destination only."""
+
+    @staticmethod
+    def forward(ctx, mask, edge_index):
+        ctx.save_for_backward(edge_index)
+        ctx.n = mask.shape[0]
+        return (mask[edge_index[0]] * mask[edge_index[1]]).to(torch.float)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (edge_index,) = ctx.saved_tensors
+        return P.scatter_sum(grad_output, edge_index[1], ctx.n), None
+
+
 def node_mask_to_edge_mask(mask: Tensor, edge_index: Tensor) -> Tensor:
+    if mask.requires_grad:
+        return _NodeMaskToEdgeMaskFn.apply(mask, edge_index)
     return (mask[edge_index[0]] * mask[edge_index[1]]).to(torch.float)
 
 
@@ -80,7 +102,13 @@ def masking_model_forward(sd, p: str, x: Tensor, u: Tensor, batch: Tensor, cfg: 
     if cfg.use_topk:                                                   # :158
         dense, m = P.to_dense_batch(gate, batch)                       # :162  (pad = 0.0, quirk Q1)
         aux["dense"] = dense
-        if cfg.sampler_type == "imle":                                 # :163-173
+        if cfg.sampler_type == "imle" and cfg.training:                # :164-170 (sampler_train, masking.py:222-231)
+            out = S.ImleTrain.apply(dense, noise, cfg.sample_k, cfg.imle_alpha, cfg.imle_beta, cfg.tau, cfg.tau)
+            res = out.squeeze(0)[m]
+        elif cfg.sampler_type == "aimle" and cfg.training:             # masking.py:257-268
+            out = S.AimleTrain.apply(dense, noise, cfg.sample_k, cfg.aimle_states[p], cfg.tau, cfg.tau)
+            res = out[m]
+        elif cfg.sampler_type == "imle":                               # :163-173
             out = S.imle_eval(dense, cfg.sample_k, noise, 0.0)
             res = out.squeeze(0)[m]
         elif cfg.sampler_type == "aimle":
