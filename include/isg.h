@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 2
+#define ISG_ABI_VERSION 3
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -154,10 +154,12 @@ int isg_topk_gumbel(const float *scores, const int32_t *ptr, int64_t B, int32_t 
  * (wrapper.py:93-100 with temperature 0 for I-MLE -> pass noise_scale = 0 and noise = NULL;
  * aimle.py:109-117 with temperature tau for AIMLE).  out = (v >= k-th largest v) as 0/1;
  * k >= Nmax -> all ones.  With noise == NULL and noise_scale != 0 the in-kernel draw is
- * Gumbel(0, 0.3) (masking.py:236,273) times noise_scale. */
+ * Gumbel(0, 0.3) (masking.py:236,273) times noise_scale.
+ * dense_out (optional) fp32[B, nmax_host]: the selection of every slot of the padded row, pads included, zero beyond
+ * the batch's longest graph (the AIMLE backward counts flipped slots over the whole padded row, target_aimle.py:137). */
 int isg_topk_threshold(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
                        const int32_t *nmax_dev, const float *noise, float noise_scale, uint64_t seed,
-                       int32_t k, float *out, void *stream);
+                       int32_t k, float *out, float *dense_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-graph attention / normalisation / pooling

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -34,7 +34,7 @@ SIGNATURES = {
     "isg_topk_gumbel": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_int32,
                                 c_float, c_void_p, c_void_p, c_void_p]),
     "isg_topk_threshold": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_float, c_uint64,
-                                   c_int32, c_void_p, c_void_p]),
+                                   c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_scatter_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_graph_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int32, c_void_p,
                                c_int64, c_int32, c_void_p]),

@@ -1,0 +1,357 @@
+"""Training of the hot path: autograd wiring around the HIP kernels.
+
+`ops.*` dispatch here when autograd is recording and an input requires grad; inside a Function's forward autograd is
+off, so the same `ops.*` call runs the plain forward kernel.  Three kinds of backward:
+
+  * hand-written HIP kernels for the operators the reference differentiates by hand or that dominate the step:
+      GatV2MP            isg_gatv2_mp_bwd            (PyG propagate autograd behind mgat_v2_conv.py:215-279)
+      NodeToEdgeMask     isg_node_to_edge_mask_bwd   (NodeMaskToEdgeMask.backward, sampling/node_edge_masks.py:13-19)
+      GumbelTopK         isg_topk_gumbel_bwd         (straight-through, gumbel_scheme.py:83-90)
+      ImleTopK/AimleTopK isg_topk_threshold again    (second MAP solve, wrapper.py:124-172; aimle.py:141-243;
+                                                      adaptive beta, target_aimle.py:88-162 -- state kept ON THE DEVICE)
+  * Linear: forward on the bf16x6 matrix-core kernel, dX / dW as fp32 GEMMs through torch (hipBLASLt);
+  * the light per-node ops (instruction gate, node gate, layer tail, pooling, GraphNorm, scatter ops): the forward is the
+    fused kernel, the backward re-evaluates a torch-op restatement ON THE DEVICE under autograd (`_Recomputed`).  These
+    are plain autograd in the reference too.
+
+Nothing here runs on the CPU and nothing imports `oracle/`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import ops
+
+
+def recording(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
+# ------------------------------------------------------------------------------------------------
+# Generic: fused forward, recomputed torch backward
+# ------------------------------------------------------------------------------------------------
+class _Recomputed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fused, restate, consts, *tensors):
+        ctx.restate, ctx.consts = restate, consts
+        ctx.save_for_backward(*tensors)
+        out = fused(*tensors, *consts)
+        return out
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        tensors = ctx.saved_tensors
+        need = ctx.needs_input_grad[3:]
+        with torch.enable_grad():
+            ins = [None if t is None else (t.detach().requires_grad_(True) if n else t.detach())
+                   for t, n in zip(tensors, need)]
+            outs = ctx.restate(*ins, *ctx.consts)
+            outs = outs if isinstance(outs, tuple) else (outs,)
+            pairs = [(o, g) for o, g in zip(outs, gouts) if g is not None and o.requires_grad]
+            wanted = [i for i, n in zip(ins, need) if n]
+            grads = torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True)
+        it = iter(grads)
+        return (None, None, None) + tuple(next(it) if n else None for n in need)
+
+
+def _seg_sum(v: Tensor, batch: Tensor, B: int) -> Tensor:
+    return torch.zeros((B,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device).index_add_(0, batch, v)
+
+
+def _seg_softmax(logits: Tensor, batch: Tensor, B: int, eps: float = 0.0) -> Tensor:
+    m = torch.full((B,), -math.inf, dtype=logits.dtype, device=logits.device)
+    m = m.scatter_reduce(0, batch, logits.detach(), "amax", include_self=True)
+    e = (logits - m[batch]).exp()
+    return e / (_seg_sum(e, batch, B)[batch] + eps)
+
+
+def _instr_gate_t(x, instr, batch):
+    return F.gelu(x * instr[batch])
+
+
+def instr_gate(x, instr, batch):
+    return _Recomputed.apply(ops.instr_gate, _instr_gate_t, (batch,), x, instr)
+
+
+def _node_gate_t(xn, q, batch, double_index):
+    idx = batch[batch] if double_index else batch
+    return F.gelu((xn * q[idx]).sum(-1, keepdim=True) / math.sqrt(xn.size(1)))
+
+
+def node_gate(xn, q, batch, double_index):
+    return _Recomputed.apply(ops.node_gate, _node_gate_t, (batch, double_index), xn, q)
+
+
+def _graph_norm_t(v, weight, bias, mean_scale, batch, B, eps, fp64):
+    dt = v.dtype
+    if fp64:
+        v, weight, bias, mean_scale = v.double(), weight.double(), bias.double(), mean_scale.double()
+    cnt = torch.bincount(batch, minlength=B).clamp(min=1).to(v.dtype).unsqueeze(1)
+    mean = _seg_sum(v, batch, B) / cnt
+    out = v - mean[batch] * mean_scale
+    var = _seg_sum(out * out, batch, B) / cnt
+    return (weight * out / (var + eps).sqrt()[batch] + bias).to(dt)
+
+
+def _layer_tail_t(ins, c, h, weight, bias, mean_scale, node_mask, batch, B, eps):
+    att = _seg_softmax((ins[batch] * c).sum(-1) / math.sqrt(c.size(1)), batch, B)
+    y = _graph_norm_t(att.unsqueeze(1) * c, weight, bias, mean_scale, batch, B, eps, False) + h
+    return y if node_mask is None else node_mask.view(-1, 1) * y
+
+
+def _layer_tail_f(ins, c, h, weight, bias, mean_scale, node_mask, plan, eps):
+    return ops.mgat_layer_tail(ins, c, h, plan, weight, bias, mean_scale, eps, node_mask=node_mask)
+
+
+def mgat_layer_tail(ins, c, h, plan, weight, bias, mean_scale, eps, node_mask):
+    batch, B = plan.batch, plan.B
+    return _Recomputed.apply(_layer_tail_f, lambda *a: _layer_tail_t(*a[:7], batch, B, eps), (plan, eps),
+                             ins, c, h, weight, bias, mean_scale, node_mask)
+
+
+def _pool_t(xn, q, node_mask, batch, B):
+    x = xn if node_mask is None else xn * node_mask.view(-1, 1)
+    gate = _seg_softmax((x * q[batch]).sum(-1) / math.sqrt(x.size(1)), batch, B, 1e-16).unsqueeze(1)
+    return _seg_sum(gate * x, batch, B), gate
+
+
+def _pool_f(xn, q, node_mask, plan):
+    return ops.global_attn_pool(xn, q, plan, node_mask)
+
+
+def global_attn_pool(xn, q, plan, node_mask):
+    batch, B = plan.batch, plan.B
+    return _Recomputed.apply(_pool_f, lambda a, b, c, _p: _pool_t(a, b, c, batch, B), (plan,), xn, q, node_mask)
+
+
+def graph_norm(x, plan, weight, bias, mean_scale, eps, fp64):
+    batch, B = plan.batch, plan.B
+    return _Recomputed.apply(lambda v, w, b, m, p, e, f: ops.graph_norm(v, p, w, b, m, e, f),
+                             lambda v, w, b, m, p, e, f: _graph_norm_t(v, w, b, m, batch, B, e, f),
+                             (plan, eps, fp64), x, weight, bias, mean_scale)
+
+
+def scatter_attention(query, key, plan, value):
+    batch, B = plan.batch, plan.B
+
+    def restate(qr, k, v, _p):
+        att = _seg_softmax((qr[batch] * k).sum(-1) / math.sqrt(k.size(1)), batch, B)
+        return att.unsqueeze(1) * v
+    return _Recomputed.apply(lambda qr, k, v, p: ops.scatter_attention(qr, k, p, v), restate, (plan,), query, key, value)
+
+
+def scatter_mean(msg, plan):
+    dst = plan.edge_index[1]
+    N = plan.N
+
+    def restate(m, _p):
+        cnt = torch.bincount(dst, minlength=N).clamp(min=1).to(m.dtype).unsqueeze(1)
+        return _seg_sum(m, dst, N) / cnt
+    return _Recomputed.apply(ops.scatter_mean, restate, (plan,), msg)
+
+
+# ------------------------------------------------------------------------------------------------
+# Dense projection
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b): forward on isg_linear_bf16x6 (pre-activation kept when act = GELU), backward as fp32 GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gelu):
+        z = ops.linear(x, weight, bias, gelu=False, cache_planes=False)
+        ctx.gelu = gelu
+        ctx.save_for_backward(x, weight, z if gelu else None)
+        ctx.has_bias = bias is not None
+        return F.gelu(z) if gelu else z
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, z = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.gelu:
+            g = torch.ops.aten.gelu_backward(g, z)
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dw = g.t() @ x if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias, gelu):
+    return _Linear.apply(x, weight, bias, gelu)
+
+
+# ------------------------------------------------------------------------------------------------
+# Message passing and the node -> edge mask
+# ------------------------------------------------------------------------------------------------
+class _GatV2MP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_l, x_r, e_proj, att, bias, node_mask, edge_mask, plan, heads, slope, kernel):
+        out, alpha = ops.gatv2_mp(x_l, x_r, e_proj, att, plan, heads, bias=bias, node_mask=node_mask,
+                                  edge_mask=edge_mask, negative_slope=slope, kernel=kernel)
+        ctx.save_for_backward(x_l, x_r, e_proj, att, alpha, node_mask, edge_mask)
+        ctx.cfg = (plan, heads, slope, bias is not None)
+        ctx.mark_non_differentiable(alpha)
+        return out, alpha
+
+    @staticmethod
+    def backward(ctx, g_out, _g_alpha):
+        x_l, x_r, e_proj, att, alpha, node_mask, edge_mask = ctx.saved_tensors
+        plan, heads, slope, has_bias = ctx.cfg
+        need = ctx.needs_input_grad
+        want_mask = (node_mask is not None and need[5]) or (edge_mask is not None and need[6])
+        d_xl, d_xr, d_e, d_att, d_bias, d_m = ops.gatv2_mp_backward(
+            x_l, x_r, e_proj, att, alpha, g_out, plan, heads, node_mask=node_mask, edge_mask=edge_mask,
+            negative_slope=slope, want_mask_grad=want_mask)
+        d_node = d_edge = None
+        if want_mask and node_mask is not None:       # the fused mask[src]*mask[dst] product keeps the reference's rule
+            d_node = ops.node_to_edge_mask_backward(d_m, plan).view_as(node_mask)
+        elif want_mask:
+            d_edge = d_m.view_as(edge_mask)
+        return (d_xl, d_xr, d_e, d_att.view_as(att), d_bias if has_bias else None, d_node, d_edge,
+                None, None, None, None)
+
+
+def gatv2_mp(x_l, x_r, e_proj, att, plan, heads, bias, node_mask, edge_mask, negative_slope, kernel):
+    return _GatV2MP.apply(x_l, x_r, e_proj, att, bias, node_mask, edge_mask, plan, heads, negative_slope, kernel)
+
+
+class _NodeToEdgeMask(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mask, edge_index, plan):
+        ctx.plan = plan
+        ctx.shape = mask.shape
+        return ops.node_to_edge_mask(mask, edge_index)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.node_to_edge_mask_backward(g.contiguous(), ctx.plan).view(ctx.shape), None, None
+
+
+def node_to_edge_mask(mask, edge_index, plan):
+    return _NodeToEdgeMask.apply(mask, edge_index, plan)
+
+
+# ------------------------------------------------------------------------------------------------
+# Samplers
+# ------------------------------------------------------------------------------------------------
+class _GumbelTopK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, k, tau, plan, noise, seed):
+        ctx.save_for_backward(scores, noise)
+        ctx.cfg = (k, tau, plan, seed)
+        return ops.topk_gumbel(scores, k, tau, plan=plan, noise=noise, seed=seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        scores, noise = ctx.saved_tensors
+        k, tau, plan, seed = ctx.cfg
+        return ops.topk_gumbel_backward(scores, g, k, tau, plan=plan, noise=noise, seed=seed), None, None, None, None, None
+
+
+def topk_gumbel(scores, k, tau, plan, noise, seed):
+    return _GumbelTopK.apply(scores, k, tau, plan, noise, seed)
+
+
+class _ImleTopK(torch.autograd.Function):
+    """z = MAP(theta + tau_in * eps);  d theta = z - MAP(alpha * theta - beta * dy + tau_t * eps)."""
+
+    @staticmethod
+    def forward(ctx, scores, k, plan, noise, seed, alpha, beta, tau_in, tau_target):
+        z = ops.topk_threshold(scores, k, plan=plan, noise=noise, noise_scale=tau_in, seed=seed)
+        ctx.save_for_backward(scores, noise, z)
+        ctx.cfg = (k, plan, seed, alpha, beta, tau_target)
+        return z
+
+    @staticmethod
+    def backward(ctx, dy):
+        scores, noise, z = ctx.saved_tensors
+        k, plan, seed, alpha, beta, tau_target = ctx.cfg
+        target = alpha * scores - beta * dy                                              # target.py:43
+        z_t = ops.topk_threshold(target.contiguous(), k, plan=plan, noise=noise, noise_scale=tau_target, seed=seed)
+        return (z - z_t,) + (None,) * 8                                                  # wrapper.py:170-172 (S = 1)
+
+
+class AdaptiveTarget:
+    """AdaptiveTargetDistribution (target_aimle.py:88-162) with beta / grad_norm as 0-dim DEVICE tensors, so the
+    backward never synchronises (the reference calls .item() three times per backward)."""
+
+    def __init__(self, initial_alpha: float = 1.0, initial_beta: float = 1.0, initial_grad_norm: float = 1.0,
+                 beta_update_step: float = 0.0001, beta_update_momentum: float = 0.0, grad_norm_decay_rate: float = 0.9,
+                 target_norm: float = 1.0):
+        self.alpha = initial_alpha
+        self._beta0, self._gn0 = float(initial_beta), float(initial_grad_norm)
+        self.beta_t: Optional[Tensor] = None        # float64, like the reference's Python float
+        self.grad_norm_t: Optional[Tensor] = None   # float32
+        self.prev_update_t: Optional[Tensor] = None
+        self.beta_update_step, self.beta_update_momentum = beta_update_step, beta_update_momentum
+        self.grad_norm_decay_rate, self.target_norm = grad_norm_decay_rate, target_norm
+
+    def _init(self, device):
+        if self.beta_t is None or self.beta_t.device != device:
+            self.beta_t = torch.tensor(self._beta0, dtype=torch.float64, device=device)
+            self.grad_norm_t = torch.tensor(self._gn0, dtype=torch.float32, device=device)
+            self.prev_update_t = torch.zeros((), dtype=torch.float64, device=device)
+
+    @property
+    def beta(self) -> float:
+        return self._beta0 if self.beta_t is None else float(self.beta_t)
+
+    @property
+    def grad_norm(self) -> float:
+        return self._gn0 if self.grad_norm_t is None else float(self.grad_norm_t)
+
+    def magnitude(self, theta: Tensor, dy: Tensor) -> Tensor:
+        self._init(theta.device)
+        norm_dy = torch.linalg.norm(dy)
+        pm = self.beta_t.float() * (torch.linalg.norm(theta) / norm_dy)                  # :114-116
+        return torch.where(norm_dy > 0, pm, torch.zeros_like(pm))
+
+    def update(self, grad_dense: Tensor, n_gradients: int) -> None:
+        nnz = torch.count_nonzero(grad_dense).float()                                    # :137
+        d = self.grad_norm_decay_rate
+        self.grad_norm_t = d * self.grad_norm_t + (1.0 - d) * (nnz / n_gradients)        # :144-146
+        step = torch.where(self.grad_norm_t < self.target_norm, self.beta_update_step, -self.beta_update_step)
+        upd = self.beta_update_momentum * self.prev_update_t + step.double()             # :149-154
+        self.beta_t = torch.clamp(self.beta_t + upd, min=0.0)                            # :157
+        self.prev_update_t = upd
+
+
+class _AimleTopK(torch.autograd.Function):
+    """z = MAP(theta + tau * eps);  d theta = (MAP(theta'_L + eps') - MAP(theta'_R + eps')) / 2 / lambda with
+    theta'_{R,L} = alpha * theta -/+ lambda * dy (symmetric perturbation).  The two target solves also return their
+    selection over the padded rows: the adaptive rule counts the flipped slots INCLUDING the pads."""
+
+    @staticmethod
+    def forward(ctx, scores, k, plan, noise, seed, state, tau_theta, tau_target):
+        z = ops.topk_threshold(scores, k, plan=plan, noise=noise, noise_scale=tau_theta, seed=seed)
+        ctx.save_for_backward(scores, noise)
+        ctx.cfg = (k, plan, seed, state, tau_target)
+        return z
+
+    @staticmethod
+    def backward(ctx, dy):
+        scores, noise = ctx.saved_tensors
+        k, plan, seed, state, tau_target = ctx.cfg
+        pm = state.magnitude(scores, dy)
+        t_r = (state.alpha * scores - pm * dy).contiguous()                              # aimle.py:173-176
+        t_l = (state.alpha * scores + pm * dy).contiguous()                              # :178-182 (params(theta, -dy))
+        z_r, dense_r = ops.topk_threshold(t_r, k, plan=plan, noise=noise, noise_scale=tau_target, seed=seed,
+                                          return_dense=True)
+        z_l, dense_l = ops.topk_threshold(t_l, k, plan=plan, noise=noise, noise_scale=tau_target, seed=seed,
+                                          return_dense=True)
+        state.update((dense_l - dense_r) / 2.0, dense_l.size(0))                         # target_aimle.py:131-159
+        g = (z_l - z_r) / 2.0 / torch.where(pm > 0, pm, torch.ones_like(pm))             # aimle.py:231-237, :161
+        return (g,) + (None,) * 7
+
+
+def imle_topk(scores, k, plan, noise, seed, alpha, beta, tau_in, tau_target):
+    return _ImleTopK.apply(scores, k, plan, noise, seed, alpha, beta, tau_in, tau_target)
+
+
+def aimle_topk(scores, k, plan, noise, seed, state, tau_theta, tau_target):
+    return _AimleTopK.apply(scores, k, plan, noise, seed, state, tau_theta, tau_target)

@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(RowArgs a) {
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int j = s * 64 + lane;
-    if (j < n && j < nmax) a.out[base + j] = (all || v[s] >= thresh) ? 1.f : 0.f;   // :41-42
+    const float z = (j < nmax && (all || v[s] >= thresh)) ? 1.f : 0.f;               // :41-42
+    if (j < n && j < nmax) a.out[base + j] = z;
+    if (a.khot_out && j < a.nmax_host) a.khot_out[(size_t)b * a.nmax_host + j] = z;  // dense row, pads included
   }
 }
 
@@ -306,11 +308,11 @@ extern "C" int isg_topk_gumbel(const float *scores, const int32_t *ptr, int64_t 
 
 extern "C" int isg_topk_threshold(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
                                   const int32_t *nmax_dev, const float *noise, float noise_scale, uint64_t seed,
-                                  int32_t k, float *out, void *stream) {
+                                  int32_t k, float *out, float *dense_out, void *stream) {
   int st = check_rows(scores, B, nmax_host, k, out);
   if (st != ISG_OK) return st;
   if (B == 0 || nmax_host == 0) return ISG_OK;
-  RowArgs a{scores, ptr, nmax_dev, noise, out, nullptr, (int)B, nmax_host, k, 1.f, noise_scale, seed};
+  RowArgs a{scores, ptr, nmax_dev, noise, out, dense_out, (int)B, nmax_host, k, 1.f, noise_scale, seed};
   dim3 grid((unsigned)((B + 3) / 4)), block(256);
   hipStream_t s = as_stream(stream);
   switch (pick_slots(nmax_host)) {

@@ -37,6 +37,7 @@ class MaskingModel(torch.nn.Module):
         self.masking_threshold = int(masking_threshold) if masking_threshold > 1 else masking_threshold
         self.dim_nodes, self.dim_questions = dim_nodes, dim_questions
         self.nb_samples, self.tau = nb_samples, tau
+        self.gate_dropout = 0.2                                                          # masking.py:159,196
 
         self.gate_nn = torch.nn.Sequential(torch.nn.Linear(dim_questions, dim_questions), torch.nn.GELU(),
                                            torch.nn.Linear(dim_questions, 1))          # unused in forward (:139)
@@ -79,9 +80,9 @@ class MaskingModel(torch.nn.Module):
             plan = ops.GraphPlan.build(batch, None, num_graphs=size)
         gate = self.gate_scores(x, u, batch, u_is_per_graph)
         if not self.use_topk:                                               # masking.py:195-198
-            gate = F.dropout(gate, p=0.2, training=self.training)
+            gate = F.dropout(gate, p=self.gate_dropout, training=self.training)
             return (torch.sigmoid(gate) > 0.5).to(dtype=gate.dtype)
-        gate = F.dropout(gate, p=0.2, training=self.training)                # :159
+        gate = F.dropout(gate, p=self.gate_dropout, training=self.training)  # :159
         B, nmax = plan.B, plan.nmax
         if self.sampler_type == "gumbel":
             if noise is None and seed is None:                               # torch generator, like the reference
@@ -92,6 +93,11 @@ class MaskingModel(torch.nn.Module):
         if self.sampler_type in ("imle", "aimle"):
             sampler = self.sampler_train if self.training else self.sampler_val
             temp = sampler.noise_temperature
+            if self.training and ops._rec(gate):       # estimator with the second MAP solve in its backward
+                if noise is None and seed is None:
+                    noise = sampler.noise_distribution.sample(torch.Size([B, 1, nmax, 1])).to(gate.device)
+                nz = None if noise is None else noise.reshape(B, nmax).contiguous().float()
+                return sampler.differentiable(gate, plan, nz, 0 if seed is None else seed)
             if temp == 0.0:
                 return ops.topk_threshold(gate, int(self.sample_k), plan=plan)
             if noise is None and seed is None:

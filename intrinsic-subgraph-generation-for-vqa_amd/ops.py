@@ -2,11 +2,13 @@
 
 PyTorch is plumbing here: it owns device memory and the stream; every operator validates its
 operands on the host (device, dtype, contiguity, shapes -- a wrong shape must never reach a
-kernel) and then hands raw pointers to libisg_hip.so on torch's current stream.  Forward only:
-operators refuse tensors that require grad while grad mode is on (SURVEY §8f-1 is a later row).
+kernel) and then hands raw pointers to libisg_hip.so on torch's current stream.  When autograd is
+recording through an operand the call is routed through autograd.py; an operator
+without a backward refuses such an operand loudly.
 """
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -39,6 +41,12 @@ class KernelTimer:
 MP_TIMER: Optional[KernelTimer] = None   # set by bench.py around its timed region
 
 
+def _rec(*tensors) -> bool:
+    """True when autograd is recording through any of the tensors: the call is then routed through autograd.py, whose
+    Function.forward re-enters the same ops.* function with autograd off."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -58,8 +66,8 @@ def _chk(t: Optional[Tensor], name: str, dtype, shape=None, optional=False) -> i
         raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
     if torch.is_grad_enabled() and t.requires_grad:
         raise NotImplementedError(
-            f"{name} requires grad: the HIP path is forward-only (wrap the call in torch.no_grad()); "
-            "backward of the hot path is SURVEY §8(f) row 1")
+            f"{name} requires grad but this operator has no backward (see autograd.py for the differentiable set); "
+            "wrap the call in torch.no_grad() or detach the input")
     return t.data_ptr()
 
 
@@ -70,7 +78,7 @@ def _chk_rows(t: Tensor, name: str) -> int:
     if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or (t.stride(0) & 3) or (t.data_ptr() & 15):
         raise ValueError(f"{name}: expected fp32 [rows, cols] with contiguous columns and 16-byte aligned rows")
     if torch.is_grad_enabled() and t.requires_grad:
-        raise NotImplementedError(f"{name} requires grad: the HIP path is forward-only")
+        raise NotImplementedError(f"{name} requires grad but this operator has no backward (see autograd.py)")
     return t.data_ptr()
 
 
@@ -102,6 +110,7 @@ class GraphPlan:
     src: Optional[Tensor] = None
     dst: Optional[Tensor] = None
     eptr: Optional[Tensor] = None
+    batch: Optional[Tensor] = None           # kept for the backward restatements (autograd.py)
     edge_index: Optional[Tensor] = None      # kept for the lazily built CSR by source (backward only)
     _by_src: Optional[Tuple[Tensor, Tensor, Tensor]] = None
 
@@ -138,7 +147,7 @@ class GraphPlan:
         nmax_dev = bounds[:1]
         _lib.check(lib.isg_graph_ptr(batch.data_ptr(), N, B, ptr.data_ptr(), nmax_dev.data_ptr(), _stream()),
                    "isg_graph_ptr")
-        plan = GraphPlan(N=N, E=0, B=B, ptr=ptr, nmax_dev=nmax_dev, nmax=0)
+        plan = GraphPlan(N=N, E=0, B=B, ptr=ptr, nmax_dev=nmax_dev, nmax=0, batch=batch)
         if edge_index is not None:
             _chk(edge_index, "edge_index", torch.int64)
             if edge_index.dim() != 2 or edge_index.size(0) != 2:
@@ -168,6 +177,23 @@ class GraphPlan:
             raise _lib.IsgError(f"graphs with more than {MAX_NODES_PER_GRAPH} nodes are unsupported (got {plan.nmax})")
         return plan
 
+    @staticmethod
+    def edges_only(edge_index: Tensor, num_nodes: int) -> "GraphPlan":
+        """CSR by destination without any per-graph structure (for callers that only have edge_index)."""
+        lib = _lib.load()
+        _chk(edge_index, "edge_index", torch.int64)
+        dev, N, E = edge_index.device, int(num_nodes), edge_index.size(1)
+        plan = GraphPlan(N=N, E=E, B=0, ptr=torch.zeros(1, dtype=torch.int32, device=dev),
+                         nmax_dev=torch.zeros(1, dtype=torch.int32, device=dev), nmax=0, edge_index=edge_index)
+        plan.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        plan.eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        plan.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        ws_bytes = lib.isg_csr_workspace_bytes(N, E)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.isg_csr_build(edge_index.data_ptr(), N, E, plan.rowptr.data_ptr(), plan.eid.data_ptr(),
+                                     plan.src.data_ptr(), 0, ws.data_ptr(), ws_bytes, _stream()), "isg_csr_build")
+        return plan
+
     def require_csr(self) -> None:
         if self.rowptr is None:
             raise ValueError("this GraphPlan was built without edge_index")
@@ -178,6 +204,9 @@ class GraphPlan:
 # ------------------------------------------------------------------------------------------------
 def instr_gate(x: Tensor, instr: Tensor, batch: Tensor) -> Tensor:
     """gelu(x * instr[batch])   (mgat_v2_conv.py:156-157)"""
+    if _rec(x, instr):
+        from . import autograd
+        return autograd.instr_gate(x, instr, batch)
     lib = _lib.load()
     N, C = x.shape
     out = torch.empty_like(x)
@@ -187,8 +216,14 @@ def instr_gate(x: Tensor, instr: Tensor, batch: Tensor) -> Tensor:
     return out
 
 
-def node_to_edge_mask(mask: Tensor, edge_index: Tensor) -> Tensor:
-    """mask[src] * mask[dst]   (sampling/node_edge_masks.py:7-10).  mask [N,1] or [N] -> [E,1] / [E]."""
+def node_to_edge_mask(mask: Tensor, edge_index: Tensor, plan: Optional[GraphPlan] = None) -> Tensor:
+    """mask[src] * mask[dst]   (sampling/node_edge_masks.py:7-10).  mask [N,1] or [N] -> [E,1] / [E].
+    ``plan`` (CSR by destination) is only needed when the mask requires grad."""
+    if _rec(mask):
+        from . import autograd
+        if plan is None:
+            raise ValueError("node_to_edge_mask needs the GraphPlan to differentiate (its backward walks the CSR)")
+        return autograd.node_to_edge_mask(mask, edge_index, plan)
     lib = _lib.load()
     E = edge_index.size(1)
     flat = mask.reshape(-1)
@@ -205,6 +240,9 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
              bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
              negative_slope: float = 0.2, kernel: Optional[str] = None) -> Tuple[Tensor, Tensor]:
     """MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:243-279).  Returns (out[N,H*C], alpha[E,H])."""
+    if _rec(x_l, x_r, e_proj, att, bias, node_mask, edge_mask):
+        from . import autograd
+        return autograd.gatv2_mp(x_l, x_r, e_proj, att, plan, heads, bias, node_mask, edge_mask, negative_slope, kernel)
     lib = _lib.load()
     plan.require_csr()
     N, HC = x_l.shape
@@ -296,6 +334,9 @@ def mp_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool, feat_byte
 
 def scatter_mean(msg: Tensor, plan: GraphPlan) -> Tensor:
     """scatter_mean(msg, dst, dim_size=N)   (scene_graph_encoder.py:141)"""
+    if _rec(msg):
+        from . import autograd
+        return autograd.scatter_mean(msg, plan)
     lib = _lib.load()
     plan.require_csr()
     E, C = msg.shape
@@ -312,6 +353,9 @@ def scatter_mean(msg: Tensor, plan: GraphPlan) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 def node_gate(xn: Tensor, q: Tensor, batch: Tensor, double_index: bool) -> Tensor:
     """gelu(<xn_n, q[r(n)]>/sqrt(C)) -> [N,1]   (masking.py:151-155)"""
+    if _rec(xn, q):
+        from . import autograd
+        return autograd.node_gate(xn, q, batch, double_index)
     lib = _lib.load()
     N, C = xn.shape
     gate = torch.empty(N, 1, dtype=torch.float32, device=xn.device)
@@ -350,6 +394,11 @@ def topk_gumbel(scores: Tensor, k: int, tau: float = 0.1, plan: Optional[GraphPl
     Ragged (plan given): scores [N] / [N,1] -> mask of the same shape (the dense-pad and the `[mask]`
     un-pad of masking.py:162,176 are fused).  Dense: scores [B,Nmax] -> [B,Nmax].
     """
+    if _rec(scores):
+        from . import autograd
+        if return_khot:
+            raise ValueError("return_khot is an inspection output and is not differentiable")
+        return autograd.topk_gumbel(scores, k, tau, plan, noise, seed)
     lib = _lib.load()
     flat, ptr, B, nmax, nmax_dev = _rows(scores, plan)
     out = torch.empty_like(flat)
@@ -363,14 +412,35 @@ def topk_gumbel(scores: Tensor, k: int, tau: float = 0.1, plan: Optional[GraphPl
 
 
 def topk_threshold(scores: Tensor, k: int, plan: Optional[GraphPlan] = None, noise: Optional[Tensor] = None,
-                   noise_scale: float = 0.0, seed: int = 0) -> Tensor:
-    """(scores + noise*noise_scale) >= k-th largest, per row (deterministic_scheme.py:36-43)."""
+                   noise_scale: float = 0.0, seed: int = 0, return_dense: bool = False):
+    """(scores + noise*noise_scale) >= k-th largest, per row (deterministic_scheme.py:36-43).  Not differentiable by
+    itself: the I-MLE / AIMLE estimators around it are autograd.imle_topk / aimle_topk.  ``return_dense`` also returns
+    the selection over the padded [B, Nmax] rows (pads included)."""
     lib = _lib.load()
+    scores = scores.detach()
     flat, ptr, B, nmax, nmax_dev = _rows(scores, plan)
     out = torch.empty_like(flat)
+    dense = torch.empty(B, nmax, dtype=torch.float32, device=scores.device) if return_dense else None
     _lib.check(lib.isg_topk_threshold(_chk(flat, "scores", torch.float32), ptr, B, nmax, nmax_dev,
                                       _noise_ptr(noise, B, nmax), float(noise_scale), int(seed) & (2 ** 64 - 1), int(k),
-                                      out.data_ptr(), _stream()), "isg_topk_threshold")
+                                      out.data_ptr(), 0 if dense is None else dense.data_ptr(), _stream()),
+               "isg_topk_threshold")
+    out = out.view(scores.shape)
+    return (out, dense) if return_dense else out
+
+
+def topk_gumbel_backward(scores: Tensor, grad_out: Tensor, k: int, tau: float = 0.1, plan: Optional[GraphPlan] = None,
+                         noise: Optional[Tensor] = None, seed: int = 0) -> Tensor:
+    """d scores of topk_gumbel for d out = grad_out (straight-through, gumbel_scheme.py:83-90); same arguments as the
+    forward (the relaxation is replayed from scores + noise/seed)."""
+    lib = _lib.load()
+    flat, ptr, B, nmax, nmax_dev = _rows(scores, plan)
+    g = grad_out.reshape(flat.shape).contiguous()
+    out = torch.empty_like(flat)
+    _lib.check(lib.isg_topk_gumbel_bwd(_chk(flat, "scores", torch.float32), ptr, B, nmax, nmax_dev,
+                                       _noise_ptr(noise, B, nmax), int(seed) & (2 ** 64 - 1), int(k), float(tau),
+                                       _chk(g, "grad_out", torch.float32), out.data_ptr(), _stream()),
+               "isg_topk_gumbel_bwd")
     return out.view(scores.shape)
 
 
@@ -379,10 +449,13 @@ def topk_threshold(scores: Tensor, k: int, plan: Optional[GraphPlan] = None, noi
 # ------------------------------------------------------------------------------------------------
 def scatter_attention(query: Tensor, key: Tensor, plan: GraphPlan, value: Optional[Tensor] = None) -> Tensor:
     """softmax_g(<query_g, key_n>/sqrt(C)) * value_n   (utils/scatter_scaled_dot_product.py:6-15)"""
-    lib = _lib.load()
-    N, C = key.shape
     if value is None:
         value = key
+    if _rec(query, key, value):
+        from . import autograd
+        return autograd.scatter_attention(query, key, plan, value)
+    lib = _lib.load()
+    N, C = key.shape
     out = torch.empty_like(value)
     _lib.check(lib.isg_scatter_attention(_chk(query, "query", torch.float32, (plan.B, C)),
                                          _chk(key, "key", torch.float32, (plan.N, C)),
@@ -395,6 +468,9 @@ def scatter_attention(query: Tensor, key: Tensor, plan: GraphPlan, value: Option
 def graph_norm(x: Tensor, plan: GraphPlan, weight: Tensor, bias: Tensor, mean_scale: Tensor, eps: float = 1e-5,
                fp64: bool = False) -> Tensor:
     """PyG GraphNorm forward (mgat.py:171); fp64=True mirrors scene_graph_encoder.py:99-102."""
+    if _rec(x, weight, bias, mean_scale):
+        from . import autograd
+        return autograd.graph_norm(x, plan, weight, bias, mean_scale, eps, fp64)
     lib = _lib.load()
     N, C = x.shape
     out = torch.empty_like(x)
@@ -408,6 +484,9 @@ def graph_norm(x: Tensor, plan: GraphPlan, weight: Tensor, bias: Tensor, mean_sc
 def mgat_layer_tail(ins: Tensor, c: Tensor, h: Tensor, plan: GraphPlan, weight: Tensor, bias: Tensor,
                     mean_scale: Tensor, eps: float = 1e-5, node_mask: Optional[Tensor] = None) -> Tensor:
     """scatter attention -> GraphNorm -> + h [-> * mask], fused (mgat.py:168-177)."""
+    if _rec(ins, c, h, weight, bias, mean_scale, node_mask):
+        from . import autograd
+        return autograd.mgat_layer_tail(ins, c, h, plan, weight, bias, mean_scale, eps, node_mask)
     lib = _lib.load()
     N, C = c.shape
     out = torch.empty_like(h)
@@ -422,6 +501,9 @@ def mgat_layer_tail(ins: Tensor, c: Tensor, h: Tensor, plan: GraphPlan, weight: 
 
 def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional[Tensor] = None):
     """GlobalAttention soft-max pooling (att_pooling.py:63-73).  Returns (out[B,C], gate[N,1])."""
+    if _rec(xn, q, node_mask):
+        from . import autograd
+        return autograd.global_attn_pool(xn, q, plan, node_mask)
     lib = _lib.load()
     N, C = xn.shape
     out = torch.empty(plan.B, C, dtype=torch.float32, device=xn.device)
@@ -437,14 +519,15 @@ def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional
 # Dense projections: fp32 accuracy on the bf16 matrix cores (csrc/isg_gemm.hip)
 # ------------------------------------------------------------------------------------------------
 GEMM_BACKEND = "bf16x6"      # "bf16x6": isg_linear_bf16x6; "torch": hipBLASLt fp32 through torch (A/B switch)
-_PLANES = {}                 # id(weight) -> (version, data_ptr, planes): static weights are split once
+_PLANES = {}                 # id(weight) -> (weakref, version, data_ptr, planes): static weights are split once
 
 
-def _weight_planes(weight: Tensor) -> Tensor:
+def _weight_planes(weight: Tensor, cache: bool = True) -> Tensor:
     key = id(weight)
-    hit = _PLANES.get(key)
-    if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
-        return hit[2]
+    hit = _PLANES.get(key) if cache else None
+    # the weak reference pins the identity: a freed weight's id (and even its address) can be reused by another model
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
     lib = _lib.load()
     N, K = weight.shape
     Kp = (K + 31) // 32 * 32
@@ -452,21 +535,30 @@ def _weight_planes(weight: Tensor) -> Tensor:
     w = weight.detach()
     _lib.check(lib.isg_split_bf16x3(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(), _stream()),
                "isg_split_bf16x3")
-    _PLANES[key] = (weight._version, weight.data_ptr(), planes)
+    if cache:
+        if len(_PLANES) > 256:
+            for k in [k for k, v in _PLANES.items() if v[0]() is None]:
+                del _PLANES[k]
+        _PLANES[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), planes)
     return planes
 
 
-def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False,
+           cache_planes: bool = True) -> Tensor:
     """act(x @ weight^T + bias), x [M,K] fp32, weight [N,K] (torch Linear layout).  Uses the bf16x6 matrix-core kernel
-    when the shape allows it, hipBLASLt through torch otherwise (K not a multiple of 4)."""
+    when the shape allows it, hipBLASLt through torch otherwise (K not a multiple of 4).  ``cache_planes=False``: the
+    weight is being trained (or is a temporary), so its bf16 planes are split per call instead of cached."""
     M, K = x.shape
+    if _rec(x, weight, bias) and GEMM_BACKEND == "bf16x6" and (K & 3) == 0 and M > 0:
+        from . import autograd
+        return autograd.linear(x, weight, bias, gelu)
     N = weight.size(0)
     if GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or M == 0:
         y = torch.nn.functional.linear(x, weight, bias)
         return torch.nn.functional.gelu(y) if gelu else y
     lib = _lib.load()
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    planes = _weight_planes(weight)
+    planes = _weight_planes(weight, cache_planes)
     _lib.check(lib.isg_linear_bf16x6(_chk(x, "x", torch.float32), planes.data_ptr(),
                                      _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
                                      out.data_ptr(), M, N, K, K, N, 1 if gelu else 0, _stream()), "isg_linear_bf16x6")
@@ -489,21 +581,35 @@ def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:
     return x
 
 
-_CAT = {}   # (ids of the weights) -> (versions, concatenated weight, concatenated bias)
+_CAT = {}   # (ids of the weights) -> (versions, concatenated weight, concatenated bias, weakrefs of the weights)
 
 
 def linear_fused(x: Tensor, layers) -> Tuple[Tensor, ...]:
     """Several Linear layers that share their input as ONE projection (weights concatenated along the output dim, cached);
     returns one column-slice view of the fused output per layer (row stride = total width)."""
+    if _rec(x, *[m.weight for m in layers]):      # training: differentiable concatenation, nothing cached
+        w = torch.cat([m.weight for m in layers], dim=0)
+        b = torch.cat([m.bias if m.bias is not None else torch.zeros(m.weight.size(0), device=w.device)
+                       for m in layers]) if any(m.bias is not None for m in layers) else None
+        y = linear(x, w, b)
+        outs, o = [], 0
+        for m in layers:
+            n = m.weight.size(0)
+            outs.append(y[:, o:o + n])
+            o += n
+        return tuple(outs)
     key = tuple(id(m.weight) for m in layers)
     ver = tuple((m.weight._version, m.weight.data_ptr(), None if m.bias is None else m.bias._version) for m in layers)
     hit = _CAT.get(key)
-    if hit is None or hit[0] != ver:
+    if hit is None or hit[0] != ver or any(r() is not m.weight for r, m in zip(hit[3], layers)):
         w = torch.cat([m.weight.detach() for m in layers], dim=0).contiguous()
         has_b = any(m.bias is not None for m in layers)
         b = torch.cat([m.bias.detach() if m.bias is not None else torch.zeros(m.weight.size(0), device=w.device)
                        for m in layers]) if has_b else None
-        hit = (ver, w, b)
+        if len(_CAT) > 256:
+            for k in [k for k, v in _CAT.items() if any(r() is None for r in v[3])]:
+                del _CAT[k]
+        hit = (ver, w, b, tuple(weakref.ref(m.weight) for m in layers))
         _CAT[key] = hit
     y = linear(x, hit[1], hit[2])
     outs, o = [], 0

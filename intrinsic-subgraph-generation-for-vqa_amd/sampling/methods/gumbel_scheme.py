@@ -37,12 +37,10 @@ class GumbelSampler(torch.nn.Module):
         repeat = self.train_ensemble if train else self.val_ensemble
         if repeat != 1:
             raise NotImplementedError("ensembles > 1 are never used by ISubGVQA (masking.py:122)")
-        if torch.is_grad_enabled() and scores.requires_grad:
-            raise NotImplementedError("straight-through backward is not implemented on the HIP path (SURVEY §8f-1)")
         B, nmax, ens = scores.shape
         if ens != 1:
             raise NotImplementedError("ensemble dimension must be 1")
-        dense = scores.detach().reshape(B, nmax).contiguous()
+        dense = scores.reshape(B, nmax).contiguous()      # differentiable: straight-through backward (:83-90)
         if noise is None and seed is None:
             noise = gumbel_from_uniform(torch.rand(B, nmax, device=scores.device))
         res = ops.topk_gumbel(dense, int(self.k), float(self.tau), noise=noise, seed=0 if seed is None else seed)

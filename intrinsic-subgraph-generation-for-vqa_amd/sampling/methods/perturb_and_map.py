@@ -1,6 +1,11 @@
-"""Forward pass of the I-MLE and AIMLE perturb-and-MAP wrappers.
+"""The I-MLE and AIMLE perturb-and-MAP wrappers.
 
-Reference behaviour (forward only; the backward passes are SURVEY §8f row 1):
+Backward: I-MLE solves MAP(alpha*theta - beta*dy + tau*eps) once more and returns z - z'
+(wrapper.py:124-172); AIMLE solves the two symmetric targets alpha*theta -/+ lambda*dy and adapts lambda's beta
+(aimle.py:141-243, target_aimle.py:88-162).  Both are autograd.imle_topk / aimle_topk: the same isg_topk_threshold
+kernel on the target scores with the forward's noise.
+
+Reference behaviour of the forward:
   * I-MLE  ISubGVQA/sampling/methods/wrapper.py:75-121: noise [B, S, ...] is drawn, scaled by
     input_noise_temperature, added to the input, the solver is run on [B*S, ...] and the result is
     returned as ([S, B, ...], aux).
@@ -27,25 +32,55 @@ class PerturbAndMAP:
         self.nb_samples = int(nb_samples)
         self.noise_temperature = float(noise_temperature)
         self.kind = kind                                   # "imle" | "aimle"
-        self.target_distribution = target_distribution      # backward only
-        self.target_noise_temperature = target_noise_temperature
+        self.target_noise_temperature = float(target_noise_temperature)
         self.__name__ = getattr(function, "__name__", "perturb_and_map")
+        # backward only.  I-MLE: (alpha, beta); AIMLE: the stateful adaptive target (one per sampler, like the reference)
+        from .target import TargetDistribution
+        from .target_aimle import AdaptiveTargetDistribution
+        if isinstance(target_distribution, tuple):        # ("imle", alpha, beta) / ("aimle", alpha, beta0) shorthand
+            _, a, b = target_distribution
+            target_distribution = (TargetDistribution(alpha=a, beta=b) if kind == "imle"
+                                   else AdaptiveTargetDistribution(initial_alpha=a, initial_beta=b))
+        if target_distribution is None and kind == "imle":
+            target_distribution = TargetDistribution(alpha=1.0, beta=1.0)               # wrapper.py:57-58
+        self.target_distribution = target_distribution
 
     def _scheme_k(self) -> Optional[int]:
         """k of the wrapped IMLEScheme when the solver is the stock threshold top-k, else None."""
         return getattr(self.function, "_isg_threshold_k", None)
 
+    def differentiable(self, scores: Tensor, plan, noise: Optional[Tensor], seed: int = 0) -> Tensor:
+        """The estimator on one row layout (ragged with ``plan``, dense [B, Nmax] without); scores requires grad.
+        ``noise`` [B, Nmax] Gumbel(0, 0.3) draw or None for the in-kernel Philox stream of ``seed``."""
+        from ... import autograd
+        k = self._scheme_k()
+        if self.nb_samples != 1 or k is None:
+            raise NotImplementedError("backward needs nb_samples == 1 and the stock threshold top-k solver")
+        if self.kind == "imle":
+            t = self.target_distribution
+            return autograd.imle_topk(scores, int(k), plan, noise, seed, float(t.alpha), float(t.beta),
+                                      self.noise_temperature, self.target_noise_temperature)
+        from .target_aimle import AdaptiveTargetDistribution
+        if not isinstance(self.target_distribution, AdaptiveTargetDistribution):
+            raise NotImplementedError("AIMLE backward is implemented for the adaptive target (masking.py:258-260)")
+        return autograd.aimle_topk(scores, int(k), plan, noise, seed, self.target_distribution,
+                                   self.noise_temperature, self.target_noise_temperature)
+
     def __call__(self, theta: Tensor, *args, noise: Optional[Tensor] = None):
-        if torch.is_grad_enabled() and theta.requires_grad:
-            raise NotImplementedError("I-MLE/AIMLE backward is not implemented on the HIP path (SURVEY §8f-1)")
         if theta.dim() != 3:
             raise ValueError(f"expected theta [B, Nmax, 1], got {tuple(theta.shape)}")
         B, nmax, ens = theta.shape
         S = self.nb_samples
-        if noise is None and self.noise_distribution is not None and self.noise_temperature != 0.0:
+        if noise is None and self.noise_distribution is not None and (self.noise_temperature != 0.0 or ops._rec(theta)):
             noise = self.noise_distribution.sample(torch.Size([B, S, nmax, ens])).to(theta.device)
         k = self._scheme_k()
-        if S == 1 and ens == 1 and k is not None:
+        if ops._rec(theta):
+            if ens != 1:
+                raise NotImplementedError("ensemble dimension must be 1")
+            nz = None if noise is None else noise.reshape(B, nmax).contiguous().float()
+            z = self.differentiable(theta.reshape(B, nmax), None, nz).view(B, nmax, 1)
+            aux = None
+        elif S == 1 and ens == 1 and k is not None:
             dense = theta.detach().reshape(B, nmax).contiguous()
             z = ops.topk_threshold(dense, k, noise=None if (noise is None or self.noise_temperature == 0.0)
                                    else noise.reshape(B, nmax).contiguous().float(),

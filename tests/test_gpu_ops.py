@@ -367,3 +367,16 @@ def test_csr_build_large_batch_scan(dev):
     order = torch.sort(dst, stable=True).indices
     assert torch.equal(plan.eid.cpu().long(), order)
     assert plan.nmax == 37
+
+
+def test_weight_plane_cache_survives_id_and_address_reuse(dev):
+    """The bf16 planes of a weight are cached per tensor object; a new weight that lands on a freed one's id / address
+    must not pick up the stale planes."""
+    from isubgvqa_amd import ops
+    x = torch.randn(256, 64, device=dev)
+    for seed in range(6):
+        w = torch.randn(96, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+        got = ops.linear(x, w)
+        ref = x.double() @ w.double().t()
+        assert (got.double() - ref).abs().max() < 1e-4, seed
+        del w, got

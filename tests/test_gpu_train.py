@@ -1,0 +1,270 @@
+"""Training of the hot path on a real MI355X: gradients of the HIP path against
+  * the CPU oracle differentiated by torch autograd (with the reference's custom backward rules restated), and
+  * gradients produced by the real reference (goldens G6 samplers, G7 MGAT + pooling in train() mode).
+Tolerances: masks / I-MLE gradients are integers and must be exact; fp32 gradients within 2e-4 relative to the tensor's
+largest entry (summation order differs: CSR order on the GPU, edge order on the CPU)."""
+import glob
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X (run with -m gpu on the GPU box)"
+    return torch.device("cuda:0")
+
+
+def close(got, ref, tol=2e-4, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max()) / scale
+    assert err < tol, f"{what}: max |diff| / max |ref| = {err:.3e} (tol {tol})"
+
+
+def random_graph_batch(sizes, extra, seed, hub=0):
+    gen = torch.Generator().manual_seed(seed)
+    batch, src, dst, off = [], [], [], 0
+    for g, n in enumerate(sizes):
+        batch += [g] * n
+        for v in range(n):
+            src.append(off + v); dst.append(off + v)
+        for _ in range(extra * n):
+            src.append(off + int(torch.randint(0, n, (1,), generator=gen)))
+            dst.append(off + int(torch.randint(0, n, (1,), generator=gen)))
+        if g == 0:
+            for _ in range(hub):          # many edges into node 0 of graph 0: beyond the per-wave LDS strip
+                src.append(off + int(torch.randint(0, n, (1,), generator=gen))); dst.append(off)
+        off += n
+    ei = torch.tensor([src, dst], dtype=torch.long)
+    return torch.tensor(batch, dtype=torch.long), ei[:, torch.randperm(ei.size(1), generator=gen)]
+
+
+@pytest.mark.parametrize("mask_kind", ["none", "node", "edge"])
+@pytest.mark.parametrize("H,C,hub", [(4, 8, 0), (4, 128, 0), (4, 300, 50), (2, 16, 0), (1, 32, 40), (8, 12, 0)])
+def test_gatv2_mp_backward_matches_oracle_autograd(dev, mask_kind, H, C, hub):
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    batch, ei = random_graph_batch([5, 1, 9, 17, 3], 2, seed=H * 1000 + C, hub=hub)
+    N, E = batch.numel(), ei.size(1)
+    gen = torch.Generator().manual_seed(7)
+    x_l, x_r = torch.randn(N, H * C, generator=gen), torch.randn(N, H * C, generator=gen)
+    e_proj, att = torch.randn(E, H * C, generator=gen), torch.randn(1, H, C, generator=gen)
+    bias = torch.randn(H * C, generator=gen)
+    w = torch.randn(N, H * C, generator=gen)
+    node_mask = (torch.rand(N, 1, generator=gen) < 0.6).float()
+    edge_mask = (torch.rand(E, 1, generator=gen) < 0.6).float() * (0.5 + torch.rand(E, 1, generator=gen))
+
+    cpu = [t.clone().requires_grad_(True) for t in (x_l, x_r, e_proj, att, bias)]
+    m_cpu = None
+    if mask_kind == "node":
+        m_cpu = node_mask.clone().requires_grad_(True)
+        em = OM.node_mask_to_edge_mask(m_cpu, ei)
+    elif mask_kind == "edge":
+        m_cpu = edge_mask.clone().requires_grad_(True)
+        em = m_cpu
+    else:
+        em = None
+    out_ref, _ = OM.gatv2_message_passing(cpu[0].view(N, H, C), cpu[1].view(N, H, C), cpu[2].view(E, H, C), cpu[3], ei, em)
+    ((out_ref.reshape(N, H * C) + cpu[4]) * w).sum().backward()
+
+    gpu = [t.to(dev).requires_grad_(True) for t in (x_l, x_r, e_proj, att, bias)]
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=5)
+    m_gpu = None
+    kw = {}
+    if mask_kind == "node":
+        m_gpu = node_mask.to(dev).requires_grad_(True)
+        kw["node_mask"] = m_gpu
+    elif mask_kind == "edge":
+        m_gpu = edge_mask.to(dev).requires_grad_(True)
+        kw["edge_mask"] = m_gpu
+    out, alpha = ops.gatv2_mp(gpu[0], gpu[1], gpu[2], gpu[3], plan, H, bias=gpu[4], **kw)
+    assert not alpha.requires_grad
+    close(out, out_ref.reshape(N, H * C) + cpu[4], 1e-5, "forward")
+    (out * w.to(dev)).sum().backward()
+    for name, a, b in zip(("d x_l", "d x_r", "d e_proj", "d att", "d bias"), gpu, cpu):
+        close(a.grad, b.grad, 2e-4, name)
+    if m_gpu is not None:
+        close(m_gpu.grad, m_cpu.grad, 2e-4, f"d {mask_kind} mask")
+
+
+def test_node_to_edge_mask_backward_keeps_the_reference_rule(dev):
+    from isubgvqa_amd.sampling.node_edge_masks import NodeMaskToEdgeMask
+    _, ei = random_graph_batch([6, 4, 11], 3, seed=3)
+    N, E = 21, ei.size(1)
+    gen = torch.Generator().manual_seed(5)
+    mask = torch.rand(N, 1, generator=gen)
+    w = torch.randn(E, 1, generator=gen)
+    m = mask.to(dev).requires_grad_(True)
+    em = NodeMaskToEdgeMask.apply(m, ei.to(dev), torch.tensor(N))
+    assert torch.equal(em.cpu(), mask[ei[0]] * mask[ei[1]])
+    (em * w.to(dev)).sum().backward()
+    ref = torch.zeros(N, 1).index_add_(0, ei[1], w)          # destination only, no product rule
+    close(m.grad, ref, 1e-6, "d mask")
+
+
+# ---- samplers against gradients produced by the reference (G6) -------------------------------------------------------
+def _ragged(c, dev):
+    """(scores[N,1], batch[N], plan, slot index of every real node in the dense [B*Nmax] layout)"""
+    from isubgvqa_amd import ops
+    lens = c["lens"]
+    B, nmax = c["scores"].shape[:2]
+    batch = torch.repeat_interleave(torch.arange(B), lens)
+    pos = torch.cat([torch.arange(int(n)) for n in lens])
+    slot = batch * nmax + pos
+    plan = ops.GraphPlan.build(batch.to(dev), None, num_graphs=B)
+    return slot, batch, plan
+
+
+def test_gumbel_straight_through_gradient_matches_reference(dev):
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.sampling.methods.gumbel_scheme import GumbelSampler
+    for c in load_golden("g6_sampler_grads.pt")["gumbel"]:
+        B, nmax = c["scores"].shape[:2]
+        # dense, through the drop-in sampler class
+        th = c["scores"].to(dev).requires_grad_(True)
+        res, _ = GumbelSampler(k=c["k"], policy="edge_candid", train_ensemble=1, val_ensemble=1)(
+            th, train=True, noise=c["noise"].to(dev))
+        assert torch.equal(res.detach().cpu() > 0.5, c["out"] > 0.5)
+        (res.squeeze(0) * c["w"].to(dev)).sum().backward()
+        close(th.grad, c["grad"], 2e-4, "gumbel dense grad")
+        # ragged rows (what MaskingModel runs): rows of different lengths inside one padded batch
+        if int(c["lens"].max()) == nmax:
+            slot, _, plan = _ragged(c, dev)
+            sc = c["scores"].reshape(-1)[slot].view(-1, 1).to(dev).requires_grad_(True)
+            out = ops.topk_gumbel(sc, c["k"], 0.1, plan=plan, noise=c["noise"].to(dev))
+            assert torch.equal(out.detach().cpu().view(-1) > 0.5, c["out"].reshape(-1)[slot] > 0.5)
+            (out * c["w"].reshape(-1)[slot].view(-1, 1).to(dev)).sum().backward()
+            close(sc.grad.view(-1), c["grad"].reshape(-1)[slot], 2e-4, "gumbel ragged grad")
+
+
+def test_imle_second_map_solve_matches_reference(dev):
+    from isubgvqa_amd.models.masking import get_imle_samplers
+    for c in load_golden("g6_sampler_grads.pt")["imle"]:
+        B, nmax = c["scores"].shape[:2]
+        train, _ = get_imle_samplers(sample_k=c["k"], device=dev, nb_samples=1, alpha=1.0, beta=c["beta"], tau=1.0)
+        th = c["scores"].to(dev).requires_grad_(True)
+        res = train(th, noise=c["noise"].to(dev))[0]
+        assert torch.equal(res.detach().cpu(), c["out"])
+        (res.squeeze(0) * c["w"].to(dev)).sum().backward()
+        assert torch.equal(th.grad.cpu(), c["grad"]), "I-MLE gradient (z - z') differs from the reference"
+        if int(c["lens"].max()) == nmax:
+            slot, _, plan = _ragged(c, dev)
+            sc = c["scores"].reshape(-1)[slot].view(-1, 1).to(dev).requires_grad_(True)
+            out = train.differentiable(sc, plan, c["noise"].reshape(B, nmax).to(dev))
+            (out * c["w"].reshape(-1)[slot].view(-1, 1).to(dev)).sum().backward()
+            assert torch.equal(sc.grad.cpu().view(-1), c["grad"].reshape(-1)[slot])
+
+
+def test_aimle_adaptive_target_matches_reference_over_steps(dev):
+    from isubgvqa_amd.sampling.methods.aimle import aimle
+    from isubgvqa_amd.sampling.methods.deterministic_scheme import IMLEScheme
+    from isubgvqa_amd.sampling.methods.noise import GumbelDistribution
+    from isubgvqa_amd.sampling.methods.target_aimle import AdaptiveTargetDistribution
+    from isubgvqa_amd.models.masking import _scheme_fn
+    for c in load_golden("g6_sampler_grads.pt")["aimle"]:
+        target = AdaptiveTargetDistribution(initial_alpha=1.0, initial_beta=c["beta0"])
+        train = aimle(_scheme_fn(IMLEScheme("edge_candid", c["k"], 1, 1)), target_distribution=target,
+                      noise_distribution=GumbelDistribution(0.0, 0.3, dev), nb_samples=1,
+                      theta_noise_temperature=c["tau"], target_noise_temperature=c["tau"], symmetric_perturbation=True)
+        for st in c["steps"]:
+            th = st["scores"].to(dev).requires_grad_(True)
+            res = train(th, noise=st["noise"].to(dev))
+            assert torch.equal(res.detach().cpu(), st["out"])
+            (res * st["w"].to(dev)).sum().backward()
+            close(th.grad, st["grad"], 1e-5, "aimle grad") if float(st["grad"].abs().max()) > 0 else \
+                (lambda: None)()
+            assert float(th.grad.abs().max()) > 0 or float(st["grad"].abs().max()) == 0
+            assert abs(target.beta - st["beta_after"]) < 1e-9
+            assert abs(target.grad_norm - st["grad_norm_after"]) < 1e-5
+
+
+# ---- the MGAT stack in train() mode against the reference's gradients (G7) ------------------------------------------
+G7 = sorted(glob.glob(os.path.join(GOLDEN, "g7_train_*.pt")))
+
+
+def _load_g7(path, dev):
+    from isubgvqa_amd.models import MGAT, GlobalAttention
+    from isubgvqa_amd.sampling.methods.target_aimle import AdaptiveTargetDistribution
+    g = torch.load(path, map_location="cpu", weights_only=False)
+    c = g["cfg"]
+    m = MGAT(channels=c["C"], num_ins=c["L"], heads=4, use_instr=True, masking_thresholds=c["masks"], use_topk=True,
+             interpretable_mode=c["interp"], sampler_type=c["sampler"], sample_k=c["k"], beta=g["beta"])
+    m.load_state_dict({k[len("gat_seq."):]: v for k, v in g["sd"].items() if k.startswith("gat_seq.")}, strict=False)
+    p = GlobalAttention(c["C"], c["C"])
+    p.load_state_dict({k[len("graph_global_attention_pooling."):]: v for k, v in g["sd"].items()
+                       if k.startswith("graph_global_attention_pooling.")})
+    for conv in m.convs:
+        conv.mask.gate_dropout = 0.0          # the goldens were made with the gate dropout patched to identity
+        if c["sampler"] == "aimle":
+            conv.mask.sampler_train.target_distribution = AdaptiveTargetDistribution(initial_alpha=1.0,
+                                                                                     initial_beta=g["beta"])
+    return g, m.to(dev).train(), p.to(dev).train()
+
+
+@pytest.mark.parametrize("path", G7, ids=[os.path.basename(p)[9:-3] for p in G7])
+def test_training_step_matches_reference_gradients(dev, path):
+    g, m, p = _load_g7(path, dev)
+    ins = {k: g[k].to(dev).requires_grad_(True) for k in ("x", "edge_attr", "instr", "glf")}
+    noises = {i: n.to(dev) for i, n in g["noises"].items()}
+    h, mask, _, _ = m(x=ins["x"], edge_index=g["edge_index"].to(dev), instr_vectors=ins["instr"],
+                      global_language_feats=ins["glf"], edge_attr=ins["edge_attr"], batch=g["batch"].to(dev),
+                      return_masks=True, noises=noises)
+    emb, _ = p(x=h, u=ins["glf"], batch=g["batch"].to(dev), size=None, return_mask=True, node_mask=mask)
+    if g["mask"] is not None:
+        assert torch.equal(mask.detach().cpu() > 0.5, g["mask"] > 0.5)
+    close(h, g["h"], 1e-5, "h")
+    loss = (h * g["w_h"].to(dev)).sum() + (emb * g["w_e"].to(dev)).sum()
+    close(loss, g["loss"], 1e-4, "loss")
+    loss.backward()
+    got = {"gat_seq." + k: v.grad for k, v in m.named_parameters() if v.grad is not None}
+    got.update({"graph_global_attention_pooling." + k: v.grad for k, v in p.named_parameters() if v.grad is not None})
+    missing = [k for k, ref in g["grads"].items() if k not in got and float(ref.abs().max()) > 0]
+    assert not missing, f"parameters without a gradient: {missing}"
+    for k, ref in g["grads"].items():
+        if k in got:
+            close(got[k].reshape(ref.shape), ref, 5e-4, k)
+    for k in ("x", "edge_attr", "instr", "glf"):
+        close(ins[k].grad, g["grad_" + k], 5e-4, "d " + k)
+    for li, beta in g["aimle_beta_after"].items():
+        assert abs(m.convs[li].mask.sampler_train.target_distribution.beta - beta) < 1e-9
+
+
+def test_training_step_cfg2_shape_matches_oracle(dev):
+    """A cfg2-shaped batch (C=128, H=4, L=3, Gumbel k=5) small enough for CPU autograd: every parameter gradient of
+    MGAT + pooling + classifier against the oracle."""
+    from isubgvqa_amd import synthetic
+    from oracle import model as OM
+    from test_gpu_models import _noises, _oracle_cfg
+    cfg = synthetic.WorkloadConfig(num_graphs=48, seed=99, masks=(1.0, 0.15, 0.15))
+    wl = synthetic.make_workload(cfg)
+    model = synthetic.build_answer_model(cfg).to(dev).train()
+    for conv in model.gat_seq.convs:
+        conv.mask.gate_dropout = 0.0
+    model.embedding[2].p = 0.0
+    noises = _noises(cfg, wl, 5)
+    gen = torch.Generator().manual_seed(1)
+    w = torch.randn(cfg.num_graphs, 1842, generator=gen)
+    logits, mask, _ = model(wl.to(dev), noises={i: n.to(dev) for i, n in noises.items()})
+    (logits * w.to(dev)).sum().backward()
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()
+          if v.is_floating_point()}
+    ocfg = _oracle_cfg(cfg)
+    ocfg.training = True
+    ref_logits, ref_mask = OM.mgat_pool_classify(sd, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf,
+                                                 ocfg, noises)[:2]
+    (ref_logits * w).sum().backward()
+    assert int((mask.detach().cpu().view(-1) != ref_mask.detach().view(-1)).sum()) == 0
+    close(logits, ref_logits, 1e-4, "logits")
+    for k, v in model.named_parameters():
+        if sd[k].grad is None:
+            continue
+        assert v.grad is not None, k
+        close(v.grad, sd[k].grad.reshape(v.grad.shape), 1e-3, k)
