@@ -9,7 +9,8 @@ off, so the same `ops.*` call runs the plain forward kernel.  Three kinds of bac
       GumbelTopK         isg_topk_gumbel_bwd         (straight-through, gumbel_scheme.py:83-90)
       ImleTopK/AimleTopK isg_topk_threshold again    (second MAP solve, wrapper.py:124-172; aimle.py:141-243;
                                                       adaptive beta, target_aimle.py:88-162 -- state kept ON THE DEVICE)
-  * Linear: forward on the bf16x6 matrix-core kernel, dX / dW as fp32 GEMMs through torch (hipBLASLt);
+  * Linear: forward and dX on the bf16x6 matrix-core kernel, dW (a reduction over the rows) as an fp32 GEMM through
+    torch (hipBLASLt);
   * the light per-node ops (instruction gate, node gate, layer tail, pooling, GraphNorm, scatter ops): the forward is the
     fused kernel, the backward re-evaluates a torch-op restatement ON THE DEVICE under autograd (`_Recomputed`).  These
     are plain autograd in the reference too.
@@ -175,7 +176,10 @@ class _Linear(torch.autograd.Function):
         g = g.contiguous()
         if ctx.gelu:
             g = torch.ops.aten.gelu_backward(g, z)
-        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:     # dX = g W: the same matrix-core kernel on the transposed weight
+            dx = (ops.linear(g, weight.detach().t().contiguous(), None, cache_planes=False)
+                  if (g.size(1) & 3) == 0 else g @ weight)
         dw = g.t() @ x if ctx.needs_input_grad[1] else None
         db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
