@@ -103,8 +103,10 @@ class ISubGVQA(torch.nn.Module):
         glf, instr_vectors = self.language_features(questions, qsts_att_mask)
         if explainer and explainer_stage > 0:                                            # :249-253
             node_embeddings, expl_bypass_x = expl_bypass_x, node_embeddings.clone()
-        if plan is None:
-            plan = ops.GraphPlan.build(batch, edge_index, num_graphs=questions.size(0))
+        if plan is None:   # a loader.SceneGraphBatch carries the per-graph bounds: the plan is then built without a sync
+            plan = ops.GraphPlan.build(batch, edge_index, num_graphs=questions.size(0),
+                                       max_nodes=getattr(scene_graphs, "max_nodes", None),
+                                       max_edges=getattr(scene_graphs, "max_edges", None))
         x_enc, e_enc = self.scene_graph_encoder(node_embeddings, edge_index=edge_index, edge_attr=edge_embeddings,
                                                 batch=batch, explainer=explainer, explainer_stage=explainer_stage,
                                                 gt_scene_graphs=scene_graphs, plan=plan)  # :255

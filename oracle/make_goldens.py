@@ -18,6 +18,10 @@ travels to the GPU box); writes small data-only fixtures to tests/golden/*.pt:
   g7_train_*.pt    MGAT + GlobalAttention in train() mode (dropout patched to identity), loss gradients for every
                    parameter and input, through the reference's custom backward rules
 
+  g8_loader.pt     GQASceneGraphs.convert_one_gqa_scene_graph / query_and_translate (the real functions, imported over
+                   stand-ins for torchtext and torch_geometric.data.Data) on synthetic scene-graph JSON with a synthetic
+                   vocabulary: the JSON text, the token lists and the per-image tensors
+
 Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_goldens
 No reference source text is written anywhere; fixtures hold tensors only.
 """
@@ -409,6 +413,84 @@ def gen_mgat_train():
                    os.path.join(OUT, f"g7_train_{c['name']}.pt"))
 
 
+class _Data:
+    """Attribute bag with the constructor of torch_geometric.data.Data (scene_graph.py:378-387 only sets attributes)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _synthetic_scene_graphs(gen):
+    names = ["window", "man", "shirt", "tree", "wall", "building", "person", "sky", "table", "dog", "caf\u00e9 sign"]
+    attrs = ["white", "black", "green", "large", "wooden", "small", "blue", "tall"]
+    rels = ["to the left of", "to the right of", "on", "wearing", "near", "holding", "behind"]
+    oov = ["zeppelin", "glorp"]
+
+    def pick(lst):
+        return lst[int(torch.randint(0, len(lst), (1,), generator=gen))]
+
+    graphs = {}
+    for g in range(14):
+        n = int(torch.randint(2, 9, (1,), generator=gen))
+        ids = [str(int(torch.randint(100000, 4000000, (1,), generator=gen))) for _ in range(n)]
+        ids = list(dict.fromkeys(ids))
+        objs = {}
+        for oid in ids:
+            na = int(torch.randint(0, 3, (1,), generator=gen)) if g % 3 else int(torch.randint(0, 6, (1,), generator=gen))
+            a = [pick(attrs + oov[:1]) for _ in range(na)]
+            if g % 3 != 0:
+                a = a[:1]                       # at most one attribute: the set() order cannot matter
+            rel = [{"object": pick(ids), "name": pick(rels + oov[1:])} for _ in range(int(torch.randint(0, 4, (1,), generator=gen)))]
+            o = {"name": pick(names + oov), "attributes": a, "relations": rel,
+                 "x": int(torch.randint(0, 500, (1,), generator=gen)), "y": 3, "w": 40, "h": 50}
+            if g % 4 == 1:
+                o.update(x1=int(torch.randint(0, 300, (1,), generator=gen)), y1=7, x2=311, y2=int(torch.randint(0, 300, (1,), generator=gen)))
+            objs[oid] = o
+        graphs[f"img{g}"] = {"width": 500, "height": 333, "objects": objs}
+    graphs["empty"] = {"width": 1, "height": 1, "objects": {}}                        # -> 2-node dummy
+    graphs["single"] = {"objects": {"7": {"name": "dog", "attributes": [], "relations": []}}}   # 1 edge -> 6-node dummy
+    graphs["selfrel"] = {"objects": {"5": {"name": "man", "attributes": ["tall", "tall"], "relations": [
+        {"object": "5", "name": "near"}, {"object": "9", "name": "on"}, {"object": "9", "name": "on"}]},
+        "9": {"name": "table", "attributes": ["wooden"], "relations": [{"object": "5", "name": "near"}]},
+        "10": {"name": "wall", "attributes": [], "relations": []}}}                     # "10" sorts before "5"
+    return graphs, [names[:6], attrs, rels, names[3:] + ["pokemon"], rels[:2], attrs[:3]]
+
+
+def gen_loader():
+    import json
+    import types
+    tt = types.ModuleType("torchtext")
+    tt_data = types.ModuleType("torchtext.data")
+    tt_utils = types.ModuleType("torchtext.data.utils")
+    tt_utils.get_tokenizer = lambda *a, **k: None
+    tt_vocab = types.ModuleType("torchtext.vocab")
+    tt_vocab.GloVe = tt_vocab.vocab = None
+    sys.modules.update({"torchtext": tt, "torchtext.data": tt_data, "torchtext.data.utils": tt_utils,
+                        "torchtext.vocab": tt_vocab})
+    sys.modules["torch_geometric"].data.Data = _Data
+    sys.modules["torch_geometric.data"].Data = _Data
+    from ISubGVQA.datasets.scene_graph import GQASceneGraphs
+    from . import loader as L
+
+    gen = torch.Generator().manual_seed(4242)
+    graphs, token_lists = _synthetic_scene_graphs(gen)
+    stoi = L.build_vocab(token_lists)          # torchtext is absent: the vocabulary comes from the restatement
+
+    class _V:
+        def get_stoi(self):
+            return stoi
+
+    me = types.SimpleNamespace(vocab_sg=_V(), obj_mapping={}, attr_mapping={}, rel_mapping={}, scene_graphs=graphs)
+    me.convert_one_gqa_scene_graph = lambda sg: GQASceneGraphs.convert_one_gqa_scene_graph(me, sg)
+    per_image = {}
+    for key in list(graphs) + ["not-in-the-file"]:
+        d = GQASceneGraphs.query_and_translate(me, key)
+        per_image[key] = dict(x=d.x.clone(), edge_index=d.edge_index.clone(), edge_attr=d.edge_attr.clone(),
+                              x_bbox=d.x_bbox.clone(), added_sym_edge=d.added_sym_edge.clone())
+    torch.save(dict(json=json.dumps(graphs), token_lists=token_lists, stoi=stoi, per_image=per_image),
+               os.path.join(OUT, "g8_loader.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.dont_write_bytecode = True
@@ -419,6 +501,7 @@ def main():
     gen_mgat()
     gen_sampler_grads()
     gen_mgat_train()
+    gen_loader()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -293,3 +293,43 @@ def test_full_isubgvqa_model_matches_oracle(dev, sampler):
     print(f"full model ({sampler}): max |logit diff| = {err:.3e}")
     assert err < LOGIT_TOL
     assert torch.allclose(gg.cpu(), rg, atol=1e-5)
+
+
+def test_loader_to_full_model_end_to_end(dev):
+    """SURVEY §8f row 2 joined to the path: scene-graph JSON -> C++ loader (pinned batch, plan hints) -> full ISubGVQA on
+    the GPU, against the oracle fed by the oracle's own conversion + collate of the same JSON."""
+    import json
+    from isubgvqa_amd import loader
+    from isubgvqa_amd.models import build_model
+    from oracle import loader as OL
+    from oracle import model as OM
+    g8 = load_golden("g8_loader.pt")
+    graphs = json.loads(g8["json"])
+    # single-attribute images only, so both conversions agree on every token (multi-attribute order is hash-seed bound)
+    keys = [k for k in list(graphs) + ["unknown-image"]
+            if all(len(set(o["attributes"])) <= 1 for o in graphs.get(k, {"objects": {}})["objects"].values())]
+    assert len(keys) >= 8
+    torch.manual_seed(0)
+    args = _full_args(sampler_type="imle", sg_vocab_size=len(g8["stoi"]))
+    model = build_model(args, None).eval()
+    store = loader.SceneGraphStore(loader.SceneGraphVocab(g8["token_lists"])).add_json(g8["json"])
+    b = store.collate(keys)                      # pinned
+    assert b.x.is_pinned()
+    ref = OL.collate([OL.dataset_item(OL.query_and_translate(graphs, k, g8["stoi"])) for k in keys])
+    for name in ("x", "edge_index", "edge_attr", "x_bbox", "added_sym_edge", "batch"):
+        assert torch.equal(getattr(b, name), ref[name]), name
+    B, T = len(keys), 9
+    gen = torch.Generator().manual_seed(3)
+    q = torch.randint(0, 512, (B, T), generator=gen)
+    qmask = (torch.arange(T)[None] < torch.randint(4, T + 1, (B,), generator=gen)[:, None]).long()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ocfg = OM.PathConfig(heads=4, masking_thresholds=[1.0, 1.0, 1.0, 0.15], sampler_type="imle", sample_k=5)
+    with torch.no_grad():
+        rl, rm, _, _, _ = OM.isubgvqa_forward(sd, ref["x"], ref["edge_index"], ref["edge_attr"], ref["batch"], q, qmask,
+                                              ref["x_bbox"], ref["added_sym_edge"], ocfg, None)
+        model = model.to(dev)
+        d = b.to(dev)
+        gl, gm, _, _, _ = model(d.x, d.edge_index, d.edge_attr, d.batch, q.to(dev), qmask.to(dev), return_masks=True,
+                                scene_graphs=d)
+    assert torch.equal(gm.cpu() > 0.5, rm > 0.5)
+    assert (gl.cpu() - rl).abs().max().item() < LOGIT_TOL
