@@ -36,8 +36,8 @@ HBM_COPY_GBPS = 6290.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=512)
@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-hints", action="store_true", help="let the plan read Nmax back from the device (one sync)")
     ap.add_argument("--mp-kernel", choices=["graph", "chunk"], default="graph")
     ap.add_argument("--gemm", choices=["bf16x6", "torch"], default="bf16x6")
+    ap.add_argument("--features", choices=["fp32", "fp16"], default="fp32",
+                    help="storage of the projected rows (fp16 = BASELINE configs[4]'s variant; NOT the headline config)")
     return ap.parse_args()
 
 
@@ -125,7 +127,7 @@ def main():
     ops.MP_KERNEL = args.mp_kernel
     ops.GEMM_BACKEND = args.gemm
     cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": args.graphs,
-                                      "seed": synthetic.CFG2.seed + rank})
+                                      "seed": synthetic.CFG2.seed + rank, "feature_dtype": args.features})
     wl = synthetic.make_workload(cfg).to(dev)
     model = synthetic.build_answer_model(cfg).to(dev).eval()
     N, E = wl.x.size(0), wl.edge_index.size(1)
@@ -174,7 +176,7 @@ def main():
     dt = float(t.item())
 
     durs = timer.durations_ms()
-    bytes_l = [ops.mp_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"]) for m in timer.meta]
+    bytes_l = [ops.mp_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"], m.get("feat_bytes", 4)) for m in timer.meta]
     mp_ms = sum(durs) / max(len(durs), 1)
     mp_bytes = sum(bytes_l) / max(len(bytes_l), 1)
     achieved = mp_bytes / (mp_ms * 1e-3) / 1e9 if durs else 0.0
@@ -193,7 +195,7 @@ def main():
                        "nodes_per_gpu": N, "edges_per_gpu": E, "channels": cfg.channels, "heads": cfg.heads,
                        "layers": cfg.layers, "sampler": "gumbel(in-kernel Philox noise)", "k": cfg.sample_k,
                        "parallelism": f"dp{world} (graphs sharded, RCCL all-gather of logits)" if world > 1 else "dp1",
-                       "launch": "eager", "dense": ("isg_linear_bf16x6 (fp32 via 3-way bf16 split on MFMA)" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
+                       "feature_rows": args.features, "launch": "eager", "dense": ("isg_linear_bf16x6 (fp32 via 3-way bf16 split on MFMA)" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
             "roofline": {"bound": "hbm", "kernel": ("gatv2_mp_graph_kernel<2,1>" if args.mp_kernel == "graph" else "gatv2_mp_kernel<4,2>") + " (isg_gatv2_mp_fwd)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),

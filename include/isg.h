@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 3
+#define ISG_ABI_VERSION 4
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -111,6 +111,17 @@ int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, co
                      int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
                      const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
                      int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e, void *stream);
+
+/* Same operator with fp16 FEATURE ROWS (BASELINE configs[4], SURVEY §8d "fp16 features / fp32 accumulate"): x_l, x_r,
+ * e_proj and out hold IEEE half, everything else (att, bias, masks, alpha, all arithmetic) stays fp32; out is rounded to
+ * nearest even once.  ld_* count halves.  Only the per-graph kernel has this form: the batch must fit its tables
+ * (ISG_EUNSUPPORTED otherwise). */
+int isg_gatv2_mp_fwd_f16(const uint16_t *x_l, const uint16_t *x_r, const uint16_t *e_proj, const float *att,
+                         const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                         const float *node_mask, const float *edge_mask, uint16_t *out, float *alpha, int64_t N,
+                         int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
+                         const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
+                         int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e, void *stream);
 
 /* out[i,:] = sum_{e: dst(e)=i} msg[e,:] / max(deg(i),1)       torch_scatter.scatter_mean at
  * ISubGVQA/models/scene_graph_encoder.py:141.  msg fp32[E,C] (original edge order); out fp32[N,C]. */
@@ -241,6 +252,13 @@ int isg_split_bf16x3(const float *w, int64_t rows, int32_t K, uint16_t *planes, 
  * Requires 4 | K, 4 | lda, a 16-byte aligned. */
 int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const float *bias, float *d, int64_t M, int32_t N,
                       int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream);
+
+/* isg_linear_bf16x6 reading A as fp16 (a_is_f16) and / or writing D as fp16 (d_is_f16, one rounding after bias and
+ * activation); lda / ldd count elements of the respective type.  The products are still exact: an fp16 value splits
+ * into two bf16 terms. */
+int isg_linear_bf16x6_f16(const void *a, int32_t a_is_f16, const uint16_t *w_planes, const float *bias, void *d,
+                          int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                          void *stream);
 
 #ifdef __cplusplus
 }

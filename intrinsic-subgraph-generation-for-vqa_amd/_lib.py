@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -27,6 +27,8 @@ SIGNATURES = {
     "isg_instr_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_to_edge_mask": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "isg_gatv2_mp_fwd": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_gatv2_mp_fwd_f16": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_graph_edge_ptr": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "isg_scatter_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
@@ -47,6 +49,8 @@ SIGNATURES = {
     "isg_split_bf16x3": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "isg_linear_bf16x6": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                   c_int32, c_void_p]),
+    "isg_linear_bf16x6_f16": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
+                                      c_int32, c_int32, c_int32, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

@@ -64,10 +64,26 @@ __global__ void split_bf16x3_kernel(const float *__restrict__ w, int rows, int K
 
 // DBG: compile-time ablation switches for profiling (outputs wrong unless 0): 1 no MFMA, 2 no fragment reads,
 // 4 no split / LDS stores, 8 no in-loop global loads, 16 no epilogue stores
-template <int ACT, int DBG>   // ACT: 0 none, 1 exact GELU
+// A16 / D16: A is read / D is written as fp16 (feature rows of the fp16 message-passing variant); lda / ldd in elements
+typedef _Float16 gm_f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned gm_u32x2 __attribute__((ext_vector_type(2)));
+template <bool A16> struct GmRawA { typedef float4 type; };
+template <> struct GmRawA<true> { typedef gm_u32x2 type; };
+__device__ __forceinline__ void gm_zero(float4 &v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void gm_zero(gm_u32x2 &v) { v = gm_u32x2{0u, 0u}; }
+__device__ __forceinline__ float4 gm_cvt(const float4 &v) { return v; }
+__device__ __forceinline__ float4 gm_cvt(const gm_u32x2 &v) {
+  const gm_f16x4 h = __builtin_bit_cast(gm_f16x4, v);
+  return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+}
+
+template <int ACT, int DBG, bool A16, bool D16>   // ACT: 0 none, 1 exact GELU
 __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__restrict__ A, const __bf16 *__restrict__ Wp,
                                                             const float *__restrict__ bias, float *__restrict__ D, int M,
                                                             int N, int K, int Kp, int lda, int ldd) {
+  typedef typename GmRawA<A16>::type RawA;
+  const void *Av = A;   // fp16 variants: the same pointers, half elements
+  void *Dv = D;
   __shared__ __attribute__((aligned(16))) __bf16 sA[3][GM_BM][GM_LD];
   __shared__ __attribute__((aligned(16))) __bf16 sB[3][GM_BN][GM_LD];
 
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // two register images (tiles t+1 and t+2): a tile's global loads get two MFMA phases to land
-  float4 ra0[2], ra1[2];        // A: 2 float4 per thread per tile
+  RawA ra0[2], ra1[2];          // A: 4 elements per thread per tile and u, raw (fp32: 16 B, fp16: 8 B)
   bf16x8 rb0[3], rb1[3];        // W: 16 B per plane per thread per tile
 
   // next tile -> registers (global loads only; the LDS image is written below, in one place, so that every LDS access
@@ -97,7 +113,10 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
       const int row = i >> 3, c4 = i & 7;                                                                      \
       /* never a conditional load (the compiler would wait for it at once): clamp the address, mask at store time */ \
       const int gr = min(m0 + row, M - 1), gk = min((k0) + c4 * 4, K - 4);                                     \
-      RA[u] = *reinterpret_cast<const float4 *>(A + (int64_t)gr * lda + gk);                                   \
+      if constexpr (A16)                                                                                       \
+        RA[u] = *reinterpret_cast<const RawA *>(reinterpret_cast<const _Float16 *>(Av) + (int64_t)gr * lda + gk); \
+      else                                                                                                     \
+        RA[u] = *reinterpret_cast<const RawA *>(A + (int64_t)gr * lda + gk);                                   \
     }                                                                                                          \
     {                                                                                                          \
       const int row = tid >> 2, c8 = tid & 3;                                                                  \
@@ -119,19 +138,20 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
     if ((kt) > 0) __syncthreads(); /* everyone is done reading the previous tile */                            \
     /* registers -> LDS: split the fp32 A values into their three bf16 planes, copy the W planes */            \
     if constexpr (DBG & 4) {                                                                                   \
-      keep(RA[0]);                                                                                             \
-      keep(RA[1]);                                                                                             \
+      keep(gm_cvt(RA[0]));                                                                                     \
+      keep(gm_cvt(RA[1]));                                                                                     \
       _Pragma("unroll") for (int q = 0; q < 3; ++q) keep(RB[q]);                                               \
     } else _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                     \
       const int i = tid + 512 * u;                                                                             \
       const int row = i >> 3, c4 = i & 7;                                                                      \
-      if (m0 + row >= M || GM_KT(kt) * GM_BK + c4 * 4 >= K) RA[u] = make_float4(0.f, 0.f, 0.f, 0.f);           \
+      if (m0 + row >= M || GM_KT(kt) * GM_BK + c4 * 4 >= K) gm_zero(RA[u]);                                    \
+      const float4 av = gm_cvt(RA[u]);                                                                         \
       bf16x4 p0, p1, p2;                                                                                       \
       __bf16 t0, t1, t2;                                                                                       \
-      split3(RA[u].x, t0, t1, t2); p0[0] = t0; p1[0] = t1; p2[0] = t2;                                         \
-      split3(RA[u].y, t0, t1, t2); p0[1] = t0; p1[1] = t1; p2[1] = t2;                                         \
-      split3(RA[u].z, t0, t1, t2); p0[2] = t0; p1[2] = t1; p2[2] = t2;                                         \
-      split3(RA[u].w, t0, t1, t2); p0[3] = t0; p1[3] = t1; p2[3] = t2;                                         \
+      split3(av.x, t0, t1, t2); p0[0] = t0; p1[0] = t1; p2[0] = t2;                                            \
+      split3(av.y, t0, t1, t2); p0[1] = t0; p1[1] = t1; p2[1] = t2;                                            \
+      split3(av.z, t0, t1, t2); p0[2] = t0; p1[2] = t1; p2[2] = t2;                                            \
+      split3(av.w, t0, t1, t2); p0[3] = t0; p1[3] = t1; p2[3] = t2;                                            \
       *reinterpret_cast<bf16x4 *>(&sA[0][row][c4 * 4]) = p0;                                                   \
       *reinterpret_cast<bf16x4 *>(&sA[1][row][c4 * 4]) = p1;                                                   \
       *reinterpret_cast<bf16x4 *>(&sA[2][row][c4 * 4]) = p2;                                                   \
@@ -197,14 +217,27 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
     }
     __builtin_amdgcn_wave_barrier();
     const int rowb = m0 + wm * 32;
-    const bool vec_ok = (ldd & 3) == 0 && colb + 32 <= N && (reinterpret_cast<uintptr_t>(D) & 15) == 0;
+    const bool vec_ok = (ldd & 3) == 0 && colb + 32 <= N && (reinterpret_cast<uintptr_t>(Dv) & 15) == 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = q * 64 + lane;
       const int rr = idx >> 3, c4 = idx & 7;
       const float4 v = *reinterpret_cast<const float4 *>(&patch[rr * 36 + c4 * 4]);
       const int row = rowb + rr;
-      if ((DBG & 16) ? (row < 0) : (row < M)) {
+      if constexpr (D16) {
+        if ((DBG & 16) ? (row < 0) : (row < M)) {
+          _Float16 *dst = reinterpret_cast<_Float16 *>(Dv) + (int64_t)row * ldd + colb + c4 * 4;
+          if (vec_ok) {
+            gm_f16x4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<gm_f16x4 *>(dst) = hv;
+          } else {
+            if (colb + c4 * 4 + 0 < N) dst[0] = (_Float16)v.x;
+            if (colb + c4 * 4 + 1 < N) dst[1] = (_Float16)v.y;
+            if (colb + c4 * 4 + 2 < N) dst[2] = (_Float16)v.z;
+            if (colb + c4 * 4 + 3 < N) dst[3] = (_Float16)v.w;
+          }
+        }
+      } else if ((DBG & 16) ? (row < 0) : (row < M)) {
         float *dst = D + (int64_t)row * ldd + colb + c4 * 4;
         if (vec_ok) {
           *reinterpret_cast<float4 *>(dst) = v;
@@ -236,28 +269,43 @@ extern "C" int isg_split_bf16x3(const float *w, int64_t rows, int32_t K, uint16_
   return check_launch();
 }
 
-extern "C" int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const float *bias, float *d, int64_t M,
-                                 int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream) {
+static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const float *bias, void *d, int d16,
+                         int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream) {
   if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 1) return ISG_EINVAL;
   if (M == 0) return ISG_OK;
   if (!a || !w_planes || !d) return ISG_EINVAL;
-  // float4 loads of A need 16-byte aligned rows and K a multiple of 4
-  if ((K & 3) != 0 || (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(a) & 15) != 0 || M >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  // 4-element loads of A need aligned rows (16 bytes fp32, 8 bytes fp16) and K a multiple of 4
+  const uintptr_t amask = a16 ? 7 : 15;
+  if ((K & 3) != 0 || (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(a) & amask) != 0 || M >= (1ll << 31)) return ISG_EUNSUPPORTED;
   const int Kp = (K + GM_BK - 1) / GM_BK * GM_BK;
   const long long mt = (M + GM_BM - 1) / GM_BM;
   if (mt > 65535) return ISG_EUNSUPPORTED;
   dim3 grid((unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)mt), block(512);
   const __bf16 *wp = reinterpret_cast<const __bf16 *>(w_planes);
+  hipStream_t st = as_stream(stream);
 #ifdef ISG_GEMM_ABLATION   // profiling build only (tools/build_ablation.sh): select a compile-time ablated variant by env
   const char *dv = getenv("ISG_GEMM_DBG");
   const int dbg = dv ? atoi(dv) : 0;
-#define ISG_DBG_CASE(v) if (dbg == v) { linear_bf16x6_kernel<0, v><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd); return check_launch(); }
+#define ISG_DBG_CASE(v) if (dbg == v) { linear_bf16x6_kernel<0, v, false, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd); return check_launch(); }
   ISG_DBG_CASE(1) ISG_DBG_CASE(3) ISG_DBG_CASE(7) ISG_DBG_CASE(15) ISG_DBG_CASE(16) ISG_DBG_CASE(31) ISG_DBG_CASE(8) ISG_DBG_CASE(4)
 #undef ISG_DBG_CASE
 #endif
-  if (act == 1)
-    linear_bf16x6_kernel<1, 0><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd);
-  else
-    linear_bf16x6_kernel<0, 0><<<grid, block, 0, as_stream(stream)>>>(a, wp, bias, d, (int)M, N, K, Kp, lda, ldd);
+#define ISG_LIN(ACT_, A_, D_) linear_bf16x6_kernel<ACT_, 0, A_, D_><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd)
+  if (!a16 && !d16) { if (act == 1) ISG_LIN(1, false, false); else ISG_LIN(0, false, false); }
+  else if (a16 && !d16) { if (act == 1) ISG_LIN(1, true, false); else ISG_LIN(0, true, false); }
+  else if (!a16 && d16) { if (act == 1) ISG_LIN(1, false, true); else ISG_LIN(0, false, true); }
+  else { if (act == 1) ISG_LIN(1, true, true); else ISG_LIN(0, true, true); }
+#undef ISG_LIN
   return check_launch();
+}
+
+extern "C" int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const float *bias, float *d, int64_t M,
+                                 int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream) {
+  return linear_launch(a, 0, w_planes, bias, d, 0, M, N, K, lda, ldd, act, stream);
+}
+
+extern "C" int isg_linear_bf16x6_f16(const void *a, int32_t a_is_f16, const uint16_t *w_planes, const float *bias, void *d,
+                                     int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd,
+                                     int32_t act, void *stream) {
+  return linear_launch(a, a_is_f16 != 0, w_planes, bias, d, d_is_f16 != 0, M, N, K, lda, ldd, act, stream);
 }

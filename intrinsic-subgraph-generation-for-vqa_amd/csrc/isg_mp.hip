@@ -248,12 +248,12 @@ __global__ __launch_bounds__(256) void scatter_mean_kernel(const float4 *__restr
 
 using namespace isg;
 
-extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
-                                const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
-                                const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
-                                int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
-                                const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
-                                int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e, void *stream) {
+static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const float *att, const float *bias,
+                  const int32_t *rowptr, const int32_t *eid, const int32_t *src, const float *node_mask,
+                  const float *edge_mask, void *out, float *alpha, int64_t N, int64_t E, int32_t H, int32_t C,
+                  float negative_slope, const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst,
+                  int64_t B, int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e,
+                  void *stream, int f16) {
   if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
   if (N == 0) return ISG_OK;
   if (!x_l || !x_r || !att || !rowptr || !out || (E > 0 && (!e_proj || !eid || !src || !alpha))) return ISG_EINVAL;
@@ -272,6 +272,7 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
   a.N = (int)N; a.C = C; a.H = H; a.slope = negative_slope;
   a.ldl4 = ld_l >> 2; a.ldr4 = ld_r >> 2; a.lde4 = ld_e >> 2;
   a.graph_ptr = graph_ptr; a.graph_eptr = graph_eptr; a.dst = dst; a.B = (int)B; a.lrows = 0;
+  a.f16 = f16;
   {
     const char *f = getenv("ISG_MP_FLAGS");   // experiment switch; default = tuned setting
     a.flags = f ? atoi(f) : ISG_MP_DEFAULT_FLAGS;
@@ -282,6 +283,7 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
     int rc = launch_mp_graph(a, nmax_host, emax_host, st);
     if (rc != ISG_EUNSUPPORTED) return rc;   // shapes without a per-graph instantiation use the node-chunk kernel
   }
+  if (f16) return ISG_EUNSUPPORTED;          // fp16 rows exist in the per-graph kernel only
   switch (H) {
     case 1: return launch_mp<1>(a, st);
     case 2: return launch_mp<2>(a, st);
@@ -289,6 +291,27 @@ extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float 
     case 8: return launch_mp<8>(a, st);
     default: return ISG_EUNSUPPORTED;
   }
+}
+
+extern "C" int isg_gatv2_mp_fwd(const float *x_l, const float *x_r, const float *e_proj, const float *att,
+                                const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                const float *node_mask, const float *edge_mask, float *out, float *alpha, int64_t N,
+                                int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
+                                const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
+                                int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e, void *stream) {
+  return mp_fwd(x_l, x_r, e_proj, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
+                negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, ld_r, ld_e, stream, 0);
+}
+
+extern "C" int isg_gatv2_mp_fwd_f16(const uint16_t *x_l, const uint16_t *x_r, const uint16_t *e_proj, const float *att,
+                                    const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                    const float *node_mask, const float *edge_mask, uint16_t *out, float *alpha,
+                                    int64_t N, int64_t E, int32_t H, int32_t C, float negative_slope,
+                                    const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst, int64_t B,
+                                    int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e,
+                                    void *stream) {
+  return mp_fwd(x_l, x_r, e_proj, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
+                negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, ld_r, ld_e, stream, 1);
 }
 
 extern "C" int isg_instr_gate(const float *x, const float *instr, const int64_t *batch, float *out, int64_t N,

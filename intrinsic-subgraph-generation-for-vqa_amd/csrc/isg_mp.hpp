@@ -24,6 +24,7 @@ struct MpArgs {
   float slope;
   const int *graph_ptr, *graph_eptr, *dst;   // per-graph kernel only
   int B, lrows;           // graphs; x_l rows of a graph kept in LDS
+  int f16;                // x_l / x_r / e_proj / out hold fp16 (per-graph kernel only)
   int flags;              // bit0: non-temporal e_proj loads / out stores; bit1: XCD-aware chunk mapping
   int nchunks;
 };
@@ -40,6 +41,62 @@ __device__ __forceinline__ void st_stream(float4 *p, const float4 &v, bool nt) {
     __builtin_nontemporal_store(w, reinterpret_cast<f32x4 *>(p));
   } else {
     *p = v;
+  }
+}
+
+// ---- feature rows stored as fp32 (16 bytes per 4 channels) or fp16 (8 bytes per 4 channels; BASELINE configs[4]:
+//      "fp16 features / fp32 accumulate") -- same index units (4 channels), the arithmetic is always fp32 ----
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 h4_to_f4(u32x2 r) {
+  const f16x4 h = __builtin_bit_cast(f16x4, r);
+  return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+}
+__device__ __forceinline__ u32x2 f4_to_h4(const float4 &v) {
+  f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};   // round to nearest even
+  return __builtin_bit_cast(u32x2, h);
+}
+// raw register image of 4 channels (conversion is deferred to the point of use so that a batch of loads stays in flight)
+template <bool F16> struct RawQ { typedef float4 type; };
+template <> struct RawQ<true> { typedef u32x2 type; };
+__device__ __forceinline__ float4 cvtq(const float4 &v) { return v; }
+__device__ __forceinline__ float4 cvtq(const u32x2 &v) { return h4_to_f4(v); }
+template <bool F16>
+__device__ __forceinline__ typename RawQ<F16>::type ldraw(const float4 *base, size_t i) {
+  if constexpr (F16) return reinterpret_cast<const u32x2 *>(base)[i];
+  else return base[i];
+}
+template <bool F16>
+__device__ __forceinline__ typename RawQ<F16>::type ldraw_stream(const float4 *base, size_t i, bool nt) {
+  if constexpr (F16) {
+    const u32x2 *p = reinterpret_cast<const u32x2 *>(base) + i;
+    return nt ? __builtin_nontemporal_load(p) : *p;
+  } else {
+    return ld_stream(base + i, nt);
+  }
+}
+template <bool F16>
+__device__ __forceinline__ float4 ldq(const float4 *base, size_t i) {
+  if constexpr (F16) return h4_to_f4(reinterpret_cast<const u32x2 *>(base)[i]);
+  else return base[i];
+}
+template <bool F16>
+__device__ __forceinline__ float4 ldq_stream(const float4 *base, size_t i, bool nt) {
+  if constexpr (F16) {
+    const u32x2 *p = reinterpret_cast<const u32x2 *>(base) + i;
+    return h4_to_f4(nt ? __builtin_nontemporal_load(p) : *p);
+  } else {
+    return ld_stream(base + i, nt);
+  }
+}
+template <bool F16>
+__device__ __forceinline__ void stq_stream(float4 *base, size_t i, const float4 &v, bool nt) {
+  if constexpr (F16) {
+    u32x2 *p = reinterpret_cast<u32x2 *>(base) + i;
+    const u32x2 h = f4_to_h4(v);
+    if (nt) __builtin_nontemporal_store(h, p); else *p = h;
+  } else {
+    st_stream(base + i, v, nt);
   }
 }
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ float unif(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
-template <int HS, int P, bool MASKED, bool EXACT, int GK_NCAP, int GK_ECAP>
+template <int HS, int P, bool MASKED, bool EXACT, int GK_NCAP, int GK_ECAP, bool F16>
 __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
   constexpr int G = 64 / HS;
   extern __shared__ __attribute__((aligned(16))) float4 s_xl[];   // [lrows][HS*Q]
@@ -98,16 +98,16 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
     for (int r0 = wave; r0 < rows; r0 += GK_WAVES * 4) {
 #pragma unroll 1
       for (int c = lane; c < RQ; c += 64) {
-        float4 v0, v1, v2, v3;
+        typename RawQ<F16>::type v0, v1, v2, v3;
         const int r1 = r0 + GK_WAVES, r2 = r0 + 2 * GK_WAVES, r3 = r0 + 3 * GK_WAVES;
-        v0 = a.x_l[(size_t)(nb + r0) * a.ldl4 + hoff + c];
-        if (r1 < rows) v1 = a.x_l[(size_t)(nb + r1) * a.ldl4 + hoff + c];
-        if (r2 < rows) v2 = a.x_l[(size_t)(nb + r2) * a.ldl4 + hoff + c];
-        if (r3 < rows) v3 = a.x_l[(size_t)(nb + r3) * a.ldl4 + hoff + c];
-        s_xl[r0 * RQ + c] = v0;
-        if (r1 < rows) s_xl[r1 * RQ + c] = v1;
-        if (r2 < rows) s_xl[r2 * RQ + c] = v2;
-        if (r3 < rows) s_xl[r3 * RQ + c] = v3;
+        v0 = ldraw<F16>(a.x_l, (size_t)(nb + r0) * a.ldl4 + hoff + c);
+        if (r1 < rows) v1 = ldraw<F16>(a.x_l, (size_t)(nb + r1) * a.ldl4 + hoff + c);
+        if (r2 < rows) v2 = ldraw<F16>(a.x_l, (size_t)(nb + r2) * a.ldl4 + hoff + c);
+        if (r3 < rows) v3 = ldraw<F16>(a.x_l, (size_t)(nb + r3) * a.ldl4 + hoff + c);
+        s_xl[r0 * RQ + c] = cvtq(v0);
+        if (r1 < rows) s_xl[r1 * RQ + c] = cvtq(v1);
+        if (r2 < rows) s_xl[r2 * RQ + c] = cvtq(v2);
+        if (r3 < rows) s_xl[r3 * RQ + c] = cvtq(v3);
       }
     }
     if (tid <= n) s_rowptr[tid] = v_rp;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
   if (!(a.flags & 8)) {
 #pragma unroll 1
     for (int tb = wave * GK_U; tb < ne; tb += GK_WAVES * GK_U) {
-      float4 epv[GK_U][P], xrv[GK_U][P];
+      typename RawQ<F16>::type epv[GK_U][P], xrv[GK_U][P];
       int jl[GK_U];
       float me[GK_U];
 #pragma unroll
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
         const int4 rec = s_tab[t];
         jl[u] = uni(rec.x);
         me[u] = unif(__int_as_float(rec.w));
-        const float4 *ep = a.e_proj + (size_t)uni(rec.y) * a.lde4 + hoff;
-        const float4 *xr = a.x_r + (size_t)(nb + uni(rec.z)) * a.ldr4 + hoff;
+        const size_t ep = (size_t)uni(rec.y) * a.lde4 + hoff;
+        const size_t xr = (size_t)(nb + uni(rec.z)) * a.ldr4 + hoff;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (ok[p]) {
-            epv[u][p] = ld_stream(ep + off[p], nt);
-            xrv[u][p] = xr[off[p]];
+            epv[u][p] = ldraw_stream<F16>(a.e_proj, ep + off[p], nt);
+            xrv[u][p] = ldraw<F16>(a.x_r, xr + off[p]);
           }
         }
       }
@@ -165,9 +165,9 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (ok[p]) {
-            const float4 v = epv[u][p], r4 = xrv[u][p];
+            const float4 v = cvtq(epv[u][p]), r4 = cvtq(xrv[u][p]);
             float4 w4 = xl_s[off[p]];
-            if (!in_lds) w4 = a.x_l[(size_t)(nb + jl[u]) * a.ldl4 + hoff + off[p]];
+            if (!in_lds) w4 = ldq<F16>(a.x_l, (size_t)(nb + jl[u]) * a.ldl4 + hoff + off[p]);
             float4 s;
             s.x = (r4.x + w4.x) + v.x;
             s.y = (r4.y + w4.y) + v.y;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
         for (int p = 0; p < P; ++p) {
           if (ok[p]) {
             float4 u4 = xl_s[off[p]];
-            if (!in_lds) u4 = a.x_l[(size_t)(nb + jl) * a.ldl4 + hoff + off[p]];
+            if (!in_lds) u4 = ldq<F16>(a.x_l, (size_t)(nb + jl) * a.ldl4 + hoff + off[p]);
             acc[p].x = __fadd_rn(acc[p].x, __fmul_rn(u4.x, wm));
             acc[p].y = __fadd_rn(acc[p].y, __fmul_rn(u4.y, wm));
             acc[p].z = __fadd_rn(acc[p].z, __fmul_rn(u4.z, wm));
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
           }
         }
       }
-      float4 *orow = a.out + (size_t)(nb + k) * R + hoff;
+      const size_t orow = (size_t)(nb + k) * R + hoff;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         if (ok[p]) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
             const float4 b = a.bias[hoff + off[p]];
             o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
           }
-          st_stream(orow + off[p], o, nt);
+          stq_stream<F16>(a.out, orow + off[p], o, nt);
         }
       }
     }
@@ -255,13 +255,15 @@ static int launch_sized(MpArgs a, int nmax_host, hipStream_t st) {
   dim3 grid((unsigned)items), block(GK_THREADS);
   const bool masked = a.node_mask || a.edge_mask;
   const bool exact = (a.C >> 2) == (64 / HS) * P;
-  if (masked) {
-    if (exact) gatv2_mp_graph_kernel<HS, P, true, true, NC, EC><<<grid, block, dyn, st>>>(a);
-    else gatv2_mp_graph_kernel<HS, P, true, false, NC, EC><<<grid, block, dyn, st>>>(a);
+#define ISG_GK_LAUNCH(M_, X_, F_) gatv2_mp_graph_kernel<HS, P, M_, X_, NC, EC, F_><<<grid, block, dyn, st>>>(a)
+  if (a.f16) {
+    if (masked) { if (exact) ISG_GK_LAUNCH(true, true, true); else ISG_GK_LAUNCH(true, false, true); }
+    else { if (exact) ISG_GK_LAUNCH(false, true, true); else ISG_GK_LAUNCH(false, false, true); }
   } else {
-    if (exact) gatv2_mp_graph_kernel<HS, P, false, true, NC, EC><<<grid, block, dyn, st>>>(a);
-    else gatv2_mp_graph_kernel<HS, P, false, false, NC, EC><<<grid, block, dyn, st>>>(a);
+    if (masked) { if (exact) ISG_GK_LAUNCH(true, true, false); else ISG_GK_LAUNCH(true, false, false); }
+    else { if (exact) ISG_GK_LAUNCH(false, true, false); else ISG_GK_LAUNCH(false, false, false); }
   }
+#undef ISG_GK_LAUNCH
   return check_launch();
 }
 

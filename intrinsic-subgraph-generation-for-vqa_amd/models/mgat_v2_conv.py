@@ -62,6 +62,9 @@ class MaskingGATv2Conv(torch.nn.Module):
                                  sampler_type=sampler_type, sample_k=sample_k, nb_samples=nb_samples, alpha=alpha,
                                  beta=beta, tau=tau)
         self.masking = NodeMaskToEdgeMask.apply
+        # storage type of the projected rows x_l / x_r / e_proj and of the aggregated output (fp32 arithmetic either way):
+        # torch.float16 is BASELINE configs[4] ("fp16 features / fp32 accumulate"), inference only
+        self.feature_dtype = torch.float32
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -95,16 +98,17 @@ class MaskingGATv2Conv(torch.nn.Module):
             mask = self.mask(x, imle_att, batch, edge_index, use_all_instrs=False, plan=plan, noise=noise,
                              seed=seed, u_is_per_graph=True)                              # :166-168
 
+        fdt = self.feature_dtype
         if self.share_weights:
-            x_l = x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias)                # :177-179
+            x_l = x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt)  # :177-179
         else:   # lin_l and lin_r share their input: one [N, 2*H*C] projection, x_l / x_r are its column halves
-            x_l, x_r = ops.linear_fused(x, (self.lin_l, self.lin_r))                     # :177,181
+            x_l, x_r = ops.linear_fused(x, (self.lin_l, self.lin_r), out_dtype=fdt)      # :177,181
         if e_proj is None:
             if edge_attr is None or self.lin_edge is None:
                 raise NotImplementedError("edge_attr=None: MGAT always passes edge features (mgat.py:147)")
             if edge_attr.dim() == 1:
                 edge_attr = edge_attr.view(-1, 1)
-            e_proj = ops.linear(edge_attr.float().contiguous(), self.lin_edge.weight, None)   # :259
+            e_proj = ops.linear(edge_attr.float().contiguous(), self.lin_edge.weight, None, out_dtype=fdt)   # :259
         out, alpha = ops.gatv2_mp(x_l, x_r, e_proj, self.att, plan, H, bias=self.bias, node_mask=mask,
                                   negative_slope=self.negative_slope)                    # :215-232
         if isinstance(return_attention_weights, bool):

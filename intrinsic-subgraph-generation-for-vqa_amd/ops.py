@@ -71,12 +71,14 @@ def _chk(t: Optional[Tensor], name: str, dtype, shape=None, optional=False) -> i
     return t.data_ptr()
 
 
-def _chk_rows(t: Tensor, name: str) -> int:
-    """Like _chk for a 2-D fp32 tensor whose rows may be strided (columns contiguous, 16-byte aligned rows)."""
+def _chk_rows(t: Tensor, name: str, dtype=torch.float32) -> int:
+    """Like _chk for a 2-D fp32 (or fp16) tensor whose rows may be strided (columns contiguous, rows aligned to 4
+    elements)."""
     if not t.is_cuda:
         raise _lib.IsgError(f"{name} must live on the GPU (got {t.device}); this path has no CPU fallback")
-    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or (t.stride(0) & 3) or (t.data_ptr() & 15):
-        raise ValueError(f"{name}: expected fp32 [rows, cols] with contiguous columns and 16-byte aligned rows")
+    align = 15 if dtype == torch.float32 else 7
+    if t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1 or (t.stride(0) & 3) or (t.data_ptr() & align):
+        raise ValueError(f"{name}: expected {dtype} [rows, cols] with contiguous columns and rows aligned to 4 elements")
     if torch.is_grad_enabled() and t.requires_grad:
         raise NotImplementedError(f"{name} requires grad but this operator has no backward (see autograd.py)")
     return t.data_ptr()
@@ -255,16 +257,23 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
     ld_l, ld_r, ld_e = x_l.stride(0), x_r.stride(0), (e_proj.stride(0) if E > 0 else HC)
     if x_l.stride(1) != 1 or x_r.stride(1) != 1 or tuple(x_r.shape) != (N, HC) or tuple(e_proj.shape) != (E, HC):
         raise ValueError("x_l / x_r must be [N, H*C] and e_proj [E, H*C], columns contiguous")
-    out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
+    fdt = x_l.dtype                # feature rows: fp32, or fp16 (BASELINE configs[4]; fp32 arithmetic, per-graph kernel)
+    if fdt not in (torch.float32, torch.float16) or x_r.dtype != fdt or (E > 0 and e_proj.dtype != fdt):
+        raise TypeError(f"x_l / x_r / e_proj must share one dtype (fp32 or fp16), got {x_l.dtype}/{x_r.dtype}/{e_proj.dtype}")
+    out = torch.empty(N, HC, dtype=fdt, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     use_graph = (kernel or MP_KERNEL) == "graph" and plan.B > 0 and plan.nmax > 0
+    if fdt == torch.float16 and not use_graph:
+        raise _lib.IsgError("fp16 feature rows need the per-graph kernel (a GraphPlan built with edge_index)")
     timer = MP_TIMER
     if timer is not None:
-        ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None})
+        ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None,
+                                  "feat_bytes": 2 if fdt == torch.float16 else 4})
         ev0.record()
-    _lib.check(lib.isg_gatv2_mp_fwd(
-        _chk_rows(x_l, "x_l"), _chk_rows(x_r, "x_r"),
-        _chk_rows(e_proj, "e_proj") if E > 0 else 0, _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+    entry = lib.isg_gatv2_mp_fwd if fdt == torch.float32 else lib.isg_gatv2_mp_fwd_f16
+    _lib.check(entry(
+        _chk_rows(x_l, "x_l", fdt), _chk_rows(x_r, "x_r", fdt),
+        _chk_rows(e_proj, "e_proj", fdt) if E > 0 else 0, _chk(att.reshape(-1), "att", torch.float32, (HC,)),
         _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
         plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
@@ -544,11 +553,14 @@ def _weight_planes(weight: Tensor, cache: bool = True) -> Tensor:
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False,
-           cache_planes: bool = True) -> Tensor:
+           cache_planes: bool = True, out_dtype=torch.float32) -> Tensor:
     """act(x @ weight^T + bias), x [M,K] fp32, weight [N,K] (torch Linear layout).  Uses the bf16x6 matrix-core kernel
     when the shape allows it, hipBLASLt through torch otherwise (K not a multiple of 4).  ``cache_planes=False``: the
     weight is being trained (or is a temporary), so its bf16 planes are split per call instead of cached."""
     M, K = x.shape
+    f16_io = x.dtype == torch.float16 or out_dtype == torch.float16
+    if f16_io and (GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or _rec(x, weight, bias)):
+        raise _lib.IsgError("fp16 feature rows are an inference feature of the bf16x6 kernel (K % 4 == 0, no autograd)")
     if _rec(x, weight, bias) and GEMM_BACKEND == "bf16x6" and (K & 3) == 0 and M > 0:
         from . import autograd
         return autograd.linear(x, weight, bias, gelu)
@@ -557,15 +569,23 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         y = torch.nn.functional.linear(x, weight, bias)
         return torch.nn.functional.gelu(y) if gelu else y
     lib = _lib.load()
-    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    out = torch.empty(M, N, dtype=out_dtype, device=x.device)
     planes = _weight_planes(weight, cache_planes)
+    if f16_io:
+        if M > 0:
+            _lib.check(lib.isg_linear_bf16x6_f16(
+                _chk(x, "x", x.dtype), 1 if x.dtype == torch.float16 else 0, planes.data_ptr(),
+                _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
+                out.data_ptr(), 1 if out_dtype == torch.float16 else 0, M, N, K, K, N, 1 if gelu else 0, _stream()),
+                "isg_linear_bf16x6_f16")
+        return out
     _lib.check(lib.isg_linear_bf16x6(_chk(x, "x", torch.float32), planes.data_ptr(),
                                      _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
                                      out.data_ptr(), M, N, K, K, N, 1 if gelu else 0, _stream()), "isg_linear_bf16x6")
     return out
 
 
-def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:
+def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:   # x may be fp16 feature rows; the output is fp32
     """Run an nn.Sequential of Linear / GELU / Dropout(eval) modules with every Linear(+GELU) pair as one launch."""
     mods = list(seq)
     i = 0
@@ -584,7 +604,7 @@ def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:
 _CAT = {}   # (ids of the weights) -> (versions, concatenated weight, concatenated bias, weakrefs of the weights)
 
 
-def linear_fused(x: Tensor, layers) -> Tuple[Tensor, ...]:
+def linear_fused(x: Tensor, layers, out_dtype=torch.float32) -> Tuple[Tensor, ...]:
     """Several Linear layers that share their input as ONE projection (weights concatenated along the output dim, cached);
     returns one column-slice view of the fused output per layer (row stride = total width)."""
     if _rec(x, *[m.weight for m in layers]):      # training: differentiable concatenation, nothing cached
@@ -611,7 +631,7 @@ def linear_fused(x: Tensor, layers) -> Tuple[Tensor, ...]:
                 del _CAT[k]
         hit = (ver, w, b, tuple(weakref.ref(m.weight) for m in layers))
         _CAT[key] = hit
-    y = linear(x, hit[1], hit[2])
+    y = linear(x, hit[1], hit[2], out_dtype=out_dtype)
     outs, o = [], 0
     for m in layers:
         n = m.weight.size(0)

@@ -35,6 +35,7 @@ class WorkloadConfig:
     edges_per_graph: float = 50.0       # self-loops included
     degree: str = "uniform"             # uniform | powerlaw (in-degree, cfg5)
     interpretable_mode: bool = False
+    feature_dtype: str = "fp32"         # "fp16": projected rows / aggregated output stored as half (configs[4])
     seed: int = 2345
 
 
@@ -160,6 +161,9 @@ class AnswerModel(torch.nn.Module):
 def build_answer_model(cfg: WorkloadConfig, weight_seed: int = 0) -> AnswerModel:
     torch.manual_seed(weight_seed)
     m = AnswerModel(cfg.channels, cfg.layers, cfg.masks, cfg.sampler, cfg.sample_k, cfg.heads, cfg.interpretable_mode)
+    if cfg.feature_dtype == "fp16":
+        for conv in m.gat_seq.convs:
+            conv.feature_dtype = torch.float16
     # GraphNorm / bias parameters start at their trivial values; perturb them so parity covers them
     g = torch.Generator().manual_seed(weight_seed + 1)
     with torch.no_grad():

@@ -40,6 +40,9 @@ class PathConfig:
     gumbel_tau: float = 0.1               # GumbelSampler default (gumbel_scheme.py:15)
     interpretable_mode: bool = False
     use_global_mask: bool = False
+    # BASELINE configs[4] "fp16 features / fp32 accumulate": the projected rows x_l / x_r / e_proj and the aggregated
+    # output (+bias) are rounded to IEEE half once each; all arithmetic stays fp32
+    fp16_features: bool = False
     # training mode: train samplers + custom backward rules; dropout is NOT modelled (treated as p=0)
     training: bool = False
     imle_alpha: float = 1.0
@@ -182,10 +185,14 @@ def gatv2_conv_forward(sd, p: str, x: Tensor, edge_index: Tensor, batch: Tensor,
     x_l = linear(sd, p + ".lin_l", x).view(-1, H, C)                   # :177
     x_r = linear(sd, p + ".lin_r", x).view(-1, H, C)                   # :181
     e_proj = F.linear(edge_attr, sd[p + ".lin_edge.weight"]).view(-1, H, C)        # :259-260
+    if cfg.fp16_features:
+        x_l, x_r, e_proj = x_l.half().float(), x_r.half().float(), e_proj.half().float()
     out, alpha = gatv2_message_passing(x_l, x_r, e_proj, sd[p + ".att"], edge_index,
                                        edge_mask, cfg.negative_slope)
     out = out.view(-1, H * C)                                          # :227
     out = out + sd[p + ".bias"]                                        # :232
+    if cfg.fp16_features:
+        out = out.half().float()
     return out, mask, alpha
 
 

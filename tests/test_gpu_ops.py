@@ -380,3 +380,72 @@ def test_weight_plane_cache_survives_id_and_address_reuse(dev):
         ref = x.double() @ w.double().t()
         assert (got.double() - ref).abs().max() < 1e-4, seed
         del w, got
+
+
+# ------------------------------------------------------------------------------------ fp16 feature rows (configs[4])
+F16_CASES = [
+    (4, 128, [20, 17, 33, 4, 9], 1.5, None, None),
+    (4, 128, [20, 17, 33, 4, 9], 1.5, None, "node"),
+    (4, 128, [50, 3, 60], 1.5, None, "edge"),           # graphs larger than the LDS window
+    (4, 32, [150, 6, 90], 1.0, (0, 300), "node"),       # large tables, hub with in-degree 300+
+    (2, 36, [9, 30], 2.0, None, None),                   # ragged passes (C/4 not a multiple of the lane group)
+    (8, 16, [9, 30], 2.0, None, "edge"),
+]
+
+
+@pytest.mark.parametrize("H,C,sizes,extra,hub,mask", F16_CASES)
+def test_gatv2_message_passing_fp16_rows_match_oracle(dev, H, C, sizes, extra, hub, mask):
+    """x_l / x_r / e_proj / out stored as half, fp32 arithmetic: the oracle on the same half-rounded rows, its output
+    rounded to half once.  Tolerance: one half ulp on out (1e-3 relative), fp32 tolerance on alpha."""
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(H * 1000 + C + 1)
+    batch, ei = _rand_graphs(gen, sizes, extra, hub)
+    N, E = batch.numel(), ei.size(1)
+    x_l, x_r = torch.randn(N, H * C, generator=gen).half(), torch.randn(N, H * C, generator=gen).half()
+    e_proj = torch.randn(E, H * C, generator=gen).half()
+    att, bias = torch.randn(1, H, C, generator=gen), torch.randn(H * C, generator=gen)
+    nm = em = None
+    if mask == "node":
+        nm = (torch.rand(N, 1, generator=gen) > 0.4).float()
+        em = OM.node_mask_to_edge_mask(nm, ei)
+    elif mask == "edge":
+        em = (torch.rand(E, 1, generator=gen) > 0.4).float()
+    ref_out, ref_alpha = OM.gatv2_message_passing(x_l.float().view(N, H, C), x_r.float().view(N, H, C),
+                                                  e_proj.float().view(E, H, C), att, ei, em, 0.2)
+    ref_out = (ref_out.view(N, H * C) + bias)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    out, alpha = ops.gatv2_mp(x_l.to(dev), x_r.to(dev), e_proj.to(dev), att.to(dev), plan, H, bias=bias.to(dev),
+                              node_mask=None if mask != "node" else nm.to(dev),
+                              edge_mask=None if mask != "edge" else em.to(dev))
+    assert out.dtype == torch.float16 and alpha.dtype == torch.float32
+    assert torch.allclose(alpha.cpu(), ref_alpha, atol=2e-6, rtol=1e-5)
+    got, ref = out.cpu().float(), ref_out.half().float()
+    # one half step at |ref|, plus the fp32 summation-order noise that decides the rounding of entries near zero
+    ulp = torch.maximum(ref.abs(), torch.tensor(6.1e-5)) * 2.0 ** -10 + 4e-6
+    assert ((got - ref).abs() <= ulp).all(), ((got - ref).abs() / ulp).max()
+    assert (got != ref).float().mean() < 0.02          # a different rounding only where fp32 sums differ in the last bits
+    with pytest.raises(Exception):                       # fp16 rows exist in the per-graph kernel only
+        ops.gatv2_mp(x_l.to(dev), x_r.to(dev), e_proj.to(dev), att.to(dev), plan, H, kernel="chunk")
+
+
+@pytest.mark.parametrize("a16,d16", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K,gelu", [(1000, 512, 128, False), (777, 130, 64, True), (300, 128, 512, True)])
+def test_linear_bf16x6_fp16_io(dev, a16, d16, M, N, K, gelu):
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=gen)
+    if a16:
+        x = x.half()
+    w, b = torch.randn(N, K, generator=gen) / K ** 0.5, torch.randn(N, generator=gen)
+    ref = x.double() @ w.double().t() + b.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    got = ops.linear(x.to(dev), w.to(dev), b.to(dev), gelu=gelu, out_dtype=torch.float16 if d16 else torch.float32)
+    assert got.dtype == (torch.float16 if d16 else torch.float32)
+    if d16:
+        r = ref.float().half().float()
+        ulp = torch.maximum(r.abs(), torch.tensor(6.1e-5)) * 2.0 ** -10 + 4e-6
+        assert ((got.cpu().float() - r).abs() <= ulp).all()
+    else:
+        assert (got.cpu().double() - ref).abs().max() < 2e-6 * max(1.0, float(ref.abs().max()))
