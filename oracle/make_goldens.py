@@ -22,7 +22,10 @@ travels to the GPU box); writes small data-only fixtures to tests/golden/*.pt:
                    stand-ins for torchtext and torch_geometric.data.Data) on synthetic scene-graph JSON with a synthetic
                    vocabulary: the JSON text, the token lists and the per-image tensors
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_goldens
+  g9_simple.pt     EdgeSIMPLEBatched.forward (policy 'edge_candid'): masks, marginals and input gradients on ragged
+                   padded batches, incl. rows with more zero pads than k (the circuit's padding accidents) and a NaN row
+
+Usage:  TORCHDYNAMO_DISABLE=1 (the reference decorates its circuit passes with torch.compile) PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_goldens
 No reference source text is written anywhere; fixtures hold tensors only.
 """
 from __future__ import annotations
@@ -491,6 +494,44 @@ def gen_loader():
                os.path.join(OUT, "g8_loader.pt"))
 
 
+def gen_simple():
+    import math
+    import tempfile
+    assert os.environ.get("TORCHDYNAMO_DISABLE") == "1", "run with TORCHDYNAMO_DISABLE=1 (simple.py uses torch.compile)"
+    sys.modules["torch_geometric"].utils.index_sort = lambda *a, **k: None       # tensor_utils.py imports the name only
+    from ISubGVQA.sampling.methods.simple_scheme import EdgeSIMPLEBatched
+    cases = []
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:      # Layer() pickles its circuit into ./simple_configs (simple.py:122-130)
+        os.chdir(tmp)
+        try:
+            for ci, (B, Nmax, k) in enumerate([(3, 6, 2), (5, 8, 5), (6, 20, 5), (4, 33, 3), (2, 4, 5), (3, 16, 1),
+                                               (8, 24, 5), (1, 9, 5)]):
+                gen = torch.Generator().manual_seed(900 + ci)
+                scores = torch.randn(B, Nmax, 1, generator=gen)
+                lens = [Nmax]
+                for b in range(1, B):
+                    n = int(torch.randint(1, Nmax + 1, (1,), generator=gen))
+                    scores[b, n:] = 0.0
+                    lens.append(n)
+                w = torch.randn(B, Nmax, 1, generator=gen) * (torch.arange(Nmax)[None, :, None] < torch.tensor(lens)[:, None, None])
+                sampler = EdgeSIMPLEBatched(k=k, device="cpu", policy="edge_candid")
+                for train in (True, False):
+                    th = scores.clone().requires_grad_(True)
+                    seed = 9900 + 2 * ci + int(train)
+                    torch.manual_seed(seed)
+                    mask, marg = sampler(th, train=train)
+                    (torch.nan_to_num(mask.squeeze(0)) * w).sum().backward()
+                    n2 = 2 ** math.ceil(math.log2(Nmax))
+                    torch.manual_seed(seed)
+                    uniform = torch.rand(1, B, n2)
+                    cases.append(dict(scores=scores, lens=torch.tensor(lens), k=k, train=train, w=w, uniform=uniform,
+                                      mask=mask.detach().clone(), marginals=marg.detach().clone(), grad=th.grad.clone()))
+        finally:
+            os.chdir(cwd)
+    torch.save(cases, os.path.join(OUT, "g9_simple.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.dont_write_bytecode = True
@@ -502,6 +543,7 @@ def main():
     gen_sampler_grads()
     gen_mgat_train()
     gen_loader()
+    gen_simple()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
