@@ -206,6 +206,17 @@ int isg_instr_attn_graphnorm_residual(const float *ins, const float *c, const fl
 int isg_global_attn_pool(const float *xn, const float *q, const int32_t *ptr, const float *node_mask,
                          float *out, float *gate, int64_t B, int32_t C, void *stream);
 
+/* SIMPLE sampler: EdgeSIMPLEBatched.forward, policy 'edge_candid', one sample,
+ * ISubGVQA/sampling/methods/simple_scheme.py:44-162 over Layer.log_pr / sample (simple.py:203-251) and the exactly-k
+ * circuit of create_simple_constraint.py:34-73.  Per row: scores padded with 0.0 up to nmax (to_dense_batch) and with
+ * -1e10 up to n = 2^ceil(log2 nmax); marginals = exp(log-marginals of the circuit's positive literals), including the
+ * reference's dummy-node padding of element and parent lists; sample = k largest of scores - log(-log(u));
+ * out = (sample - marginals) + marginals.  nmax must be the batch's TRUE longest row (it fixes the circuit).
+ * scores ragged [N] with ptr or dense [B,nmax]; uniform fp32[B,n] (the torch.rand draw) or NULL for the in-kernel
+ * Philox stream of `seed`; out in the layout of scores; marg_out optional fp32[B,nmax].  k <= 16, nmax <= 1024. */
+int isg_simple_topk(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax, const float *uniform,
+                    uint64_t seed, int32_t k, float *out, float *marg_out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Backward (training of the hot path)
  * ------------------------------------------------------------------------------------------- */

@@ -42,6 +42,8 @@ SIGNATURES = {
                                c_int64, c_int32, c_void_p]),
     "isg_instr_attn_graphnorm_residual": (c_int, [c_void_p] * 7 + [c_double, c_void_p, c_void_p, c_int64, c_int32,
                                                                   c_void_p]),
+    "isg_simple_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_uint64, c_int32, c_void_p, c_void_p,
+                                c_void_p]),
     "isg_topk_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_int32,
                                     c_float, c_void_p, c_void_p, c_void_p]),
     "isg_gatv2_mp_bwd": (c_int, [c_void_p] * 19 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p]),

@@ -261,6 +261,33 @@ def topk_gumbel(scores, k, tau, plan, noise, seed):
     return _GumbelTopK.apply(scores, k, tau, plan, noise, seed)
 
 
+def simple_topk(scores, k, plan, uniform, seed, return_marginals):
+    """forward = isg_simple_topk; backward = autograd over the torch restatement of the circuit's marginals (the only
+    differentiable part: out = (sample - marginals).detach() + marginals)."""
+    from .sampling.methods.simple import LARGE_NUMBER, log_marginals
+    if plan is not None:
+        B, nmax, slots = plan.B, plan.nmax, plan.dense_slots()
+    else:
+        B, nmax, slots = scores.shape[0], scores.shape[1], None
+    n = 1 << max(nmax - 1, 0).bit_length()
+    kk = min(int(k), nmax)
+
+    def fused(sc, *_c):
+        return ops.simple_topk(sc, k, plan, uniform, seed, return_marginals)
+
+    def restate(sc, *_c):
+        if slots is not None:
+            dense = torch.zeros(B * nmax, dtype=sc.dtype, device=sc.device).index_put((slots,), sc.reshape(-1)).view(B, nmax)
+        else:
+            dense = sc.reshape(B, nmax)
+        flat = torch.cat([dense, torch.full((B, n - nmax), -LARGE_NUMBER, dtype=sc.dtype, device=sc.device)], dim=1)
+        marg = log_marginals(flat, kk).exp()[:, :nmax]
+        out = marg.reshape(-1)[slots].view(sc.shape) if slots is not None else marg.view(sc.shape)
+        return (out, marg) if return_marginals else out
+
+    return _Recomputed.apply(fused, restate, (), scores)
+
+
 class _ImleTopK(torch.autograd.Function):
     """z = MAP(theta + tau_in * eps);  d theta = z - MAP(alpha * theta - beta * dy + tau_t * eps)."""
 

@@ -55,7 +55,8 @@ class MaskingModel(torch.nn.Module):
         elif sampler_type == "gumbel":
             self.sampler = GumbelSampler(k=sample_k, policy="edge_candid", train_ensemble=1, val_ensemble=1)
         elif sampler_type == "simple":
-            raise NotImplementedError("the SIMPLE sampler is SURVEY §8(f) row 4, not part of this path")
+            from ..sampling.methods.simple_scheme import EdgeSIMPLEBatched
+            self.sampler = EdgeSIMPLEBatched(k=sample_k, device="cuda", policy="edge_candid")    # masking.py:110-119
 
     def reset_parameters(self):
         for seq in (self.gate_nn, self.node_nn, self.ques_nn):
@@ -90,6 +91,11 @@ class MaskingModel(torch.nn.Module):
                 noise = gumbel_from_uniform(torch.rand(B, nmax, device=gate.device))
             return ops.topk_gumbel(gate, int(self.sample_k), float(self.sampler.tau), plan=plan, noise=noise,
                                    seed=0 if seed is None else seed)
+        if self.sampler_type == "simple":          # masking.py:175-176 (same call as the Gumbel sampler)
+            n = 1 << max(nmax - 1, 0).bit_length()
+            if noise is None and seed is None:
+                noise = torch.rand(B, n, device=gate.device)
+            return ops.simple_topk(gate, int(self.sample_k), plan=plan, uniform=noise, seed=0 if seed is None else seed)
         if self.sampler_type in ("imle", "aimle"):
             sampler = self.sampler_train if self.training else self.sampler_val
             temp = sampler.noise_temperature

@@ -115,6 +115,7 @@ class GraphPlan:
     batch: Optional[Tensor] = None           # kept for the backward restatements (autograd.py)
     edge_index: Optional[Tensor] = None      # kept for the lazily built CSR by source (backward only)
     _by_src: Optional[Tuple[Tensor, Tensor, Tensor]] = None
+    _slots: Optional[Tensor] = None
 
     def source_csr(self) -> Tuple[Tensor, Tensor, Tensor]:
         """(rowptr_s[N+1], eid_s[E], dst_s[E]): out-edges of every node in edge-id order.  Only the backward of the
@@ -195,6 +196,13 @@ class GraphPlan:
         _lib.check(lib.isg_csr_build(edge_index.data_ptr(), N, E, plan.rowptr.data_ptr(), plan.eid.data_ptr(),
                                      plan.src.data_ptr(), 0, ws.data_ptr(), ws_bytes, _stream()), "isg_csr_build")
         return plan
+
+    def dense_slots(self) -> Tensor:
+        """Position of every node in the padded [B * nmax] layout of to_dense_batch (int64 [N])."""
+        if self._slots is None:
+            b = self.batch
+            self._slots = b * self.nmax + (torch.arange(self.N, device=b.device) - self.ptr.long()[b])
+        return self._slots
 
     def require_csr(self) -> None:
         if self.rowptr is None:
@@ -436,6 +444,29 @@ def topk_threshold(scores: Tensor, k: int, plan: Optional[GraphPlan] = None, noi
                "isg_topk_threshold")
     out = out.view(scores.shape)
     return (out, dense) if return_dense else out
+
+
+def simple_topk(scores: Tensor, k: int, plan: Optional[GraphPlan] = None, uniform: Optional[Tensor] = None,
+                seed: int = 0, return_marginals: bool = False):
+    """SIMPLE sampler (simple_scheme.py:44-162): mask = (Gumbel top-k sample - marginals) + marginals, marginals exact
+    through the exactly-k circuit.  Ragged (plan given; plan.nmax must be the batch's true longest row): scores [N] /
+    [N,1]; dense: scores [B,Nmax].  ``uniform``: the [B, n] torch.rand draw (n = Nmax rounded up to a power of two)."""
+    if _rec(scores):
+        from . import autograd
+        return autograd.simple_topk(scores, k, plan, uniform, seed, return_marginals)
+    lib = _lib.load()
+    flat, ptr, B, nmax, _ = _rows(scores, plan)
+    out = torch.empty_like(flat)
+    n = 1 << max(nmax - 1, 0).bit_length() if nmax > 0 else 0
+    if uniform is not None and uniform.numel() != B * n:
+        raise ValueError(f"uniform must hold B*n = {B}*{n} values, got {tuple(uniform.shape)}")
+    marg = torch.empty(B, nmax, dtype=torch.float32, device=scores.device) if return_marginals else None
+    _lib.check(lib.isg_simple_topk(_chk(flat, "scores", torch.float32), ptr, B, nmax,
+                                   0 if uniform is None else _chk(uniform.reshape(B, n), "uniform", torch.float32),
+                                   int(seed) & (2 ** 64 - 1), int(k), out.data_ptr(),
+                                   0 if marg is None else marg.data_ptr(), _stream()), "isg_simple_topk")
+    out = out.view(scores.shape)
+    return (out, marg) if return_marginals else out
 
 
 def topk_gumbel_backward(scores: Tensor, grad_out: Tensor, k: int, tau: float = 0.1, plan: Optional[GraphPlan] = None,

@@ -117,6 +117,11 @@ def masking_model_forward(sd, p: str, x: Tensor, u: Tensor, batch: Tensor, cfg: 
         elif cfg.sampler_type == "aimle":
             out = S.aimle_eval(dense, cfg.sample_k, noise, cfg.tau)
             res = out[m]
+        elif cfg.sampler_type == "simple":                             # :175-176; noise = the [1, B, n] torch.rand draw
+            from . import simple as SS
+            out, marg = SS.simple_forward(dense, cfg.sample_k, noise)
+            aux["marginals"] = marg
+            res = out.squeeze(0)[m]
         elif cfg.sampler_type == "gumbel":                             # :175-176
             out, khot, ind = S.gumbel_relaxed_topk(dense, cfg.sample_k, noise, cfg.gumbel_tau)
             aux["khot"], aux["ind"] = khot, ind

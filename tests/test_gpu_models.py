@@ -112,6 +112,9 @@ def _noises(cfg, wl, seed):
                 out[i] = OS.uniform_to_gumbel(torch.rand(cfg.num_graphs, wl.max_nodes, generator=gen))
             elif cfg.sampler == "aimle":
                 out[i] = OS.uniform_to_gumbel(torch.rand(cfg.num_graphs, 1, wl.max_nodes, 1, generator=gen), 0.0, 0.3)
+            elif cfg.sampler == "simple":     # the raw torch.rand draw behind the Gumbel keys, [1, B, n]
+                n = 1 << max(wl.max_nodes - 1, 0).bit_length()
+                out[i] = torch.rand(1, cfg.num_graphs, n, generator=gen)
     return out
 
 
@@ -188,6 +191,17 @@ def test_cfg5_skewed_graphs_aimle_fp16_features(dev):
     err = (gl[~bad] - rl[~bad]).abs().max()
     print(f"cfg5 fp16 features: max |logit diff| = {err:.2e}, graphs with a flipped mask: {int(bad.sum())}")
     assert err < 1e-3
+
+
+def test_simple_sampler_model_level(dev):
+    """SURVEY §8f row 4 inside the model: ragged batch (most graphs have more zero pads than k, i.e. the circuit's
+    padding accidents decide their marginals), masks bit-exact, logits within 1e-4."""
+    from isubgvqa_amd import synthetic
+    cfg = synthetic.WorkloadConfig(num_graphs=48, channels=64, layers=3, masks=(1.0, 0.15, 0.15), sampler="simple",
+                                   sample_k=5, seed=31)
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    assert torch.equal(gm > 0.5, rm > 0.5)
+    assert (gl - rl).abs().max() < LOGIT_TOL, (gl - rl).abs().max()
 
 
 def test_interpretable_mode_masks_hidden_state(dev):

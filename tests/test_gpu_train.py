@@ -268,3 +268,28 @@ def test_training_step_cfg2_shape_matches_oracle(dev):
             continue
         assert v.grad is not None, k
         close(v.grad, sd[k].grad.reshape(v.grad.shape), 1e-3, k)
+
+
+# ---- SIMPLE sampler against the reference (G9) ------------------------------------------------------------------------
+def test_simple_sampler_matches_reference(dev):
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.sampling.methods.simple_scheme import EdgeSIMPLEBatched
+    for c in load_golden("g9_simple.pt"):
+        B, nmax = c["scores"].shape[:2]
+        n = c["uniform"].shape[-1]
+        sampler = EdgeSIMPLEBatched(k=c["k"], device=dev, policy="edge_candid")
+        th = c["scores"].to(dev).requires_grad_(True)
+        mask, marg = sampler(th, train=c["train"], uniform=c["uniform"].view(B, n).to(dev))
+        assert torch.equal(torch.isnan(marg.cpu()), torch.isnan(c["marginals"]))
+        torch.testing.assert_close(marg.detach().cpu(), c["marginals"], rtol=2e-5, atol=2e-6, equal_nan=True)
+        torch.testing.assert_close(mask.detach().cpu(), c["mask"], rtol=0, atol=2e-6, equal_nan=True)
+        (torch.nan_to_num(mask.squeeze(0)) * c["w"].to(dev)).sum().backward()
+        torch.testing.assert_close(th.grad.cpu(), c["grad"], rtol=2e-4, atol=5e-6, equal_nan=True)
+        # ragged rows, as MaskingModel calls it (only when the padded batch really has a full-length row)
+        if int(c["lens"].max()) == nmax and not torch.isnan(c["marginals"]).any():
+            slot, _, plan = _ragged(c, dev)
+            sc = c["scores"].reshape(-1)[slot].view(-1, 1).to(dev).requires_grad_(True)
+            out = ops.simple_topk(sc, c["k"], plan=plan, uniform=c["uniform"].view(B, n).to(dev))
+            torch.testing.assert_close(out.detach().cpu().view(-1), c["mask"].reshape(-1)[slot], rtol=0, atol=2e-6)
+            (out * c["w"].reshape(-1)[slot].view(-1, 1).to(dev)).sum().backward()
+            torch.testing.assert_close(sc.grad.cpu().view(-1), c["grad"].reshape(-1)[slot], rtol=2e-4, atol=5e-6)
