@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import math
+
 import torch
 from torch import Tensor
 
@@ -34,8 +36,6 @@ class ISubGVQA(torch.nn.Module):
         self.use_mgat, self.interpretable_mode = use_mgat, interpretable_mode
         self.concat_instr, self.embed_cat = concat_instr, embed_cat
         self.text_sampling = getattr(args, "text_sampling", False)
-        if self.text_sampling:
-            raise NotImplementedError("--text_sampling uses the SIMPLE sampler (SURVEY §8f row 4)")
 
         self.general_hidden_dim = args.general_hidden_dim
         self.scene_graph_encoder = SceneGraphEncoder(hidden_dim=self.general_hidden_dim,
@@ -48,6 +48,11 @@ class ISubGVQA(torch.nn.Module):
         self.question_encoder = QuestionEncoder(text_vocab_embedding=self.text_vocab_embedding,
                                                 text_emb_dim=self.text_emb_dim, ninp=self.text_emb_dim, nhead=8,
                                                 nhid=4 * hidden_dim, nlayers=4, dropout=0.1)
+        if self.text_sampling:                                                           # :135-148
+            from ..sampling.methods.simple_scheme import EdgeSIMPLEBatched
+            self.text_sampler = EdgeSIMPLEBatched(k=args.mgat_layers, device="cuda", policy="edge_candid")
+            self.qsts_att_keys = torch.nn.Sequential(torch.nn.Linear(hidden_dim, hidden_dim), torch.nn.GELU())
+            self.qsts_att_query = torch.nn.Sequential(torch.nn.Linear(hidden_dim, hidden_dim), torch.nn.GELU())
         self.program_decoder = QuestionDecoder(n_instructions=args.mgat_layers, ninp=self.text_emb_dim, nhead=8,
                                                nhid=4 * hidden_dim, nlayers=3, dropout=0.1)
         self.gat_seq = MGAT(channels=self.general_hidden_dim, num_ins=args.mgat_layers, use_instr=use_instruction,
@@ -69,8 +74,18 @@ class ISubGVQA(torch.nn.Module):
         self.logit_fc = torch.nn.Linear(512, NUM_ANSWERS)
 
     # -- pieces of forward that the benchmark also drives on their own -------------------------------
-    def language_features(self, questions: Tensor, qsts_att_mask: Tensor):
+    def language_features(self, questions: Tensor, qsts_att_mask: Tensor, text_uniform: Optional[Tensor] = None,
+                          seed: Optional[int] = None):
         enc = self.question_encoder(questions, mask=qsts_att_mask)                       # :228
+        self.last_mask_text = None
+        if self.text_sampling:                                                           # :229-241: SIMPLE over the tokens
+            T, B, D = enc.shape
+            keys = ops.mlp(self.qsts_att_keys, enc.reshape(T * B, D).contiguous()).view(T, B, D)
+            queries = ops.mlp(self.qsts_att_query, enc.reshape(T * B, D).contiguous()).view(T, B, D)
+            logits = torch.bmm(keys.permute(1, 0, 2), queries.permute(1, 2, 0)).sum(-1) / math.sqrt(D)
+            mask_text, _ = self.text_sampler(logits.unsqueeze(-1), train=self.training, uniform=text_uniform, seed=seed)
+            enc = (enc.permute(1, 0, 2) * mask_text.squeeze(0)).permute(1, 0, 2)
+            self.last_mask_text = mask_text
         qst_feats = self.program_decoder(memory=enc)                                     # :243
         # :244-246 -- a .view, not a permute: rows 4b..4b+3 of the flattened [n_ins*B, 512] (quirk Q4)
         flat = qst_feats.contiguous().view(qst_feats.size(1), int(qst_feats.size(0)), qst_feats.size(2)).flatten(1)
@@ -94,13 +109,14 @@ class ISubGVQA(torch.nn.Module):
     def forward(self, node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask,
                 return_masks=False, explainer=False, explainer_stage=False, expl_bypass_x=False, scene_graphs=None,
                 noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
-                plan: Optional[ops.GraphPlan] = None):
+                plan: Optional[ops.GraphPlan] = None, text_uniform: Optional[Tensor] = None):
         if not return_masks:
             # the reference unpacks two values from GlobalAttention.forward, which returns a bare tensor when
             # return_mask=False (isubgvqa.py:280, att_pooling.py:75-77): return_masks=True is mandatory there
             raise ValueError("return_masks=True is required (isubgvqa.py:280 unpacks (embed, gate))")
-        mask_text = None
-        glf, instr_vectors = self.language_features(questions, qsts_att_mask)
+        glf, instr_vectors = self.language_features(questions, qsts_att_mask, text_uniform,
+                                                    None if seed is None else seed + 7919)
+        mask_text = self.last_mask_text
         if explainer and explainer_stage > 0:                                            # :249-253
             node_embeddings, expl_bypass_x = expl_bypass_x, node_embeddings.clone()
         if plan is None:   # a loader.SceneGraphBatch carries the per-graph bounds: the plan is then built without a sync

@@ -409,11 +409,19 @@ def mgat_pool_classify(sd, x: Tensor, edge_index: Tensor, edge_attr: Tensor, bat
 def isubgvqa_forward(sd, node_embeddings: Tensor, edge_index: Tensor, edge_embeddings: Tensor,
                      batch: Tensor, questions: Tensor, qsts_att_mask: Tensor, x_bbox: Tensor,
                      added_sym_edge: Tensor, cfg: PathConfig,
-                     noises: Optional[Dict[int, Tensor]] = None):
+                     noises: Optional[Dict[int, Tensor]] = None, text_uniform: Optional[Tensor] = None):
     enc = question_encoder_forward(sd, "question_encoder", questions, qsts_att_mask, cfg.nhead_text)  # :228
+    mask_text = None
+    if text_uniform is not None:                                       # --text_sampling (:229-241), k = mgat_layers
+        from . import simple as SS
+        keys = P.gelu(linear(sd, "qsts_att_keys.0", enc))
+        queries = P.gelu(linear(sd, "qsts_att_query.0", enc))
+        logits = torch.bmm(keys.permute(1, 0, 2), queries.permute(1, 2, 0)).sum(-1) / math.sqrt(enc.size(-1))
+        mask_text, _ = SS.simple_forward(logits.unsqueeze(-1), len(cfg.masking_thresholds), text_uniform)
+        enc = (enc.permute(1, 0, 2) * mask_text.squeeze(0)).permute(1, 0, 2)
     qst_feats = question_decoder_forward(sd, "program_decoder", enc, cfg.nhead_text)                 # :243
     glf, instr = language_features(sd, qst_feats)
     x_enc, e_enc = scene_graph_encoder_forward(sd, "scene_graph_encoder", node_embeddings, edge_index,
                                                edge_embeddings, batch, x_bbox, added_sym_edge, cfg)  # :255
     logits, mask, gate = mgat_pool_classify(sd, x_enc, edge_index, e_enc, batch, instr, glf, cfg, noises)
-    return logits, mask, gate, [], None                                                              # :297
+    return logits, mask, gate, [], mask_text                                                         # :297

@@ -328,6 +328,42 @@ def test_full_isubgvqa_model_matches_oracle(dev, sampler):
     assert torch.allclose(gg.cpu(), rg, atol=1e-5)
 
 
+def test_full_model_with_text_sampling(dev):
+    """--text_sampling (isubgvqa.py:229-241): the SIMPLE sampler (k = mgat_layers) masks question tokens before the
+    program decoder."""
+    from isubgvqa_amd import synthetic
+    from isubgvqa_amd.models import build_model
+    from oracle import model as OM
+    torch.manual_seed(0)
+    args = _full_args(sampler_type="imle", text_sampling=True)
+    model = build_model(args, None).eval()
+    assert {"qsts_att_keys.0.weight", "qsts_att_query.0.bias"} <= set(model.state_dict())
+    gen = torch.Generator().manual_seed(23)
+    cfg = synthetic.WorkloadConfig(num_graphs=10, nodes_dist="uniform", nodes_min=2, nodes_max=16, edges_per_graph=0.0,
+                                   seed=98)
+    batch, ei, nmax = synthetic.make_topology(cfg, gen)
+    N, E, B, T = batch.numel(), ei.size(1), 10, 11
+    x = torch.randint(0, 2578, (N, 4), generator=gen)
+    edge_attr = torch.randint(0, 2578, (E,), generator=gen)
+    x_bbox = torch.randint(0, 640, (N, 4), generator=gen)
+    sym = torch.randint(0, 10, (12,), generator=gen)
+    q = torch.randint(0, 512, (B, T), generator=gen)
+    qmask = (torch.arange(T)[None] < torch.randint(6, T + 1, (B,), generator=gen)[:, None]).long()
+    uni = torch.rand(1, B, 16, generator=gen)                      # n = 16 >= T
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ocfg = OM.PathConfig(heads=4, masking_thresholds=[1.0, 1.0, 1.0, 0.15], sampler_type="imle", sample_k=5)
+    with torch.no_grad():
+        rl, rm, _, _, rt = OM.isubgvqa_forward(sd, x, ei, edge_attr, batch, q, qmask, x_bbox, sym, ocfg, None, uni)
+        model = model.to(dev)
+        sgd = argparse.Namespace(x_bbox=x_bbox.to(dev), added_sym_edge=sym.to(dev))
+        gl, gm, _, _, gt = model(x.to(dev), ei.to(dev), edge_attr.to(dev), batch.to(dev), q.to(dev), qmask.to(dev),
+                                 return_masks=True, scene_graphs=sgd, text_uniform=uni.view(B, 16).to(dev))
+    assert gt.shape == rt.shape == (1, B, T, 1)
+    assert torch.equal(gt.cpu() > 0.5, rt > 0.5) and int((rt > 0.5).sum()) == 4 * B
+    assert torch.equal(gm.cpu() > 0.5, rm > 0.5)
+    assert (gl.cpu() - rl).abs().max().item() < LOGIT_TOL
+
+
 def test_loader_to_full_model_end_to_end(dev):
     """SURVEY §8f row 2 joined to the path: scene-graph JSON -> C++ loader (pinned batch, plan hints) -> full ISubGVQA on
     the GPU, against the oracle fed by the oracle's own conversion + collate of the same JSON."""
