@@ -29,10 +29,6 @@ from torch import Tensor
 from . import ops
 
 
-def recording(*tensors) -> bool:
-    return torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
-
-
 # ------------------------------------------------------------------------------------------------
 # Generic: fused forward, recomputed torch backward
 # ------------------------------------------------------------------------------------------------

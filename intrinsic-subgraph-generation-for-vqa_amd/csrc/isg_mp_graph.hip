@@ -39,7 +39,10 @@ constexpr int GK_THREADS = GK_WAVES * 64;
 // with hubs (BASELINE configs[4]: up to 200 nodes); the small one leaves more LDS for x_l rows
 constexpr int GK_NCAP_S = 64, GK_ECAP_S = 256;
 constexpr int GK_NCAP_L = 256, GK_ECAP_L = 1024;
-constexpr int GK_U = 4;        // slots a wave has in flight in phase B
+#ifndef ISG_GK_U
+#define ISG_GK_U 4
+#endif
+constexpr int GK_U = ISG_GK_U;   // slots a wave has in flight in phase B (tuning builds: -DISG_GK_U=n)
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v) {

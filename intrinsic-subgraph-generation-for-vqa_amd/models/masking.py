@@ -17,11 +17,9 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .. import ops
-from ..sampling.methods.aimle import aimle
 from ..sampling.methods.deterministic_scheme import IMLEScheme
 from ..sampling.methods.gumbel_scheme import GumbelSampler
 from ..sampling.methods.noise import GumbelDistribution
-from ..sampling.methods.wrapper import imle
 from .layers import TopKPoolingParams
 
 _IMLE_NOISE_SCALE = 0.3    # masking.py:215,249

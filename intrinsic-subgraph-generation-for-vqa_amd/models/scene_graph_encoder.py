@@ -17,7 +17,6 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
-from torch import Tensor
 
 from .. import ops
 from .layers import GraphNorm

@@ -12,8 +12,6 @@ from __future__ import annotations
 
 import math
 from functools import lru_cache
-from typing import List, Tuple
-
 import torch
 from torch import Tensor
 

@@ -11,7 +11,7 @@ only runs at C=300 (GraphNorm(300) in the scene-graph encoder).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
 import torch
