@@ -79,8 +79,8 @@ class SceneGraphEncoder(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr, batch, explainer=False, explainer_stage=False, gt_scene_graphs=None,
                 plan: Optional[ops.GraphPlan] = None):
-        if self.training:
-            raise NotImplementedError("forward-only path: call model.eval() (BatchNorm uses running statistics)")
+        # train(): the BatchNorm layers use batch statistics like the reference's (torch modules); the two HIP operators
+        # of this encoder (scatter_mean, fp64 GraphNorm) differentiate through autograd.py
         first = explainer and (explainer_stage == 0)
         x_embed_sum = x if first else torch.sum(self.sg_vocab_embedding(x), dim=-2)      # :63-70
         x_bbox = self.bbox_encoding(gt_scene_graphs.x_bbox.to(dtype=x_embed_sum.dtype))  # :72

@@ -342,7 +342,9 @@ def question_decoder_forward(sd, p: str, memory: Tensor, nhead: int = 8) -> Tens
 # ---------------------------------------------------------------------------
 # A4  SceneGraphEncoder.forward (models/scene_graph_encoder.py:53-143), eval mode
 # ---------------------------------------------------------------------------
-def _batchnorm_eval(sd, p: str, x: Tensor, eps: float = 1e-5) -> Tensor:
+def _batchnorm_eval(sd, p: str, x: Tensor, eps: float = 1e-5, training: bool = False) -> Tensor:
+    if training:      # train(): batch statistics (the running-stat update is a side effect, not modelled)
+        return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.0, eps)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
 
@@ -351,13 +353,15 @@ def scene_graph_encoder_forward(sd, p: str, x: Tensor, edge_index: Tensor, edge_
                                 batch: Tensor, x_bbox: Tensor, added_sym_edge: Tensor,
                                 cfg: PathConfig):
     emb = sd[p + ".sg_vocab_embedding.weight"]
-    x_embed_sum = emb[x].sum(dim=-2)                                               # :63-70
+    # nn.Embedding(..., padding_idx=<pad>) (scene_graph_encoder.py:19-21): same values, no gradient into the pad row
+    x_embed_sum = F.embedding(x, emb, padding_idx=1).sum(dim=-2)                   # :63-70
     xb = x_bbox.to(x_embed_sum.dtype)                                              # :72
-    xb = P.gelu(linear(sd, p + ".bbox_encoding.1", _batchnorm_eval(sd, p + ".bbox_encoding.0", xb)))
-    xb = P.gelu(linear(sd, p + ".bbox_encoding.4", _batchnorm_eval(sd, p + ".bbox_encoding.3", xb)))
+    tr = cfg.training
+    xb = P.gelu(linear(sd, p + ".bbox_encoding.1", _batchnorm_eval(sd, p + ".bbox_encoding.0", xb, training=tr)))
+    xb = P.gelu(linear(sd, p + ".bbox_encoding.4", _batchnorm_eval(sd, p + ".bbox_encoding.3", xb, training=tr)))
     xs = torch.cat((x_embed_sum, xb), dim=1)                                       # :73
-    xs = P.gelu(linear(sd, p + ".feat_reduc.1", _batchnorm_eval(sd, p + ".feat_reduc.0", xs)))   # :74
-    e = emb[edge_attr].clone()                                                     # :76
+    xs = P.gelu(linear(sd, p + ".feat_reduc.1", _batchnorm_eval(sd, p + ".feat_reduc.0", xs, training=tr)))   # :74
+    e = F.embedding(edge_attr, emb, padding_idx=1).clone()                         # :76
     e[added_sym_edge, :] = e[added_sym_edge, :] * -1                               # :80 (quirk Q6)
     row, col = edge_index[0], edge_index[1]
     lp = p + ".scene_graph_encoding_layer"

@@ -293,3 +293,63 @@ def test_simple_sampler_matches_reference(dev):
             torch.testing.assert_close(out.detach().cpu().view(-1), c["mask"].reshape(-1)[slot], rtol=0, atol=2e-6)
             (out * c["w"].reshape(-1)[slot].view(-1, 1).to(dev)).sum().backward()
             torch.testing.assert_close(sc.grad.cpu().view(-1), c["grad"].reshape(-1)[slot], rtol=2e-4, atol=5e-6)
+
+
+def test_full_model_training_step_matches_oracle(dev):
+    """The whole ISubGVQA model in train() mode (question encoder/decoder, scene-graph encoder with batch-statistics
+    BatchNorm and fp64 GraphNorm, MGAT with the I-MLE estimator, pooling, classifier): every parameter gradient against
+    oracle autograd.  All dropouts are set to 0 (their masks are RNG-private)."""
+    import argparse
+    from isubgvqa_amd import synthetic
+    from isubgvqa_amd.models import build_model
+    from oracle import model as OM
+    from test_gpu_models import _full_args
+    torch.manual_seed(0)
+    args = _full_args(sampler_type="imle", mgat_masks=[1.0, 0.15, 1.0, 0.15])
+    model = build_model(args, None).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+        if hasattr(m, "gate_dropout"):
+            m.gate_dropout = 0.0
+    gen = torch.Generator().manual_seed(29)
+    cfg = synthetic.WorkloadConfig(num_graphs=10, nodes_dist="uniform", nodes_min=2, nodes_max=16, edges_per_graph=0.0,
+                                   seed=97)
+    batch, ei, nmax = synthetic.make_topology(cfg, gen)
+    N, E, B, T = batch.numel(), ei.size(1), 10, 9
+    x = torch.randint(0, 2578, (N, 4), generator=gen)
+    edge_attr = torch.randint(0, 2578, (E,), generator=gen)
+    x_bbox = torch.randint(0, 640, (N, 4), generator=gen)
+    sym = torch.randint(0, 10, (12,), generator=gen)
+    q = torch.randint(0, 512, (B, T), generator=gen)
+    qmask = (torch.arange(T)[None] < torch.randint(5, T + 1, (B,), generator=gen)[:, None]).long()
+    w = torch.randn(B, 1842, generator=gen)
+    from oracle import samplers as OS
+    noises = {i: OS.uniform_to_gumbel(torch.rand(B, 1, nmax, 1, generator=gen), 0.0, 0.3) for i in (1, 3)}
+
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v.detach().clone())
+          for k, v in model.state_dict().items()}
+    ocfg = OM.PathConfig(heads=4, masking_thresholds=[1.0, 0.15, 1.0, 0.15], sampler_type="imle", sample_k=5,
+                         training=True, imle_beta=10.0)
+    rl, rm, _, _, _ = OM.isubgvqa_forward(sd, x, ei, edge_attr, batch, q, qmask, x_bbox, sym, ocfg, noises)
+    (rl * w).sum().backward()
+
+    model = model.to(dev)
+    sgd = argparse.Namespace(x_bbox=x_bbox.to(dev), added_sym_edge=sym.to(dev))
+    gl, gm, _, _, _ = model(x.to(dev), ei.to(dev), edge_attr.to(dev), batch.to(dev), q.to(dev), qmask.to(dev),
+                            return_masks=True, scene_graphs=sgd, noises={i: n.to(dev) for i, n in noises.items()})
+    assert torch.equal(gm.detach().cpu() > 0.5, rm.detach() > 0.5)
+    close(gl, rl, 1e-4, "logits")
+    (gl * w.to(dev)).sum().backward()
+    checked = 0
+    for k, v in model.named_parameters():
+        ref = sd[k].grad
+        # (a bias in front of a GraphNorm has an analytically ~zero gradient: pure cancellation noise, 1e-7)
+        if ref is None or float(ref.abs().max()) < 1e-5:
+            continue
+        assert v.grad is not None, k
+        close(v.grad, ref.reshape(v.grad.shape), 2e-3, k)
+        checked += 1
+    assert checked > 100
