@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 4
+#define ISG_ABI_VERSION 5
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -240,6 +240,32 @@ int isg_gatv2_mp_bwd(const float *x_l, const float *x_r, const float *e_proj, co
 int isg_topk_gumbel_bwd(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
                         const int32_t *nmax_dev, const float *noise, uint64_t seed, int32_t k, float tau,
                         const float *d_out, float *d_scores, void *stream);
+
+/* Backward of isg_instr_attn_graphnorm_residual (autograd over mgat.py:168-177 in the reference).  grad_out fp32[N,C].
+ * d_ins fp32[B,C], d_c / d_h fp32[N,C], d_mask fp32[N] or NULL; partial fp32[B,3,C]: per-graph rows of
+ * (d weight, d bias, d mean_scale), summed over B by the caller (fixed order, no atomics). */
+int isg_instr_attn_graphnorm_residual_bwd(const float *ins, const float *c, const float *h, const int32_t *ptr,
+                                          const float *weight, const float *bias, const float *mean_scale, double eps,
+                                          const float *node_mask, const float *grad_out, float *d_ins, float *d_c,
+                                          float *d_h, float *d_mask, float *partial, int64_t B, int32_t C, void *stream);
+
+/* Backward of isg_global_attn_pool (att_pooling.py:63-73).  grad_out fp32[B,C]; grad_gate fp32[N] or NULL;
+ * d_xn fp32[N,C], d_q fp32[B,C], d_mask fp32[N] or NULL. */
+int isg_global_attn_pool_bwd(const float *xn, const float *q, const int32_t *ptr, const float *node_mask,
+                             const float *grad_out, const float *grad_gate, float *d_xn, float *d_q, float *d_mask,
+                             int64_t B, int32_t C, void *stream);
+
+/* Backward of isg_instr_gate (mgat_v2_conv.py:156-157) for a sorted batch: ptr int32[B+1] from isg_graph_ptr.
+ * d_x fp32[N,C], d_instr fp32[B,C]. */
+int isg_instr_gate_bwd(const float *x, const float *instr, const int32_t *ptr, const float *grad_out, float *d_x,
+                       float *d_instr, int64_t B, int32_t C, void *stream);
+
+/* Backward of isg_node_gate (masking.py:151-155).  grad_gate fp32[N]; d_xn fp32[N,C]; d_q_partial fp32[B,C]: row g is
+ * the contribution of graph g's nodes to d q[r(g)], r(g) = batch[g] with double_index (quirk Q3) else g; the caller
+ * scatters the rows (several graphs may share one row of q). */
+int isg_node_gate_bwd(const float *xn, const float *q, const int64_t *batch, int32_t double_index, const int32_t *ptr,
+                      const float *grad_gate, float *d_xn, float *d_q_partial, int64_t N, int64_t B, int32_t C,
+                      void *stream);
 
 /* NodeMaskToEdgeMask.backward, ISubGVQA/sampling/node_edge_masks.py:13-19: d_node_mask[i] = sum over edges INTO i of
  * d_edge_mask[e] (the reference's rule: destination only, no product rule).  CSR by destination. */

@@ -11,9 +11,11 @@ off, so the same `ops.*` call runs the plain forward kernel.  Three kinds of bac
                                                       adaptive beta, target_aimle.py:88-162 -- state kept ON THE DEVICE)
   * Linear: forward and dX on the bf16x6 matrix-core kernel, dW (a reduction over the rows) as an fp32 GEMM through
     torch (hipBLASLt);
-  * the light per-node ops (instruction gate, node gate, layer tail, pooling, GraphNorm, scatter ops): the forward is the
-    fused kernel, the backward re-evaluates a torch-op restatement ON THE DEVICE under autograd (`_Recomputed`).  These
-    are plain autograd in the reference too.
+  * the per-graph operators around the message passing -- layer tail (instruction attention + GraphNorm + residual),
+    pooling, instruction gate, node gate: per-graph HIP backward kernels (csrc/isg_tail_bwd.hip);
+  * what only the scene-graph encoder / stand-alone utilities use (GraphNorm alone, scatter attention alone,
+    scatter_mean, the SIMPLE marginals): forward = fused kernel, backward re-evaluates a torch-op restatement ON THE
+    DEVICE under autograd (`_Recomputed`).  These are plain autograd in the reference too.
 
 Nothing here runs on the CPU and nothing imports `oracle/`.
 """
@@ -71,7 +73,23 @@ def _instr_gate_t(x, instr, batch):
     return F.gelu(x * instr[batch])
 
 
-def instr_gate(x, instr, batch):
+class _InstrGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, instr, batch, plan):
+        ctx.save_for_backward(x, instr)
+        ctx.plan = plan
+        return ops.instr_gate(x, instr, batch)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, instr = ctx.saved_tensors
+        d_x, d_instr = ops.instr_gate_backward(x, instr, ctx.plan, g.contiguous())
+        return d_x, d_instr, None, None
+
+
+def instr_gate(x, instr, batch, plan=None):
+    if plan is not None and instr.size(0) == plan.B:
+        return _InstrGate.apply(x, instr, batch, plan)
     return _Recomputed.apply(ops.instr_gate, _instr_gate_t, (batch,), x, instr)
 
 
@@ -80,7 +98,24 @@ def _node_gate_t(xn, q, batch, double_index):
     return F.gelu((xn * q[idx]).sum(-1, keepdim=True) / math.sqrt(xn.size(1)))
 
 
-def node_gate(xn, q, batch, double_index):
+class _NodeGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xn, q, batch, double_index, plan):
+        ctx.save_for_backward(xn, q, batch)
+        ctx.cfg = (double_index, plan)
+        return ops.node_gate(xn, q, batch, double_index)
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, q, batch = ctx.saved_tensors
+        double_index, plan = ctx.cfg
+        d_xn, d_q = ops.node_gate_backward(xn, q, batch, double_index, plan, g.contiguous())
+        return d_xn, d_q, None, None, None
+
+
+def node_gate(xn, q, batch, double_index, plan=None):
+    if plan is not None:
+        return _NodeGate.apply(xn, q, batch, double_index, plan)
     return _Recomputed.apply(ops.node_gate, _node_gate_t, (batch, double_index), xn, q)
 
 
@@ -105,10 +140,25 @@ def _layer_tail_f(ins, c, h, weight, bias, mean_scale, node_mask, plan, eps):
     return ops.mgat_layer_tail(ins, c, h, plan, weight, bias, mean_scale, eps, node_mask=node_mask)
 
 
+class _LayerTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ins, c, h, weight, bias, mean_scale, node_mask, plan, eps):
+        ctx.save_for_backward(ins, c, h, weight, bias, mean_scale, node_mask)
+        ctx.cfg = (plan, eps)
+        return ops.mgat_layer_tail(ins, c, h, plan, weight, bias, mean_scale, eps, node_mask=node_mask)
+
+    @staticmethod
+    def backward(ctx, g):
+        ins, c, h, weight, bias, mean_scale, node_mask = ctx.saved_tensors
+        plan, eps = ctx.cfg
+        want_mask = node_mask is not None and ctx.needs_input_grad[6]
+        d_ins, d_c, d_h, d_w, d_b, d_ms, d_m = ops.layer_tail_backward(
+            ins, c, h, plan, weight, bias, mean_scale, eps, node_mask, g.contiguous(), want_mask)
+        return d_ins, d_c, d_h, d_w, d_b, d_ms, (d_m.view_as(node_mask) if want_mask else None), None, None
+
+
 def mgat_layer_tail(ins, c, h, plan, weight, bias, mean_scale, eps, node_mask):
-    batch, B = plan.batch, plan.B
-    return _Recomputed.apply(_layer_tail_f, lambda *a: _layer_tail_t(*a[:7], batch, B, eps), (plan, eps),
-                             ins, c, h, weight, bias, mean_scale, node_mask)
+    return _LayerTail.apply(ins, c, h, weight, bias, mean_scale, node_mask, plan, eps)
 
 
 def _pool_t(xn, q, node_mask, batch, B):
@@ -121,9 +171,27 @@ def _pool_f(xn, q, node_mask, plan):
     return ops.global_attn_pool(xn, q, plan, node_mask)
 
 
+class _Pool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xn, q, node_mask, plan):
+        ctx.save_for_backward(xn, q, node_mask)
+        ctx.plan = plan
+        ctx.set_materialize_grads(False)          # the gate output is usually unused: its gradient arrives as None
+        return ops.global_attn_pool(xn, q, plan, node_mask)
+
+    @staticmethod
+    def backward(ctx, g_out, g_gate):
+        xn, q, node_mask = ctx.saved_tensors
+        if g_out is None:
+            g_out = torch.zeros(ctx.plan.B, xn.size(1), dtype=xn.dtype, device=xn.device)
+        want_mask = node_mask is not None and ctx.needs_input_grad[2]
+        d_xn, d_q, d_m = ops.global_attn_pool_backward(xn, q, ctx.plan, node_mask, g_out.contiguous(),
+                                                       None if g_gate is None else g_gate.contiguous(), want_mask)
+        return d_xn, d_q, (d_m.view_as(node_mask) if want_mask else None), None
+
+
 def global_attn_pool(xn, q, plan, node_mask):
-    batch, B = plan.batch, plan.B
-    return _Recomputed.apply(_pool_f, lambda a, b, c, _p: _pool_t(a, b, c, batch, B), (plan,), xn, q, node_mask)
+    return _Pool.apply(xn, q, node_mask, plan)
 
 
 def graph_norm(x, plan, weight, bias, mean_scale, eps, fp64):

@@ -62,13 +62,14 @@ class MaskingModel(torch.nn.Module):
                 if hasattr(m, "reset_parameters"):
                     m.reset_parameters()
 
-    def gate_scores(self, x: Tensor, u: Tensor, batch: Tensor, u_is_per_graph: bool = False) -> Tensor:
+    def gate_scores(self, x: Tensor, u: Tensor, batch: Tensor, u_is_per_graph: bool = False, plan=None) -> Tensor:
         """masking.py:137,151-155 -> [N,1].  ``u_is_per_graph``: u is [B,C] and the caller would have passed
         u[batch]; the reference then indexes ques_nn(u[batch]) with batch AGAIN (quirk Q3), which equals
         ques_nn(u)[batch[batch]] row for row -- computed here without the N-row GEMM."""
         xn = ops.mlp(self.node_nn, x)
         q = ops.mlp(self.ques_nn, u)
-        return ops.node_gate(xn.contiguous(), q.contiguous(), batch, double_index=u_is_per_graph)
+        return ops.node_gate(xn.contiguous(), q.contiguous(), batch, double_index=u_is_per_graph,
+                             plan=plan)
 
     def forward(self, x, u, batch, edge_index, size=None, use_all_instrs=True, plan: Optional[ops.GraphPlan] = None,
                 noise: Optional[Tensor] = None, seed: Optional[int] = None, u_is_per_graph: bool = False):
@@ -77,7 +78,7 @@ class MaskingModel(torch.nn.Module):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         if plan is None:
             plan = ops.GraphPlan.build(batch, None, num_graphs=size)
-        gate = self.gate_scores(x, u, batch, u_is_per_graph)
+        gate = self.gate_scores(x, u, batch, u_is_per_graph, plan)
         if not self.use_topk:                                               # masking.py:195-198
             gate = F.dropout(gate, p=self.gate_dropout, training=self.training)
             return (torch.sigmoid(gate) > 0.5).to(dtype=gate.dtype)

@@ -91,7 +91,7 @@ class MaskingGATv2Conv(torch.nn.Module):
                                        num_graphs=None if instruction is None else instruction.size(0))
         x = x.float().contiguous()
         if self.use_instr:
-            x = ops.instr_gate(x, instruction.contiguous(), batch)                       # :156-157
+            x = ops.instr_gate(x, instruction.contiguous(), batch, plan=plan)            # :156-157
 
         mask = None
         if self.mask.masking_threshold != 1.0:                                           # :161

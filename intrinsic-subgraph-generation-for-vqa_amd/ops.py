@@ -212,11 +212,11 @@ class GraphPlan:
 # ------------------------------------------------------------------------------------------------
 # Message passing
 # ------------------------------------------------------------------------------------------------
-def instr_gate(x: Tensor, instr: Tensor, batch: Tensor) -> Tensor:
-    """gelu(x * instr[batch])   (mgat_v2_conv.py:156-157)"""
+def instr_gate(x: Tensor, instr: Tensor, batch: Tensor, plan: Optional["GraphPlan"] = None) -> Tensor:
+    """gelu(x * instr[batch])   (mgat_v2_conv.py:156-157).  ``plan`` selects the HIP backward (else torch recompute)."""
     if _rec(x, instr):
         from . import autograd
-        return autograd.instr_gate(x, instr, batch)
+        return autograd.instr_gate(x, instr, batch, plan)
     lib = _lib.load()
     N, C = x.shape
     out = torch.empty_like(x)
@@ -343,6 +343,71 @@ def node_to_edge_mask_backward(d_edge_mask: Tensor, plan: GraphPlan) -> Tensor:
     return out
 
 
+def layer_tail_backward(ins, c, h, plan: GraphPlan, weight, bias, mean_scale, eps, node_mask, grad_out, want_mask: bool):
+    """(d_ins, d_c, d_h, d_weight, d_bias, d_mean_scale, d_mask|None) of mgat_layer_tail."""
+    lib = _lib.load()
+    N, C = c.shape
+    dev = c.device
+    d_ins = torch.empty(plan.B, C, dtype=torch.float32, device=dev)
+    d_c, d_h = torch.empty(N, C, dtype=torch.float32, device=dev), torch.empty(N, C, dtype=torch.float32, device=dev)
+    d_mask = torch.empty(N, dtype=torch.float32, device=dev) if want_mask else None
+    part = torch.empty(plan.B, 3, C, dtype=torch.float32, device=dev)
+    _lib.check(lib.isg_instr_attn_graphnorm_residual_bwd(
+        _chk(ins, "ins", torch.float32, (plan.B, C)), _chk(c, "c", torch.float32, (plan.N, C)),
+        _chk(h, "h", torch.float32, (plan.N, C)), plan.ptr.data_ptr(), _chk(weight, "weight", torch.float32, (C,)),
+        _chk(bias, "bias", torch.float32, (C,)), _chk(mean_scale, "mean_scale", torch.float32, (C,)), float(eps),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        _chk(grad_out, "grad_out", torch.float32, (N, C)), d_ins.data_ptr(), d_c.data_ptr(), d_h.data_ptr(),
+        0 if d_mask is None else d_mask.data_ptr(), part.data_ptr(), plan.B, C, _stream()),
+        "isg_instr_attn_graphnorm_residual_bwd")
+    sums = part.sum(0)
+    return d_ins, d_c, d_h, sums[0], sums[1], sums[2], d_mask
+
+
+def global_attn_pool_backward(xn, q, plan: GraphPlan, node_mask, grad_out, grad_gate, want_mask: bool):
+    """(d_xn, d_q, d_mask|None) of global_attn_pool."""
+    lib = _lib.load()
+    N, C = xn.shape
+    d_xn = torch.empty(N, C, dtype=torch.float32, device=xn.device)
+    d_q = torch.empty(plan.B, C, dtype=torch.float32, device=xn.device)
+    d_mask = torch.empty(N, dtype=torch.float32, device=xn.device) if want_mask else None
+    _lib.check(lib.isg_global_attn_pool_bwd(
+        _chk(xn, "xn", torch.float32, (plan.N, C)), _chk(q, "q", torch.float32, (plan.B, C)), plan.ptr.data_ptr(),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        _chk(grad_out, "grad_out", torch.float32, (plan.B, C)),
+        _chk(None if grad_gate is None else grad_gate.reshape(-1), "grad_gate", torch.float32, (N,), optional=True),
+        d_xn.data_ptr(), d_q.data_ptr(), 0 if d_mask is None else d_mask.data_ptr(), plan.B, C, _stream()),
+        "isg_global_attn_pool_bwd")
+    return d_xn, d_q, d_mask
+
+
+def instr_gate_backward(x, instr, plan: GraphPlan, grad_out):
+    lib = _lib.load()
+    N, C = x.shape
+    d_x = torch.empty_like(x)
+    d_instr = torch.empty(plan.B, C, dtype=torch.float32, device=x.device)
+    _lib.check(lib.isg_instr_gate_bwd(_chk(x, "x", torch.float32, (plan.N, C)),
+                                      _chk(instr, "instr", torch.float32, (plan.B, C)), plan.ptr.data_ptr(),
+                                      _chk(grad_out, "grad_out", torch.float32, (N, C)), d_x.data_ptr(),
+                                      d_instr.data_ptr(), plan.B, C, _stream()), "isg_instr_gate_bwd")
+    return d_x, d_instr
+
+
+def node_gate_backward(xn, q, batch, double_index: bool, plan: GraphPlan, grad_gate):
+    """(d_xn, d_q): the per-graph partial rows are scattered into d_q here (several graphs may share a row of q)."""
+    lib = _lib.load()
+    N, C = xn.shape
+    d_xn = torch.empty_like(xn)
+    part = torch.empty(plan.B, C, dtype=torch.float32, device=xn.device)
+    _lib.check(lib.isg_node_gate_bwd(_chk(xn, "xn", torch.float32, (plan.N, C)), _chk(q, "q", torch.float32, (q.size(0), C)),
+                                     _chk(batch, "batch", torch.int64, (N,)), 1 if double_index else 0,
+                                     plan.ptr.data_ptr(), _chk(grad_gate.reshape(-1), "grad_gate", torch.float32, (N,)),
+                                     d_xn.data_ptr(), part.data_ptr(), N, plan.B, C, _stream()), "isg_node_gate_bwd")
+    g = torch.arange(plan.B, device=xn.device)
+    rows = batch[g.clamp(max=max(N - 1, 0))] if double_index else g
+    return d_xn, torch.zeros_like(q).index_add_(0, rows, part)
+
+
 def mp_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool, feat_bytes: int = 4) -> int:
     """bytes_mp = s*(3*N*HC + E*HC) + 4*E*H + 16*E (+4*E if edge-masked)."""
     HC = H * C
@@ -368,11 +433,11 @@ def scatter_mean(msg: Tensor, plan: GraphPlan) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # Node gate + samplers
 # ------------------------------------------------------------------------------------------------
-def node_gate(xn: Tensor, q: Tensor, batch: Tensor, double_index: bool) -> Tensor:
-    """gelu(<xn_n, q[r(n)]>/sqrt(C)) -> [N,1]   (masking.py:151-155)"""
+def node_gate(xn: Tensor, q: Tensor, batch: Tensor, double_index: bool, plan: Optional["GraphPlan"] = None) -> Tensor:
+    """gelu(<xn_n, q[r(n)]>/sqrt(C)) -> [N,1]   (masking.py:151-155).  ``plan`` selects the HIP backward."""
     if _rec(xn, q):
         from . import autograd
-        return autograd.node_gate(xn, q, batch, double_index)
+        return autograd.node_gate(xn, q, batch, double_index, plan)
     lib = _lib.load()
     N, C = xn.shape
     gate = torch.empty(N, 1, dtype=torch.float32, device=xn.device)

@@ -353,3 +353,55 @@ def test_full_model_training_step_matches_oracle(dev):
         close(v.grad, ref.reshape(v.grad.shape), 2e-3, k)
         checked += 1
     assert checked > 100
+
+
+# ---- per-graph backward kernels against torch autograd of the same function on the device ---------------------------
+@pytest.mark.parametrize("C", [8, 64, 128, 300])
+@pytest.mark.parametrize("masked", [False, True])
+def test_tail_pool_and_gate_backward_kernels(dev, C, masked):
+    from isubgvqa_amd import autograd as AG
+    from isubgvqa_amd import ops
+    sizes = [5, 1, 70, 17, 3, 0, 9]          # incl. an empty graph and one longer than a wave
+    B = len(sizes)
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes)).to(dev)
+    N = batch.numel()
+    plan = ops.GraphPlan.build(batch, None, num_graphs=B)
+    gen = torch.Generator().manual_seed(C + int(masked))
+    mk = lambda *s: torch.randn(*s, generator=gen).to(dev).requires_grad_(True)
+    mask = (torch.rand(N, 1, generator=gen) > 0.3).float().to(dev).requires_grad_(True) if masked else None
+
+    def compare(run_hip, run_ref, tensors, what):
+        outs = run_hip()
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        ws = [torch.randn(o.shape, generator=gen).to(dev) for o in outs]
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        got = [t.grad.clone() for t in tensors]
+        for t in tensors:
+            t.grad = None
+        refs = run_ref()
+        refs = refs if isinstance(refs, tuple) else (refs,)
+        for o, r in zip(outs, refs):
+            close(o, r, 2e-5, what + " forward")
+        sum((o * w).sum() for o, w in zip(refs, ws)).backward()
+        for i, (t, gt) in enumerate(zip(tensors, got)):
+            close(gt, t.grad, 3e-4, f"{what} grad #{i}")
+            t.grad = None
+
+    # layer tail
+    ins, c, h = mk(B, C), mk(N, C), mk(N, C)
+    w, b, ms = mk(C), mk(C), mk(C)
+    ts = [ins, c, h, w, b, ms] + ([mask] if masked else [])
+    compare(lambda: ops.mgat_layer_tail(ins, c, h, plan, w, b, ms, 1e-5, node_mask=mask),
+            lambda: AG._layer_tail_t(ins, c, h, w, b, ms, mask, batch, B, 1e-5), ts, "tail")
+    # pooling (both outputs carry gradient)
+    xn, q = mk(N, C), mk(B, C)
+    ts = [xn, q] + ([mask] if masked else [])
+    compare(lambda: ops.global_attn_pool(xn, q, plan, mask), lambda: AG._pool_t(xn, q, mask, batch, B), ts, "pool")
+    # instruction gate
+    x, instr = mk(N, C), mk(B, C)
+    compare(lambda: ops.instr_gate(x, instr, batch, plan=plan), lambda: AG._instr_gate_t(x, instr, batch), [x, instr], "instr gate")
+    # node gate, with the double index (several graphs share a row of q) and without
+    xg, qg = mk(N, C), mk(B, C)
+    for dbl in (True, False):
+        compare(lambda: ops.node_gate(xg, qg, batch, dbl, plan=plan), lambda: AG._node_gate_t(xg, qg, batch, dbl),
+                [xg, qg], f"node gate dbl={dbl}")
