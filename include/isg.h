@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 5
+#define ISG_ABI_VERSION 6
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -266,6 +266,14 @@ int isg_instr_gate_bwd(const float *x, const float *instr, const int32_t *ptr, c
 int isg_node_gate_bwd(const float *xn, const float *q, const int64_t *batch, int32_t double_index, const int32_t *ptr,
                       const float *grad_gate, float *d_xn, float *d_q_partial, int64_t N, int64_t B, int32_t C,
                       void *stream);
+
+/* Weight gradient of a linear layer, dW[N,K] = grad_out^T x (grad_out fp32[M,N] row stride ldg, x fp32[M,K] row stride
+ * ldx): a split-M GEMM on the fp32 matrix-core instruction.  partial fp32[splits,N,K] receives one partial result per
+ * split (every element is written); dW is their sum over the first axis, left to the caller (fixed order).
+ * isg_linear_wgrad_splits returns the recommended number of splits for a shape. */
+int64_t isg_linear_wgrad_splits(int64_t M, int32_t N, int32_t K);
+int isg_linear_wgrad(const float *grad_out, const float *x, float *partial, int64_t M, int32_t N, int32_t K,
+                     int32_t ldg, int32_t ldx, int64_t splits, void *stream);
 
 /* NodeMaskToEdgeMask.backward, ISubGVQA/sampling/node_edge_masks.py:13-19: d_node_mask[i] = sum over edges INTO i of
  * d_edge_mask[e] (the reference's rule: destination only, no product rule).  CSR by destination. */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -49,6 +49,9 @@ SIGNATURES = {
     "isg_instr_gate_bwd": (c_int, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
     "isg_node_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int64, c_int32, c_void_p]),
+    "isg_linear_wgrad_splits": (c_int64, [c_int64, c_int32, c_int32]),
+    "isg_linear_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int64,
+                                 c_void_p]),
     "isg_topk_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_int32,
                                     c_float, c_void_p, c_void_p, c_void_p]),
     "isg_gatv2_mp_bwd": (c_int, [c_void_p] * 19 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p]),

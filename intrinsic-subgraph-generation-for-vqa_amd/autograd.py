@@ -9,8 +9,8 @@ off, so the same `ops.*` call runs the plain forward kernel.  Three kinds of bac
       GumbelTopK         isg_topk_gumbel_bwd         (straight-through, gumbel_scheme.py:83-90)
       ImleTopK/AimleTopK isg_topk_threshold again    (second MAP solve, wrapper.py:124-172; aimle.py:141-243;
                                                       adaptive beta, target_aimle.py:88-162 -- state kept ON THE DEVICE)
-  * Linear: forward and dX on the bf16x6 matrix-core kernel, dW (a reduction over the rows) as an fp32 GEMM through
-    torch (hipBLASLt);
+  * Linear: forward and dX on the bf16x6 matrix-core kernel, dW (a reduction over the rows) as a split-M GEMM on the
+    fp32 matrix-core instruction (csrc/isg_wgrad.hip);
   * the per-graph operators around the message passing -- layer tail (instruction attention + GraphNorm + residual),
     pooling, instruction gate, node gate: per-graph HIP backward kernels (csrc/isg_tail_bwd.hip);
   * what only the scene-graph encoder / stand-alone utilities use (GraphNorm alone, scatter attention alone,
@@ -244,7 +244,9 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:     # dX = g W: the same matrix-core kernel on the transposed weight
             dx = (ops.linear(g, weight.detach().t().contiguous(), None, cache_planes=False)
                   if (g.size(1) & 3) == 0 else g @ weight)
-        dw = g.t() @ x if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:   # long-and-thin reductions on the split-M kernel; short ones are hipBLASLt's home turf
+            dw = ops.linear_wgrad(g, x.contiguous()) if g.size(0) >= 16384 else g.t() @ x
         db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 

@@ -681,6 +681,20 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     return out
 
 
+def linear_wgrad(grad_out: Tensor, x: Tensor) -> Tensor:
+    """dW[N,K] = grad_out^T x for y = x W^T: split-M GEMM on the fp32 matrix cores (csrc/isg_wgrad.hip)."""
+    lib = _lib.load()
+    M, N = grad_out.shape
+    K = x.size(1)
+    if M == 0:
+        return torch.zeros(N, K, dtype=torch.float32, device=x.device)
+    splits = int(lib.isg_linear_wgrad_splits(M, N, K))
+    part = torch.empty(splits, N, K, dtype=torch.float32, device=x.device)
+    _lib.check(lib.isg_linear_wgrad(_chk(grad_out, "grad_out", torch.float32, (M, N)), _chk(x, "x", torch.float32, (M, K)),
+                                    part.data_ptr(), M, N, K, N, K, splits, _stream()), "isg_linear_wgrad")
+    return part.sum(0) if splits > 1 else part[0]
+
+
 def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:   # x may be fp16 feature rows; the output is fp32
     """Run an nn.Sequential of Linear / GELU / Dropout(eval) modules with every Linear(+GELU) pair as one launch."""
     mods = list(seq)

@@ -449,3 +449,19 @@ def test_linear_bf16x6_fp16_io(dev, a16, d16, M, N, K, gelu):
         assert ((got.cpu().float() - r).abs() <= ulp).all()
     else:
         assert (got.cpu().double() - ref).abs().max() < 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (777, 130, 20), (5, 16, 8), (82286, 512, 128), (4096, 1842, 512),
+                                   (33, 300, 900)])
+def test_linear_wgrad_matches_fp64(dev, M, N, K):
+    """dW = g^T x on the fp32 matrix cores, split over the rows: exact products, fp32 accumulation."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    g, x = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+    ref = g.double().t() @ x.double()
+    got = ops.linear_wgrad(g.to(dev), x.to(dev))
+    assert got.shape == (N, K)
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err < 3e-6 * (M ** 0.5) * 4 + 1e-5, err
+    again = ops.linear_wgrad(g.to(dev), x.to(dev))
+    assert torch.equal(got, again), "split-M reduction must be bitwise reproducible"
