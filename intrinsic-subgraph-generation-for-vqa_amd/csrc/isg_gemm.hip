@@ -77,7 +77,7 @@ __device__ __forceinline__ float4 gm_cvt(const gm_u32x2 &v) {
   return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
 }
 
-template <int ACT, int DBG, bool A16, bool D16>   // ACT: 0 none, 1 exact GELU
+template <int ACT, int DBG, bool A16, bool D16, bool XCD>   // ACT: 0 none, 1 exact GELU; XCD: tile order, see below
 __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__restrict__ A, const __bf16 *__restrict__ Wp,
                                                             const float *__restrict__ bias, float *__restrict__ D, int M,
                                                             int N, int K, int Kp, int lda, int ldd) {
@@ -89,7 +89,21 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
-  const int n0 = blockIdx.x * GM_BN, m0 = blockIdx.y * GM_BM;
+  // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  The n-tiles
+  // of one row-block read the same A rows, so they are made consecutive WITHIN an XCD (ids congruent mod 8): the A tile
+  // is fetched into one L2 once instead of into up to min(8, n-tiles) of them.  gridDim.y is padded to a multiple of 8.
+  int n0, m0;
+  if (XCD) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, nt = gridDim.x;
+    const int slot = L >> 3;
+    const int mt = (L & 7) + 8 * (slot / nt);
+    n0 = (slot % nt) * GM_BN;
+    m0 = mt * GM_BM;
+    if (m0 >= M) return;
+  } else {
+    n0 = blockIdx.x * GM_BN;
+    m0 = blockIdx.y * GM_BM;
+  }
   const int64_t plane_stride = (int64_t)N * Kp;
 
   f32x16 acc[1][2];
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
   // Row-blocks walk K from different starting tiles (wrapping): with a power-of-two row stride every workgroup would
   // otherwise touch the same 128-byte column of its rows at the same moment, i.e. the same few HBM channels
   // ("partition camping").  Only the order of the fp32 accumulation changes, deterministically per row-block.
-  const int kshift = (int)(blockIdx.y % (unsigned)nk);
+  const int kshift = (int)((unsigned)(m0 / GM_BM) % (unsigned)nk);
 #define GM_KT(t) ((((t) + kshift) >= nk ? (t) + kshift - nk : (t) + kshift))
 #define GM_STEP(RA, RB, kt)                                                                                    \
   {                                                                                                            \
@@ -286,11 +300,17 @@ static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const
 #ifdef ISG_GEMM_ABLATION   // profiling build only (tools/build_ablation.sh): select a compile-time ablated variant by env
   const char *dv = getenv("ISG_GEMM_DBG");
   const int dbg = dv ? atoi(dv) : 0;
-#define ISG_DBG_CASE(v) if (dbg == v) { linear_bf16x6_kernel<0, v, false, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd); return check_launch(); }
+#define ISG_DBG_CASE(v) if (dbg == v) { linear_bf16x6_kernel<0, v, false, false, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd); return check_launch(); }
   ISG_DBG_CASE(1) ISG_DBG_CASE(3) ISG_DBG_CASE(7) ISG_DBG_CASE(15) ISG_DBG_CASE(16) ISG_DBG_CASE(31) ISG_DBG_CASE(8) ISG_DBG_CASE(4)
 #undef ISG_DBG_CASE
 #endif
-#define ISG_LIN(ACT_, A_, D_) linear_bf16x6_kernel<ACT_, 0, A_, D_><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd)
+  const bool xcd = grid.x > 1 && getenv("ISG_GEMM_NO_XCD") == nullptr;
+  dim3 gridx(grid.x, (grid.y + 7) / 8 * 8);
+#define ISG_LIN(ACT_, A_, D_)                                                                                                \
+  do {                                                                                                                       \
+    if (xcd) linear_bf16x6_kernel<ACT_, 0, A_, D_, true><<<gridx, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd); \
+    else linear_bf16x6_kernel<ACT_, 0, A_, D_, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd); \
+  } while (0)
   if (!a16 && !d16) { if (act == 1) ISG_LIN(1, false, false); else ISG_LIN(0, false, false); }
   else if (a16 && !d16) { if (act == 1) ISG_LIN(1, true, false); else ISG_LIN(0, true, false); }
   else if (!a16 && d16) { if (act == 1) ISG_LIN(1, false, true); else ISG_LIN(0, false, true); }
