@@ -80,7 +80,7 @@ __device__ __forceinline__ float4 gm_cvt(const gm_u32x2 &v) {
 template <int ACT, int DBG, bool A16, bool D16, bool XCD>   // ACT: 0 none, 1 exact GELU; XCD: tile order, see below
 __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__restrict__ A, const __bf16 *__restrict__ Wp,
                                                             const float *__restrict__ bias, float *__restrict__ D, int M,
-                                                            int N, int K, int Kp, int lda, int ldd) {
+                                                            int N, int K, int Kp, int lda, int ldd, int nt_store) {
   typedef typename GmRawA<A16>::type RawA;
   const void *Av = A;   // fp16 variants: the same pointers, half elements
   void *Dv = D;
@@ -254,7 +254,13 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
       } else if ((DBG & 16) ? (row < 0) : (row < M)) {
         float *dst = D + (int64_t)row * ldd + colb + c4 * 4;
         if (vec_ok) {
-          *reinterpret_cast<float4 *>(dst) = v;
+          if (nt_store) {   // streaming result (see isg_linear launch): do not displace the operands in L2 / Infinity Cache
+            typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+            nt_f32x4 w4 = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w4, reinterpret_cast<nt_f32x4 *>(dst));
+          } else {
+            *reinterpret_cast<float4 *>(dst) = v;
+          }
         } else {
           if (colb + c4 * 4 + 0 < N) dst[0] = v.x;
           if (colb + c4 * 4 + 1 < N) dst[1] = v.y;
@@ -297,19 +303,25 @@ static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const
   dim3 grid((unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)mt), block(512);
   const __bf16 *wp = reinterpret_cast<const __bf16 *>(w_planes);
   hipStream_t st = as_stream(stream);
+  // results of at least ISG_GEMM_NT_MB MB (default 0: all) are written with non-temporal stores: the projected rows are
+  // consumed by a LATER kernel and are larger than the caches, while the operands (A re-read per n-tile, W planes)
+  // should stay resident (end-to-end A/B on configs[1]: +4 %)
+  const char *ntv = getenv("ISG_GEMM_NT_MB");
+  const long long nt_mb = ntv ? atoll(ntv) : 0;
+  const int nt = nt_mb >= 0 && (long long)M * N * (d16 ? 2 : 4) >= nt_mb * 1000000ll;
+  dim3 gridx(grid.x, (grid.y + 7) / 8 * 8);
 #ifdef ISG_GEMM_ABLATION   // profiling build only (tools/build_ablation.sh): select a compile-time ablated variant by env
   const char *dv = getenv("ISG_GEMM_DBG");
   const int dbg = dv ? atoi(dv) : 0;
-#define ISG_DBG_CASE(v) if (dbg == v) { linear_bf16x6_kernel<0, v, false, false, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd); return check_launch(); }
+#define ISG_DBG_CASE(v) if (dbg == v) { linear_bf16x6_kernel<0, v, false, false, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); return check_launch(); }
   ISG_DBG_CASE(1) ISG_DBG_CASE(3) ISG_DBG_CASE(7) ISG_DBG_CASE(15) ISG_DBG_CASE(16) ISG_DBG_CASE(31) ISG_DBG_CASE(8) ISG_DBG_CASE(4)
 #undef ISG_DBG_CASE
 #endif
   const bool xcd = grid.x > 1 && getenv("ISG_GEMM_NO_XCD") == nullptr;
-  dim3 gridx(grid.x, (grid.y + 7) / 8 * 8);
 #define ISG_LIN(ACT_, A_, D_)                                                                                                \
   do {                                                                                                                       \
-    if (xcd) linear_bf16x6_kernel<ACT_, 0, A_, D_, true><<<gridx, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd); \
-    else linear_bf16x6_kernel<ACT_, 0, A_, D_, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd); \
+    if (xcd) linear_bf16x6_kernel<ACT_, 0, A_, D_, true><<<gridx, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
+    else linear_bf16x6_kernel<ACT_, 0, A_, D_, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
   } while (0)
   if (!a16 && !d16) { if (act == 1) ISG_LIN(1, false, false); else ISG_LIN(0, false, false); }
   else if (a16 && !d16) { if (act == 1) ISG_LIN(1, true, false); else ISG_LIN(0, true, false); }
