@@ -17,7 +17,7 @@
 
 #include <stdlib.h>
 
-#define ISG_MP_DEFAULT_FLAGS 1
+#define ISG_MP_DEFAULT_FLAGS (1 | 4)   // measured inside the layer pipeline (profiles/r01_c, r01_r), not on cold caches
 
 namespace isg {
 

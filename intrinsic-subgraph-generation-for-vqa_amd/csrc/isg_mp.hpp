@@ -25,7 +25,9 @@ struct MpArgs {
   const int *graph_ptr, *graph_eptr, *dst;   // per-graph kernel only
   int B, lrows;           // graphs; x_l rows of a graph kept in LDS
   int f16;                // x_l / x_r / e_proj / out hold fp16 (per-graph kernel only)
-  int flags;              // bit0: non-temporal e_proj loads / out stores; bit1: XCD-aware chunk mapping
+  int flags;              // bit0: non-temporal e_proj loads / out stores; bit1: XCD-aware chunk mapping (chunk kernel);
+                          // per-graph kernel: bit2 non-temporal x_l staging loads, bit5 x_r loads, bit6 alpha stores;
+                          // bits 3 / 4 skip the logit / aggregation phase (ablation)
   int nchunks;
 };
 

@@ -72,6 +72,8 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
   const int hoff = hg * RQ;      // first float4 of this workgroup's head slice inside a row
   const int rows = min(n, a.lrows);
   const bool nt = a.flags & 1;
+  const bool nt_xl = a.flags & 4;   // the staged x_l slice is read exactly once per workgroup
+  const bool nt_xr = a.flags & 32, nt_al = a.flags & 64;   // experiments: x_r rows, alpha stores
 
   // ---- phase A: stage (loads first, LDS stores after) ------------------------------------------------------------
   {
@@ -103,10 +105,10 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
       for (int c = lane; c < RQ; c += 64) {
         typename RawQ<F16>::type v0, v1, v2, v3;
         const int r1 = r0 + GK_WAVES, r2 = r0 + 2 * GK_WAVES, r3 = r0 + 3 * GK_WAVES;
-        v0 = ldraw<F16>(a.x_l, (size_t)(nb + r0) * a.ldl4 + hoff + c);
-        if (r1 < rows) v1 = ldraw<F16>(a.x_l, (size_t)(nb + r1) * a.ldl4 + hoff + c);
-        if (r2 < rows) v2 = ldraw<F16>(a.x_l, (size_t)(nb + r2) * a.ldl4 + hoff + c);
-        if (r3 < rows) v3 = ldraw<F16>(a.x_l, (size_t)(nb + r3) * a.ldl4 + hoff + c);
+        v0 = ldraw_stream<F16>(a.x_l, (size_t)(nb + r0) * a.ldl4 + hoff + c, nt_xl);
+        if (r1 < rows) v1 = ldraw_stream<F16>(a.x_l, (size_t)(nb + r1) * a.ldl4 + hoff + c, nt_xl);
+        if (r2 < rows) v2 = ldraw_stream<F16>(a.x_l, (size_t)(nb + r2) * a.ldl4 + hoff + c, nt_xl);
+        if (r3 < rows) v3 = ldraw_stream<F16>(a.x_l, (size_t)(nb + r3) * a.ldl4 + hoff + c, nt_xl);
         s_xl[r0 * RQ + c] = cvtq(v0);
         if (r1 < rows) s_xl[r1 * RQ + c] = cvtq(v1);
         if (r2 < rows) s_xl[r2 * RQ + c] = cvtq(v2);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
         for (int p = 0; p < P; ++p) {
           if (ok[p]) {
             epv[u][p] = ldraw_stream<F16>(a.e_proj, ep + off[p], nt);
-            xrv[u][p] = ldraw<F16>(a.x_r, xr + off[p]);
+            xrv[u][p] = ldraw_stream<F16>(a.x_r, xr + off[p], nt_xr);
           }
         }
       }
@@ -208,7 +210,10 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
       for (int t = rb; t < re; ++t) {
         const int4 rec = s_tab[t];
         const float w = __builtin_amdgcn_exp2f((s_lg[t * HS + grp] - mx) * 1.4426950408889634f) * rden;
-        if (l == 0) a.alpha[(size_t)uni(rec.y) * a.H + hd] = w;
+        if (l == 0) {
+          if (nt_al) __builtin_nontemporal_store(w, a.alpha + (size_t)uni(rec.y) * a.H + hd);
+          else a.alpha[(size_t)uni(rec.y) * a.H + hd] = w;
+        }
         const float wm = MASKED ? __fmul_rn(w, unif(__int_as_float(rec.w))) : w;
         const int jl = uni(rec.x);
         const bool in_lds = jl < rows;
