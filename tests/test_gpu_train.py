@@ -405,3 +405,21 @@ def test_tail_pool_and_gate_backward_kernels(dev, C, masked):
     for dbl in (True, False):
         compare(lambda: ops.node_gate(xg, qg, batch, dbl, plan=plan), lambda: AG._node_gate_t(xg, qg, batch, dbl),
                 [xg, qg], f"node gate dbl={dbl}")
+
+
+def test_simple_sampler_long_rows_against_oracle(dev):
+    """Rows beyond the 64 KB default LDS window (n = 1024: 98 KB of tree per row) and k at the table limit."""
+    from isubgvqa_amd.sampling.methods.simple_scheme import EdgeSIMPLEBatched
+    from oracle import simple as OSI
+    for (B, nmax, k) in [(3, 700, 5), (2, 130, 16), (4, 257, 1)]:
+        gen = torch.Generator().manual_seed(nmax + k)
+        scores = torch.randn(B, nmax, 1, generator=gen)
+        scores[1, nmax // 2:] = 0.0                       # a ragged row: zero pads forced into the subset
+        n = 1 << (nmax - 1).bit_length()
+        uni = torch.rand(1, B, n, generator=gen)
+        ref_mask, ref_marg = OSI.simple_forward(scores, k, uni)
+        mask, marg = EdgeSIMPLEBatched(k=k, device=dev, policy="edge_candid")(scores.to(dev), train=False,
+                                                                              uniform=uni.view(B, n).to(dev))
+        assert torch.equal(torch.isnan(marg.cpu()), torch.isnan(ref_marg))
+        torch.testing.assert_close(marg.cpu(), ref_marg, rtol=5e-5, atol=5e-6, equal_nan=True)
+        torch.testing.assert_close(mask.cpu(), ref_mask, rtol=0, atol=5e-6, equal_nan=True)
