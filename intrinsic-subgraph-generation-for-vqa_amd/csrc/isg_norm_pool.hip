@@ -59,6 +59,9 @@ __device__ __forceinline__ void phase_softmax(int n, float eps_add, float *s_a) 
 // MODE 0: out = a_n * value_n                      (scatter_scaled_dot_product_attention)
 // MODE 1: out = GraphNorm(x)                        (x = key)
 // MODE 2: out = GraphNorm(a_n * value_n) + h  [* node_mask]   (fused MGAT layer tail)
+#ifndef ISG_TAIL_UNROLL
+#define ISG_TAIL_UNROLL 8
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256) void graph_tail_kernel(const float *__restrict__ query, const float *__restrict__ key,
                                                          const float *h, const int *__restrict__ ptr,
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void graph_tail_kernel(const float *__restrict
       continue;
     }
     float sum = 0.f;
+#pragma unroll ISG_TAIL_UNROLL
     for (int k = 0; k < n; ++k) {
       float v = col[(size_t)k * C];
       if (MODE == 2) v = __fmul_rn(s_a[k], v);
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256) void graph_tail_kernel(const float *__restrict
     }
     const float mean_ms = __fmul_rn(sum / cnt, mean_scale[ch]);
     float sq = 0.f;
+#pragma unroll ISG_TAIL_UNROLL
     for (int k = 0; k < n; ++k) {
       float v = col[(size_t)k * C];
       if (MODE == 2) v = __fmul_rn(s_a[k], v);
@@ -101,6 +106,7 @@ __global__ __launch_bounds__(256) void graph_tail_kernel(const float *__restrict
     }
     const float stdv = sqrtf(__fadd_rn(sq / cnt, eps));
     const float w = weight[ch], b = bias[ch];
+#pragma unroll ISG_TAIL_UNROLL
     for (int k = 0; k < n; ++k) {
       float v = col[(size_t)k * C];
       if (MODE == 2) v = __fmul_rn(s_a[k], v);
