@@ -84,8 +84,15 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
   typedef typename GmRawA<A16>::type RawA;
   const void *Av = A;   // fp16 variants: the same pointers, half elements
   void *Dv = D;
-  __shared__ __attribute__((aligned(16))) __bf16 sA[3][GM_BM][GM_LD];
-  __shared__ __attribute__((aligned(16))) __bf16 sB[3][GM_BN][GM_LD];
+  // one LDS object, so that the epilogue's per-wave patches (36.9 KB) may legally run from the A planes into the W planes
+  struct Smem {
+    __bf16 a[3][GM_BM][GM_LD];
+    __bf16 b[3][GM_BN][GM_LD];
+  };
+  __shared__ __attribute__((aligned(16))) Smem sm;
+#define sA sm.a
+#define sB sm.b
+  static_assert(sizeof(Smem) >= 8 * 32 * 36 * sizeof(float), "the epilogue patches must fit the operand block");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
   // ---- epilogue: + bias, optional GELU, then each 32x32 accumulator tile goes through a private LDS patch so that the
   //      global stores are 16 bytes per lane along a row (4 store instructions per tile instead of 16 dword stores) ----
   __syncthreads();   // every wave is done with the operand tiles: the LDS is free
-  float *patch = reinterpret_cast<float *>(&sA[0][0][0]) + wave * (32 * 36);   // [32][32 + 4 pad] floats per wave
+  float *patch = reinterpret_cast<float *>(&sm) + wave * (32 * 36);   // [32][32 + 4 pad] floats per wave
   const int h = lane >> 5;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -271,6 +278,8 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
     }
     __builtin_amdgcn_wave_barrier();
   }
+#undef sA
+#undef sB
 }
 
 }  // namespace isg
