@@ -312,11 +312,12 @@ static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const
   dim3 grid((unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)mt), block(512);
   const __bf16 *wp = reinterpret_cast<const __bf16 *>(w_planes);
   hipStream_t st = as_stream(stream);
-  // results of at least ISG_GEMM_NT_MB MB (default 0: all) are written with non-temporal stores: the projected rows are
-  // consumed by a LATER kernel and are larger than the caches, while the operands (A re-read per n-tile, W planes)
-  // should stay resident (end-to-end A/B on configs[1]: +4 %)
+  // results of at least ISG_GEMM_NT_MB MB (default 128) are written with non-temporal stores: the big projected rows
+  // (x_l|x_r 337 MB, e_proj 420 MB) exceed the caches and are consumed by a LATER kernel -- which itself runs 6 % faster
+  // when they were streamed -- while the operands (A re-read per n-tile, W planes) and the small results that the very
+  // next kernel reads (x_proj, MLPs: <= 84 MB) should stay resident (profiles/r01_e, r01_q / r01_x)
   const char *ntv = getenv("ISG_GEMM_NT_MB");
-  const long long nt_mb = ntv ? atoll(ntv) : 0;
+  const long long nt_mb = ntv ? atoll(ntv) : 128;
   const int nt = nt_mb >= 0 && (long long)M * N * (d16 ? 2 : 4) >= nt_mb * 1000000ll;
   dim3 gridx(grid.x, (grid.y + 7) / 8 * 8);
 #ifdef ISG_GEMM_ABLATION   // profiling build only (tools/build_ablation.sh): select a compile-time ablated variant by env
