@@ -27,27 +27,32 @@ class MGAT(torch.nn.Module):
             raise NotImplementedError("use_instr=False leaves the reference without its layer lists (mgat.py:46-64)")
         if num_ins > 4:
             raise ValueError("the reference supports at most 4 instruction layers (mgat.py:47-53)")
-        self.masking_thresholds = masking_thresholds
-        self.use_global_mask = use_global_mask
-        self.node_classification = node_classification
-        self.heads, self.use_instr, self.use_topk = heads, use_instr, use_topk
+        # options the forward pass consults
+        self.heads, self.use_instr, self.use_topk, self.dropout = heads, use_instr, use_topk, dropout
+        self.masking_thresholds, self.use_global_mask = masking_thresholds, use_global_mask
         self.interpretable_mode, self.use_all_instrs = interpretable_mode, use_all_instrs
-        self.in_channels = channels * 2 if concat_instr else channels
+        self.node_classification = node_classification
+        width_in = 2 * channels if concat_instr else channels
+        self.in_channels = width_in
+        wide, mid = heads * channels, channels * int(heads / 2)        # H*C -> C*H/2 -> C   (mgat.py:66-91)
 
-        self.convs = torch.nn.ModuleList([
-            MaskingGATv2Conv(in_channels=self.in_channels, out_channels=channels, heads=heads, edge_dim=channels,
-                             masking_threshold=masking_thresholds[i], add_self_loops=False, use_instr=True,
-                             use_topk=use_topk, concat_instr=concat_instr, use_all_instrs=use_all_instrs,
-                             sampler_type=sampler_type, sample_k=sample_k, nb_samples=nb_samples, alpha=alpha,
-                             beta=beta, tau=tau)
-            for i in range(num_ins)])
-        self.x_proj = torch.nn.ModuleList([
-            torch.nn.Sequential(torch.nn.Linear(heads * channels, channels * int(heads / 2)), torch.nn.GELU(),
-                                torch.nn.Linear(channels * int(heads / 2), channels), torch.nn.GELU())
-            for _ in range(num_ins)])
-        self.bns = torch.nn.ModuleList([GraphNorm(channels) for _ in range(num_ins)])
-        self.dropout = dropout
-        # constructed by the reference, never used in forward (mgat.py:98-102); kept for checkpoint keys
+        sampler_opts = dict(sampler_type=sampler_type, sample_k=sample_k, nb_samples=nb_samples, alpha=alpha, beta=beta,
+                            tau=tau)
+
+        def conv_layer(threshold):
+            return MaskingGATv2Conv(width_in, channels, heads=heads, edge_dim=channels, add_self_loops=False,
+                                    masking_threshold=threshold, use_instr=True, use_topk=use_topk,
+                                    concat_instr=concat_instr, use_all_instrs=use_all_instrs, **sampler_opts)
+
+        def head_projection():
+            gelu = torch.nn.GELU
+            return torch.nn.Sequential(torch.nn.Linear(wide, mid), gelu(), torch.nn.Linear(mid, channels), gelu())
+
+        layers = range(num_ins)
+        self.convs = torch.nn.ModuleList(conv_layer(masking_thresholds[i]) for i in layers)
+        self.x_proj = torch.nn.ModuleList(head_projection() for _ in layers)
+        self.bns = torch.nn.ModuleList(GraphNorm(channels) for _ in layers)
+        # built by the reference and never called in forward (mgat.py:98-102): present only for checkpoint keys
         self.node_logits = torch.nn.Sequential(torch.nn.Linear(channels, 512), torch.nn.GELU(),
                                                torch.nn.Linear(512, 2577))
 
