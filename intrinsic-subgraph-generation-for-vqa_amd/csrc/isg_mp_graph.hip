@@ -293,6 +293,10 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   const int G = 64 / HS;
   const int P = (Q + G - 1) / G;
   if (P > 2) return ISG_EUNSUPPORTED;
+  // one head per workgroup whose row needs a second, mostly idle pass (the reference's default C = 300: 75 of 128 lane
+  // slots, and the CSR tables staged once per HEAD): the node-chunk kernel is faster there (tools/time_mp_c300.py:
+  // 672 vs 762 us at H = 4, C = 300 on the configs[1] topology)
+  if (HS == 1 && a.H > 1 && P == 2 && Q * 10 < G * P * 7 && getenv("ISG_MP_FORCE_GRAPH") == nullptr) return ISG_EUNSUPPORTED;
 #define ISG_GK(hs, p) if (HS == hs && P == p) return launch_one<hs, p>(a, nmax_host, emax_host, st)
   ISG_GK(1, 1); ISG_GK(1, 2);
   ISG_GK(2, 1); ISG_GK(2, 2);
