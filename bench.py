@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """Benchmark of the ISubGVQA inference hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N>1 runs one rank per GPU under torch.distributed.run (RCCL).  Started WITHOUT a launcher (WORLD_SIZE unset) the
+script starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` itself as a CHILD
+process -- before anything touches the GPU, never by exec -- forwards rank 0's JSON line and exits with the child's
+status (the reference's launch shape: run_training_ddp.sh:23 `torchrun --standalone --nproc_per_node=4`, main.py:72-94).
+Started by a launcher (WORLD_SIZE set) it is a rank; WORLD_SIZE != --gpus is an error.
 
 A step = one pass of the hot path over one resident batch: BASELINE.json configs[1]
 (4096 synthetic GQA-shaped scene graphs per GPU, ~20 nodes / ~50 edges, 3 masked-GATv2 layers at C=128, H=4,
@@ -22,6 +28,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +41,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 T
 HBM_COPY_GBPS = 6290.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -48,7 +56,39 @@ def parse():
     ap.add_argument("--gemm", choices=["bf16x6", "torch"], default="bf16x6")
     ap.add_argument("--features", choices=["fp32", "fp16"], default="fp32",
                     help="storage of the projected rows (fp16 = BASELINE configs[4]'s variant; NOT the headline config)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launcher_argv(gpus: int, script_args, port: int):
+    """Command line of the child that runs this script as `gpus` ranks on one node (rendezvous on 127.0.0.1: the
+    container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *script_args]
+
+
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, script_args, run=subprocess.Popen) -> int:
+    """--gpus N>1 without a launcher: start torch.distributed.run as a child process (this process has not imported
+    torch, let alone initialised the GPU), pass rank 0's JSON line through on stdout, everything else on stderr, and
+    return the child's exit status."""
+    cmd = launcher_argv(args.gpus, script_args, _free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        if line.lstrip().startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def cpu_baseline(cfg, sample_graphs: int, seconds: float, threads: int):
@@ -97,8 +137,15 @@ def load_traffic(N: int, E: int, kernel: str):
     return None
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        raise SystemExit(self_launch(args, argv))
+    if int(world_env or "1") != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world_env} does not match --gpus {args.gpus}: start `python bench.py --gpus N` "
+                         "without a launcher, or give torch.distributed.run --nproc-per-node the same N")
     import torch
     import torch.distributed as dist
     from isubgvqa_amd import ops, synthetic
@@ -107,9 +154,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the product path has no CPU fallback"
     # ISG_BENCH_SINGLE_DEVICE=1 + ISG_BENCH_BACKEND=gloo: rehearse the N>1 code path with every rank on cuda:0
     # (a one-GPU box cannot form an RCCL communicator with two ranks on one device)
@@ -174,6 +218,16 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # evidence that the communicator saw every rank: backend, world size, each rank's device index and GPU name
+    devs = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=dev)
+    if world > 1:
+        all_devs = [torch.empty_like(devs) for _ in range(world)]
+        dist.all_gather(all_devs, devs)
+        rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(),
+                "devices": [int(d.item()) for d in all_devs], "collective": "all_gather_into_tensor(logits[B_local,1842] f32)"}
+    else:
+        rccl = {"backend": None, "world": 1, "devices": [int(devs.item())], "collective": None}
+    rccl["gpu"] = torch.cuda.get_device_name(dev)
 
     durs = timer.durations_ms()
     bytes_l = [ops.mp_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"], m.get("feat_bytes", 4)) for m in timer.meta]
@@ -202,6 +256,7 @@ def main():
                          "traffic": load_traffic(N, E, args.mp_kernel), "algorithmic_bytes_per_launch": int(mp_bytes),
                          "avg_launch_us": round(mp_ms * 1e3, 2), "launches_timed": len(durs)},
         }
+        res["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_graphs, args.cpu_seconds, args.cpu_threads)
         else:

@@ -1,0 +1,86 @@
+"""`python bench.py --gpus N` must start its own ranks: the launcher is a child process running
+torch.distributed.run, chosen before anything touches the GPU.  Reference launch shape: run_training_ddp.sh:23
+(`torchrun --standalone --nproc_per_node=4`), main.py:72-94."""
+import io
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_launcher_argv_shape():
+    argv = bench.launcher_argv(8, ["--gpus", "8", "--steps", "5", "--warmup", "2"], 29511)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=8" in argv
+    i = argv.index("--master-addr")
+    assert argv[i + 1] == "127.0.0.1"            # the container hostname may not resolve
+    assert argv[argv.index("--master-port") + 1] == "29511"
+    script = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[script + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]   # same flags, verbatim
+
+
+class _FakeProc:
+    def __init__(self, lines, rc):
+        self.stdout = io.StringIO("".join(lines))
+        self._rc = rc
+
+    def wait(self):
+        return self._rc
+
+
+def test_self_launch_forwards_the_json_line_and_the_status(capsys, monkeypatch):
+    seen = {}
+
+    def fake_popen(cmd, stdout=None, text=None, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return _FakeProc(["W0000 some launcher chatter\n", '{"metric": "GQA questions/sec", "value": 1.0}\n'], 3)
+
+    args = bench.parse(["--gpus", "4", "--steps", "2"])
+    rc = bench.self_launch(args, ["--gpus", "4", "--steps", "2"], run=fake_popen)
+    out = capsys.readouterr()
+    assert rc == 3
+    assert out.out == '{"metric": "GQA questions/sec", "value": 1.0}\n'     # stdout carries the ONE JSON line
+    assert "launcher chatter" in out.err
+    assert "--nproc-per-node=4" in seen["cmd"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_world_size_mismatch_is_an_error(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4"])
+    assert "does not match" in str(e.value)
+
+
+def test_main_self_launches_when_no_launcher_is_present(monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    called = {}
+
+    def fake_self_launch(args, argv):
+        called["gpus"], called["argv"] = args.gpus, argv
+        return 0
+
+    monkeypatch.setattr(bench, "self_launch", fake_self_launch)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2", "--steps", "1"])
+    assert e.value.code == 0 and called == {"gpus": 2, "argv": ["--gpus", "2", "--steps", "1"]}
+
+
+@pytest.mark.timeout(300)
+def test_real_launch_reaches_the_ranks_and_returns_their_status():
+    """No GPU here: each rank must come up under torch.distributed.run with WORLD_SIZE=2 and stop at the product path's
+    'needs an MI355X' assertion; the parent must report the failure, not hang or succeed."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the real run is bench.py's job")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=280)
+    assert p.returncode != 0
+    assert "needs an MI355X" in p.stderr
+    assert p.stdout.strip() == ""
