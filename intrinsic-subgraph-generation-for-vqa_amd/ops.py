@@ -84,6 +84,32 @@ def _chk_rows(t: Tensor, name: str, dtype=torch.float32) -> int:
     return t.data_ptr()
 
 
+# GraphPlan.build trusts the caller's max_nodes / max_edges hints to stay free of a device->host sync; the true bounds
+# are computed on the device anyway, so every hinted build queues an asynchronous copy of them into pinned memory and
+# the comparison happens later, on the host, once the copy has landed: at the next build (polled, never waited for) or
+# at check_plans().  An understated hint (which would size the LDS tables / sampler rows too small and truncate
+# graphs silently) therefore raises -- one step late, but loudly and without stalling the stream.
+_PENDING_HINTS = []      # (event, pinned int32[2] = true [max nodes, max edges], hinted max_nodes, hinted max_edges)
+
+
+def check_plans(block: bool = True) -> None:
+    """Raise IsgError if a GraphPlan was built with hints smaller than the batch's true per-graph bounds.
+    block=False only looks at copies that have already completed."""
+    keep, bad = [], None
+    for ev, host, hn, he in _PENDING_HINTS:
+        if not block and not ev.query():
+            keep.append((ev, host, hn, he))
+            continue
+        ev.synchronize()
+        n_true, e_true = int(host[0]), int(host[1])
+        if n_true > hn or (he is not None and e_true > he):
+            bad = bad or (n_true, e_true, hn, he)
+    _PENDING_HINTS[:] = keep
+    if bad is not None:
+        raise _lib.IsgError(f"GraphPlan hints understate the batch: max_nodes={bad[2]} / max_edges={bad[3]} given, "
+                            f"but a graph has {bad[0]} nodes / {bad[1]} edges; results of that batch are invalid")
+
+
 def _f32(t: Tensor) -> Tensor:
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
@@ -172,8 +198,18 @@ class GraphPlan:
                                               bounds[1:].data_ptr(), _stream()), "isg_graph_edge_ptr")
         if max_nodes is None or (edge_index is not None and max_edges is None):
             got = bounds.tolist()                   # one D2H sync per batch (to_dense_batch syncs per layer)
-            max_nodes = got[0] if max_nodes is None else max_nodes
-            max_edges = got[1] if max_edges is None else max_edges
+            max_nodes = got[0] if max_nodes is None else max(int(max_nodes), got[0])
+            max_edges = got[1] if max_edges is None else max(int(max_edges), got[1])
+        else:                                       # hinted: verify later, without a sync (see check_plans)
+            if _PENDING_HINTS:
+                check_plans(block=False)
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(bounds, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _PENDING_HINTS.append((ev, host, int(max_nodes), None if edge_index is None else int(max_edges)))
+            if len(_PENDING_HINTS) > 64:
+                check_plans(block=True)
         plan.nmax = int(max_nodes)
         plan.emax = int(max_edges or 0)
         if plan.nmax > MAX_NODES_PER_GRAPH:
@@ -625,6 +661,14 @@ def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional
 # ------------------------------------------------------------------------------------------------
 GEMM_BACKEND = "bf16x6"      # "bf16x6": isg_linear_bf16x6; "torch": hipBLASLt fp32 through torch (A/B switch)
 _PLANES = {}                 # id(weight) -> (weakref, version, data_ptr, planes): static weights are split once
+
+
+def invalidate_weight_cache() -> None:
+    """Drop every cached bf16 plane set and fused weight.  The caches are validated by (object identity, tensor._version,
+    data_ptr); a write THROUGH `.data` (weight.data.copy_/mul_, as init / EMA / weight-surgery code does) bumps neither,
+    so such code must call this (Module.load_state_dict goes through copy_ on the Parameter and is safe)."""
+    _PLANES.clear()
+    _CAT.clear()
 
 
 def _weight_planes(weight: Tensor, cache: bool = True) -> Tensor:

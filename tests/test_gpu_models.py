@@ -146,18 +146,34 @@ def test_cfg1_cpu_config_logits_and_masks_match_oracle(dev, sampler):
 
 def test_cfg2_full_size_logits_within_tolerance(dev):
     """BASELINE configs[1] at full size: B=4096, ~20 nodes / ~50 edges, C=128, 3 layers, Gumbel k=5.
-    Masks are compared first; a graph whose mask differs (a near-tie in khot decided by the last ulp of the GEMM
-    feeding the gate) has unrelated logits, so logits are compared on graphs with identical masks and the number
-    of differing graphs is bounded."""
+    north_star: top-k mask indices bit-exact.  The count of differing graphs is printed and must be 0 -- unless a
+    differing graph is a TIE of the reference's own selection: the oracle's relaxed accumulator khot (gumbel_scheme.py:
+    75-88) has its k-th and (k+1)-th largest entries within 2 fp32 ulps, where `torch.topk` itself is at the mercy of the
+    last bit of the GEMM feeding the gate.  Anything else fails."""
     from isubgvqa_amd import synthetic
+    from oracle import model as OM
     cfg = synthetic.CFG2
-    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    wl = synthetic.make_workload(cfg)
+    model = synthetic.build_answer_model(cfg).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    noises = _noises(cfg, wl, 5)
+    trace = []
+    with torch.no_grad():
+        rl, rm, rg = OM.mgat_pool_classify(sd, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf,
+                                           _oracle_cfg(cfg), noises, trace)
+        gl, gm, gg = (t.cpu() for t in model.to(dev)(wl.to(dev), noises={i: n.to(dev) for i, n in noises.items()}))
     same_node = (gm > 0.5) == (rm > 0.5)
     bad_graph = torch.zeros(cfg.num_graphs, dtype=torch.bool).index_put_((wl.batch[~same_node.view(-1)],),
                                                                          torch.tensor(True))
     n_bad = int(bad_graph.sum())
     print(f"cfg2: graphs with a differing top-k mask: {n_bad}/{cfg.num_graphs}")
-    assert n_bad <= 2
+    if n_bad:
+        khot = [t["khot"] for t in trace if t.get("khot") is not None][-1]          # [B, Nmax] of the masked layer
+        top = khot[bad_graph].topk(cfg.sample_k + 1, dim=1).values
+        gap = (top[:, cfg.sample_k - 1] - top[:, cfg.sample_k]).abs()
+        ulp = torch.finfo(torch.float32).eps * top[:, cfg.sample_k - 1].abs().clamp_min(1e-30)
+        print(f"cfg2: khot gap at the k-th slot of the differing graphs (in ulps): {(gap / ulp).tolist()}")
+        assert bool((gap <= 2 * ulp).all()), "a top-k mask differs on a graph that is NOT a tie of the reference's selection"
     ok = ~bad_graph
     err = (gl[ok] - rl[ok]).abs().max().item()
     print(f"cfg2: max |logit diff| = {err:.3e}")
@@ -326,6 +342,50 @@ def test_full_isubgvqa_model_matches_oracle(dev, sampler):
     print(f"full model ({sampler}): max |logit diff| = {err:.3e}")
     assert err < LOGIT_TOL
     assert torch.allclose(gg.cpu(), rg, atol=1e-5)
+
+
+G10 = load_golden("g10_full.pt")
+
+
+@pytest.mark.parametrize("ci", range(len(G10)))
+def test_full_model_matches_the_reference_forward_golden(dev, ci):
+    """G10: the HIP model against outputs of the REFERENCE's own `ISubGVQA.forward` / `SceneGraphEncoder.forward`
+    (oracle/make_goldens.py::gen_full) at the default architecture; weights from the seeded recipe on both sides."""
+    from isubgvqa_amd.models import build_model
+    from oracle import recipe as R
+    case = G10[ci]
+    c = case["cfg"]
+    args = _full_args(sampler_type=c["sampler"], sample_k=c["k"], mgat_layers=c["L"], mgat_masks=list(c["masks"]),
+                      interpretable_mode=c["interp"], text_vocab_size=c["text_vocab"], sg_vocab_size=c["sg_vocab"])
+    model = build_model(args, None).eval()
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    for k, shape in case["keys"].items():            # the reference's state_dict layout loads into the mirror
+        assert have.get(k) == shape or k.endswith("gate_top.select.weight") or k.endswith("gate_top.weight"), (k, shape, have.get(k))
+    R.fill_state_dict(model, case["seed"])
+    sd = model.state_dict()
+    for k, want in case["checksums"].items():
+        assert abs(float(sd[k].double().sum()) - want) <= 1e-9 * max(1.0, abs(want)), f"recipe stream drifted at {k}"
+    model = model.to(dev)
+    t = lambda k: case[k].to(dev)
+    sg = argparse.Namespace(x_bbox=t("x_bbox"), added_sym_edge=t("added_sym_edge"))
+    noises = {i: n.to(dev) for i, n in case["noises"].items()} or None
+    with torch.no_grad():
+        x_enc, e_enc = model.scene_graph_encoder(t("x"), edge_index=t("edge_index"), edge_attr=t("edge_attr"),
+                                                 batch=t("batch"), gt_scene_graphs=sg)
+        enc = model.question_encoder(t("questions"), mask=t("att_mask"))
+        dec = model.program_decoder(memory=enc)
+        logits, mask, gate, nl, mt = model(t("x"), t("edge_index"), t("edge_attr"), t("batch"), t("questions"),
+                                           t("att_mask"), return_masks=True, scene_graphs=sg, noises=noises)
+    assert nl == [] and mt is None
+    e_err = (e_enc.cpu() - case["e_enc"]).abs().max().item()
+    x_err = (x_enc.cpu() - case["x_enc"]).abs().max().item()
+    t_err = max((enc.cpu() - case["enc_out"]).abs().max().item(), (dec.cpu() - case["dec_out"]).abs().max().item())
+    err = (logits.cpu() - case["logits"]).abs().max().item()
+    print(f"G10[{ci}] HIP vs REFERENCE: e_enc {e_err:.2e}  x_enc {x_err:.2e}  enc/dec {t_err:.2e}  logits {err:.3e}")
+    assert e_err < 2e-5 and x_err < 5e-5 and t_err < 3e-5
+    assert torch.equal(mask.cpu() > 0.5, case["mask"] > 0.5), "top-k node mask differs from the reference"
+    assert err < LOGIT_TOL
+    assert torch.allclose(gate.cpu(), case["gate"], atol=1e-5)
 
 
 def test_full_model_with_text_sampling(dev):

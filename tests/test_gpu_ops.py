@@ -343,7 +343,10 @@ def test_linear_bf16x6_has_fp32_accuracy(dev, M, K, N, bias, gelu):
     err = (got - ref).abs().max().item()
     err32 = (f32.double() - ref).abs().max().item()
     assert got.shape == (M, N)
-    assert err <= max(6.0 * err32, 2e-6), (err, err32)     # fp32 accumulation over K in one chain (MFMA) vs blocked
+    print(f"bf16x6 [{M}x{N}x{K}] max err vs fp64: {err:.3e}; plain fp32 GEMM: {err32:.3e}; ratio {err / max(err32, 1e-30):.2f}")
+    # the `dtype: "f32"` claim of bench.py rests on this: never worse than 2x a plain fp32 GEMM's error (the six bf16
+    # products are exact in the fp32 accumulator; the dropped terms are < 2^-24 relative; GELU adds its own last ulp)
+    assert err <= max(2.0 * err32, 1e-6), (err, err32)
     # weights are split once and cached; an in-place update must invalidate the cache
     with torch.no_grad():
         wd.mul_(2.0)
@@ -465,3 +468,40 @@ def test_linear_wgrad_matches_fp64(dev, M, N, K):
     assert err < 3e-6 * (M ** 0.5) * 4 + 1e-5, err
     again = ops.linear_wgrad(g.to(dev), x.to(dev))
     assert torch.equal(got, again), "split-M reduction must be bitwise reproducible"
+
+
+# ------------------------------------------------------------------------------------ host-side guards
+def test_understated_plan_hints_raise(dev):
+    """GraphPlan.build takes max_nodes / max_edges hints to avoid a device->host sync; a hint smaller than the batch's
+    true bound would size the LDS tables and sampler rows too small.  The true bounds are checked asynchronously."""
+    from isubgvqa_amd import ops, _lib
+    batch = torch.tensor([0] * 5 + [1] * 9 + [2] * 3, device=dev)
+    n = batch.numel()
+    ei = torch.stack([torch.arange(n), torch.arange(n)]).to(dev)
+    ops.check_plans()                                             # drain anything older
+    ops.GraphPlan.build(batch, ei, num_graphs=3, max_nodes=9, max_edges=9)
+    ops.check_plans()                                             # exact hints are fine
+    ops.GraphPlan.build(batch, ei, num_graphs=3, max_nodes=8, max_edges=9)
+    with pytest.raises(_lib.IsgError, match="understate"):
+        ops.check_plans()
+    ops.GraphPlan.build(batch, ei, num_graphs=3, max_nodes=16, max_edges=4)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.IsgError, match="understate"):       # ... also when polled by the next build
+        ops.GraphPlan.build(batch, ei, num_graphs=3, max_nodes=16, max_edges=16)
+    ops.check_plans()
+    # a partial hint goes through the synchronous path and can only widen
+    plan = ops.GraphPlan.build(batch, ei, num_graphs=3, max_nodes=4)
+    assert plan.nmax == 9 and plan.emax == 9
+
+
+def test_invalidate_weight_cache_after_a_write_through_data(dev):
+    """A write through `.data` bumps neither the version nor the address of a weight: the cached bf16 planes go stale
+    until ops.invalidate_weight_cache() is called (documented in INTEGRATION.md)."""
+    from isubgvqa_amd import ops
+    x = torch.randn(64, 32, device=dev)
+    w = torch.nn.Parameter(torch.randn(48, 32, device=dev))
+    y0 = ops.linear(x, w)
+    w.data.mul_(2.0)
+    ops.invalidate_weight_cache()
+    y1 = ops.linear(x, w)
+    assert torch.allclose(y1, 2.0 * y0, atol=1e-5, rtol=1e-5)
