@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 6
+#define ISG_ABI_VERSION 7
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -304,6 +304,19 @@ int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const float *bia
 int isg_linear_bf16x6_f16(const void *a, int32_t a_is_f16, const uint16_t *w_planes, const float *bias, void *d,
                           int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
                           void *stream);
+
+/* Row-panel form of the same Linear (csrc/isg_gemm_panel.hip; same call sites as isg_linear_bf16x6, same arithmetic:
+ * three bf16 planes per operand, six MFMA terms, fp32 accumulate).  The weight planes are stored FRAGMENT-MAJOR,
+ * planes[q][n/32][k/16][lane][8] (zero padded to 32 rows / 16 k), so that one matrix-core B operand is one contiguous
+ * 1 KB load; isg_split_bf16x3_frag_elems gives the uint16 count to allocate.  A 64-row panel of `a` is split into its
+ * planes once and serves every output column when K <= 128.  The accumulation order of an output element depends only
+ * on K: a row's result does not depend on where the row sits in the batch.  a / d may be fp16 as in
+ * isg_linear_bf16x6_f16.  Requires 4 | K, 4 | lda, a aligned to 16 bytes (8 for fp16). */
+int64_t isg_split_bf16x3_frag_elems(int64_t rows, int32_t K);
+int isg_split_bf16x3_frag(const float *w, int64_t rows, int32_t K, uint16_t *planes, void *stream);
+int isg_linear_panel(const void *a, int32_t a_is_f16, const uint16_t *w_frag, const float *bias, void *d,
+                     int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -61,6 +61,10 @@ SIGNATURES = {
                                   c_int32, c_void_p]),
     "isg_linear_bf16x6_f16": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                       c_int32, c_int32, c_int32, c_void_p]),
+    "isg_split_bf16x3_frag_elems": (c_int64, [c_int64, c_int32]),
+    "isg_split_bf16x3_frag": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "isg_linear_panel": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
+                                 c_int32, c_int32, c_int32, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

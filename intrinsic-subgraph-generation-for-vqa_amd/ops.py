@@ -659,8 +659,9 @@ def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional
 # ------------------------------------------------------------------------------------------------
 # Dense projections: fp32 accuracy on the bf16 matrix cores (csrc/isg_gemm.hip)
 # ------------------------------------------------------------------------------------------------
-GEMM_BACKEND = "bf16x6"      # "bf16x6": isg_linear_bf16x6; "torch": hipBLASLt fp32 through torch (A/B switch)
-_PLANES = {}                 # id(weight) -> (weakref, version, data_ptr, planes): static weights are split once
+GEMM_BACKEND = "bf16x6"      # "bf16x6": this library's kernels; "torch": hipBLASLt fp32 through torch (A/B switch)
+GEMM_KERNEL = "panel"        # "panel": isg_linear_panel (row panels, W fragment-major); "tile": isg_linear_bf16x6
+_PLANES = {}                 # (id(weight), layout) -> (weakref, version, data_ptr, planes): static weights are split once
 
 
 def invalidate_weight_cache() -> None:
@@ -671,19 +672,24 @@ def invalidate_weight_cache() -> None:
     _CAT.clear()
 
 
-def _weight_planes(weight: Tensor, cache: bool = True) -> Tensor:
-    key = id(weight)
+def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> Tensor:
+    key = (id(weight), layout)
     hit = _PLANES.get(key) if cache else None
     # the weak reference pins the identity: a freed weight's id (and even its address) can be reused by another model
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3]
     lib = _lib.load()
     N, K = weight.shape
-    Kp = (K + 31) // 32 * 32
-    planes = torch.empty(3 * N * Kp, dtype=torch.int16, device=weight.device)
     w = weight.detach()
-    _lib.check(lib.isg_split_bf16x3(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(), _stream()),
-               "isg_split_bf16x3")
+    if layout == "panel":      # fragment-major planes of isg_linear_panel
+        planes = torch.empty(int(lib.isg_split_bf16x3_frag_elems(N, K)), dtype=torch.int16, device=weight.device)
+        _lib.check(lib.isg_split_bf16x3_frag(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(),
+                                             _stream()), "isg_split_bf16x3_frag")
+    else:
+        Kp = (K + 31) // 32 * 32
+        planes = torch.empty(3 * N * Kp, dtype=torch.int16, device=weight.device)
+        _lib.check(lib.isg_split_bf16x3(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(), _stream()),
+                   "isg_split_bf16x3")
     if cache:
         if len(_PLANES) > 256:
             for k in [k for k, v in _PLANES.items() if v[0]() is None]:
@@ -710,6 +716,14 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         return torch.nn.functional.gelu(y) if gelu else y
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    if GEMM_KERNEL == "panel":
+        planes = _weight_planes(weight, cache_planes, "panel")
+        _lib.check(lib.isg_linear_panel(
+            _chk(x, "x", x.dtype), 1 if x.dtype == torch.float16 else 0, planes.data_ptr(),
+            _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
+            out.data_ptr(), 1 if out_dtype == torch.float16 else 0, M, N, K, K, N, 1 if gelu else 0, _stream()),
+            "isg_linear_panel")
+        return out
     planes = _weight_planes(weight, cache_planes)
     if f16_io:
         if M > 0:

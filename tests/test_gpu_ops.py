@@ -322,10 +322,17 @@ def test_per_graph_kernels_match_oracle(dev, C, sizes):
     (64, 600, 300, True, False),        # N = 300: not a multiple of 32
     (5, 384, 512, True, True),          # classifier input width 3C
     (1, 4, 8, True, False),
+    (4096, 512, 1842, True, False),     # answer classifier: N = 1842 (58 subtiles, tail of 18 columns)
+    (333, 2048, 512, True, False),      # text FFN second layer: 16 k chunks
+    (200, 136, 96, False, True),        # K just past one chunk (tail chunk of a single k-step)
+    (65, 300, 300, True, True),         # two panels, the second with one row; odd number of k-steps (19)
 ])
-def test_linear_bf16x6_has_fp32_accuracy(dev, M, K, N, bias, gelu):
-    """isg_linear_bf16x6 against an fp64 reference: the 3-way bf16 split must not cost accuracy relative to an fp32 GEMM."""
+@pytest.mark.parametrize("kernel", ["panel", "tile"])
+def test_linear_bf16x6_has_fp32_accuracy(dev, M, K, N, bias, gelu, kernel, monkeypatch):
+    """isg_linear_panel / isg_linear_bf16x6 against an fp64 reference: the 3-way bf16 split must not cost accuracy
+    relative to an fp32 GEMM."""
     from isubgvqa_amd import ops
+    monkeypatch.setattr(ops, "GEMM_KERNEL", kernel)
     gen = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=gen)
     w = torch.randn(N, K, generator=gen) / math.sqrt(K)
