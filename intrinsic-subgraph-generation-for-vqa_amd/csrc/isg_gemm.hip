@@ -77,7 +77,12 @@ __device__ __forceinline__ float4 gm_cvt(const gm_u32x2 &v) {
   return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
 }
 
-template <int ACT, int DBG, bool A16, bool D16, bool XCD>   // ACT: 0 none, 1 exact GELU; XCD: tile order, see below
+// DUAL (long reductions, K > 256): the five small product terms accumulate in a second accumulator, so that the main
+// chain takes ONE rounding at the magnitude of the result per 16-deep k-step instead of six -- a K-long sequential fp32
+// chain otherwise carries ~sqrt(6 K / 16) half-ulps of error (measured 4.2x a blocked CPU GEMM's at K = 1200, 4.4x at
+// K = 2048; 1.7x / 1.8x with the second accumulator).  Its 32 registers are paid for with one register image instead of
+// two (loads one k-tile ahead), which keeps 4 waves per SIMD.
+template <int ACT, int DBG, bool A16, bool D16, bool XCD, bool DUAL = false>   // ACT: 0 none, 1 exact GELU; XCD: tile order, see below
 __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__restrict__ A, const __bf16 *__restrict__ Wp,
                                                             const float *__restrict__ bias, float *__restrict__ D, int M,
                                                             int N, int K, int Kp, int lda, int ldd, int nt_store) {
@@ -113,13 +118,19 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
   }
   const int64_t plane_stride = (int64_t)N * Kp;
 
-  f32x16 acc[1][2];
+  f32x16 acc[1][2], acc2[DUAL ? 2 : 1];
 #pragma unroll
   for (int i = 0; i < 1; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+  }
 
   // two register images (tiles t+1 and t+2): a tile's global loads get two MFMA phases to land
   RawA ra0[2], ra1[2];          // A: 4 elements per thread per tile and u, raw (fp32: 16 B, fp16: 8 B)
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
     }                                                                                                          \
     __syncthreads();                                                                                           \
     if constexpr (!(DBG & 8))                                                                                  \
-      if ((kt) + 2 < nk) GM_LOAD_TILE(RA, RB, GM_KT((kt) + 2) * GM_BK) /* lands two MFMA phases from now */    \
+      if ((kt) + (DUAL ? 1 : 2) < nk) GM_LOAD_TILE(RA, RB, GM_KT((kt) + (DUAL ? 1 : 2)) * GM_BK) /* lands two (DUAL: one) MFMA phases from now */ \
     if constexpr (!(DBG & 2)) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                               \
       bf16x8 a[3], b[2][3];                                                                                    \
       _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                            \
@@ -196,6 +207,17 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
           keep(a[q]);                                                                                          \
           keep(b[0][q]);                                                                                       \
           keep(b[1][q]);                                                                                       \
+        }                                                                                                      \
+      } else if constexpr (DUAL) {                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+          f32x16 c2 = acc2[j];                                                                                 \
+          c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], c2, 0, 0, 0);                            \
+          c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], c2, 0, 0, 0);                            \
+          c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], c2, 0, 0, 0);                            \
+          c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], c2, 0, 0, 0);                            \
+          c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], c2, 0, 0, 0);                            \
+          acc2[j] = c2;                                                                                        \
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[0][j], 0, 0, 0);              \
         }                                                                                                      \
       } else _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
         f32x16 c = acc[0][j];                                                                                  \
@@ -211,10 +233,14 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
   }
 
   GM_LOAD_TILE(ra0, rb0, GM_KT(0) * GM_BK)
-  if (nk > 1) GM_LOAD_TILE(ra1, rb1, GM_KT(1) * GM_BK)
-  for (int kt = 0; kt < nk; kt += 2) {
-    GM_STEP(ra0, rb0, kt)
-    if (kt + 1 < nk) GM_STEP(ra1, rb1, kt + 1)
+  if constexpr (DUAL) {
+    for (int kt = 0; kt < nk; ++kt) GM_STEP(ra0, rb0, kt)
+  } else {
+    if (nk > 1) GM_LOAD_TILE(ra1, rb1, GM_KT(1) * GM_BK)
+    for (int kt = 0; kt < nk; kt += 2) {
+      GM_STEP(ra0, rb0, kt)
+      if (kt + 1 < nk) GM_STEP(ra1, rb1, kt + 1)
+    }
   }
 #undef GM_STEP
 #undef GM_LOAD_TILE
@@ -232,7 +258,9 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
     const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = acc[0][j][r] + bv;
+      float v = acc[0][j][r];
+      if constexpr (DUAL) v += acc2[j][r];
+      v += bv;
       if (ACT == 1) v = gelu_exact(v);
       patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + fr] = v;
     }
@@ -316,8 +344,7 @@ static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const
   // (x_l|x_r 337 MB, e_proj 420 MB) exceed the caches and are consumed by a LATER kernel -- which itself runs 6 % faster
   // when they were streamed -- while the operands (A re-read per n-tile, W planes) and the small results that the very
   // next kernel reads (x_proj, MLPs: <= 84 MB) should stay resident (profiles/r01_e, r01_q / r01_x)
-  const char *ntv = getenv("ISG_GEMM_NT_MB");
-  const long long nt_mb = ntv ? atoll(ntv) : 128;
+  static const long long nt_mb = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return e ? atoll(e) : 128ll; }();   // read once
   const int nt = nt_mb >= 0 && (long long)M * N * (d16 ? 2 : 4) >= nt_mb * 1000000ll;
   dim3 gridx(grid.x, (grid.y + 7) / 8 * 8);
 #ifdef ISG_GEMM_ABLATION   // profiling build only (tools/build_ablation.sh): select a compile-time ablated variant by env
@@ -327,10 +354,16 @@ static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const
   ISG_DBG_CASE(1) ISG_DBG_CASE(3) ISG_DBG_CASE(7) ISG_DBG_CASE(15) ISG_DBG_CASE(16) ISG_DBG_CASE(31) ISG_DBG_CASE(8) ISG_DBG_CASE(4)
 #undef ISG_DBG_CASE
 #endif
-  const bool xcd = grid.x > 1 && getenv("ISG_GEMM_NO_XCD") == nullptr;
+  static const bool xcd_on = getenv("ISG_GEMM_NO_XCD") == nullptr;   // read once
+  const bool xcd = grid.x > 1 && xcd_on;
+  static const int dual_k = [] { const char *e = getenv("ISG_GEMM_DUAL_K"); return e ? atoi(e) : 256; }();   // read once
+  const bool dual = K > dual_k;
 #define ISG_LIN(ACT_, A_, D_)                                                                                                \
   do {                                                                                                                       \
-    if (xcd) linear_bf16x6_kernel<ACT_, 0, A_, D_, true><<<gridx, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
+    if (dual) {                                                                                                              \
+      if (xcd) linear_bf16x6_kernel<ACT_, 0, A_, D_, true, true><<<gridx, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
+      else linear_bf16x6_kernel<ACT_, 0, A_, D_, false, true><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
+    } else if (xcd) linear_bf16x6_kernel<ACT_, 0, A_, D_, true><<<gridx, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
     else linear_bf16x6_kernel<ACT_, 0, A_, D_, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
   } while (0)
   if (!a16 && !d16) { if (act == 1) ISG_LIN(1, false, false); else ISG_LIN(0, false, false); }

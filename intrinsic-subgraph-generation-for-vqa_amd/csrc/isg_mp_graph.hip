@@ -254,8 +254,8 @@ static int launch_sized(MpArgs a, int nmax_host, hipStream_t st) {
   const size_t static_bytes = (size_t)EC * 16 + (size_t)EC * HS * 4 + (NC + 4) * 4;
   // LDS window: as many x_l rows as fit 40 KB per workgroup (4 workgroups = 32 waves per CU), never more than the
   // largest graph needs; rows beyond the window are read from global memory
-  const char *kb = getenv("ISG_MP_LDS_KB");
-  const size_t budget = (size_t)(kb ? atoi(kb) : 40) * 1024;
+  static const int lds_kb = [] { const char *e = getenv("ISG_MP_LDS_KB"); return e ? atoi(e) : 40; }();   // read once, at first use
+  const size_t budget = (size_t)lds_kb * 1024;
   if (budget < static_bytes + 8 * row_bytes) return ISG_EUNSUPPORTED;
   a.lrows = (int)((budget - static_bytes) / row_bytes);
   if (a.lrows > nmax_host) a.lrows = nmax_host;
@@ -296,7 +296,8 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   // one head per workgroup whose row needs a second, mostly idle pass (the reference's default C = 300: 75 of 128 lane
   // slots, and the CSR tables staged once per HEAD): the node-chunk kernel is faster there (tools/time_mp_c300.py:
   // 672 vs 762 us at H = 4, C = 300 on the configs[1] topology)
-  if (HS == 1 && a.H > 1 && P == 2 && Q * 10 < G * P * 7 && getenv("ISG_MP_FORCE_GRAPH") == nullptr) return ISG_EUNSUPPORTED;
+  static const bool force_graph = getenv("ISG_MP_FORCE_GRAPH") != nullptr;   // read once
+  if (HS == 1 && a.H > 1 && P == 2 && Q * 10 < G * P * 7 && !force_graph) return ISG_EUNSUPPORTED;
 #define ISG_GK(hs, p) if (HS == hs && P == p) return launch_one<hs, p>(a, nmax_host, emax_host, st)
   ISG_GK(1, 1); ISG_GK(1, 2);
   ISG_GK(2, 1); ISG_GK(2, 2);

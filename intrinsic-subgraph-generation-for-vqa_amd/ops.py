@@ -660,8 +660,17 @@ def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional
 # Dense projections: fp32 accuracy on the bf16 matrix cores (csrc/isg_gemm.hip)
 # ------------------------------------------------------------------------------------------------
 GEMM_BACKEND = "bf16x6"      # "bf16x6": this library's kernels; "torch": hipBLASLt fp32 through torch (A/B switch)
-GEMM_KERNEL = "panel"        # "panel": isg_linear_panel (row panels, W fragment-major); "tile": isg_linear_bf16x6
 _PLANES = {}                 # (id(weight), layout) -> (weakref, version, data_ptr, planes): static weights are split once
+GEMM_KERNEL = "auto"         # "auto": per shape (below); "panel": isg_linear_panel; "tile": isg_linear_bf16x6 (A/B switch)
+
+
+def _use_panel(M: int, N: int, K: int) -> bool:
+    """The row-panel kernel wins where an A panel is split once and serves many columns (K <= 128: lin_edge 182 vs 212 us,
+    lin_l|lin_r 153 vs 166 us) and there are enough 64-row panels to fill the chip; the tile kernel elsewhere
+    (profiles/r02_a_gemm_structures.md)."""
+    if GEMM_KERNEL != "auto":
+        return GEMM_KERNEL == "panel"
+    return K <= 128 and N >= 256 and M >= 32768
 
 
 def invalidate_weight_cache() -> None:
@@ -716,7 +725,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         return torch.nn.functional.gelu(y) if gelu else y
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
-    if GEMM_KERNEL == "panel":
+    if _use_panel(M, N, K):
         planes = _weight_planes(weight, cache_planes, "panel")
         _lib.check(lib.isg_linear_panel(
             _chk(x, "x", x.dtype), 1 if x.dtype == torch.float16 else 0, planes.data_ptr(),

@@ -21,7 +21,7 @@ def test_library_exports_every_symbol_in_header():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.isg_abi_version() == 6
+    assert lib.isg_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define ISG_ABI_VERSION (\d+)", header).group(1))
     assert lib.isg_status_string(-2) == b"unsupported shape"
     assert lib.isg_csr_workspace_bytes(10, 7) == (2 * 11 + 7 + 2) * 4
 
