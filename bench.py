@@ -48,6 +48,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-model", action="store_true", help="skip the configs[2] stand-in (full model at C = 300)")
+    ap.add_argument("--full-model-graphs", type=int, default=4096)
     ap.add_argument("--cpu-sample-graphs", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads for the CPU baseline (capped at the host's)")
@@ -120,6 +122,87 @@ def cpu_baseline(cfg, sample_graphs: int, seconds: float, threads: int):
             "sample": f"{passes} passes x {sample_graphs} graphs of the configs[1] distribution "
                       f"(N={wl.x.size(0)}, E={wl.edge_index.size(1)}) in {dt:.1f} s, torch CPU fp32, "
                       f"{threads} threads of {os.cpu_count()} logical cores"}
+
+
+def cpu_model_string() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_cfg1(seconds: float = 8.0):
+    """SURVEY §8(d) / BASELINE configs[0] exactly: 256 graphs as 8 batches of 32 (<= 16 nodes, <= 32 edges), C = 300, 4 MGAT
+    layers, masks [1, 1, 1, 0.15], Gumbel k = 5 with explicit noise, the oracle under no_grad on ALL host threads."""
+    import torch
+    from isubgvqa_amd import synthetic
+    from oracle import model as OM
+    from oracle import samplers as OS
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    batches = []
+    for b in range(8):
+        scfg = synthetic.WorkloadConfig(**{**synthetic.CFG1.__dict__, "seed": synthetic.CFG1.seed + b})
+        wl = synthetic.make_workload(scfg)
+        gen = torch.Generator().manual_seed(100 + b)
+        noises = {i: OS.uniform_to_gumbel(torch.rand(scfg.num_graphs, wl.max_nodes, generator=gen))
+                  for i, t in enumerate(scfg.masks) if t != 1.0}
+        batches.append((wl, noises))
+    model = synthetic.build_answer_model(synthetic.CFG1).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ocfg = OM.PathConfig(heads=4, masking_thresholds=list(synthetic.CFG1.masks), use_topk=True, sampler_type="gumbel",
+                         sample_k=synthetic.CFG1.sample_k)
+
+    def one_pass():
+        for wl, noises in batches:
+            OM.mgat_pool_classify(sd, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, ocfg, noises)
+
+    times = []
+    with torch.no_grad():
+        one_pass()
+        one_pass()
+        t_end = time.perf_counter() + seconds
+        while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 100):
+            t0 = time.perf_counter()
+            one_pass()
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(256 / med, 1), "unit": "questions/s", "cores": threads, "kind": "port",
+            "cpu": cpu_model_string(),
+            "sample": f"BASELINE configs[0]: 256 graphs = 8 batches x 32 (<= 16 nodes, <= 32 edges), C=300, 4 layers, "
+                      f"masks [1,1,1,0.15], Gumbel k=5; median of {len(times)} passes ({med * 1e3:.1f} ms/pass), "
+                      f"torch CPU fp32, all {threads} logical cores"}
+
+
+def full_model_rate(dev, graphs: int, steps: int = 10):
+    """BASELINE configs[2] stand-in, measured in the same run: the FULL model (question encoder/decoder, scene-graph
+    encoder, 4 MGAT layers at C = 300, I-MLE k = 5, pooling, classifier) on GQA-shaped synthetic token batches."""
+    import torch
+    from isubgvqa_amd import synthetic
+    from isubgvqa_amd.models import build_model
+    torch.manual_seed(0)
+    model = build_model(synthetic.full_model_args(), None).to(dev).eval()
+    wl = synthetic.make_full_workload(graphs).to(dev)
+    sg = wl.scene_graphs()
+    with torch.no_grad():
+        for _ in range(3):
+            out = model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True,
+                        scene_graphs=sg)[0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True,
+                        scene_graphs=sg)[0]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out).all()
+    return {"workload": "BASELINE configs[2] stand-in: full ISubGVQA model, C=300, 4 MGAT layers, I-MLE k=5, 12-token "
+                        "questions, GQA-shaped synthetic scene graphs (no GQA data in the container)",
+            "graphs": graphs, "nodes": int(wl.x.size(0)), "edges": int(wl.edge_index.size(1)),
+            "ms_per_step": round(dt * 1e3, 3), "questions_per_s": round(graphs / dt, 1), "steps": steps}
 
 
 def load_traffic(N: int, E: int, kernel: str):
@@ -257,8 +340,15 @@ def main(argv=None):
                          "avg_launch_us": round(mp_ms * 1e3, 2), "launches_timed": len(durs)},
         }
         res["rccl"] = rccl
+        if world == 1 and not args.no_full_model:
+            del model, wl
+            torch.cuda.empty_cache()
+            res["full_model"] = full_model_rate(dev, args.full_model_graphs)
+        ops.check_plans()           # any understated GraphPlan hint of this run raises here
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_graphs, args.cpu_seconds, args.cpu_threads)
+            res["cpu_baseline"]["cpu"] = cpu_model_string()
+            res["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

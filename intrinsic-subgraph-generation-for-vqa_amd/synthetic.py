@@ -171,3 +171,61 @@ def build_answer_model(cfg: WorkloadConfig, weight_seed: int = 0) -> AnswerModel
             if "bns" in name or name.endswith(".bias"):
                 p.add_(0.05 * torch.randn(p.shape, generator=g))
     return m
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] stand-in: the FULL model (question encoder / decoder, scene-graph encoder, MGAT, pooling, classifier)
+# at the reference's default width on GQA-shaped synthetic A0 tensors (no GQA data in either container)
+# ----------------------------------------------------------------------------------------------------------------
+def full_model_args(**overrides):
+    """The argparse namespace `build_model` reads (ISubGVQA/utils/arg_parser.py defaults that reach the path)."""
+    import argparse
+    d = dict(text_sampling=False, general_hidden_dim=300, distributed=False, mgat_layers=4, use_all_instrs=False,
+             use_global_mask=False, node_classification=False, sampler_type="imle", sample_k=5, nb_samples=1, alpha=1.0,
+             beta=10.0, tau=1.0, use_masking=True, use_instruction=1, use_mgat=True, mgat_masks=[1.0, 1.0, 1.0, 0.15],
+             use_topk=True, interpretable_mode=False, concat_instr=0, embed_cat=0, device="cpu", text_vocab_size=49408,
+             sg_vocab_size=2578)
+    d.update(overrides)
+    return argparse.Namespace(**d)
+
+
+@dataclass
+class FullWorkload:
+    x: Tensor                 # [N, 4] token ids (name + <= 3 attributes, pad id 1)
+    edge_index: Tensor
+    edge_attr: Tensor         # [E] relation token ids
+    batch: Tensor
+    x_bbox: Tensor            # [N, 4] ints
+    added_sym_edge: Tensor    # per-graph LOCAL edge positions, concatenated without offset (quirk Q6)
+    questions: Tensor         # [B, T] CLIP token ids
+    att_mask: Tensor          # [B, T] 1 = real token
+    max_nodes: int
+    max_edges: int
+
+    def to(self, device) -> "FullWorkload":
+        mv = lambda t: t.to(device)
+        return FullWorkload(mv(self.x), mv(self.edge_index), mv(self.edge_attr), mv(self.batch), mv(self.x_bbox),
+                            mv(self.added_sym_edge), mv(self.questions), mv(self.att_mask), self.max_nodes, self.max_edges)
+
+    def scene_graphs(self):
+        import argparse
+        return argparse.Namespace(x_bbox=self.x_bbox, added_sym_edge=self.added_sym_edge, max_nodes=self.max_nodes,
+                                  max_edges=self.max_edges)
+
+
+def make_full_workload(num_graphs: int, tokens: int = 12, seed: int = 7, sg_vocab: int = 2578,
+                       text_vocab: int = 49408) -> FullWorkload:
+    gen = torch.Generator().manual_seed(seed + 1)
+    cfg = WorkloadConfig(num_graphs=num_graphs, seed=seed)
+    batch, ei, nmax = make_topology(cfg, gen)
+    N, E = batch.numel(), ei.size(1)
+    x = torch.randint(0, sg_vocab, (N, 4), generator=gen)
+    x[:, 1:][torch.rand(N, 3, generator=gen) < 0.5] = 1
+    edge_attr = torch.randint(0, sg_vocab, (E,), generator=gen)
+    x_bbox = torch.randint(0, 640, (N, 4), generator=gen)
+    sym = torch.randint(0, 10, (num_graphs,), generator=gen)
+    q = torch.randint(0, text_vocab, (num_graphs, tokens), generator=gen)
+    lens = torch.randint(max(1, tokens // 2), tokens + 1, (num_graphs,), generator=gen)
+    qmask = (torch.arange(tokens)[None] < lens[:, None]).long()
+    emax = int(torch.bincount(batch[ei[1]], minlength=num_graphs).max())
+    return FullWorkload(x, ei, edge_attr, batch, x_bbox, sym, q, qmask, nmax, emax)

@@ -383,7 +383,7 @@ def test_full_model_matches_the_reference_forward_golden(dev, ci):
     err = (logits.cpu() - case["logits"]).abs().max().item()
     print(f"G10[{ci}] HIP vs REFERENCE: e_enc {e_err:.2e}  x_enc {x_err:.2e}  enc/dec {t_err:.2e}  logits {err:.3e}")
     # e_enc is not normalised (bbox pixels through BatchNorm: |e_enc| up to ~90), so its bound is relative to the tensor
-    assert e_err < 3e-6 * case["e_enc"].abs().max().item() and x_err < 5e-5 and t_err < 3e-5
+    assert e_err < 3e-6 * case["e_enc"].abs().max().item() and x_err < LOGIT_TOL and t_err < 3e-5
     assert torch.equal(mask.cpu() > 0.5, case["mask"] > 0.5), "top-k node mask differs from the reference"
     assert err < LOGIT_TOL
     assert torch.allclose(gate.cpu(), case["gate"], atol=1e-5)

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the FULL ISubGVQA model (BASELINE configs[2] shape: C = 300, 4 MGAT layers, I-MLE k = 5, question
 encoder/decoder included) on GQA-shaped synthetic token batches.   python3 tools/time_full_model.py [graphs] [steps]"""
-import argparse
 import os
 import sys
 import time
@@ -15,30 +14,15 @@ from isubgvqa_amd.models import build_model
 graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
-args = argparse.Namespace(text_sampling=False, general_hidden_dim=300, distributed=False, mgat_layers=4, use_all_instrs=False,
-                          use_global_mask=False, node_classification=False, sampler_type="imle", sample_k=5, nb_samples=1,
-                          alpha=1.0, beta=10.0, tau=1.0, use_masking=True, use_instruction=1, use_mgat=True,
-                          mgat_masks=[1.0, 1.0, 1.0, 0.15], use_topk=True, interpretable_mode=False, concat_instr=0,
-                          embed_cat=0, device="cpu", text_vocab_size=49408, sg_vocab_size=2578)
 torch.manual_seed(0)
-model = build_model(args, None).to(dev).eval()
-gen = torch.Generator().manual_seed(1)
-cfg = synthetic.WorkloadConfig(num_graphs=graphs, seed=7)
-batch, ei, nmax = synthetic.make_topology(cfg, gen)
-N, E, T = batch.numel(), ei.size(1), 12
-x = torch.randint(0, 2578, (N, 4), generator=gen)
-x[:, 1:][torch.rand(N, 3, generator=gen) < 0.5] = 1
-edge_attr = torch.randint(0, 2578, (E,), generator=gen)
-sg = argparse.Namespace(x_bbox=torch.randint(0, 640, (N, 4), generator=gen).to(dev),
-                        added_sym_edge=torch.randint(0, 10, (graphs,), generator=gen).to(dev), max_nodes=nmax,
-                        max_edges=int(torch.bincount(batch[ei[1]], minlength=graphs).max()))
-q = torch.randint(0, 49408, (graphs, T), generator=gen).to(dev)
-qmask = (torch.arange(T)[None] < torch.randint(6, T + 1, (graphs,), generator=gen)[:, None]).long().to(dev)
-x, ei, edge_attr, batch = x.to(dev), ei.to(dev), edge_attr.to(dev), batch.to(dev)
+model = build_model(synthetic.full_model_args(), None).to(dev).eval()
+wl = synthetic.make_full_workload(graphs).to(dev)
+sg = wl.scene_graphs()
 
 
 def step():
-    return model(x, ei, edge_attr, batch, q, qmask, return_masks=True, scene_graphs=sg)[0]
+    return model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True,
+                 scene_graphs=sg)[0]
 
 
 with torch.no_grad():
@@ -50,4 +34,5 @@ with torch.no_grad():
         out = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-print(f"full model, {graphs} graphs (N={N}, E={E}, T={T}): {dt * 1e3:.2f} ms/step = {graphs / dt:,.0f} questions/s")
+print(f"full model, {graphs} graphs (N={wl.x.size(0)}, E={wl.edge_index.size(1)}, T={wl.questions.size(1)}): "
+      f"{dt * 1e3:.2f} ms/step = {graphs / dt:,.0f} questions/s")
