@@ -292,7 +292,8 @@ int isg_split_bf16x3(const float *w, int64_t rows, int32_t K, uint16_t *planes, 
 /* d[M,N] = act(a[M,K] @ W[N,K]^T + bias):  torch.nn.Linear / PyG Linear (+ the GELU that follows it) as used by
  * ISubGVQA/models/mgat_v2_conv.py:177,181,259, mgat.py:156, masking.py:137,152, att_pooling.py:62,66.
  * a fp32 with row stride lda; w_planes from isg_split_bf16x3; bias fp32[N] or NULL; d fp32 with row stride ldd;
- * act 0 = none, 1 = exact (erf) GELU.  Products are formed from the three bf16 planes of both operands (six MFMA
+ * act 0 = none, 1 = exact (erf) GELU, 2 = ReLU (nn.TransformerEncoderLayer's FFN, question_encoder.py:22-25; fp32 rows
+ * only).  Products are formed from the three bf16 planes of both operands (six MFMA
  * terms, fp32 accumulate): fp32-level accuracy (rel. rms ~1e-7) at bf16 matrix-core speed.
  * Requires 4 | K, 4 | lda, a 16-byte aligned. */
 int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const float *bias, float *d, int64_t M, int32_t N,
@@ -317,6 +318,34 @@ int isg_split_bf16x3_frag(const float *w, int64_t rows, int32_t K, uint16_t *pla
 int isg_linear_panel(const void *a, int32_t a_is_f16, const uint16_t *w_frag, const float *bias, void *d,
                      int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
                      void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scene-graph encoder (ISubGVQA/models/scene_graph_encoder.py:108-143) without its concatenations
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[e,:] = act( A[ia[e],:] + B[ib[e],:] + sign[e] * T[it[e],:] + D[e,:] + bias ),  e < E, C columns, fp32.
+ * Replaces Linear(cat([x[row], x[col], emb])) of EdgeModel (:119-120) and Linear(cat([x[row], e'])) of NodeModel
+ * (:139-140): the node parts are projected once per NODE (A, B: rows gathered by int64 index), the edge-token part is a
+ * row of a projected [vocabulary, C] table (T, with the added_sym_edge sign, :80), D is a per-edge dense term.  B / T /
+ * D / sign / bias may be NULL.  lda / ldb / ldt / ldd: row strides in floats (multiples of 4, so column slices of a wider
+ * projection are valid operands); every pointer 16-byte aligned; act 0 = none, 1 = exact GELU. */
+int isg_gather_add(const float *A, const int64_t *ia, int32_t lda, const float *B, const int64_t *ib, int32_t ldb,
+                   const float *T, const int64_t *it, const float *sign, int32_t ldt, const float *D, int32_t ldd,
+                   const float *bias, float *out, int64_t E, int32_t C, int32_t act, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Question encoder / program decoder attention (ISubGVQA/models/question_encoder.py:20-38, question_decoder.py:25-71)
+ * ------------------------------------------------------------------------------------------- */
+
+/* out = softmax(Q K^T / sqrt(hd) + key_bias) V per (batch item, head), for the short sequences of this model (Tk <= 128,
+ * hd <= 64): what nn.MultiheadAttention computes inside nn.TransformerEncoderLayer / DecoderLayer.  Rows follow torch's
+ * [T, B, D] layout (row t * B + b), heads are consecutive hd-column blocks; q / k / v may be column slices of one fused
+ * projection (ldq / ldk / ldv: row strides in floats).  key_bias fp32 [B, Tk] or NULL is ADDED to the scores -- the
+ * reference passes the HF attention mask as a FLOAT src_key_padding_mask (question_encoder.py:35-37: +1 on real tokens,
+ * padding is attended).  out fp32 rows of H * hd columns, stride ldo. */
+int isg_mha_small(const float *q, int32_t ldq, const float *k, int32_t ldk, const float *v, int32_t ldv,
+                  const float *key_bias, float *out, int32_t ldo, int64_t B, int32_t H, int32_t hd, int32_t Tq, int32_t Tk,
+                  void *stream);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,10 @@ SIGNATURES = {
     "isg_split_bf16x3_frag": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "isg_linear_panel": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                  c_int32, c_int32, c_int32, c_void_p]),
+    "isg_gather_add": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                               c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "isg_mha_small": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int64,
+                              c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

@@ -1,0 +1,96 @@
+// Multi-head attention over SHORT sequences: the question encoder / program decoder of ISubGVQA
+// (ISubGVQA/models/question_encoder.py:20-38, question_decoder.py:25-71: nn.TransformerEncoder / Decoder, d = 512,
+// 8 heads of 64, T <= 77 CLIP tokens, 4 instruction queries).  softmax(Q K^T / sqrt(hd) + key_bias) V per (batch item, head).
+//
+// The reference hands torch's MultiheadAttention a FLOAT key-padding mask, which torch ADDS to the scores (+1 on real
+// tokens, pads attended: SURVEY App. B Q5); `key_bias` is that additive term.  A question's K and V for one head are
+// T x 64 floats: they live in LDS for the whole workgroup, there is no tiling, no online softmax and nothing to
+// re-read -- one workgroup per (batch item, head), one wave per query row:
+//   scores   lane = key (two keys per lane beyond 64): dot over the head dimension from LDS (K rows padded by one float:
+//            conflict-free), scaled, biased
+//   softmax  wave max / libm expf / wave sum / IEEE divide
+//   P V      lane = channel: sum over the keys of p_s V[s][c] in key order
+// Rows follow torch's [T, B, D] layout (row = t * B + b), so q / k / v may be column slices of the fused in_proj output.
+#include "isg_common.hpp"
+
+namespace isg {
+
+struct MhaArgs {
+  const float *q, *k, *v, *key_bias;
+  float *out;
+  int B, H, hd, Tq, Tk, ldq, ldk, ldv, ldo;
+  float scale;
+};
+
+__global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
+  extern __shared__ float smem[];
+  const int hd = a.hd, Tk = a.Tk, kp = hd + 1;
+  float *Ks = smem;                       // [Tk][hd + 1]
+  float *Vs = Ks + (size_t)Tk * kp;       // [Tk][hd]
+  float *qs = Vs + (size_t)Tk * hd;       // [4][64]
+  float *ps = qs + 4 * 64;                // [4][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int col0 = h * hd;
+  for (int idx = tid; idx < Tk * hd; idx += 256) {
+    const int s = idx / hd, c = idx - s * hd;
+    const size_t row = (size_t)s * a.B + b;
+    Ks[s * kp + c] = a.k[row * a.ldk + col0 + c];
+    Vs[s * hd + c] = a.v[row * a.ldv + col0 + c];
+  }
+  __syncthreads();
+  float *qw = qs + wave * 64, *pw = ps + wave * 128;
+  for (int tq = wave; tq < a.Tq; tq += 4) {
+    const size_t qrow = (size_t)tq * a.B + b;
+    if (lane < hd) qw[lane] = a.q[qrow * a.ldq + col0 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float sc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int s = j * 64 + lane;
+      sc[j] = -INFINITY;
+      if (s < Tk) {
+        float dot = 0.f;
+        const float *kr = Ks + s * kp;
+        for (int c = 0; c < hd; ++c) dot = fmaf(qw[c], kr[c], dot);
+        dot *= a.scale;
+        if (a.key_bias) dot += a.key_bias[(size_t)b * Tk + s];
+        sc[j] = dot;
+      }
+    }
+    const float mx = wave_max(fmaxf(sc[0], sc[1]));
+    const float e0 = sc[0] == -INFINITY ? 0.f : expf(sc[0] - mx);
+    const float e1 = sc[1] == -INFINITY ? 0.f : expf(sc[1] - mx);
+    const float den = wave_sum(e0 + e1);
+    if (lane < Tk) pw[lane] = e0 / den;
+    if (64 + lane < Tk) pw[64 + lane] = e1 / den;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < hd) {
+      float o = 0.f;
+      for (int s = 0; s < Tk; ++s) o = fmaf(pw[s], Vs[s * hd + lane], o);
+      a.out[qrow * a.ldo + col0 + lane] = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace isg
+
+using namespace isg;
+
+extern "C" int isg_mha_small(const float *q, int32_t ldq, const float *k, int32_t ldk, const float *v, int32_t ldv,
+                             const float *key_bias, float *out, int32_t ldo, int64_t B, int32_t H, int32_t hd, int32_t Tq,
+                             int32_t Tk, void *stream) {
+  if (B < 0 || H <= 0 || hd <= 0 || Tq < 0 || Tk <= 0) return ISG_EINVAL;
+  if (B == 0 || Tq == 0) return ISG_OK;
+  if (!q || !k || !v || !out) return ISG_EINVAL;
+  if (hd > 64 || Tk > 128 || B * H >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  if (ldq < H * hd || ldk < H * hd || ldv < H * hd || ldo < H * hd) return ISG_EINVAL;
+  MhaArgs a{q, k, v, key_bias, out, (int)B, H, hd, Tq, Tk, ldq, ldk, ldv, ldo, (float)(1.0 / sqrt((double)hd))};
+  const size_t lds = ((size_t)Tk * (2 * hd + 1) + 4 * 64 + 4 * 128) * sizeof(float);
+  if (lds > 64 * 1024) return ISG_EUNSUPPORTED;
+  mha_small_kernel<<<(unsigned)(B * H), 256, lds, as_stream(stream)>>>(a);
+  return check_launch();
+}

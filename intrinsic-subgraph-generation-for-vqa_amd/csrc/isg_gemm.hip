@@ -82,7 +82,7 @@ __device__ __forceinline__ float4 gm_cvt(const gm_u32x2 &v) {
 // chain otherwise carries ~sqrt(6 K / 16) half-ulps of error (measured 4.2x a blocked CPU GEMM's at K = 1200, 4.4x at
 // K = 2048; 1.7x / 1.8x with the second accumulator).  Its 32 registers are paid for with one register image instead of
 // two (loads one k-tile ahead), which keeps 4 waves per SIMD.
-template <int ACT, int DBG, bool A16, bool D16, bool XCD, bool DUAL = false>   // ACT: 0 none, 1 exact GELU; XCD: tile order, see below
+template <int ACT, int DBG, bool A16, bool D16, bool XCD, bool DUAL = false>   // ACT: 0 none, 1 exact GELU, 2 ReLU; XCD: tile order, see below
 __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__restrict__ A, const __bf16 *__restrict__ Wp,
                                                             const float *__restrict__ bias, float *__restrict__ D, int M,
                                                             int N, int K, int Kp, int lda, int ldd, int nt_store) {
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
       if constexpr (DUAL) v += acc2[j][r];
       v += bv;
       if (ACT == 1) v = gelu_exact(v);
+      if (ACT == 2) v = v < 0.f ? 0.f : v;   // ReLU (a NaN stays a NaN, as in torch)
       patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + fr] = v;
     }
     __builtin_amdgcn_wave_barrier();
@@ -328,7 +329,7 @@ extern "C" int isg_split_bf16x3(const float *w, int64_t rows, int32_t K, uint16_
 
 static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const float *bias, void *d, int d16,
                          int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream) {
-  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 1) return ISG_EINVAL;
+  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 2) return ISG_EINVAL;
   if (M == 0) return ISG_OK;
   if (!a || !w_planes || !d) return ISG_EINVAL;
   // 4-element loads of A need aligned rows (16 bytes fp32, 8 bytes fp16) and K a multiple of 4
@@ -366,7 +367,8 @@ static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const
     } else if (xcd) linear_bf16x6_kernel<ACT_, 0, A_, D_, true><<<gridx, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
     else linear_bf16x6_kernel<ACT_, 0, A_, D_, false><<<grid, block, 0, st>>>((const float *)a, wp, bias, (float *)d, (int)M, N, K, Kp, lda, ldd, nt); \
   } while (0)
-  if (!a16 && !d16) { if (act == 1) ISG_LIN(1, false, false); else ISG_LIN(0, false, false); }
+  if (!a16 && !d16) { if (act == 1) ISG_LIN(1, false, false); else if (act == 2) ISG_LIN(2, false, false); else ISG_LIN(0, false, false); }
+  else if (act == 2) return ISG_EUNSUPPORTED;   // ReLU exists for the fp32 text encoder only
   else if (a16 && !d16) { if (act == 1) ISG_LIN(1, true, false); else ISG_LIN(0, true, false); }
   else if (!a16 && d16) { if (act == 1) ISG_LIN(1, false, true); else ISG_LIN(0, false, true); }
   else { if (act == 1) ISG_LIN(1, true, true); else ISG_LIN(0, true, true); }

@@ -22,6 +22,7 @@ import torch
 from .. import ops
 from .layers import GraphNorm
 
+SPLIT_LINEARS = True    # inference path without the [E, 900] / [E, 600] concatenations (A/B switch for tests and tools)
 SG_VOCAB_SIZE = 2578   # reconstruction of the reference's torchtext vocab over meta_info/* 
 
 
@@ -62,6 +63,28 @@ class _MetaLayer(torch.nn.Module):
         edge_attr = self.edge_model(x[row], x[col], edge_attr)
         return self.node_model(x, edge_index, edge_attr, plan), edge_attr
 
+    def forward_split(self, x, edge_index, edge_tokens, edge_sign, embedding, plan):
+        """The same MetaLayer round without the [E, 900] / [E, 600] concatenations (inference; csrc/isg_sgenc.hip):
+        a Linear over cat([x[row], x[col], e]) is W_a x[row] + W_b x[col] + W_c e, so the node parts are projected once
+        per NODE, W_c emb[token] is a row of a [vocabulary, C] table (the added_sym_edge sign commutes), and what is left
+        per edge is a gather-add + GELU.  Same for node_mlp_1 over cat([x[row], e']).  1.67x fewer flops."""
+        em, nm = self.edge_model.edge_mlp, self.node_model.node_mlp_1
+        nf, C = x.size(1), em[0].weight.size(0)
+        w_nodes = ops.derived_weight("sg_nodes", (em[0].weight, nm[0].weight), lambda: torch.cat(
+            [em[0].weight[:, :nf], em[0].weight[:, nf:2 * nf], nm[0].weight[:, :nf]], dim=0).contiguous())
+        w_tok = ops.derived_weight("sg_tok", (em[0].weight,), lambda: em[0].weight[:, 2 * nf:].contiguous())
+        w_e = ops.derived_weight("sg_e", (nm[0].weight,), lambda: nm[0].weight[:, nf:].contiguous())
+        row, col = edge_index[0].contiguous(), edge_index[1].contiguous()
+        P = ops.linear(x, w_nodes, None)                                   # [N, 3C]: W_a x | W_b x | W_x x
+        table = ops.linear(embedding.weight, w_tok, None)                  # [V, C]: W_c emb
+        h = ops.gather_add(P[:, :C], row, P[:, C:2 * C], col, table, edge_tokens, edge_sign, bias=em[0].bias, gelu=True)
+        e_new = ops.linear(h, em[2].weight, em[2].bias)                    # :119-120 second layer
+        g = ops.linear(e_new, w_e, None)                                   # W_e e'
+        h = ops.gather_add(P[:, 2 * C:], row, D=g, bias=nm[0].bias, gelu=True)
+        m = ops.linear(h, nm[2].weight, nm[2].bias)                        # :139-140
+        agg = ops.scatter_mean(m, plan)                                    # :141
+        return ops.mlp(self.node_model.node_mlp_2, torch.cat([x, agg], dim=1)), e_new   # :142-143
+
 
 class SceneGraphEncoder(torch.nn.Module):
     def __init__(self, hidden_dim, dist=False, vocab_size: int = SG_VOCAB_SIZE, pad_idx: Optional[int] = 1):
@@ -86,13 +109,21 @@ class SceneGraphEncoder(torch.nn.Module):
         x_embed_sum = x if first else torch.sum(self.sg_vocab_embedding(x), dim=-2)      # :63-70
         x_bbox = ops.mlp(self.bbox_encoding, gt_scene_graphs.x_bbox.to(dtype=x_embed_sum.dtype))   # :72
         x_embed_sum = ops.mlp(self.feat_reduc, torch.cat((x_embed_sum, x_bbox), dim=1))  # :73-74
-        edge_embed = self.sg_vocab_embedding(edge_attr)                                  # :76
         sym = gt_scene_graphs.added_sym_edge
-        if sym is not None and sym.numel() > 0:
-            edge_embed[sym, :] = edge_embed[sym, :] * -1                                 # :80
         if plan is None:
             plan = ops.GraphPlan.build(batch, edge_index)
-        x_enc, e_enc = self.scene_graph_encoding_layer(x_embed_sum, edge_index, edge_embed, plan)   # :91-97
+        split = SPLIT_LINEARS and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        if split:   # inference: no [E, 900] concatenation (forward_split); the sign of :80 rides along as a vector
+            sign = torch.ones(edge_attr.numel(), dtype=torch.float32, device=edge_attr.device)
+            if sym is not None and sym.numel() > 0:
+                sign[sym] = -1.0                                                         # :80 (duplicates: flipped once)
+            x_enc, e_enc = self.scene_graph_encoding_layer.forward_split(
+                x_embed_sum.contiguous(), edge_index, edge_attr.contiguous(), sign, self.sg_vocab_embedding, plan)
+        else:
+            edge_embed = self.sg_vocab_embedding(edge_attr)                              # :76
+            if sym is not None and sym.numel() > 0:
+                edge_embed[sym, :] = edge_embed[sym, :] * -1                             # :80
+            x_enc, e_enc = self.scene_graph_encoding_layer(x_embed_sum, edge_index, edge_embed, plan)   # :91-97
         gn = self.graph_layer_norm
         if x_enc.size(1) != gn.in_channels:
             raise RuntimeError(f"GraphNorm({gn.in_channels}) applied to {x_enc.size(1)} channels: the full model only "

@@ -11,7 +11,11 @@ Reference behaviour:
     not applied (:33-34).
   * QuestionDecoder, ISubGVQA/models/question_decoder.py:4-71: n_instructions learned queries through a
     3-layer post-norm TransformerDecoder over the encoder memory, no masks.
-These are plain dense contractions: they run on torch's rocBLAS/hipBLASLt MFMA GEMMs.
+Device work (inference): the torch modules only HOLD the parameters (so the state_dict keys are the reference's); the
+forward pass below walks their layers itself: every projection and FFN layer is one launch of this library's bf16x6
+matrix-core kernel with bias (+ReLU) fused (ops.linear: in_proj 512->1536 as ONE GEMM, out_proj, linear1+ReLU, linear2),
+attention is isg_mha_small (csrc/isg_attn.hip: a question's K / V live in LDS, the float key-padding mask is the additive
+bias it is in the reference), residual + LayerNorm stay torch ops.  Training (autograd recording) runs the torch modules.
 """
 from __future__ import annotations
 
@@ -19,6 +23,42 @@ import math
 
 import torch
 from torch import Tensor
+
+from .. import ops
+
+FUSED_TEXT = True     # inference path on this library's kernels (A/B switch: False = torch's nn.Transformer* forward)
+
+
+def _recording(module: torch.nn.Module) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+def _attention(mha: torch.nn.MultiheadAttention, x_q: Tensor, x_kv: Tensor, B: int, key_bias=None, self_attn=True) -> Tensor:
+    """nn.MultiheadAttention (batch_first=False) on flattened [T*B, D] rows: fused in_proj, isg_mha_small, out_proj."""
+    D = x_q.size(1)
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    if self_attn:
+        qkv = ops.linear(x_q, w, b)                                              # [T*B, 3D], one GEMM
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        wq = ops.derived_weight("mha_q", (w,), lambda: w[:D].contiguous())
+        wkv = ops.derived_weight("mha_kv", (w,), lambda: w[D:].contiguous())
+        bq = ops.derived_weight("mha_bq", (b,), lambda: b[:D].contiguous())
+        bkv = ops.derived_weight("mha_bkv", (b,), lambda: b[D:].contiguous())
+        q = ops.linear(x_q, wq, bq)
+        kv = ops.linear(x_kv, wkv, bkv)                                          # [S*B, 2D]
+        k, v = kv[:, :D], kv[:, D:]
+    att = ops.mha_small(q, k, v, B, mha.num_heads, key_bias)
+    return ops.linear(att, mha.out_proj.weight, mha.out_proj.bias)
+
+
+def _ln(norm: torch.nn.LayerNorm, x: Tensor) -> Tensor:
+    return torch.nn.functional.layer_norm(x, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
+
+
+def _ffn(layer, x: Tensor) -> Tensor:
+    h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, relu=True)       # ReLU is the layers' default activation
+    return ops.linear(h, layer.linear2.weight, layer.linear2.bias)
 
 
 class CLIPTextEmbeddings(torch.nn.Module):
@@ -64,7 +104,16 @@ class QuestionEncoder(torch.nn.Module):
 
     def forward(self, src: Tensor, mask: Tensor) -> Tensor:
         src = self.text_vocab_embedding(src)                                             # :32
-        return self.transformer_encoder(src.permute(1, 0, 2), src_key_padding_mask=mask.float())   # :35-37
+        enc = self.transformer_encoder
+        if not FUSED_TEXT or not src.is_cuda or _recording(self) or src.size(1) > 128 or src.size(2) // enc.layers[0].self_attn.num_heads > 64:
+            return enc(src.permute(1, 0, 2), src_key_padding_mask=mask.float())          # :35-37
+        B, T, D = src.shape
+        x = src.permute(1, 0, 2).reshape(T * B, D).contiguous()                          # torch's [T, B, D] row order
+        key_bias = mask.float().contiguous()                                             # :36: ADDED to the scores (Q5)
+        for layer in enc.layers:                                                         # post-norm encoder layers
+            x = _ln(layer.norm1, x + _attention(layer.self_attn, x, x, B, key_bias))
+            x = _ln(layer.norm2, x + _ffn(layer, x))
+        return _ln(enc.norm, x).view(T, B, D)
 
 
 class QuestionDecoder(torch.nn.Module):
@@ -79,4 +128,15 @@ class QuestionDecoder(torch.nn.Module):
     def forward(self, memory: Tensor) -> Tensor:
         B = memory.size(1)
         queries = self.query_embed.weight.unsqueeze(1).repeat(1, B, 1)                   # :61-63
-        return self.coarse_decoder(tgt=queries, memory=memory, tgt_mask=None)            # :64-66
+        dec = self.coarse_decoder
+        if not FUSED_TEXT or not memory.is_cuda or _recording(self) or memory.size(0) > 128 or memory.size(2) // dec.layers[0].self_attn.num_heads > 64:
+            return dec(tgt=queries, memory=memory, tgt_mask=None)                        # :64-66
+        S, _, D = memory.shape
+        n = queries.size(0)
+        x = queries.reshape(n * B, D).contiguous()
+        mem = memory.reshape(S * B, D).contiguous()
+        for layer in dec.layers:                                                         # post-norm decoder layers, no masks
+            x = _ln(layer.norm1, x + _attention(layer.self_attn, x, x, B))
+            x = _ln(layer.norm2, x + _attention(layer.multihead_attn, x, mem, B, self_attn=False))
+            x = _ln(layer.norm3, x + _ffn(layer, x))
+        return _ln(dec.norm, x).view(n, B, D)

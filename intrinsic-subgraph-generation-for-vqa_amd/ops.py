@@ -673,12 +673,70 @@ def _use_panel(M: int, N: int, K: int) -> bool:
     return K <= 128 and N >= 256 and M >= 32768
 
 
+_DERIVED = {}   # (tag, ids of the source tensors) -> (versions, weakrefs, value): weights re-laid-out once per model
+
+
+def derived_weight(tag: str, sources, build):
+    """Cache of tensors computed from static weights (slices, concatenations): rebuilt when a source was updated in place
+    (tensor._version / data_ptr) or replaced; invalidate_weight_cache() drops it."""
+    key = (tag,) + tuple(id(t) for t in sources)
+    ver = tuple((t._version, t.data_ptr()) for t in sources)
+    hit = _DERIVED.get(key)
+    if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[1], sources)):
+        return hit[2]
+    with torch.no_grad():
+        value = build()
+    if len(_DERIVED) > 256:
+        for k in [k for k, v in _DERIVED.items() if any(r() is None for r in v[1])]:
+            del _DERIVED[k]
+    _DERIVED[key] = (ver, tuple(weakref.ref(t) for t in sources), value)
+    return value
+
+
+def gather_add(A: Tensor, ia: Tensor, B: Optional[Tensor] = None, ib: Optional[Tensor] = None, T: Optional[Tensor] = None,
+               it: Optional[Tensor] = None, sign: Optional[Tensor] = None, D: Optional[Tensor] = None,
+               bias: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
+    """act(A[ia] + B[ib] + sign * T[it] + D + bias) -> [E, C]: the per-edge remainder of a Linear over
+    cat([x[row], x[col], emb]) once its node parts are projected per node (scene_graph_encoder.py:119-120,139-140;
+    csrc/isg_sgenc.hip).  A / B / T / D may be column slices of wider tensors (row stride a multiple of 4)."""
+    lib = _lib.load()
+    E, C = ia.numel(), A.size(1)
+    out = torch.empty(E, C, dtype=torch.float32, device=A.device)
+
+    def rows(t, name):
+        if t is None:
+            return 0, 0
+        if tuple(t.shape[1:]) != (C,):
+            raise ValueError(f"{name}: expected [*, {C}], got {tuple(t.shape)}")
+        return _chk_rows(t, name), t.stride(0)
+
+    def idx(t, name, n):
+        if t is None:
+            return 0
+        if t.numel() != n:
+            raise ValueError(f"{name}: expected {n} indices, got {t.numel()}")
+        return _chk(t.reshape(-1), name, torch.int64)
+
+    pa, la = rows(A, "A")
+    pb, lb = rows(B, "B")
+    pt, lt = rows(T, "T")
+    pd, ld = rows(D, "D")
+    if D is not None and D.size(0) != E:
+        raise ValueError(f"D: expected {E} rows, got {D.size(0)}")
+    _lib.check(lib.isg_gather_add(pa, idx(ia, "ia", E), la, pb, idx(ib, "ib", E), lb, pt, idx(it, "it", E),
+                                  _chk(None if sign is None else sign.reshape(-1), "sign", torch.float32, (E,), optional=True),
+                                  lt, pd, ld, _chk(bias, "bias", torch.float32, (C,), optional=True), out.data_ptr(), E, C,
+                                  1 if gelu else 0, _stream()), "isg_gather_add")
+    return out
+
+
 def invalidate_weight_cache() -> None:
     """Drop every cached bf16 plane set and fused weight.  The caches are validated by (object identity, tensor._version,
     data_ptr); a write THROUGH `.data` (weight.data.copy_/mul_, as init / EMA / weight-surgery code does) bumps neither,
     so such code must call this (Module.load_state_dict goes through copy_ on the Parameter and is safe)."""
     _PLANES.clear()
     _CAT.clear()
+    _DERIVED.clear()
 
 
 def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> Tensor:
@@ -708,7 +766,7 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False,
-           cache_planes: bool = True, out_dtype=torch.float32) -> Tensor:
+           cache_planes: bool = True, out_dtype=torch.float32, relu: bool = False) -> Tensor:
     """act(x @ weight^T + bias), x [M,K] fp32, weight [N,K] (torch Linear layout).  Uses the bf16x6 matrix-core kernel
     when the shape allows it, hipBLASLt through torch otherwise (K not a multiple of 4).  ``cache_planes=False``: the
     weight is being trained (or is a temporary), so its bf16 planes are split per call instead of cached."""
@@ -716,6 +774,10 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     f16_io = x.dtype == torch.float16 or out_dtype == torch.float16
     if f16_io and (GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or _rec(x, weight, bias)):
         raise _lib.IsgError("fp16 feature rows are an inference feature of the bf16x6 kernel (K % 4 == 0, no autograd)")
+    if relu and (gelu or f16_io):
+        raise ValueError("relu excludes gelu and fp16 rows")
+    if relu and (_rec(x, weight, bias) or GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or M == 0):
+        return torch.relu(torch.nn.functional.linear(x, weight, bias))
     if _rec(x, weight, bias) and GEMM_BACKEND == "bf16x6" and (K & 3) == 0 and M > 0:
         from . import autograd
         return autograd.linear(x, weight, bias, gelu)
@@ -725,7 +787,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         return torch.nn.functional.gelu(y) if gelu else y
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
-    if _use_panel(M, N, K):
+    if _use_panel(M, N, K) and not relu:
         planes = _weight_planes(weight, cache_planes, "panel")
         _lib.check(lib.isg_linear_panel(
             _chk(x, "x", x.dtype), 1 if x.dtype == torch.float16 else 0, planes.data_ptr(),
@@ -744,7 +806,25 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         return out
     _lib.check(lib.isg_linear_bf16x6(_chk(x, "x", torch.float32), planes.data_ptr(),
                                      _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
-                                     out.data_ptr(), M, N, K, K, N, 1 if gelu else 0, _stream()), "isg_linear_bf16x6")
+                                     out.data_ptr(), M, N, K, K, N, 2 if relu else (1 if gelu else 0), _stream()),
+               "isg_linear_bf16x6")
+    return out
+
+
+def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_bias: Optional[Tensor] = None) -> Tensor:
+    """softmax(Q K^T / sqrt(hd) + key_bias) V per (batch item, head) for short sequences (csrc/isg_attn.hip).
+    q [Tq*B, D], k / v [Tk*B, D] in torch's [T, B, D] row order (row t*B + b; column slices of a fused projection are
+    fine), key_bias fp32 [B, Tk] additive (question_encoder.py:35-37) -> [Tq*B, D]."""
+    lib = _lib.load()
+    B, H, D = int(batch_size), int(heads), q.size(1)
+    hd = D // H
+    Tq, Tk = q.size(0) // B, k.size(0) // B
+    if H * hd != D or Tq * B != q.size(0) or Tk * B != k.size(0) or tuple(v.shape) != tuple(k.shape):
+        raise ValueError(f"mha_small: q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)} vs B={B}, H={H}")
+    out = torch.empty(Tq * B, D, dtype=torch.float32, device=q.device)
+    _lib.check(lib.isg_mha_small(_chk_rows(q, "q"), q.stride(0), _chk_rows(k, "k"), k.stride(0), _chk_rows(v, "v"),
+                                 v.stride(0), _chk(key_bias, "key_bias", torch.float32, (B, Tk), optional=True),
+                                 out.data_ptr(), D, B, H, hd, Tq, Tk, _stream()), "isg_mha_small")
     return out
 
 

@@ -463,3 +463,56 @@ def test_loader_to_full_model_end_to_end(dev):
                                 scene_graphs=d)
     assert torch.equal(gm.cpu() > 0.5, rm > 0.5)
     assert (gl.cpu() - rl).abs().max().item() < LOGIT_TOL
+
+
+def test_scene_graph_encoder_split_linears_match_the_concatenated_form(dev):
+    """The inference path of the scene-graph encoder never builds cat([x[row], x[col], e]) (csrc/isg_sgenc.hip); it must
+    agree with the concatenated form (the reference's literal op order, still used for training) to fp32 rounding."""
+    from isubgvqa_amd import synthetic
+    from isubgvqa_amd.models import scene_graph_encoder as SGE
+    from isubgvqa_amd.models import build_model
+    from oracle import recipe as R
+    model = build_model(synthetic.full_model_args(sg_vocab_size=300, text_vocab_size=64), None).eval()
+    R.fill_state_dict(model, 77)
+    enc = model.scene_graph_encoder.to(dev)
+    wl = synthetic.make_full_workload(96, sg_vocab=300, text_vocab=64).to(dev)
+    sg = wl.scene_graphs()
+    outs = {}
+    with torch.no_grad():
+        for flag in (True, False):
+            SGE.SPLIT_LINEARS = flag
+            try:
+                outs[flag] = enc(wl.x, edge_index=wl.edge_index, edge_attr=wl.edge_attr, batch=wl.batch, gt_scene_graphs=sg)
+            finally:
+                SGE.SPLIT_LINEARS = True
+    (xs, es), (xc, ec) = outs[True], outs[False]
+    scale = ec.abs().max().item()
+    assert (es - ec).abs().max().item() < 2e-6 * scale, ((es - ec).abs().max().item(), scale)
+    assert (xs - xc).abs().max().item() < 5e-5
+
+
+def test_text_encoder_on_own_kernels_matches_the_torch_modules(dev):
+    """QuestionEncoder / QuestionDecoder at the reference architecture (d = 512, 8 heads, ff 2048, 4 + 3 layers): the
+    inference path on isg_linear_bf16x6 + isg_mha_small against torch's own nn.Transformer* forward of the same modules."""
+    from isubgvqa_amd.models import text_encoder as TE
+    torch.manual_seed(3)
+    emb = TE.CLIPTextEmbeddings(200, 512, 77)
+    enc = TE.QuestionEncoder(emb, 512, 512, 8, 2048, 4, 0.1).to(dev).eval()
+    dec = TE.QuestionDecoder(4, 512, 8, 2048, 3, 0.1).to(dev).eval()
+    gen = torch.Generator().manual_seed(4)
+    B, T = 37, 14
+    q = torch.randint(0, 200, (B, T), generator=gen).to(dev)
+    lens = torch.randint(1, T + 1, (B,), generator=gen)
+    mask = (torch.arange(T)[None] < lens[:, None]).long().to(dev)
+    outs = {}
+    with torch.no_grad():
+        for flag in (True, False):
+            TE.FUSED_TEXT = flag
+            try:
+                e = enc(q, mask)
+                outs[flag] = (e, dec(e))
+            finally:
+                TE.FUSED_TEXT = True
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() < 2e-5, (a - b).abs().max().item()

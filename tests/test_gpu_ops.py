@@ -515,3 +515,30 @@ def test_invalidate_weight_cache_after_a_write_through_data(dev):
     ops.invalidate_weight_cache()
     y1 = ops.linear(x, w)
     assert torch.allclose(y1, 2.0 * y0, atol=1e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ question encoder attention (A2/A3)
+@pytest.mark.parametrize("B,H,hd,Tq,Tk,bias", [(5, 8, 64, 12, 12, True), (3, 4, 8, 9, 9, True), (7, 8, 64, 4, 12, False),
+                                               (2, 8, 64, 4, 4, False), (2, 8, 64, 77, 77, True), (1, 2, 16, 1, 128, True)])
+def test_mha_small_matches_fp64_attention(dev, B, H, hd, Tq, Tk, bias):
+    """isg_mha_small against an fp64 softmax(QK^T/sqrt(hd) + bias)V, rows in torch's [T, B, D] order, operands given as
+    column slices of a fused projection (strided rows), float key-padding mask ADDED to the scores (quirk Q5)."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(B * 1000 + Tk)
+    D = H * hd
+    qkv = torch.randn(Tq * B, 3 * D, generator=gen)
+    kv = torch.randn(Tk * B, 3 * D, generator=gen) if Tk != Tq else qkv
+    kb = (torch.rand(B, Tk, generator=gen) < 0.7).float() if bias else None
+    q, k, v = qkv[:, :D], kv[:, D:2 * D], kv[:, 2 * D:]
+    qd = q.double().view(Tq, B, H, hd).permute(1, 2, 0, 3)
+    kd = k.double().view(Tk, B, H, hd).permute(1, 2, 0, 3)
+    vd = v.double().view(Tk, B, H, hd).permute(1, 2, 0, 3)
+    sc = qd @ kd.transpose(-1, -2) / math.sqrt(hd)
+    if kb is not None:
+        sc = sc + kb.double()[:, None, None, :]
+    ref = (torch.softmax(sc, -1) @ vd).permute(2, 0, 1, 3).reshape(Tq * B, D)
+    qkv_d, kv_d = qkv.to(dev), (kv.to(dev) if Tk != Tq else None)
+    kv_d = qkv_d if kv_d is None else kv_d
+    got = ops.mha_small(qkv_d[:, :D], kv_d[:, D:2 * D], kv_d[:, 2 * D:], B, H, None if kb is None else kb.to(dev))
+    assert got.shape == (Tq * B, D)
+    assert (got.cpu().double() - ref).abs().max().item() < 2e-6
