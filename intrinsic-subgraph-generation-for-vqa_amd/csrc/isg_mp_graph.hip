@@ -42,7 +42,10 @@ constexpr int GK_NCAP_L = 256, GK_ECAP_L = 1024;
 #ifndef ISG_GK_U
 #define ISG_GK_U 4
 #endif
-constexpr int GK_U = ISG_GK_U;   // slots a wave has in flight in phase B (tuning builds: -DISG_GK_U=n)
+constexpr int GK_U = ISG_GK_U;
+#ifndef ISG_GKF_U
+#define ISG_GKF_U 2
+#endif   // slots a wave has in flight in phase B (tuning builds: -DISG_GK_U=n)
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v) {
@@ -246,6 +249,249 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
   }
 }
 
+
+// ---- FLAT lane mapping: head dimensions that do not tile 64 lanes (the reference's default C = 300: 75 float4 per head) --
+// The grouped kernel above gives every head its own lane group of 64 / HS lanes; at C = 300 that is one head per
+// workgroup in two passes, the second mostly idle (75 of 128 lane slots), and the CSR records staged once per HEAD:
+// 762 us at H*C = 1200 on the configs[1] topology, worse than the node-chunk kernel (672 us, 1.41x traffic).  Here a
+// workgroup owns HS heads (HS * Q float4 per row slice) and its lanes walk the slice FLAT, lane l -> float4 l, l + 64, ...
+// (P passes; 150 of 192 slots at HS = 2, C = 300); a pass's element belongs to head (index / Q), so a lane may serve two
+// heads: per-head logits are HS full-wave sums of per-head partials, and the softmax weights of all HS heads are formed
+// in every lane.  Phases, LDS tables, arithmetic and summation orders are those of the grouped kernel.
+template <int HS, int P, bool MASKED, int GK_NCAP, int GK_ECAP>
+__global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_flat_kernel(MpArgs a) {
+  constexpr int U = ISG_GKF_U;    // CSR slots a wave has in flight in phase B (P passes x 2 operands x U rows of loads)
+  extern __shared__ __attribute__((aligned(16))) float4 s_xl[];   // [lrows][HS*Q]
+  __shared__ __attribute__((aligned(16))) int4 s_tab[GK_ECAP];    // {src - nb, eid, dst - nb, bits(edge mask)}
+  __shared__ __attribute__((aligned(16))) float s_lg[GK_ECAP * HS];
+  __shared__ __attribute__((aligned(16))) int s_rowptr[GK_NCAP + 4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int nhg = a.H / HS;
+  const int item = blockIdx.x;
+  const int g = item / nhg, hg = item - g * nhg;
+  const int nb = a.graph_ptr[g], n = min(a.graph_ptr[g + 1] - nb, GK_NCAP);
+  const int e0 = a.graph_eptr[g], ne = min(a.graph_eptr[g + 1] - e0, GK_ECAP);
+  if (n <= 0) return;
+  const int Q = a.C >> 2, R = a.H * Q, RQ = HS * Q, hoff = hg * RQ;
+  const int rows = min(n, a.lrows);
+  const bool nt = a.flags & 1, nt_xl = a.flags & 4;
+
+  // ---- phase A: stage the x_l slice, the CSR records and the row pointers ------------------------------------------
+  {
+    constexpr int RECS = (GK_ECAP + GK_THREADS - 1) / GK_THREADS;
+    int4 rec[RECS];
+    int v_rp = 0;
+    if (tid <= n) v_rp = a.rowptr[nb + tid] - e0;
+#pragma unroll
+    for (int k = 0; k < RECS; ++k) {
+      const int t = tid + k * GK_THREADS;
+      rec[k] = make_int4(0, 0, 0, __float_as_int(1.f));
+      if (t < ne) {
+        const int s = a.src[e0 + t], e = a.eid[e0 + t], d = a.dst[e0 + t];
+        rec[k].x = min(max(s - nb, 0), n - 1);
+        rec[k].y = e;
+        rec[k].z = d - nb;
+        if (MASKED) {
+          float me;
+          if (a.edge_mask) me = a.edge_mask[e];
+          else me = a.node_mask[s] * a.node_mask[d];
+          rec[k].w = __float_as_int(me);
+        }
+      }
+    }
+#pragma unroll 1
+    for (int r0 = wave; r0 < rows; r0 += GK_WAVES * 2) {
+      const int r1 = r0 + GK_WAVES;
+#pragma unroll 1
+      for (int c = lane; c < RQ; c += 64) {
+        float4 v0, v1;
+        v0 = ld_stream(a.x_l + (size_t)(nb + r0) * a.ldl4 + hoff + c, nt_xl);
+        if (r1 < rows) v1 = ld_stream(a.x_l + (size_t)(nb + r1) * a.ldl4 + hoff + c, nt_xl);
+        s_xl[r0 * RQ + c] = v0;
+        if (r1 < rows) s_xl[r1 * RQ + c] = v1;
+      }
+    }
+    if (tid <= n) s_rowptr[tid] = v_rp;
+#pragma unroll
+    for (int k = 0; k < RECS; ++k)
+      if (tid + k * GK_THREADS < ne) s_tab[tid + k * GK_THREADS] = rec[k];
+  }
+  __syncthreads();
+
+  int off[P], hof[P];     // float4 offset inside the slice; head (0 .. HS-1) it belongs to
+  bool ok[P];
+  float4 att4[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane + 64 * p;
+    ok[p] = i < RQ;
+    off[p] = ok[p] ? i : 0;
+    hof[p] = off[p] / Q;
+    att4[p] = ok[p] ? a.att[hoff + off[p]] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float slope = a.slope;
+
+  // ---- phase B: edge-parallel logits ---------------------------------------------------------------------------------
+#pragma unroll 1
+  for (int tb = wave * U; tb < ne; tb += GK_WAVES * U) {
+    float4 epv[U][P], xrv[U][P];
+    int jl[U];
+    float me[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(tb + u, ne - 1);
+      const int4 rec = s_tab[t];
+      jl[u] = uni(rec.x);
+      me[u] = unif(__int_as_float(rec.w));
+      const size_t ep = (size_t)uni(rec.y) * a.lde4 + hoff;
+      const size_t xr = (size_t)(nb + uni(rec.z)) * a.ldr4 + hoff;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (ok[p]) {
+          epv[u][p] = ld_stream(a.e_proj + ep + off[p], nt);
+          xrv[u][p] = a.x_r[xr + off[p]];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + u;
+      const bool in_lds = jl[u] < rows;
+      const float4 *xl_s = s_xl + (in_lds ? jl[u] : 0) * RQ;
+      float part[HS];
+#pragma unroll
+      for (int hh = 0; hh < HS; ++hh) part[hh] = 0.f;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (ok[p]) {
+          const float4 v = epv[u][p], r4 = xrv[u][p];
+          float4 w4 = xl_s[off[p]];
+          if (!in_lds) w4 = a.x_l[(size_t)(nb + jl[u]) * a.ldl4 + hoff + off[p]];
+          float4 s;
+          s.x = (r4.x + w4.x) + v.x;
+          s.y = (r4.y + w4.y) + v.y;
+          s.z = (r4.z + w4.z) + v.z;
+          s.w = (r4.w + w4.w) + v.w;
+          if (MASKED) { s.x *= me[u]; s.y *= me[u]; s.z *= me[u]; s.w *= me[u]; }
+          s.x = leaky(s.x, slope); s.y = leaky(s.y, slope); s.z = leaky(s.z, slope); s.w = leaky(s.w, slope);
+          if (MASKED) { s.x *= me[u]; s.y *= me[u]; s.z *= me[u]; s.w *= me[u]; }
+          const float d = dot4(s, att4[p]);
+#pragma unroll
+          for (int hh = 0; hh < HS; ++hh) part[hh] += hof[p] == hh ? d : 0.f;
+        }
+      }
+#pragma unroll
+      for (int hh = 0; hh < HS; ++hh) {
+        const float logit = wave_sum(part[hh]);
+        if (lane == 0 && t < ne) s_lg[t * HS + hh] = logit;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase C: node-parallel softmax + aggregation; every operand in LDS ---------------------------------------------
+#pragma unroll 1
+  for (int k = wave; k < n; k += GK_WAVES) {
+    const int rb = uni(s_rowptr[k]), re = min(uni(s_rowptr[k + 1]), ne);
+    float mx[HS], rden[HS];
+#pragma unroll
+    for (int hh = 0; hh < HS; ++hh) {
+      float m = -INFINITY;
+#pragma unroll 1
+      for (int t = rb; t < re; ++t) m = fmaxf(m, s_lg[t * HS + hh]);
+      float den = 0.f;
+#pragma unroll 1
+      for (int t = rb; t < re; ++t) den += __builtin_amdgcn_exp2f((s_lg[t * HS + hh] - m) * 1.4426950408889634f);
+      mx[hh] = m;
+      rden[hh] = __builtin_amdgcn_rcpf(den + 1e-16f);
+    }
+    float4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int t = rb; t < re; ++t) {
+      const int4 rec = s_tab[t];
+      float w[HS];
+#pragma unroll
+      for (int hh = 0; hh < HS; ++hh) {
+        w[hh] = __builtin_amdgcn_exp2f((s_lg[t * HS + hh] - mx[hh]) * 1.4426950408889634f) * rden[hh];
+        if (lane == 0) a.alpha[(size_t)uni(rec.y) * a.H + hg * HS + hh] = w[hh];
+        if (MASKED) w[hh] = __fmul_rn(w[hh], unif(__int_as_float(rec.w)));
+      }
+      const int jl = uni(rec.x);
+      const bool in_lds = jl < rows;
+      const float4 *xl_s = s_xl + (in_lds ? jl : 0) * RQ;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (ok[p]) {
+          float4 u4 = xl_s[off[p]];
+          if (!in_lds) u4 = a.x_l[(size_t)(nb + jl) * a.ldl4 + hoff + off[p]];
+          float wm = w[0];
+#pragma unroll
+          for (int hh = 1; hh < HS; ++hh) wm = hof[p] == hh ? w[hh] : wm;
+          acc[p].x = __fadd_rn(acc[p].x, __fmul_rn(u4.x, wm));
+          acc[p].y = __fadd_rn(acc[p].y, __fmul_rn(u4.y, wm));
+          acc[p].z = __fadd_rn(acc[p].z, __fmul_rn(u4.z, wm));
+          acc[p].w = __fadd_rn(acc[p].w, __fmul_rn(u4.w, wm));
+        }
+      }
+    }
+    const size_t orow = (size_t)(nb + k) * R + hoff;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (ok[p]) {
+        float4 o = acc[p];
+        if (a.bias) {
+          const float4 b = a.bias[hoff + off[p]];
+          o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+        }
+        st_stream(a.out + orow + off[p], o, nt);
+      }
+    }
+  }
+}
+
+template <int HS, int P, int NC, int EC>
+static int launch_flat_sized(MpArgs a, int nmax_host, hipStream_t st) {
+  const long long items = (long long)a.B * (a.H / HS);
+  if (items >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  const size_t row_bytes = (size_t)HS * a.C * 4;
+  const size_t static_bytes = (size_t)EC * 16 + (size_t)EC * HS * 4 + (NC + 4) * 4;
+  // window: 2 workgroups per CU (16 waves); a graph's rows beyond it are read from global memory (L2)
+  const size_t budget = 78 * 1024;
+  if (budget < static_bytes + 8 * row_bytes) return ISG_EUNSUPPORTED;
+  a.lrows = (int)((budget - static_bytes) / row_bytes);
+  if (a.lrows > nmax_host) a.lrows = nmax_host;
+  const size_t dyn = (size_t)a.lrows * row_bytes;
+  dim3 grid((unsigned)items), block(GK_THREADS);
+  const bool masked = a.node_mask || a.edge_mask;
+  if (masked) {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_mp_graph_flat_kernel<HS, P, true, NC, EC>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    if (!ok) return ISG_EUNSUPPORTED;
+    gatv2_mp_graph_flat_kernel<HS, P, true, NC, EC><<<grid, block, dyn, st>>>(a);
+  } else {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_mp_graph_flat_kernel<HS, P, false, NC, EC>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    if (!ok) return ISG_EUNSUPPORTED;
+    gatv2_mp_graph_flat_kernel<HS, P, false, NC, EC><<<grid, block, dyn, st>>>(a);
+  }
+  return check_launch();
+}
+
+// fp32 rows, scene-graph sized graphs (64 nodes / 256 edges): HS heads per workgroup, P = ceil(HS * C / 256) passes
+static int launch_mp_graph_flat(const MpArgs &a, int nmax_host, int emax_host, hipStream_t st) {
+  if (a.f16 || nmax_host > GK_NCAP_S || emax_host > GK_ECAP_S || (a.H & 1)) return ISG_EUNSUPPORTED;
+  const int RQ = 2 * (a.C >> 2);
+  const int P = (RQ + 63) / 64;
+  if (P == 3) return launch_flat_sized<2, 3, GK_NCAP_S, GK_ECAP_S>(a, nmax_host, st);
+  if (P == 2) return launch_flat_sized<2, 2, GK_NCAP_S, GK_ECAP_S>(a, nmax_host, st);
+  if (P == 4) return launch_flat_sized<2, 4, GK_NCAP_S, GK_ECAP_S>(a, nmax_host, st);
+  return ISG_EUNSUPPORTED;
+}
+
 template <int HS, int P, int NC, int EC>
 static int launch_sized(MpArgs a, int nmax_host, hipStream_t st) {
   const long long items = (long long)a.B * (a.H / HS);
@@ -296,8 +542,16 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   // one head per workgroup whose row needs a second, mostly idle pass (the reference's default C = 300: 75 of 128 lane
   // slots, and the CSR tables staged once per HEAD): the node-chunk kernel is faster there (tools/time_mp_c300.py:
   // 672 vs 762 us at H = 4, C = 300 on the configs[1] topology)
-  static const bool force_graph = getenv("ISG_MP_FORCE_GRAPH") != nullptr;   // read once
-  if (HS == 1 && a.H > 1 && P == 2 && Q * 10 < G * P * 7 && !force_graph) return ISG_EUNSUPPORTED;
+  static const bool force_graph = getenv("ISG_MP_FORCE_GRAPH") != nullptr;   // read once (A/B switches)
+  static const bool no_flat = getenv("ISG_MP_NO_FLAT") != nullptr;
+  if (HS == 1 && a.H > 1 && P == 2 && Q * 10 < G * P * 7 && !force_graph) {
+    // head dimension that fills < 70 % of two passes (the reference's C = 300): flat lane mapping over two heads
+    if (!no_flat) {
+      const int rc = launch_mp_graph_flat(a, nmax_host, emax_host, st);
+      if (rc != ISG_EUNSUPPORTED) return rc;
+    }
+    return ISG_EUNSUPPORTED;      // node-chunk kernel
+  }
 #define ISG_GK(hs, p) if (HS == hs && P == p) return launch_one<hs, p>(a, nmax_host, emax_host, st)
   ISG_GK(1, 1); ISG_GK(1, 2);
   ISG_GK(2, 1); ISG_GK(2, 2);
