@@ -128,15 +128,29 @@ struct Parser {
   }
   bool number(double &v) {
     ws();
+    // the text is a (pointer, length) view with no terminator: scan the number's own characters inside [p, end) and
+    // convert from a bounded, NUL-terminated copy (strtod on the raw pointer could read past the buffer)
+    char buf[64];
+    size_t n = 0;
+    while (p + n < end && n + 1 < sizeof(buf)) {
+      const char c = p[n];
+      if (!((c >= '0' && c <= '9') || c == '-' || c == '+' || c == '.' || c == 'e' || c == 'E')) break;
+      buf[n++] = c;
+    }
+    buf[n] = 0;
     char *e = nullptr;
-    v = std::strtod(p, &e);
-    if (e == p) return bad("expected number");
-    p = e;
+    v = std::strtod(buf, &e);
+    if (e == buf) return bad("expected number");
+    p += e - buf;
     return true;
   }
+  int depth = 0;                      // nesting of skipped containers
+  static constexpr int MAX_DEPTH = 64; // scene-graph JSON nests 4 deep; a hostile file must not overflow the stack
   bool skip() {   // any value
     ws();
     if (p >= end) return bad("unexpected end");
+    if (depth >= MAX_DEPTH) return bad("nesting too deep");
+    struct Guard { int &d; Guard(int &x) : d(x) { ++d; } ~Guard() { --d; } } guard(depth);
     std::string_view v;
     std::string tmp;
     switch (*p) {

@@ -19,7 +19,8 @@ from torch import Tensor
 
 ABI_VERSION = 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libisg_loader.so")
+# ISG_LOADER_LIB: an alternative build of the same library (the sanitizer build of tools/asan_loader.sh)
+LIB_PATH = os.environ.get("ISG_LOADER_LIB") or os.path.join(_HERE, "csrc", "libisg_loader.so")
 
 SIGNATURES = {
     "isg_loader_abi_version": (c_int, []),

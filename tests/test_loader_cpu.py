@@ -155,6 +155,7 @@ def test_slots_threads_and_reused_buffers_give_the_same_batch(L, g8):
     ('{"a": {"objects": {}}', "expected"),
     ('[1, 2]', "expected '{'"),
     ('{"a": {"objects": {}}} trailing', "trailing"),
+    ('{"a": {"junk": ' + "[" * 200 + "]" * 200 + ', "objects": {}}}', "nesting too deep"),
 ])
 def test_malformed_input_fails_loudly(L, g8, text, fragment):
     st = L.SceneGraphStore(L.SceneGraphVocab(g8["token_lists"]))
@@ -163,3 +164,13 @@ def test_malformed_input_fails_loudly(L, g8, text, fragment):
     assert fragment in str(e.value)
     with pytest.raises(L.LoaderError):
         st.add_json_file("/nonexistent/file.json")
+
+
+def test_number_at_the_very_end_of_an_unterminated_buffer(L, g8):
+    """The parser gets (pointer, length): a number that ends the buffer must be read from inside it (strtod on
+    the raw pointer).  The text is passed as a slice of a larger bytes object whose next bytes are digits."""
+    st = L.SceneGraphStore(L.SceneGraphVocab(g8["token_lists"]))
+    good = '{"a": {"width": 12, "objects": {}}}'
+    st.add_json(good)
+    with pytest.raises(L.LoaderError):           # truncated right after the number: must fail inside the view, not read on
+        st.add_json('{"a": {"width": 12')
