@@ -318,6 +318,15 @@ int isg_split_bf16x3_frag(const float *w, int64_t rows, int32_t K, uint16_t *pla
 int isg_linear_panel(const void *a, int32_t a_is_f16, const uint16_t *w_frag, const float *bias, void *d,
                      int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
                      void *stream);
+/* Several Linears over the SAME rows as one launch: the weights are concatenated along the output dimension (N columns
+ * in all, w_frag / bias of the concatenation) and output columns [o * out_cols, (o + 1) * out_cols) go to the o-th result
+ * tensor at d + o * out_stride (elements), row stride ldd.  MGAT hands every layer the same edge features
+ * (ISubGVQA/models/mgat.py:144-148), so the layers' lin_edge projections (mgat_v2_conv.py:259) share one pass over
+ * edge_attr: a row panel is loaded and split into its bf16 planes once for all of them, and each layer still gets its
+ * own dense [E, H*C] tensor.  out_cols a multiple of 32 that divides N. */
+int isg_linear_panel_multi(const void *a, int32_t a_is_f16, const uint16_t *w_frag, const float *bias, void *d,
+                           int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                           int32_t out_cols, int64_t out_stride, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scene-graph encoder (ISubGVQA/models/scene_graph_encoder.py:108-143) without its concatenations

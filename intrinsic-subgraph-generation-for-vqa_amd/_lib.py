@@ -69,6 +69,8 @@ SIGNATURES = {
                                c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "isg_mha_small": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int64,
                               c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_linear_panel_multi": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
+                                       c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(PN_THREADS, (WTN == 1 && SINGLE) ? 3 : 2) void line
                                                                      const __bf16 *__restrict__ Wf,
                                                                      const float *__restrict__ bias, void *__restrict__ Dv,
                                                                      int M, int N, int K, int KS, int NT, int lda, int ldd,
-                                                                     int nt_store) {
+                                                                     int nt_store, int out_cols, int64_t out_stride) {
   typedef typename PnRawA<A16>::type RawA;
   __shared__ __attribute__((aligned(16))) __bf16 sA[3][PN_BM][PN_LD];
 
@@ -239,6 +239,10 @@ __global__ __launch_bounds__(PN_THREADS, (WTN == 1 && SINGLE) ? 3 : 2) void line
         if (nt0 + j >= NT) break;                        // wave-uniform
         const int col = (nt0 + j) * 32 + fr;
         const bool cols_full = (nt0 + j) * 32 + 32 <= N; // wave-uniform
+        // several Linears over the same rows as ONE launch (weights concatenated): output tensor o = col / out_cols
+        // (wave-uniform: out_cols is a multiple of 32), column col - o * out_cols inside it
+        const int otile = ((nt0 + j) * 32) / out_cols;
+        const int64_t obase = (int64_t)otile * out_stride - (int64_t)otile * out_cols;
 #define PN_EPI(GUARD)                                                                                            \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int r = 0; r < 16; ++r) {                 \
     const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;                                                \
@@ -246,9 +250,9 @@ __global__ __launch_bounds__(PN_THREADS, (WTN == 1 && SINGLE) ? 3 : 2) void line
     if (ACT == 1) v = gelu_exact(v);                                                                             \
     if ((DBG & 2) ? (row < 0) : (GUARD)) {                                                                       \
       if constexpr (D16) {                                                                                       \
-        reinterpret_cast<_Float16 *>(Dv)[(int64_t)row * ldd + col] = (_Float16)v;                                \
+        reinterpret_cast<_Float16 *>(Dv)[obase + (int64_t)row * ldd + col] = (_Float16)v;                        \
       } else {                                                                                                   \
-        float *dst = reinterpret_cast<float *>(Dv) + (int64_t)row * ldd + col;                                   \
+        float *dst = reinterpret_cast<float *>(Dv) + obase + (int64_t)row * ldd + col;                           \
         if (nt_store) __builtin_nontemporal_store(v, dst);                                                       \
         else *dst = v;                                                                                           \
       }                                                                                                          \
@@ -299,10 +303,11 @@ static long long pn_nt_bytes() {
   return v;
 }
 
-extern "C" int isg_linear_panel(const void *a, int32_t a_is_f16, const uint16_t *w_frag, const float *bias, void *d,
-                                int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
-                                void *stream) {
-  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 1) return ISG_EINVAL;
+static int panel_launch(const void *a, int32_t a_is_f16, const uint16_t *w_frag, const float *bias, void *d,
+                        int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                        int32_t out_cols, int64_t out_stride, void *stream) {
+  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < out_cols || act < 0 || act > 1) return ISG_EINVAL;
+  if (out_cols <= 0 || (out_cols < N && (out_cols & 31) != 0) || N % out_cols != 0) return ISG_EINVAL;
   if (M == 0) return ISG_OK;
   if (!a || !w_frag || !d) return ISG_EINVAL;
   const bool a16 = a_is_f16 != 0, d16 = d_is_f16 != 0;
@@ -331,7 +336,7 @@ extern "C" int isg_linear_panel(const void *a, int32_t a_is_f16, const uint16_t 
 #define ISG_PN_DBG(v)                                                                                                   \
   if (dbg == v && !a16 && !d16) {                                                                                       \
     if (KS <= 8) linear_panel_kernel<0, 2, false, false, true, v><<<grid, block, 0, st>>>(a, wf, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt); \
-    else linear_panel_kernel<0, 2, false, false, false, v><<<grid, block, 0, st>>>(a, wf, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt); \
+    else linear_panel_kernel<0, 2, false, false, false, v><<<grid, block, 0, st>>>(a, wf, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt, out_cols, (long long)out_stride); \
     return check_launch();                                                                                              \
   }
     ISG_PN_DBG(1) ISG_PN_DBG(2) ISG_PN_DBG(3) ISG_PN_DBG(4) ISG_PN_DBG(8) ISG_PN_DBG(16) ISG_PN_DBG(17) ISG_PN_DBG(6)
@@ -341,8 +346,8 @@ extern "C" int isg_linear_panel(const void *a, int32_t a_is_f16, const uint16_t 
 #endif
 #define ISG_PN(ACT_, W_, A_, D_) \
   do {                                                                                                             \
-    if (KS <= 8) linear_panel_kernel<ACT_, W_, A_, D_, true><<<grid, block, 0, st>>>(a, wf, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt); \
-    else linear_panel_kernel<ACT_, W_, A_, D_, false><<<grid, block, 0, st>>>(a, wf, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt); \
+    if (KS <= 8) linear_panel_kernel<ACT_, W_, A_, D_, true><<<grid, block, 0, st>>>(a, wf, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt, out_cols, (long long)out_stride); \
+    else linear_panel_kernel<ACT_, W_, A_, D_, false><<<grid, block, 0, st>>>(a, wf, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt, out_cols, (long long)out_stride); \
   } while (0)
 #define ISG_PN_AD(ACT_, W_)                                  \
   do {                                                       \
@@ -356,4 +361,16 @@ extern "C" int isg_linear_panel(const void *a, int32_t a_is_f16, const uint16_t 
 #undef ISG_PN_AD
 #undef ISG_PN
   return check_launch();
+}
+
+extern "C" int isg_linear_panel(const void *a, int32_t a_is_f16, const uint16_t *w_frag, const float *bias, void *d,
+                                int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                                void *stream) {
+  return panel_launch(a, a_is_f16, w_frag, bias, d, d_is_f16, M, N, K, lda, ldd, act, N, 0, stream);
+}
+
+extern "C" int isg_linear_panel_multi(const void *a, int32_t a_is_f16, const uint16_t *w_frag, const float *bias, void *d,
+                                      int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd,
+                                      int32_t act, int32_t out_cols, int64_t out_stride, void *stream) {
+  return panel_launch(a, a_is_f16, w_frag, bias, d, d_is_f16, M, N, K, lda, ldd, act, out_cols, out_stride, stream);
 }

@@ -74,8 +74,12 @@ class MGAT(torch.nn.Module):
         mask = None
         global_mask = None
         edge_attns = []
-        # (Batching the layers' lin_edge projections into one [E, L*H*C] GEMM was measured: it saves ~60 us of GEMM time
-        #  per step and costs the same in the message-passing kernel, whose e_proj rows are then L*H*C*4 bytes apart.)
+        # every layer projects the SAME edge features (mgat.py:144-148): one launch splits each 64-row panel of
+        # edge_attr into its bf16 planes once and writes one dense [E, H*C] tensor per layer (isg_linear_panel_multi)
+        e_projs = None
+        if not torch.is_grad_enabled() and all(c.lin_edge is not None for c in self.convs) and edge_attr.dim() == 2:
+            e_projs = ops.linear_multi(edge_attr, [c.lin_edge.weight for c in self.convs],
+                                       out_dtype=self.convs[0].feature_dtype)
         for i in range(len(self.convs)):
             ins = instr_vectors[i].contiguous()
             if explainer:
@@ -84,7 +88,8 @@ class MGAT(torch.nn.Module):
                 x=h, edge_index=edge_index, edge_attr=edge_attr, instruction=ins, batch=batch,
                 return_masks=return_masks, return_attention_weights=True, imle_att=glf, all_instrs=instr_vectors,
                 plan=plan, noise=None if noises is None else noises.get(i),
-                seed=None if seed is None else seed + i)                                 # :144-154
+                seed=None if seed is None else seed + i,
+                e_proj=None if e_projs is None else e_projs[i])                          # :144-154
             if return_attention:
                 edge_attns.append(edge_att)
             conv_res = ops.mlp(self.x_proj[i], conv_res)                                 # :156 (Linear+GELU fused)

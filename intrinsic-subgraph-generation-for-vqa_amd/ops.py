@@ -811,6 +811,30 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     return out
 
 
+LINEAR_MULTI = True     # A/B switch (tools/ab_step.py)
+
+
+def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
+    """x @ W_i^T for several bias-free Linears of one shape over the same rows, as ONE launch of the row-panel kernel
+    (isg_linear_panel_multi): a tuple of dense [M, n] tensors, or None when the shape is not the panel kernel's (the caller
+    then projects layer by layer).  MGAT's per-layer lin_edge projections of the shared edge features use it."""
+    if not LINEAR_MULTI or GEMM_BACKEND != "bf16x6" or _rec(x, *weights) or len(weights) < 2:
+        return None
+    M, K = x.shape
+    n = weights[0].size(0)
+    if any(tuple(w.shape) != (n, K) for w in weights) or (n & 31) or (K & 3) or not _use_panel(M, len(weights) * n, K):
+        return None
+    lib = _lib.load()
+    cat = derived_weight("linear_multi", tuple(weights), lambda: torch.cat([w.detach() for w in weights], 0).contiguous())
+    planes = _weight_planes(cat, True, "panel")
+    L = len(weights)
+    out = torch.empty(L, M, n, dtype=out_dtype, device=x.device)
+    _lib.check(lib.isg_linear_panel_multi(
+        _chk(x, "x", x.dtype), 1 if x.dtype == torch.float16 else 0, planes.data_ptr(), 0, out.data_ptr(),
+        1 if out_dtype == torch.float16 else 0, M, L * n, K, K, n, 0, n, M * n, _stream()), "isg_linear_panel_multi")
+    return tuple(out[i] for i in range(L))
+
+
 def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_bias: Optional[Tensor] = None) -> Tensor:
     """softmax(Q K^T / sqrt(hd) + key_bias) V per (batch item, head) for short sequences (csrc/isg_attn.hip).
     q [Tq*B, D], k / v [Tk*B, D] in torch's [T, B, D] row order (row t*B + b; column slices of a fused projection are

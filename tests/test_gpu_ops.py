@@ -542,3 +542,19 @@ def test_mha_small_matches_fp64_attention(dev, B, H, hd, Tq, Tk, bias):
     got = ops.mha_small(qkv_d[:, :D], kv_d[:, D:2 * D], kv_d[:, 2 * D:], B, H, None if kb is None else kb.to(dev))
     assert got.shape == (Tq * B, D)
     assert (got.cpu().double() - ref).abs().max().item() < 2e-6
+
+
+def test_linear_multi_equals_the_separate_projections(dev):
+    """Several bias-free Linears over the same rows as one launch (MGAT's per-layer lin_edge over the shared edge
+    features): every output tensor must equal the separate launch of the same kernel bit for bit."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    M, K, n = 40000, 128, 512
+    x = torch.randn(M, K, generator=gen).to(dev)
+    ws = [(torch.randn(n, K, generator=gen) / K ** 0.5).to(dev) for _ in range(3)]
+    outs = ops.linear_multi(x, ws)
+    assert outs is not None and len(outs) == 3
+    for w, o in zip(ws, outs):
+        assert o.shape == (M, n) and o.is_contiguous()
+        assert torch.equal(o, ops.linear(x, w))
+    assert ops.linear_multi(x[:100], ws) is None            # too few rows for the panel kernel: caller falls back

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Same-process A/B of the configs[1] step (bench.py's workload) under the library's switches: boxes differ by ~10 %, so
+variants are interleaved round by round on ONE device and the median per variant is reported.
+  python tools/ab_step.py [rounds] [steps_per_round]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from isubgvqa_amd import ops, synthetic
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device("cuda:0")
+cfg = synthetic.CFG2
+wl = synthetic.make_workload(cfg).to(dev)
+model = synthetic.build_answer_model(cfg).to(dev).eval()
+variants = [
+    ("r01: tile GEMM everywhere", dict(GEMM_KERNEL="tile", LINEAR_MULTI=False)),
+    ("+ row-panel GEMM for the K=128 projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=False)),
+    ("+ the layers' lin_edge as one multi-output launch", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True)),
+]
+res = {name: [] for name, _ in variants}
+with torch.no_grad():
+    for r in range(rounds + 1):
+        for name, sw in variants:
+            for k, v in sw.items():
+                setattr(ops, k, v)
+            for i in range(3):
+                model(wl, seed=i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                model(wl, seed=100 + i)
+            torch.cuda.synchronize()
+            if r > 0:
+                res[name].append((time.perf_counter() - t0) / steps * 1e3)
+for k, v in dict(GEMM_KERNEL="auto", LINEAR_MULTI=True).items():
+    setattr(ops, k, v)
+for name, _ in variants:
+    t = sorted(res[name])
+    print(f"{name:55s} median {t[len(t) // 2]:.3f} ms/step (min {t[0]:.3f})  = {cfg.num_graphs / t[len(t) // 2] * 1e3:,.0f} q/s")
