@@ -280,6 +280,21 @@ int isg_linear_wgrad(const float *grad_out, const float *x, float *partial, int6
 int isg_node_to_edge_mask_bwd(const float *d_edge_mask, const int32_t *rowptr, const int32_t *eid, float *d_node_mask,
                               int64_t N, void *stream);
 
+/* isg_gatv2_mp_fwd with the edge projection computed inside the kernel (csrc/isg_mp_fused.hip): instead of
+ * e_proj = lin_edge(edge_attr) [E, H*C] (mgat_v2_conv.py:259-261) it takes edge_attr fp32 [E, K] (row stride ld_ea) and
+ * the fragment-major bf16 planes of lin_edge.weight [H*C, K] (isg_split_bf16x3_frag); a graph's e_proj tile is formed on
+ * the matrix cores (same six-term bf16 arithmetic as isg_linear_panel) and consumed from registers: e_proj never exists
+ * in HBM.  Same outputs as isg_gatv2_mp_fwd (alpha differs only in the summation order of the logit).  Per-graph form
+ * only: graph_ptr / graph_eptr / dst and the host bounds are required.  ISG_EUNSUPPORTED (caller uses the un-fused
+ * path) unless C == 128, H even, K <= 128, 4 | K, graphs within 64 nodes / 256 edges. */
+int isg_gatv2_mp_fused_edge_fwd(const float *x_l, const float *x_r, const float *edge_attr, const uint16_t *w_frag,
+                                const float *att, const float *bias, const int32_t *rowptr, const int32_t *eid,
+                                const int32_t *src, const float *node_mask, const float *edge_mask, float *out,
+                                float *alpha, int64_t N, int64_t E, int32_t H, int32_t C, int32_t K, float negative_slope,
+                                const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst, int64_t B,
+                                int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_ea,
+                                void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense projections (fp32 accuracy on the bf16 matrix cores)
  * ------------------------------------------------------------------------------------------- */

@@ -30,6 +30,9 @@ SIGNATURES = {
                                  c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_gatv2_mp_fwd_f16": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_gatv2_mp_fused_edge_fwd": (c_int, [c_void_p] * 13 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p,
+                                            c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                            c_void_p]),
     "isg_graph_edge_ptr": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "isg_scatter_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p]),

@@ -103,6 +103,16 @@ class MaskingGATv2Conv(torch.nn.Module):
             x_l = x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt)  # :177-179
         else:   # lin_l and lin_r share their input: one [N, 2*H*C] projection, x_l / x_r are its column halves
             x_l, x_r = ops.linear_fused(x, (self.lin_l, self.lin_r), out_dtype=fdt)      # :177,181
+        fuse = (e_proj is None and edge_attr is not None and self.lin_edge is not None and edge_attr.dim() == 2
+                and fdt == torch.float32 and not torch.is_grad_enabled()
+                and ops.fused_edge_supported(plan, H, C, edge_attr.size(1)))
+        if fuse:      # lin_edge inside the message-passing kernel: its [E, H*C] output never exists (csrc/isg_mp_fused.hip)
+            out, alpha = ops.gatv2_mp_fused_edge(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att,
+                                                 plan, H, bias=self.bias, node_mask=mask,
+                                                 negative_slope=self.negative_slope)    # :215-232, :259-261
+            if isinstance(return_attention_weights, bool):
+                return out, mask, (edge_index, alpha)
+            return out, mask
         if e_proj is None:
             if edge_attr is None or self.lin_edge is None:
                 raise NotImplementedError("edge_attr=None: MGAT always passes edge features (mgat.py:147)")

@@ -331,6 +331,54 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
     return out, alpha
 
 
+# lin_edge inside the message-passing kernel (csrc/isg_mp_fused.hip).  OFF by default: correct (tests) but slower than the
+# un-fused pair at configs[1] (632 us vs 377 us; profiles/r02_d_fused_edge.md says where the time goes) -- kept as the
+# starting point of that work, switchable for A/B runs
+FUSE_EDGE = False
+ISG_EUNSUPPORTED = 3
+
+
+def fused_edge_supported(plan: GraphPlan, heads: int, channels: int, edge_dim: int) -> bool:
+    """Shape test of isg_gatv2_mp_fused_edge_fwd (csrc/isg_mp_fused.hip)."""
+    return (FUSE_EDGE and MP_KERNEL == "graph" and channels == 128 and heads % 2 == 0 and edge_dim <= 128 and
+            edge_dim % 4 == 0 and plan.B > 0 and 0 < plan.nmax <= 64 and plan.emax <= 256 and plan.rowptr is not None)
+
+
+def gatv2_mp_fused_edge(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: GraphPlan,
+                        heads: int, bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None,
+                        edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2) -> Tuple[Tensor, Tensor]:
+    """gatv2_mp(x_l, x_r, lin_edge(edge_attr), ...) without ever writing lin_edge's output (inference, fp32 rows;
+    mgat_v2_conv.py:243-279 with :259-261 inside).  The caller checks fused_edge_supported() first."""
+    lib = _lib.load()
+    N, HC = x_l.shape
+    H = int(heads)
+    C = HC // H
+    E, K = edge_attr.shape
+    if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K) or tuple(x_r.shape) != (N, HC):
+        raise ValueError("gatv2_mp_fused_edge: operand shapes do not match the plan")
+    planes = _weight_planes(w_edge, True, "panel")
+    out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
+    alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+    timer = MP_TIMER
+    if timer is not None:     # bench.py: the roofline keeps the UN-fused algorithmic bytes (SURVEY §8d: do not re-base)
+        ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None,
+                                  "feat_bytes": 4, "fused_edge": True})
+        ev0.record()
+    _lib.check(lib.isg_gatv2_mp_fused_edge_fwd(
+        _chk_rows(x_l, "x_l"), _chk_rows(x_r, "x_r"), _chk_rows(edge_attr, "edge_attr") if E > 0 else 0,
+        planes.data_ptr(), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+        _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+        plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
+        out.data_ptr(), alpha.data_ptr(), N, E, H, C, K, float(negative_slope), plan.ptr.data_ptr(), plan.eptr.data_ptr(),
+        plan.dst.data_ptr(), plan.B, plan.nmax, plan.emax, x_l.stride(0), x_r.stride(0), edge_attr.stride(0), _stream()),
+        "isg_gatv2_mp_fused_edge_fwd")
+    if timer is not None:
+        ev1.record()
+    return out, alpha
+
+
 def gatv2_mp_backward(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, alpha: Tensor, grad_out: Tensor,
                       plan: GraphPlan, heads: int, node_mask: Optional[Tensor] = None,
                       edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_mask_grad: bool = False):

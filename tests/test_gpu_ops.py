@@ -558,3 +558,55 @@ def test_linear_multi_equals_the_separate_projections(dev):
         assert o.shape == (M, n) and o.is_contiguous()
         assert torch.equal(o, ops.linear(x, w))
     assert ops.linear_multi(x[:100], ws) is None            # too few rows for the panel kernel: caller falls back
+
+
+@pytest.mark.parametrize("mask", [None, "node", "edge"])
+@pytest.mark.parametrize("K", [128, 36])
+def test_fused_edge_message_passing_matches_the_unfused_kernel(dev, mask, K, monkeypatch):
+    """isg_gatv2_mp_fused_edge_fwd (lin_edge on the matrix cores inside the per-graph kernel) against the un-fused pair
+    isg_linear_panel / isg_linear_bf16x6 + isg_gatv2_mp_fwd and against the oracle, incl. graphs with more than 64 edges
+    (two MFMA blocks), isolated targets, a 1-node graph and rows beyond the 22-row LDS window."""
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(50 + K)
+    sizes = [20, 1, 37, 5, 64, 23, 2, 30]
+    H, C = 4, 128
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    src, dst, off = [], [], 0
+    for n in sizes:
+        for v in range(n):
+            if not (n == 5 and v == 4):                 # one isolated target
+                src.append(off + v); dst.append(off + v)
+        m = 0 if n == 1 else int(torch.randint(n, 4 * n, (1,), generator=gen))
+        m = min(m, 250 - n)
+        a_ = torch.randint(0, n, (m,), generator=gen); b_ = torch.randint(0, n, (m,), generator=gen)
+        if n == 5:
+            b_ = b_.clamp(max=3)
+        src += (off + a_).tolist(); dst += (off + b_).tolist()
+        off += n
+    ei = torch.tensor([src, dst])
+    ei = ei[:, torch.randperm(ei.size(1), generator=gen)]
+    N, E = batch.numel(), ei.size(1)
+    x_l, x_r = torch.randn(N, H * C, generator=gen), torch.randn(N, H * C, generator=gen)
+    ea = torch.randn(E, K, generator=gen)
+    w = torch.randn(H * C, K, generator=gen) / K ** 0.5
+    att, bias = torch.randn(1, H, C, generator=gen), torch.randn(H * C, generator=gen)
+    nm = (torch.rand(N, generator=gen) < 0.6).float() if mask == "node" else None
+    em = (torch.rand(E, generator=gen) < 0.6).float() if mask == "edge" else None
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    monkeypatch.setattr(ops, "FUSE_EDGE", True)            # off by default (slower than the un-fused pair so far)
+    assert plan.emax > 64 and ops.fused_edge_supported(plan, H, C, K)
+    t = lambda v: None if v is None else v.to(dev)
+    wd = w.to(dev)
+    out_f, alpha_f = ops.gatv2_mp_fused_edge(t(x_l), t(x_r), t(ea), wd, t(att), plan, H, bias=t(bias), node_mask=t(nm),
+                                             edge_mask=t(em))
+    e_proj = ops.linear(t(ea), wd)
+    out_u, alpha_u = ops.gatv2_mp(t(x_l), t(x_r), e_proj, t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em))
+    assert torch.allclose(alpha_f, alpha_u, atol=2e-6, rtol=1e-5), (alpha_f - alpha_u).abs().max()
+    assert torch.allclose(out_f, out_u, atol=2e-5, rtol=1e-5), (out_f - out_u).abs().max()
+    emask = em if em is not None else (None if nm is None else nm[ei[0]] * nm[ei[1]])
+    ref_out, ref_alpha = OM.gatv2_message_passing(x_l.view(N, H, C), x_r.view(N, H, C),
+                                                  torch.nn.functional.linear(ea, w).view(E, H, C), att, ei,
+                                                  None if emask is None else emask.view(E, 1), 0.2)
+    assert torch.allclose(alpha_f.cpu(), ref_alpha, atol=2e-6, rtol=1e-5)
+    assert torch.allclose(out_f.cpu(), ref_out.reshape(N, H * C) + bias, atol=2e-5, rtol=1e-5)
