@@ -343,6 +343,19 @@ int isg_linear_panel_multi(const void *a, int32_t a_is_f16, const uint16_t *w_fr
                            int32_t d_is_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
                            int32_t out_cols, int64_t out_stride, void *stream);
 
+/* The same Linear for K <= 128 on the fp16 matrix cores with THREE products per term (csrc/isg_gemm_f16x3.hip): every A
+ * row and every W row is scaled by its own power of two into fp16's normal range, split into two fp16 planes
+ * (hi + mid = the scaled value to 2^-24), and hi_a hi_b + hi_a mid_b + mid_a hi_b is accumulated in fp32; the epilogue
+ * scales back.  Accuracy of a plain fp32 GEMM (measured 1.0-1.1x its error) at half the matrix-core work of the bf16
+ * six-product form.  isg_split_f16x2_frag: planes uint16[isg_split_f16x2_frag_elems(rows, K)] (fragment-major, 2 planes) and
+ * inv_scale fp32[32 * ceil(rows / 32)].  out_cols / out_stride as in isg_linear_panel_multi (out_cols == N, out_stride == 0
+ * for one output).  fp32 rows only; ISG_EUNSUPPORTED for K > 128. */
+int64_t isg_split_f16x2_frag_elems(int64_t rows, int32_t K);
+int isg_split_f16x2_frag(const float *w, int64_t rows, int32_t K, uint16_t *planes, float *inv_scale, void *stream);
+int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias, float *d,
+                     int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, int32_t out_cols,
+                     int64_t out_stride, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Scene-graph encoder (ISubGVQA/models/scene_graph_encoder.py:108-143) without its concatenations
  * ------------------------------------------------------------------------------------------- */

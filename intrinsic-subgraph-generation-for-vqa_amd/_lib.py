@@ -74,6 +74,10 @@ SIGNATURES = {
                               c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_linear_panel_multi": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p]),
+    "isg_split_f16x2_frag_elems": (c_int64, [c_int64, c_int32]),
+    "isg_split_f16x2_frag": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "isg_linear_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                 c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

@@ -712,6 +712,9 @@ _PLANES = {}                 # (id(weight), layout) -> (weakref, version, data_p
 GEMM_KERNEL = "auto"         # "auto": per shape (below); "panel": isg_linear_panel; "tile": isg_linear_bf16x6 (A/B switch)
 
 
+GEMM_F16X3 = True     # K <= 128 panel shapes on the fp16 three-product kernel (isg_linear_f16x3) instead of bf16x6 (A/B switch)
+
+
 def _use_panel(M: int, N: int, K: int) -> bool:
     """The row-panel kernel wins where an A panel is split once and serves many columns (K <= 128: lin_edge 182 vs 212 us,
     lin_l|lin_r 153 vs 166 us) and there are enough 64-row panels to fill the chip; the tile kernel elsewhere
@@ -796,7 +799,13 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
     lib = _lib.load()
     N, K = weight.shape
     w = weight.detach()
-    if layout == "panel":      # fragment-major planes of isg_linear_panel
+    if layout == "f16x3":      # two scaled fp16 planes + the inverse row scales of isg_linear_f16x3
+        planes = torch.empty(int(lib.isg_split_f16x2_frag_elems(N, K)), dtype=torch.int16, device=weight.device)
+        inv = torch.empty((N + 31) // 32 * 32, dtype=torch.float32, device=weight.device)
+        _lib.check(lib.isg_split_f16x2_frag(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(),
+                                            inv.data_ptr(), _stream()), "isg_split_f16x2_frag")
+        planes = (planes, inv)
+    elif layout == "panel":      # fragment-major planes of isg_linear_panel
         planes = torch.empty(int(lib.isg_split_bf16x3_frag_elems(N, K)), dtype=torch.int16, device=weight.device)
         _lib.check(lib.isg_split_bf16x3_frag(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(),
                                              _stream()), "isg_split_bf16x3_frag")
@@ -835,6 +844,13 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         return torch.nn.functional.gelu(y) if gelu else y
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    if _use_panel(M, N, K) and not relu and GEMM_F16X3 and K <= 128 and not f16_io:
+        planes, inv = _weight_planes(weight, cache_planes, "f16x3")
+        _lib.check(lib.isg_linear_f16x3(
+            _chk(x, "x", torch.float32), planes.data_ptr(), inv.data_ptr(),
+            _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
+            out.data_ptr(), M, N, K, K, N, 1 if gelu else 0, N, 0, _stream()), "isg_linear_f16x3")
+        return out
     if _use_panel(M, N, K) and not relu:
         planes = _weight_planes(weight, cache_planes, "panel")
         _lib.check(lib.isg_linear_panel(
@@ -874,9 +890,14 @@ def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
         return None
     lib = _lib.load()
     cat = derived_weight("linear_multi", tuple(weights), lambda: torch.cat([w.detach() for w in weights], 0).contiguous())
-    planes = _weight_planes(cat, True, "panel")
     L = len(weights)
     out = torch.empty(L, M, n, dtype=out_dtype, device=x.device)
+    if GEMM_F16X3 and K <= 128 and x.dtype == torch.float32 and out_dtype == torch.float32:
+        planes, inv = _weight_planes(cat, True, "f16x3")
+        _lib.check(lib.isg_linear_f16x3(_chk(x, "x", torch.float32), planes.data_ptr(), inv.data_ptr(), 0, out.data_ptr(),
+                                        M, L * n, K, K, n, 0, n, M * n, _stream()), "isg_linear_f16x3")
+        return tuple(out[i] for i in range(L))
+    planes = _weight_planes(cat, True, "panel")
     _lib.check(lib.isg_linear_panel_multi(
         _chk(x, "x", x.dtype), 1 if x.dtype == torch.float16 else 0, planes.data_ptr(), 0, out.data_ptr(),
         1 if out_dtype == torch.float16 else 0, M, L * n, K, K, n, 0, n, M * n, _stream()), "isg_linear_panel_multi")

@@ -327,12 +327,15 @@ def test_per_graph_kernels_match_oracle(dev, C, sizes):
     (200, 136, 96, False, True),        # K just past one chunk (tail chunk of a single k-step)
     (65, 300, 300, True, True),         # two panels, the second with one row; odd number of k-steps (19)
 ])
-@pytest.mark.parametrize("kernel", ["panel", "tile"])
+@pytest.mark.parametrize("kernel", ["f16x3", "panel", "tile"])
 def test_linear_bf16x6_has_fp32_accuracy(dev, M, K, N, bias, gelu, kernel, monkeypatch):
     """isg_linear_panel / isg_linear_bf16x6 against an fp64 reference: the 3-way bf16 split must not cost accuracy
     relative to an fp32 GEMM."""
     from isubgvqa_amd import ops
-    monkeypatch.setattr(ops, "GEMM_KERNEL", kernel)
+    if kernel == "f16x3" and K > 128:
+        pytest.skip("the fp16 three-product form exists for K <= 128 (row scales need the whole row in one panel)")
+    monkeypatch.setattr(ops, "GEMM_KERNEL", "panel" if kernel == "f16x3" else kernel)
+    monkeypatch.setattr(ops, "GEMM_F16X3", kernel == "f16x3")
     gen = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=gen)
     w = torch.randn(N, K, generator=gen) / math.sqrt(K)
@@ -610,3 +613,29 @@ def test_fused_edge_message_passing_matches_the_unfused_kernel(dev, mask, K, mon
                                                   None if emask is None else emask.view(E, 1), 0.2)
     assert torch.allclose(alpha_f.cpu(), ref_alpha, atol=2e-6, rtol=1e-5)
     assert torch.allclose(out_f.cpu(), ref_out.reshape(N, H * C) + bias, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("scale,spread", [(1.0, 1.0), (1e-3, 1e-4), (300.0, 1e3), (1e-20, 1.0)])
+def test_linear_f16x3_keeps_fp32_accuracy_over_the_dynamic_range(dev, scale, spread, monkeypatch):
+    """isg_linear_f16x3 scales every row by a power of two before the fp16 split: tiny and huge magnitudes, and rows whose
+    elements span many binades, must come out with the error of an fp32 GEMM (fp16 alone would flush them); zero rows and
+    a zero weight row stay exactly zero."""
+    from isubgvqa_amd import ops
+    monkeypatch.setattr(ops, "GEMM_KERNEL", "panel")
+    monkeypatch.setattr(ops, "GEMM_F16X3", True)
+    gen = torch.Generator().manual_seed(9)
+    M, K, N = 700, 128, 320
+    x = torch.randn(M, K, generator=gen) * scale
+    x[:, ::5] *= spread
+    x[3] = 0.0
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    w[:, 1::3] *= spread
+    w[7] = 0.0
+    b = torch.randn(N, generator=gen) * scale
+    ref = x.double() @ w.double().t() + b.double()
+    f32 = torch.nn.functional.linear(x, w, b).double()
+    got = ops.linear(x.to(dev), w.to(dev), b.to(dev)).cpu().double()
+    err, err32 = (got - ref).abs().max().item(), (f32 - ref).abs().max().item()
+    print(f"f16x3 scale {scale:g} spread {spread:g}: err {err:.3e}, fp32 GEMM {err32:.3e}, ratio {err / max(err32, 1e-300):.2f}")
+    assert err <= 2.0 * err32 + 1e-30
+    assert torch.equal(got[3], b.double()) and torch.equal(got[:, 7], x.double().mul(0).sum(1) + b.double()[7])

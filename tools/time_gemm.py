@@ -22,7 +22,7 @@ if "c300" in sys.argv:
               ("text in_proj [49152,512]x[1536,512]", 49152, 512, 1536, False), ("text ffn1+relu~[49152,512]x[2048,512]", 49152, 512, 2048, False),
               ("text ffn2    [49152,2048]x[512,2048]", 49152, 2048, 512, False)]
 g = torch.Generator(device=dev).manual_seed(0)
-arms = ("torch", "tile", "panel")
+arms = ("torch", "tile", "panel", "f16x3")
 for name, M, K, N, gelu in shapes:
     x = torch.randn(M, K, device=dev, generator=g)
     w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
@@ -31,7 +31,8 @@ for name, M, K, N, gelu in shapes:
     for r in range(rounds + 2):
         for arm in arms:
             ops.GEMM_BACKEND = "torch" if arm == "torch" else "bf16x6"
-            ops.GEMM_KERNEL = arm if arm != "torch" else ops.GEMM_KERNEL
+            ops.GEMM_KERNEL = {"tile": "tile", "panel": "panel", "f16x3": "panel"}.get(arm, ops.GEMM_KERNEL)
+            ops.GEMM_F16X3 = arm == "f16x3"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = ops.linear(x, w, b, gelu=gelu)
@@ -44,4 +45,4 @@ for name, M, K, N, gelu in shapes:
     mn = {a: min(v) for a, v in res.items()}
     hbm = 4.0 * (M * K + M * N)
     print(f"{name:38s} " + "  ".join(f"{a} {med[a]:7.1f} us (min {mn[a]:6.1f}; {fl / med[a] / 1e6:6.1f} TF, {hbm / med[a] / 1e3:5.0f} GB/s)" for a in arms)
-          + f"   panel/tile x{med['tile'] / med['panel']:.2f}", flush=True)
+          + f"   f16x3/tile x{med['tile'] / med['f16x3']:.2f}", flush=True)
