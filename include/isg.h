@@ -280,6 +280,16 @@ int isg_linear_wgrad(const float *grad_out, const float *x, float *partial, int6
 int isg_node_to_edge_mask_bwd(const float *d_edge_mask, const int32_t *rowptr, const int32_t *eid, float *d_node_mask,
                               int64_t N, void *stream);
 
+/* isg_gatv2_mp_fwd that also writes rowmax fp32 [N, H] = the largest |out| of every (node, head): the row scales of the
+ * fp16 three-product GEMM that consumes `out` (isg_linear_f16x3_tile takes them as its a_rowmax with P = H), at no extra
+ * pass over `out`.  Grouped per-graph kernel only: ISG_EUNSUPPORTED for batches / widths that take another kernel. */
+int isg_gatv2_mp_fwd_rowmax(const float *x_l, const float *x_r, const float *e_proj, const float *att, const float *bias,
+                            const int32_t *rowptr, const int32_t *eid, const int32_t *src, const float *node_mask,
+                            const float *edge_mask, float *out, float *alpha, float *rowmax, int64_t N, int64_t E,
+                            int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
+                            const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
+                            int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e, void *stream);
+
 /* isg_gatv2_mp_fwd with the edge projection computed inside the kernel (csrc/isg_mp_fused.hip): instead of
  * e_proj = lin_edge(edge_attr) [E, H*C] (mgat_v2_conv.py:259-261) it takes edge_attr fp32 [E, K] (row stride ld_ea) and
  * the fragment-major bf16 planes of lin_edge.weight [H*C, K] (isg_split_bf16x3_frag); a graph's e_proj tile is formed on
@@ -350,6 +360,14 @@ int isg_linear_panel_multi(const void *a, int32_t a_is_f16, const uint16_t *w_fr
  * six-product form.  isg_split_f16x2_frag: planes uint16[isg_split_f16x2_frag_elems(rows, K)] (fragment-major, 2 planes) and
  * inv_scale fp32[32 * ceil(rows / 32)].  out_cols / out_stride as in isg_linear_panel_multi (out_cols == N, out_stride == 0
  * for one output).  fp32 rows only; ISG_EUNSUPPORTED for K > 128. */
+/* Tile form of the three-product kernel for 128 < K <= 1024 (x_proj of MGAT, mgat.py:156).  A row's scale needs the
+ * row's largest magnitude over all of K, so it is an input: a_rowmax fp32 [M, P], P partial maxima per row written by the
+ * kernel that produced `a` (isg_gatv2_mp_fwd_rowmax: P = H; this kernel: d_rowmax [M, ceil(N / 32)], or NULL).  w_planes /
+ * w_inv_scale from isg_split_f16x2_rows: uint16[2 * rows * Kp] (Kp = K rounded up to 32), fp32[rows]. */
+int isg_split_f16x2_rows(const float *w, int64_t rows, int32_t K, uint16_t *planes, float *inv_scale, void *stream);
+int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int32_t P, const uint16_t *w_planes,
+                          const float *w_inv_scale, const float *bias, float *d, float *d_rowmax, int64_t M, int32_t N,
+                          int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream);
 int64_t isg_split_f16x2_frag_elems(int64_t rows, int32_t K);
 int isg_split_f16x2_frag(const float *w, int64_t rows, int32_t K, uint16_t *planes, float *inv_scale, void *stream);
 int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias, float *d,

@@ -78,6 +78,11 @@ SIGNATURES = {
     "isg_split_f16x2_frag": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_linear_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                  c_int32, c_int32, c_int32, c_int64, c_void_p]),
+    "isg_gatv2_mp_fwd_rowmax": (c_int, [c_void_p] * 13 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                                        c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_split_f16x2_rows": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "isg_linear_f16x3_tile": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                      c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

@@ -243,3 +243,261 @@ extern "C" int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const fl
 #undef ISG_H3
   return check_launch();
 }
+
+// =====================================================================================================================
+// Tile form for K > 128 (x_proj: 512 -> 256 -> 128 at configs[1]).  A row's scale needs the row's largest magnitude over
+// ALL of K before the first k-tile is split, so it is an INPUT: a_rowmax[M, P], P partial maxima per row, written by the
+// kernel that produced A (the message-passing kernel per head, this kernel's own epilogue per 32-column subtile) -- a few
+// KB next to the rows, no extra pass over A.  Structure of isg_gemm.hip's tile kernel (128 x 128 x 32 tile, 8 waves as
+// 4 x 2, one LDS buffer, two register images, XCD-aware tile order, results through per-wave LDS patches as 16-byte row
+// stores), two planes instead of three, three MFMAs per product instead of six.
+// =====================================================================================================================
+namespace isg {
+
+constexpr int HT_BM = 128, HT_BN = 128, HT_BK = 32, HT_LD = HT_BK + 8;
+
+// planes[q][row][Kp] (q = hi, mid; Kp = K rounded up to 32, zero padded) of w[row][k] * s_row; inv[row] = 1 / s_row
+__global__ void split_f16x2_rows_kernel(const float *__restrict__ w, int N, int K, int Kp, _Float16 *__restrict__ planes,
+                                        float *__restrict__ inv_scale) {
+  const int n = blockIdx.x;
+  __shared__ float s_s;
+  float mx = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) mx = fmaxf(mx, fabsf(w[(int64_t)n * K + k]));
+  mx = wave_max(mx);
+  if (threadIdx.x == 0) {
+    float s, inv;
+    h3_scale(mx, s, inv);
+    s_s = s;
+    inv_scale[n] = inv;
+  }
+  __syncthreads();
+  const float s = s_s;
+  const int64_t total = (int64_t)N * Kp;
+  for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+    const float v = k < K ? w[(int64_t)n * K + k] * s : 0.f;
+    const _Float16 hi = (_Float16)v;
+    planes[(int64_t)n * Kp + k] = hi;
+    planes[total + (int64_t)n * Kp + k] = (_Float16)(v - (float)hi);
+  }
+}
+
+template <int ACT, bool XCD, bool RMAX>
+__global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *__restrict__ A,
+                                                                   const float *__restrict__ a_rowmax, int P,
+                                                                   const _Float16 *__restrict__ Wp,
+                                                                   const float *__restrict__ w_inv,
+                                                                   const float *__restrict__ bias, float *__restrict__ D,
+                                                                   float *__restrict__ d_rowmax, int M, int N, int K,
+                                                                   int Kp, int lda, int ldd, int nt_store) {
+  struct Smem {
+    _Float16 a[2][HT_BM][HT_LD];
+    _Float16 b[2][HT_BN][HT_LD];
+    float inv[HT_BM];
+  };
+  __shared__ __attribute__((aligned(16))) Smem sm;
+  static_assert(sizeof(_Float16) * 2 * (HT_BM + HT_BN) * HT_LD >= 8 * 32 * 36 * sizeof(float), "epilogue patches must fit");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  int n0, m0;
+  if (XCD) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, nt = gridDim.x;
+    const int slot = L >> 3;
+    const int mt = (L & 7) + 8 * (slot / nt);
+    n0 = (slot % nt) * HT_BN;
+    m0 = mt * HT_BM;
+    if (m0 >= M) return;
+  } else {
+    n0 = blockIdx.x * HT_BN;
+    m0 = blockIdx.y * HT_BM;
+  }
+  const int64_t plane_stride = (int64_t)N * Kp;
+
+  // this thread stages the same two rows in every k-tile: their scales once, from the producer's partial maxima
+  float sa[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = (tid + 512 * u) >> 3;
+    const int gr = min(m0 + row, M - 1);
+    float mx = 0.f;
+    for (int p = 0; p < P; ++p) mx = fmaxf(mx, a_rowmax[(int64_t)gr * P + p]);
+    float inv;
+    h3_scale(mx, sa[u], inv);
+    if (((tid + 512 * u) & 7) == 0) sm.inv[row] = inv;
+  }
+
+  hf32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float4 ra0[2], ra1[2];
+  hf16x8 rb0[2], rb1[2];
+#define HT_LOAD_TILE(RA, RB, k0)                                                                                 \
+  {                                                                                                              \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                              \
+      const int i = tid + 512 * u;                                                                               \
+      const int row = i >> 3, c4 = i & 7;                                                                        \
+      const int gr = min(m0 + row, M - 1), gk = min((k0) + c4 * 4, K - 4);                                       \
+      RA[u] = *reinterpret_cast<const float4 *>(A + (int64_t)gr * lda + gk);                                     \
+    }                                                                                                            \
+    {                                                                                                            \
+      const int row = tid >> 2, c8 = tid & 3;                                                                    \
+      const int gn = min(n0 + row, N - 1);                                                                       \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                              \
+        RB[q] = *reinterpret_cast<const hf16x8 *>(Wp + q * plane_stride + (int64_t)gn * Kp + (k0) + c8 * 8);     \
+    }                                                                                                            \
+  }
+  const int nk = Kp / HT_BK;
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+#define HT_STEP(RA, RB, kt)                                                                                      \
+  {                                                                                                              \
+    if ((kt) > 0) __syncthreads();                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                              \
+      const int i = tid + 512 * u;                                                                               \
+      const int row = i >> 3, c4 = i & 7;                                                                        \
+      float4 v = RA[u];                                                                                          \
+      if (m0 + row >= M || (kt) * HT_BK + c4 * 4 >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);                      \
+      v.x *= sa[u]; v.y *= sa[u]; v.z *= sa[u]; v.w *= sa[u];                                                    \
+      hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                                  \
+      hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]), \
+                    (_Float16)(v.w - (float)hi[3])};                                                             \
+      *reinterpret_cast<hf16x4 *>(&sm.a[0][row][c4 * 4]) = hi;                                                   \
+      *reinterpret_cast<hf16x4 *>(&sm.a[1][row][c4 * 4]) = mid;                                                  \
+    }                                                                                                            \
+    {                                                                                                            \
+      const int row = tid >> 2, c8 = tid & 3;                                                                    \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q) *reinterpret_cast<hf16x8 *>(&sm.b[q][row][c8 * 8]) = RB[q];  \
+    }                                                                                                            \
+    __syncthreads();                                                                                             \
+    if ((kt) + 2 < nk) HT_LOAD_TILE(RA, RB, ((kt) + 2) * HT_BK)                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
+      hf16x8 a[2], b[2][2];                                                                                      \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                              \
+        a[q] = *reinterpret_cast<const hf16x8 *>(&sm.a[q][wm * 32 + fr][ks * 16 + fk]);                          \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)                \
+        b[j][q] = *reinterpret_cast<const hf16x8 *>(&sm.b[q][wn * 64 + j * 32 + fr][ks * 16 + fk]);              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                            \
+        hf32x16 c = acc[j];                                                                                      \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[j][1], c, 0, 0, 0);                                   \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[j][0], c, 0, 0, 0);                                   \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[j][0], c, 0, 0, 0);                                   \
+        acc[j] = c;                                                                                              \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+  HT_LOAD_TILE(ra0, rb0, 0)
+  if (nk > 1) HT_LOAD_TILE(ra1, rb1, HT_BK)
+  for (int kt = 0; kt < nk; kt += 2) {
+    HT_STEP(ra0, rb0, kt)
+    if (kt + 1 < nk) HT_STEP(ra1, rb1, kt + 1)
+  }
+#undef HT_STEP
+#undef HT_LOAD_TILE
+
+  // ---- epilogue: scale back, + bias, activation, per-wave LDS patch -> 16-byte row stores (+ the row maxima of D) ------
+  float inv_a[16];
+  {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) inv_a[r] = sm.inv[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+  }
+  __syncthreads();   // every wave is done with the operand tiles and the scale table: the LDS is free
+  float *patch = reinterpret_cast<float *>(&sm) + wave * (32 * 36);
+  const int h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int colb = n0 + wn * 64 + j * 32;
+    const int col = colb + fr;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+    const float wi = w_inv[min(col, N - 1)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = (acc[j][r] * inv_a[r]) * wi + bv;
+      if (ACT == 1) v = gelu_exact(v);
+      patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + fr] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int rowb = m0 + wm * 32;
+    const bool vec_ok = (ldd & 3) == 0 && colb + 32 <= N && (reinterpret_cast<uintptr_t>(D) & 15) == 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = q * 64 + lane;
+      const int rr = idx >> 3, c4 = idx & 7;
+      const float4 v = *reinterpret_cast<const float4 *>(&patch[rr * 36 + c4 * 4]);
+      const int row = rowb + rr;
+      if (RMAX) {   // largest magnitude of this row's (up to) 32 columns; columns beyond N are not part of D
+        const int c0 = colb + c4 * 4;
+        float mx = c0 < N ? fabsf(v.x) : 0.f;
+        if (c0 + 1 < N) mx = fmaxf(mx, fabsf(v.y));
+        if (c0 + 2 < N) mx = fmaxf(mx, fabsf(v.z));
+        if (c0 + 3 < N) mx = fmaxf(mx, fabsf(v.w));
+        mx = fmaxf(mx, dpp_mov<ISG_DPP_XOR1>(mx));
+        mx = fmaxf(mx, dpp_mov<ISG_DPP_XOR2>(mx));
+        mx = fmaxf(mx, dpp_mov<ISG_DPP_HMIRROR>(mx));
+        if (c4 == 0 && row < M && colb < N) d_rowmax[(int64_t)row * ((N + 31) / 32) + (colb >> 5)] = mx;
+      }
+      if (row < M) {
+        float *dst = D + (int64_t)row * ldd + colb + c4 * 4;
+        if (vec_ok) {
+          if (nt_store) {
+            typedef float ht_f32x4 __attribute__((ext_vector_type(4)));
+            ht_f32x4 w4 = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w4, reinterpret_cast<ht_f32x4 *>(dst));
+          } else {
+            *reinterpret_cast<float4 *>(dst) = v;
+          }
+        } else {
+          if (colb + c4 * 4 + 0 < N) dst[0] = v.x;
+          if (colb + c4 * 4 + 1 < N) dst[1] = v.y;
+          if (colb + c4 * 4 + 2 < N) dst[2] = v.z;
+          if (colb + c4 * 4 + 3 < N) dst[3] = v.w;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace isg
+
+extern "C" int isg_split_f16x2_rows(const float *w, int64_t rows, int32_t K, uint16_t *planes, float *inv_scale,
+                                    void *stream) {
+  if (rows < 0 || K <= 0) return ISG_EINVAL;
+  if (rows == 0) return ISG_OK;
+  if (!w || !planes || !inv_scale) return ISG_EINVAL;
+  if (rows >= (1ll << 24)) return ISG_EUNSUPPORTED;
+  const int Kp = (K + HT_BK - 1) / HT_BK * HT_BK;
+  split_f16x2_rows_kernel<<<(unsigned)rows, 64, 0, as_stream(stream)>>>(w, (int)rows, K, Kp,
+                                                                        reinterpret_cast<_Float16 *>(planes), inv_scale);
+  return check_launch();
+}
+
+// a_rowmax fp32 [M, P]: partial maxima of |a| per row (P >= 1); d_rowmax NULL or fp32 [M, ceil(N / 32)] (written)
+extern "C" int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int32_t P, const uint16_t *w_planes,
+                                     const float *w_inv_scale, const float *bias, float *d, float *d_rowmax, int64_t M,
+                                     int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream) {
+  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 1 || P <= 0) return ISG_EINVAL;
+  if (M == 0) return ISG_OK;
+  if (!a || !a_rowmax || !w_planes || !w_inv_scale || !d) return ISG_EINVAL;
+  if ((K & 3) != 0 || (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(a) & 15) != 0 || M >= (1ll << 31) || K > 1024 || P > 64)
+    return ISG_EUNSUPPORTED;
+  const int Kp = (K + HT_BK - 1) / HT_BK * HT_BK;
+  const long long mt = (M + HT_BM - 1) / HT_BM;
+  if (mt > 65535) return ISG_EUNSUPPORTED;
+  dim3 grid((unsigned)((N + HT_BN - 1) / HT_BN), (unsigned)mt), block(512);
+  static const long long nt_mb = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return e ? atoll(e) : 128ll; }();
+  const int nt = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
+  dim3 gridx(grid.x, (grid.y + 7) / 8 * 8);
+  const bool xcd = grid.x > 1;
+  const _Float16 *wp = reinterpret_cast<const _Float16 *>(w_planes);
+  hipStream_t st = as_stream(stream);
+#define ISG_HT(ACT_, R_)                                                                                          \
+  do {                                                                                                            \
+    if (xcd) linear_f16x3_tile_kernel<ACT_, true, R_><<<gridx, block, 0, st>>>(a, a_rowmax, P, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, lda, ldd, nt); \
+    else linear_f16x3_tile_kernel<ACT_, false, R_><<<grid, block, 0, st>>>(a, a_rowmax, P, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, lda, ldd, nt); \
+  } while (0)
+  if (act == 1) { if (d_rowmax) ISG_HT(1, true); else ISG_HT(1, false); }
+  else { if (d_rowmax) ISG_HT(0, true); else ISG_HT(0, false); }
+#undef ISG_HT
+  return check_launch();
+}

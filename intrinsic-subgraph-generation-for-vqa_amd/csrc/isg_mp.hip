@@ -253,7 +253,7 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
                   const float *edge_mask, void *out, float *alpha, int64_t N, int64_t E, int32_t H, int32_t C,
                   float negative_slope, const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst,
                   int64_t B, int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e,
-                  void *stream, int f16) {
+                  void *stream, int f16, float *rowmax = nullptr) {
   if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
   if (N == 0) return ISG_OK;
   if (!x_l || !x_r || !att || !rowptr || !out || (E > 0 && (!e_proj || !eid || !src || !alpha))) return ISG_EINVAL;
@@ -273,6 +273,7 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
   a.ldl4 = ld_l >> 2; a.ldr4 = ld_r >> 2; a.lde4 = ld_e >> 2;
   a.graph_ptr = graph_ptr; a.graph_eptr = graph_eptr; a.dst = dst; a.B = (int)B; a.lrows = 0;
   a.f16 = f16;
+  a.rowmax = rowmax;
   {
     const char *f = getenv("ISG_MP_FLAGS");   // experiment switch; default = tuned setting
     a.flags = f ? atoi(f) : ISG_MP_DEFAULT_FLAGS;
@@ -283,6 +284,7 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
     int rc = launch_mp_graph(a, nmax_host, emax_host, st);
     if (rc != ISG_EUNSUPPORTED) return rc;   // shapes without a per-graph instantiation use the node-chunk kernel
   }
+  if (rowmax) return ISG_EUNSUPPORTED;       // the row maxima are written by the grouped per-graph kernel only
   if (f16) return ISG_EUNSUPPORTED;          // fp16 rows exist in the per-graph kernel only
   switch (H) {
     case 1: return launch_mp<1>(a, st);
@@ -346,4 +348,18 @@ extern "C" int isg_scatter_mean(const float *msg, const int32_t *rowptr, const i
   scatter_mean_kernel<<<(unsigned)((N + 3) / 4), 256, 0, as_stream(stream)>>>(
       (const float4 *)msg, rowptr, eid, (float4 *)out, (int)N, C >> 2);
   return check_launch();
+}
+
+// isg_gatv2_mp_fwd that also writes rowmax[N, H] = max |out[n, h*C : (h+1)*C]| (per-graph grouped kernel only;
+// ISG_EUNSUPPORTED for shapes that would take another kernel: the caller then runs isg_gatv2_mp_fwd)
+extern "C" int isg_gatv2_mp_fwd_rowmax(const float *x_l, const float *x_r, const float *e_proj, const float *att,
+                                       const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                       const float *node_mask, const float *edge_mask, float *out, float *alpha,
+                                       float *rowmax, int64_t N, int64_t E, int32_t H, int32_t C, float negative_slope,
+                                       const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst, int64_t B,
+                                       int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e,
+                                       void *stream) {
+  if (!rowmax) return ISG_EINVAL;
+  return mp_fwd(x_l, x_r, e_proj, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
+                negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, ld_r, ld_e, stream, 0, rowmax);
 }

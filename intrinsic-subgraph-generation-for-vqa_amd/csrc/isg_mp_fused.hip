@@ -345,7 +345,7 @@ extern "C" int isg_gatv2_mp_fused_edge_fwd(const float *x_l, const float *x_r, c
   a.lde4 = 0; a.ldl4 = ld_l >> 2; a.ldr4 = ld_r >> 2;
   a.slope = negative_slope;
   a.graph_ptr = graph_ptr; a.graph_eptr = graph_eptr; a.dst = dst;
-  a.B = (int)B; a.f16 = 0; a.flags = 1 | 4; a.nchunks = 0;
+  a.B = (int)B; a.f16 = 0; a.flags = 1 | 4; a.nchunks = 0; a.rowmax = nullptr;
   fa.edge_attr = edge_attr;
   fa.w_frag = reinterpret_cast<const __bf16 *>(w_frag);
   fa.K = K; fa.KS = (K + 15) / 16; fa.NT = (HC + 31) / 32; fa.ld_ea = ld_ea;

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
         }
       }
       const size_t orow = (size_t)(nb + k) * R + hoff;
+      float rmx = 0.f;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         if (ok[p]) {
@@ -242,8 +243,13 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
             const float4 b = a.bias[hoff + off[p]];
             o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
           }
+          rmx = fmaxf(rmx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
           stq_stream<F16>(a.out, orow + off[p], o, nt);
         }
+      }
+      if (!F16 && a.rowmax) {   // largest magnitude of this (node, head): the consumer GEMM's row scale
+        rmx = group_max<G>(rmx);
+        if (l == 0) a.rowmax[(size_t)(nb + k) * a.H + hd] = rmx;
       }
     }
   }
@@ -546,7 +552,7 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   static const bool no_flat = getenv("ISG_MP_NO_FLAT") != nullptr;
   if (HS == 1 && a.H > 1 && P == 2 && Q * 10 < G * P * 7 && !force_graph) {
     // head dimension that fills < 70 % of two passes (the reference's C = 300): flat lane mapping over two heads
-    if (!no_flat) {
+    if (!no_flat && !a.rowmax) {
       const int rc = launch_mp_graph_flat(a, nmax_host, emax_host, st);
       if (rc != ISG_EUNSUPPORTED) return rc;
     }

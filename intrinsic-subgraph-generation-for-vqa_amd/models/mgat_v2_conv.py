@@ -120,7 +120,8 @@ class MaskingGATv2Conv(torch.nn.Module):
                 edge_attr = edge_attr.view(-1, 1)
             e_proj = ops.linear(edge_attr.float().contiguous(), self.lin_edge.weight, None, out_dtype=fdt)   # :259
         out, alpha = ops.gatv2_mp(x_l, x_r, e_proj, self.att, plan, H, bias=self.bias, node_mask=mask,
-                                  negative_slope=self.negative_slope)                    # :215-232
+                                  negative_slope=self.negative_slope,
+                                  want_rowmax=not torch.is_grad_enabled())                # :215-232
         if isinstance(return_attention_weights, bool):
             return out, mask, (edge_index, alpha)                                        # :237
         return out, mask                                                                 # :241

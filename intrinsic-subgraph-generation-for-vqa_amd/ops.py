@@ -284,8 +284,10 @@ MP_KERNEL = "graph"    # "graph": per-graph LDS-resident kernel; "chunk": node-c
 
 def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphPlan, heads: int,
              bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
-             negative_slope: float = 0.2, kernel: Optional[str] = None) -> Tuple[Tensor, Tensor]:
-    """MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:243-279).  Returns (out[N,H*C], alpha[E,H])."""
+             negative_slope: float = 0.2, kernel: Optional[str] = None, want_rowmax: bool = False) -> Tuple[Tensor, Tensor]:
+    """MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:243-279).  Returns (out[N,H*C], alpha[E,H]).
+    want_rowmax (inference, fp32 rows): the kernel also writes max |out| per (node, head) and `out` carries it as
+    ``out._isg_rowmax`` [N, H] -- the row scales of the fp16 three-product GEMM that reads `out` next (x_proj)."""
     if _rec(x_l, x_r, e_proj, att, bias, node_mask, edge_mask):
         from . import autograd
         return autograd.gatv2_mp(x_l, x_r, e_proj, att, plan, heads, bias, node_mask, edge_mask, negative_slope, kernel)
@@ -314,6 +316,26 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None,
                                   "feat_bytes": 2 if fdt == torch.float16 else 4})
         ev0.record()
+    rowmax = None
+    if want_rowmax and use_graph and fdt == torch.float32 and E > 0:
+        rowmax = torch.empty(N, H, dtype=torch.float32, device=x_l.device)
+        rc = lib.isg_gatv2_mp_fwd_rowmax(
+            _chk_rows(x_l, "x_l", fdt), _chk_rows(x_r, "x_r", fdt), _chk_rows(e_proj, "e_proj", fdt),
+            _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+            _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+            plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
+            _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+            _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
+            out.data_ptr(), alpha.data_ptr(), rowmax.data_ptr(), N, E, H, C, float(negative_slope), plan.ptr.data_ptr(),
+            plan.eptr.data_ptr(), plan.dst.data_ptr(), plan.B, plan.nmax, plan.emax, ld_l, ld_r, ld_e, _stream())
+        if rc == ISG_EUNSUPPORTED:
+            rowmax = None              # this batch / width takes another kernel: plain call below
+        else:
+            _lib.check(rc, "isg_gatv2_mp_fwd_rowmax")
+            if timer is not None:
+                ev1.record()
+            out._isg_rowmax = rowmax
+            return out, alpha
     entry = lib.isg_gatv2_mp_fwd if fdt == torch.float32 else lib.isg_gatv2_mp_fwd_f16
     _lib.check(entry(
         _chk_rows(x_l, "x_l", fdt), _chk_rows(x_r, "x_r", fdt),
@@ -335,7 +357,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
 # un-fused pair at configs[1] (632 us vs 377 us; profiles/r02_d_fused_edge.md says where the time goes) -- kept as the
 # starting point of that work, switchable for A/B runs
 FUSE_EDGE = False
-ISG_EUNSUPPORTED = 3
+ISG_EUNSUPPORTED = -2      # include/isg.h
 
 
 def fused_edge_supported(plan: GraphPlan, heads: int, channels: int, edge_dim: int) -> bool:
@@ -712,6 +734,7 @@ _PLANES = {}                 # (id(weight), layout) -> (weakref, version, data_p
 GEMM_KERNEL = "auto"         # "auto": per shape (below); "panel": isg_linear_panel; "tile": isg_linear_bf16x6 (A/B switch)
 
 
+F16X3_TILE = True     # ... and 128 < K <= 1024 when the producer of the input left its row maxima (isg_linear_f16x3_tile)
 GEMM_F16X3 = True     # K <= 128 panel shapes on the fp16 three-product kernel (isg_linear_f16x3) instead of bf16x6 (A/B switch)
 
 
@@ -799,7 +822,14 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
     lib = _lib.load()
     N, K = weight.shape
     w = weight.detach()
-    if layout == "f16x3":      # two scaled fp16 planes + the inverse row scales of isg_linear_f16x3
+    if layout == "f16x3_rows":  # row-major scaled fp16 planes of isg_linear_f16x3_tile
+        Kp = (K + 31) // 32 * 32
+        planes = torch.empty(2 * N * Kp, dtype=torch.int16, device=weight.device)
+        inv = torch.empty(N, dtype=torch.float32, device=weight.device)
+        _lib.check(lib.isg_split_f16x2_rows(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(),
+                                            inv.data_ptr(), _stream()), "isg_split_f16x2_rows")
+        planes = (planes, inv)
+    elif layout == "f16x3":      # two scaled fp16 planes + the inverse row scales of isg_linear_f16x3
         planes = torch.empty(int(lib.isg_split_f16x2_frag_elems(N, K)), dtype=torch.int16, device=weight.device)
         inv = torch.empty((N + 31) // 32 * 32, dtype=torch.float32, device=weight.device)
         _lib.check(lib.isg_split_f16x2_frag(_chk(w.contiguous(), "weight", torch.float32), N, K, planes.data_ptr(),
@@ -823,7 +853,7 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False,
-           cache_planes: bool = True, out_dtype=torch.float32, relu: bool = False) -> Tensor:
+           cache_planes: bool = True, out_dtype=torch.float32, relu: bool = False, want_rowmax: bool = False) -> Tensor:
     """act(x @ weight^T + bias), x [M,K] fp32, weight [N,K] (torch Linear layout).  Uses the bf16x6 matrix-core kernel
     when the shape allows it, hipBLASLt through torch otherwise (K not a multiple of 4).  ``cache_planes=False``: the
     weight is being trained (or is a temporary), so its bf16 planes are split per call instead of cached."""
@@ -844,6 +874,20 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         return torch.nn.functional.gelu(y) if gelu else y
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    a_rowmax = getattr(x, "_isg_rowmax", None)
+    if (a_rowmax is not None and GEMM_F16X3 and F16X3_TILE and GEMM_KERNEL == "auto" and 128 < K <= 1024 and not relu and not f16_io
+            and a_rowmax.dim() == 2 and a_rowmax.size(0) == M and a_rowmax.size(1) <= 64):
+        # the producer of x left its row maxima: fp16 three-product tile kernel (row scales need the whole row)
+        planes, inv = _weight_planes(weight, cache_planes, "f16x3_rows")
+        d_rowmax = torch.empty(M, (N + 31) // 32, dtype=torch.float32, device=x.device) if want_rowmax else None
+        _lib.check(lib.isg_linear_f16x3_tile(
+            _chk(x, "x", torch.float32), _chk(a_rowmax, "a_rowmax", torch.float32), a_rowmax.size(1), planes.data_ptr(),
+            inv.data_ptr(), _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
+            out.data_ptr(), 0 if d_rowmax is None else d_rowmax.data_ptr(), M, N, K, K, N, 1 if gelu else 0, _stream()),
+            "isg_linear_f16x3_tile")
+        if d_rowmax is not None:
+            out._isg_rowmax = d_rowmax
+        return out
     if _use_panel(M, N, K) and not relu and GEMM_F16X3 and K <= 128 and not f16_io:
         planes, inv = _weight_planes(weight, cache_planes, "f16x3")
         _lib.check(lib.isg_linear_f16x3(
@@ -943,8 +987,14 @@ def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:   # x may be fp16 featur
         m = mods[i]
         if isinstance(m, torch.nn.Linear) or (hasattr(m, "weight") and hasattr(m, "bias") and m.weight.dim() == 2):
             fuse = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.GELU) and mods[i + 1].approximate == "none"
-            x = linear(x.contiguous(), m.weight, m.bias, gelu=fuse)
-            i += 2 if fuse else 1
+            nxt = i + (2 if fuse else 1)
+            more = nxt < len(mods) and hasattr(mods[nxt], "weight") and getattr(mods[nxt].weight, "dim", lambda: 0)() == 2
+            rm = getattr(x, "_isg_rowmax", None)
+            x = x.contiguous()
+            if rm is not None:
+                x._isg_rowmax = rm
+            x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more and rm is not None)
+            i = nxt
         else:
             x = m(x)
             i += 1

@@ -639,3 +639,32 @@ def test_linear_f16x3_keeps_fp32_accuracy_over_the_dynamic_range(dev, scale, spr
     print(f"f16x3 scale {scale:g} spread {spread:g}: err {err:.3e}, fp32 GEMM {err32:.3e}, ratio {err / max(err32, 1e-300):.2f}")
     assert err <= 2.0 * err32 + 1e-30
     assert torch.equal(got[3], b.double()) and torch.equal(got[:, 7], x.double().mul(0).sum(1) + b.double()[7])
+
+
+@pytest.mark.parametrize("M,K,N,gelu", [(777, 512, 256, True), (513, 256, 128, True), (300, 1000, 300, False), (64, 132, 40, True)])
+def test_linear_f16x3_tile_with_producer_row_maxima(dev, M, K, N, gelu):
+    """isg_linear_f16x3_tile: the row scales come from partial row maxima left by the producer of the input (here computed
+    with torch in 4 uneven pieces); accuracy of an fp32 GEMM over a wide dynamic range, and the row maxima it leaves for
+    the next layer are exact."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=gen) * torch.logspace(-6, 3, M).unsqueeze(1)      # rows from 1e-6 to 1e3
+    x[:, ::3] *= 1e-4
+    w, b = torch.randn(N, K, generator=gen) / K ** 0.5, torch.randn(N, generator=gen)
+    ref = x.double() @ w.double().t() + b.double()
+    f32 = torch.nn.functional.linear(x, w, b)
+    if gelu:
+        ref, f32 = torch.nn.functional.gelu(ref), torch.nn.functional.gelu(f32)
+    xd = x.to(dev)
+    cuts = [0, K // 5, K // 2, K - 3, K]
+    xd._isg_rowmax = torch.stack([xd[:, a:b_].abs().amax(1) for a, b_ in zip(cuts[:-1], cuts[1:])], 1).contiguous()
+    got = ops.linear(xd, w.to(dev), b.to(dev), gelu=gelu, want_rowmax=True)
+    rm = got._isg_rowmax
+    err, err32 = (got.cpu().double() - ref).abs().max().item(), (f32.double() - ref).abs().max().item()
+    # per-row comparison: every row has its own magnitude
+    rel = ((got.cpu().double() - ref).abs().amax(1) / ((f32.double() - ref).abs().amax(1) + 1e-300))
+    print(f"f16x3 tile [{M}x{N}x{K}]: err {err:.3e}, fp32 GEMM {err32:.3e}; worst row ratio {rel.max().item():.2f}, median {rel.median().item():.2f}")
+    assert err <= 2.0 * err32
+    assert rel.median().item() <= 2.0 and rel.max().item() <= 6.0
+    want = torch.stack([got[:, c:c + 32].abs().amax(1) for c in range(0, N, 32)], 1)
+    assert torch.equal(rm, want)

@@ -18,10 +18,11 @@ cfg = synthetic.CFG2
 wl = synthetic.make_workload(cfg).to(dev)
 model = synthetic.build_answer_model(cfg).to(dev).eval()
 variants = [
-    ("r01: tile GEMM everywhere", dict(GEMM_KERNEL="tile", LINEAR_MULTI=False, FUSE_EDGE=False, GEMM_F16X3=False)),
-    ("+ row-panel GEMM for the K=128 projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=False, FUSE_EDGE=False, GEMM_F16X3=False)),
-    ("+ the layers' lin_edge as one multi-output launch", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=False)),
-    ("+ fp16 three-product form for those projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=True)),
+    ("r01: tile GEMM everywhere", dict(GEMM_KERNEL="tile", LINEAR_MULTI=False, FUSE_EDGE=False, GEMM_F16X3=False, F16X3_TILE=False)),
+    ("+ row-panel GEMM for the K=128 projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=False, FUSE_EDGE=False, GEMM_F16X3=False, F16X3_TILE=False)),
+    ("+ the layers' lin_edge as one multi-output launch", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=False, F16X3_TILE=False)),
+    ("+ fp16 three-product form for those projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=True, F16X3_TILE=False)),
+    ("+ the same for x_proj (row maxima from the producer kernels)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=True, F16X3_TILE=True)),
 ]
 res = {name: [] for name, _ in variants}
 with torch.no_grad():
@@ -38,7 +39,7 @@ with torch.no_grad():
             torch.cuda.synchronize()
             if r > 0:
                 res[name].append((time.perf_counter() - t0) / steps * 1e3)
-for k, v in dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=True).items():
+for k, v in dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=True, F16X3_TILE=True).items():
     setattr(ops, k, v)
 for name, _ in variants:
     t = sorted(res[name])
