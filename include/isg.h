@@ -363,11 +363,17 @@ int isg_linear_panel_multi(const void *a, int32_t a_is_f16, const uint16_t *w_fr
 /* Tile form of the three-product kernel for 128 < K <= 1024 (x_proj of MGAT, mgat.py:156).  A row's scale needs the
  * row's largest magnitude over all of K, so it is an input: a_rowmax fp32 [M, P], P partial maxima per row written by the
  * kernel that produced `a` (isg_gatv2_mp_fwd_rowmax: P = H; this kernel: d_rowmax [M, ceil(N / 32)], or NULL).  w_planes /
- * w_inv_scale from isg_split_f16x2_rows: uint16[2 * rows * Kp] (Kp = K rounded up to 32), fp32[rows]. */
+ * w_inv_scale from isg_split_f16x2_rows: uint16[2 * rows * Kp] (Kp = K rounded up to 32), fp32[rows].  act 0 none, 1 exact
+ * GELU, 2 ReLU.  Reductions longer than 1024 run as K-chunks: a call covers columns [k_offset, k_offset + K) of a weight
+ * with K_total columns (`a` points at the chunk's first column, a_rowmax holds the chunk's row maxima) and, with
+ * accumulate != 0, adds to what `d` holds before bias and activation -- every chunk is its own fp32 accumulation chain. */
 int isg_split_f16x2_rows(const float *w, int64_t rows, int32_t K, uint16_t *planes, float *inv_scale, void *stream);
 int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int32_t P, const uint16_t *w_planes,
                           const float *w_inv_scale, const float *bias, float *d, float *d_rowmax, int64_t M, int32_t N,
-                          int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream);
+                          int32_t K, int32_t lda, int32_t ldd, int32_t act, int32_t K_total, int32_t k_offset,
+                          int32_t accumulate, void *stream);
+/* rowmax[m] = max_k |a[m, k]| (fp32 [M]): a_rowmax (P = 1) for an input whose producer left none; one pass over `a`. */
+int isg_row_absmax(const float *a, int64_t M, int32_t K, int32_t lda, float *rowmax, void *stream);
 int64_t isg_split_f16x2_frag_elems(int64_t rows, int32_t K);
 int isg_split_f16x2_frag(const float *w, int64_t rows, int32_t K, uint16_t *planes, float *inv_scale, void *stream);
 int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias, float *d,

@@ -82,7 +82,8 @@ SIGNATURES = {
                                         c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_split_f16x2_rows": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_linear_f16x3_tile": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                      c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+                                      c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_row_absmax": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

@@ -281,14 +281,16 @@ __global__ void split_f16x2_rows_kernel(const float *__restrict__ w, int N, int 
   }
 }
 
-template <int ACT, bool XCD, bool RMAX>
+// ACCUM: D already holds the sum over an earlier part of K (reductions longer than 1024 are run as K-chunks, each its own
+// accumulation chain, so the fp32 chain error does not grow with K): v = this chunk + D, then bias / activation
+template <int ACT, bool XCD, bool RMAX, bool ACCUM>
 __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *__restrict__ A,
                                                                    const float *__restrict__ a_rowmax, int P,
                                                                    const _Float16 *__restrict__ Wp,
                                                                    const float *__restrict__ w_inv,
                                                                    const float *__restrict__ bias, float *__restrict__ D,
                                                                    float *__restrict__ d_rowmax, int M, int N, int K,
-                                                                   int Kp, int lda, int ldd, int nt_store) {
+                                                                   int Kp, int ldw, int lda, int ldd, int nt_store) {
   struct Smem {
     _Float16 a[2][HT_BM][HT_LD];
     _Float16 b[2][HT_BN][HT_LD];
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
     n0 = blockIdx.x * HT_BN;
     m0 = blockIdx.y * HT_BM;
   }
-  const int64_t plane_stride = (int64_t)N * Kp;
+  const int64_t plane_stride = (int64_t)N * ldw;     // ldw: row stride of the W planes (the whole weight's padded K)
 
   // this thread stages the same two rows in every k-tile: their scales once, from the producer's partial maxima
   float sa[2];
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
       const int row = tid >> 2, c8 = tid & 3;                                                                    \
       const int gn = min(n0 + row, N - 1);                                                                       \
       _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                              \
-        RB[q] = *reinterpret_cast<const hf16x8 *>(Wp + q * plane_stride + (int64_t)gn * Kp + (k0) + c8 * 8);     \
+        RB[q] = *reinterpret_cast<const hf16x8 *>(Wp + q * plane_stride + (int64_t)gn * ldw + (k0) + c8 * 8);    \
     }                                                                                                            \
   }
   const int nk = Kp / HT_BK;
@@ -408,14 +410,9 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
   for (int j = 0; j < 2; ++j) {
     const int colb = n0 + wn * 64 + j * 32;
     const int col = colb + fr;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
     const float wi = w_inv[min(col, N - 1)];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = (acc[j][r] * inv_a[r]) * wi + bv;
-      if (ACT == 1) v = gelu_exact(v);
-      patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + fr] = v;
-    }
+    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + fr] = (acc[j][r] * inv_a[r]) * wi;
     __builtin_amdgcn_wave_barrier();
     const int rowb = m0 + wm * 32;
     const bool vec_ok = (ldd & 3) == 0 && colb + 32 <= N && (reinterpret_cast<uintptr_t>(D) & 15) == 0;
@@ -423,8 +420,31 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
     for (int q = 0; q < 4; ++q) {
       const int idx = q * 64 + lane;
       const int rr = idx >> 3, c4 = idx & 7;
-      const float4 v = *reinterpret_cast<const float4 *>(&patch[rr * 36 + c4 * 4]);
+      float4 v = *reinterpret_cast<const float4 *>(&patch[rr * 36 + c4 * 4]);
       const int row = rowb + rr;
+      const int cc = colb + c4 * 4;
+      if (ACCUM && row < M) {
+        const float *src = D + (int64_t)row * ldd + cc;
+        if (vec_ok) {
+          const float4 o = *reinterpret_cast<const float4 *>(src);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        } else {
+          if (cc + 0 < N) v.x += src[0];
+          if (cc + 1 < N) v.y += src[1];
+          if (cc + 2 < N) v.z += src[2];
+          if (cc + 3 < N) v.w += src[3];
+        }
+      }
+      if (bias) {
+        v.x += cc + 0 < N ? bias[cc + 0] : 0.f;
+        v.y += cc + 1 < N ? bias[cc + 1] : 0.f;
+        v.z += cc + 2 < N ? bias[cc + 2] : 0.f;
+        v.w += cc + 3 < N ? bias[cc + 3] : 0.f;
+      }
+      if (ACT == 1) { v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w); }
+      if (ACT == 2) {     // ReLU (a NaN stays a NaN, as in torch)
+        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+      }
       if (RMAX) {   // largest magnitude of this row's (up to) 32 columns; columns beyond N are not part of D
         const int c0 = colb + c4 * 4;
         float mx = c0 < N ? fabsf(v.x) : 0.f;
@@ -472,16 +492,21 @@ extern "C" int isg_split_f16x2_rows(const float *w, int64_t rows, int32_t K, uin
   return check_launch();
 }
 
-// a_rowmax fp32 [M, P]: partial maxima of |a| per row (P >= 1); d_rowmax NULL or fp32 [M, ceil(N / 32)] (written)
+// a_rowmax fp32 [M, P]: partial maxima of |a| per row (P >= 1); d_rowmax NULL or fp32 [M, ceil(N / 32)] (written).
+// k_offset / accumulate: this call covers columns [k_offset, k_offset + K) of a weight whose planes have `K_total` columns
+// (k_offset a multiple of 32); with accumulate != 0 the result is added to what `d` holds before bias and activation.
 extern "C" int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int32_t P, const uint16_t *w_planes,
                                      const float *w_inv_scale, const float *bias, float *d, float *d_rowmax, int64_t M,
-                                     int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream) {
-  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 1 || P <= 0) return ISG_EINVAL;
+                                     int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, int32_t K_total,
+                                     int32_t k_offset, int32_t accumulate, void *stream) {
+  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 2 || P <= 0) return ISG_EINVAL;
+  if (K_total < K || k_offset < 0 || k_offset + K > K_total || (k_offset & 31)) return ISG_EINVAL;
   if (M == 0) return ISG_OK;
   if (!a || !a_rowmax || !w_planes || !w_inv_scale || !d) return ISG_EINVAL;
   if ((K & 3) != 0 || (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(a) & 15) != 0 || M >= (1ll << 31) || K > 1024 || P > 64)
     return ISG_EUNSUPPORTED;
   const int Kp = (K + HT_BK - 1) / HT_BK * HT_BK;
+  const int ldw = (K_total + HT_BK - 1) / HT_BK * HT_BK;
   const long long mt = (M + HT_BM - 1) / HT_BM;
   if (mt > 65535) return ISG_EUNSUPPORTED;
   dim3 grid((unsigned)((N + HT_BN - 1) / HT_BN), (unsigned)mt), block(512);
@@ -489,15 +514,45 @@ extern "C" int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int3
   const int nt = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
   dim3 gridx(grid.x, (grid.y + 7) / 8 * 8);
   const bool xcd = grid.x > 1;
-  const _Float16 *wp = reinterpret_cast<const _Float16 *>(w_planes);
+  const _Float16 *wp = reinterpret_cast<const _Float16 *>(w_planes) + k_offset;
   hipStream_t st = as_stream(stream);
-#define ISG_HT(ACT_, R_)                                                                                          \
+#define ISG_HT3(ACT_, R_, C_)                                                                                     \
   do {                                                                                                            \
-    if (xcd) linear_f16x3_tile_kernel<ACT_, true, R_><<<gridx, block, 0, st>>>(a, a_rowmax, P, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, lda, ldd, nt); \
-    else linear_f16x3_tile_kernel<ACT_, false, R_><<<grid, block, 0, st>>>(a, a_rowmax, P, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, lda, ldd, nt); \
+    if (xcd) linear_f16x3_tile_kernel<ACT_, true, R_, C_><<<gridx, block, 0, st>>>(a, a_rowmax, P, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, ldw, lda, ldd, nt); \
+    else linear_f16x3_tile_kernel<ACT_, false, R_, C_><<<grid, block, 0, st>>>(a, a_rowmax, P, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, ldw, lda, ldd, nt); \
   } while (0)
+#define ISG_HT(ACT_, R_) do { if (accumulate) ISG_HT3(ACT_, R_, true); else ISG_HT3(ACT_, R_, false); } while (0)
   if (act == 1) { if (d_rowmax) ISG_HT(1, true); else ISG_HT(1, false); }
+  else if (act == 2) { if (d_rowmax) ISG_HT(2, true); else ISG_HT(2, false); }
   else { if (d_rowmax) ISG_HT(0, true); else ISG_HT(0, false); }
 #undef ISG_HT
+#undef ISG_HT3
+  return check_launch();
+}
+
+// rowmax[m] = max_k |a[m, k]|: the row scales of isg_linear_f16x3_tile for an input whose producer did not leave them.
+// One extra pass over `a` (M*K*4 bytes): worth it when the Linear is wide (the caller's policy: N >= 512).
+namespace isg {
+__global__ __launch_bounds__(256) void row_absmax_kernel(const float *__restrict__ a, int M, int K, int lda,
+                                                         float *__restrict__ rowmax) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float4 *r4 = reinterpret_cast<const float4 *>(a + (int64_t)row * lda);
+  float mx = 0.f;
+  for (int c = lane; c < (K >> 2); c += 64) {
+    const float4 v = r4[c];
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) rowmax[row] = mx;
+}
+}  // namespace isg
+
+extern "C" int isg_row_absmax(const float *a, int64_t M, int32_t K, int32_t lda, float *rowmax, void *stream) {
+  if (M < 0 || K <= 0 || lda < K) return ISG_EINVAL;
+  if (M == 0) return ISG_OK;
+  if (!a || !rowmax) return ISG_EINVAL;
+  if ((K & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(a) & 15) || (M + 3) / 4 >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  row_absmax_kernel<<<(unsigned)((M + 3) / 4), 256, 0, as_stream(stream)>>>(a, (int)M, K, lda, rowmax);
   return check_launch();
 }

@@ -875,16 +875,37 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
     a_rowmax = getattr(x, "_isg_rowmax", None)
-    if (a_rowmax is not None and GEMM_F16X3 and F16X3_TILE and GEMM_KERNEL == "auto" and 128 < K <= 1024 and not relu and not f16_io
-            and a_rowmax.dim() == 2 and a_rowmax.size(0) == M and a_rowmax.size(1) <= 64):
-        # the producer of x left its row maxima: fp16 three-product tile kernel (row scales need the whole row)
+    f16x3_tile = GEMM_F16X3 and F16X3_TILE and GEMM_KERNEL == "auto" and K > 128 and not f16_io and M < (1 << 23)
+    if f16x3_tile and (a_rowmax is None or K > 640) and not (N >= 256 and M >= 4096):
+        f16x3_tile = False         # a pass over x for the row maxima only pays for wide Linears over many rows
+    if f16x3_tile and a_rowmax is not None and (a_rowmax.dim() != 2 or a_rowmax.size(0) != M or a_rowmax.size(1) > 64):
+        a_rowmax = None
+    if f16x3_tile:
+        # fp16 three-product tile kernel.  Row scales: the producer's partial maxima, or one pass over x; reductions longer
+        # than 640 run as K-chunks that accumulate into `out` (every chunk its own fp32 chain and its own row scales)
         planes, inv = _weight_planes(weight, cache_planes, "f16x3_rows")
+        act = 2 if relu else (1 if gelu else 0)
+        bptr = _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True)
         d_rowmax = torch.empty(M, (N + 31) // 32, dtype=torch.float32, device=x.device) if want_rowmax else None
-        _lib.check(lib.isg_linear_f16x3_tile(
-            _chk(x, "x", torch.float32), _chk(a_rowmax, "a_rowmax", torch.float32), a_rowmax.size(1), planes.data_ptr(),
-            inv.data_ptr(), _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
-            out.data_ptr(), 0 if d_rowmax is None else d_rowmax.data_ptr(), M, N, K, K, N, 1 if gelu else 0, _stream()),
-            "isg_linear_f16x3_tile")
+        xp = _chk(x, "x", torch.float32)
+        nchunk = (K + 639) // 640          # chains of at most 640: 2.75x an fp32 GEMM's error at 1024-long chains, < 2x here
+        step = (K + nchunk - 1) // nchunk
+        step = (step + 31) // 32 * 32
+        k0, c = 0, 0
+        while k0 < K:
+            kc = min(step, K - k0)
+            last = k0 + kc >= K
+            if nchunk == 1 and a_rowmax is not None:
+                rm = a_rowmax
+            else:
+                rm = torch.empty(M, 1, dtype=torch.float32, device=x.device)
+                _lib.check(lib.isg_row_absmax(xp + 4 * k0, M, kc, K, rm.data_ptr(), _stream()), "isg_row_absmax")
+            _lib.check(lib.isg_linear_f16x3_tile(
+                xp + 4 * k0, rm.data_ptr(), rm.size(1), planes.data_ptr(), inv.data_ptr(), bptr if last else 0,
+                out.data_ptr(), d_rowmax.data_ptr() if (last and d_rowmax is not None) else 0, M, N, kc, K, N,
+                act if last else 0, K, k0, 1 if c > 0 else 0, _stream()), "isg_linear_f16x3_tile")
+            k0 += kc
+            c += 1
         if d_rowmax is not None:
             out._isg_rowmax = d_rowmax
         return out

@@ -641,7 +641,26 @@ def test_linear_f16x3_keeps_fp32_accuracy_over_the_dynamic_range(dev, scale, spr
     assert torch.equal(got[3], b.double()) and torch.equal(got[:, 7], x.double().mul(0).sum(1) + b.double()[7])
 
 
-@pytest.mark.parametrize("M,K,N,gelu", [(777, 512, 256, True), (513, 256, 128, True), (300, 1000, 300, False), (64, 132, 40, True)])
+@pytest.mark.parametrize("M,K,N,relu", [(5000, 2048, 512, False), (4100, 1200, 600, True), (4096, 512, 1536, False),
+                                         (4500, 300, 300, False)])
+def test_wide_linears_take_the_f16x3_tile_kernel_with_their_own_row_pass(dev, M, K, N, relu):
+    """ops.linear's policy for wide Linears over many rows whose producer left no row maxima (the full model's text and
+    C = 300 projections): isg_row_absmax + isg_linear_f16x3_tile, K > 1024 as accumulating K-chunks.  fp32-GEMM accuracy."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(K + N)
+    x = torch.randn(M, K, generator=gen)
+    w, b = torch.randn(N, K, generator=gen) / K ** 0.5, torch.randn(N, generator=gen)
+    ref = x.double() @ w.double().t() + b.double()
+    f32 = torch.nn.functional.linear(x, w, b)
+    if relu:
+        ref, f32 = torch.relu(ref), torch.relu(f32)
+    got = ops.linear(x.to(dev), w.to(dev), b.to(dev), relu=relu).cpu().double()
+    err, err32 = (got - ref).abs().max().item(), (f32.double() - ref).abs().max().item()
+    print(f"wide linear [{M}x{N}x{K}]: err {err:.3e}, fp32 GEMM {err32:.3e}, ratio {err / err32:.2f}")
+    assert err <= 2.0 * err32
+
+
+@pytest.mark.parametrize("M,K,N,gelu", [(777, 512, 256, True), (513, 256, 128, True), (300, 640, 300, False), (64, 132, 40, True)])
 def test_linear_f16x3_tile_with_producer_row_maxima(dev, M, K, N, gelu):
     """isg_linear_f16x3_tile: the row scales come from partial row maxima left by the producer of the input (here computed
     with torch in 4 uneven pieces); accuracy of an fp32 GEMM over a wide dynamic range, and the row maxima it leaves for
