@@ -108,20 +108,22 @@ def cpu_baseline(cfg, sample_graphs: int, seconds: float, threads: int):
     gen = torch.Generator().manual_seed(1)
     noises = {i: OS.uniform_to_gumbel(torch.rand(sample_graphs, wl.max_nodes, generator=gen))
               for i, t in enumerate(scfg.masks) if t != 1.0}
-    threads = max(1, min(threads, os.cpu_count() or 1))
+    threads = max(1, min(threads, usable_cpus()))
     torch.set_num_threads(threads)       # many-core hosts: small graph ops slow down past a few dozen threads
     with torch.no_grad():
+        t0 = time.perf_counter()
         OM.mgat_pool_classify(sd, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, ocfg, noises)
+        progress(f"cpu_baseline: warm pass over {sample_graphs} graphs {time.perf_counter() - t0:.2f} s on {threads} threads")
         t0 = time.perf_counter()
         passes = 0
-        while passes < 3 or (time.perf_counter() - t0 < seconds and passes < 200):
+        while passes < 1 or (time.perf_counter() - t0 < seconds and passes < 200):
             OM.mgat_pool_classify(sd, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, ocfg, noises)
             passes += 1
         dt = time.perf_counter() - t0
     return {"value": round(sample_graphs * passes / dt, 1), "unit": "questions/s", "cores": threads, "kind": "port",
             "sample": f"{passes} passes x {sample_graphs} graphs of the configs[1] distribution "
                       f"(N={wl.x.size(0)}, E={wl.edge_index.size(1)}) in {dt:.1f} s, torch CPU fp32, "
-                      f"{threads} threads of {os.cpu_count()} logical cores"}
+                      f"{threads} threads ({usable_cpus()} CPUs usable by the process, host has {os.cpu_count()})"}
 
 
 def cpu_model_string() -> str:
@@ -134,14 +136,45 @@ def cpu_model_string() -> str:
     return "unknown"
 
 
-def cpu_baseline_cfg1(seconds: float = 8.0):
+def usable_cpus() -> int:
+    """CPUs this process may actually run on: the affinity mask, cut by the cgroup's CPU quota when there is one.
+    os.cpu_count() is the HOST's count; on a GPU box with a 16-CPU share, that many OpenMP threads over 32-graph batches
+    is an oversubscribed crawl (round 1: 390 q/s on 128 threads, 1638 q/s on 16), and it made this leg run past 7 minutes."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def progress(msg: str):
+    """One line per leg on stderr (rank 0's JSON line stays the only thing on stdout): a run that is killed for
+    silence or at its limit says where it was."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline_cfg1(seconds: float = 8.0, max_threads: int = 32):
     """SURVEY §8(d) / BASELINE configs[0] exactly: 256 graphs as 8 batches of 32 (<= 16 nodes, <= 32 edges), C = 300, 4 MGAT
-    layers, masks [1, 1, 1, 0.15], Gumbel k = 5 with explicit noise, the oracle under no_grad on ALL host threads."""
+    layers, masks [1, 1, 1, 0.15], Gumbel k = 5 with explicit noise, the oracle under no_grad on every CPU this process
+    may use (`usable_cpus`, at most `max_threads`).  Bounded: one warm pass, then timed passes until `seconds` are spent
+    (at least one, so a slow host costs one pass, not five)."""
     import torch
     from isubgvqa_amd import synthetic
     from oracle import model as OM
     from oracle import samplers as OS
-    threads = os.cpu_count() or 1
+    threads = min(usable_cpus(), max_threads)
     torch.set_num_threads(threads)
     batches = []
     for b in range(8):
@@ -162,10 +195,11 @@ def cpu_baseline_cfg1(seconds: float = 8.0):
 
     times = []
     with torch.no_grad():
+        t0 = time.perf_counter()
         one_pass()
-        one_pass()
+        progress(f"cpu_baseline.cfg1: warm pass {time.perf_counter() - t0:.2f} s on {threads} threads")
         t_end = time.perf_counter() + seconds
-        while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 100):
+        while not times or (time.perf_counter() < t_end and len(times) < 100):
             t0 = time.perf_counter()
             one_pass()
             times.append(time.perf_counter() - t0)
@@ -174,7 +208,8 @@ def cpu_baseline_cfg1(seconds: float = 8.0):
             "cpu": cpu_model_string(),
             "sample": f"BASELINE configs[0]: 256 graphs = 8 batches x 32 (<= 16 nodes, <= 32 edges), C=300, 4 layers, "
                       f"masks [1,1,1,0.15], Gumbel k=5; median of {len(times)} passes ({med * 1e3:.1f} ms/pass), "
-                      f"torch CPU fp32, all {threads} logical cores"}
+                      f"torch CPU fp32, {threads} threads = the CPUs usable by the process "
+                      f"(host has {os.cpu_count()} logical cores)"}
 
 
 def full_model_rate(dev, graphs: int, steps: int = 10):
@@ -332,7 +367,7 @@ def main(argv=None):
                        "nodes_per_gpu": N, "edges_per_gpu": E, "channels": cfg.channels, "heads": cfg.heads,
                        "layers": cfg.layers, "sampler": "gumbel(in-kernel Philox noise)", "k": cfg.sample_k,
                        "parallelism": f"dp{world} (graphs sharded, RCCL all-gather of logits)" if world > 1 else "dp1",
-                       "feature_rows": args.features, "launch": "eager", "dense": ("isg_linear_bf16x6 (fp32 via 3-way bf16 split on MFMA)" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
+                       "feature_rows": args.features, "launch": "eager", "dense": ("exact-split fp32 Linears on MFMA: isg_linear_f16x3 / _f16x3_tile (2 fp16 planes, 3 products, per-row scales), isg_linear_bf16x6 for the small ones" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
             "roofline": {"bound": "hbm", "kernel": ("gatv2_mp_graph_kernel<2,1>" if args.mp_kernel == "graph" else "gatv2_mp_kernel<4,2>") + " (isg_gatv2_mp_fwd)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
@@ -343,9 +378,11 @@ def main(argv=None):
         if world == 1 and not args.no_full_model:
             del model, wl
             torch.cuda.empty_cache()
+            progress(f"configs[1] step timed: {dt / args.steps * 1e3:.3f} ms; full model leg ({args.full_model_graphs} graphs)")
             res["full_model"] = full_model_rate(dev, args.full_model_graphs)
         ops.check_plans()           # any understated GraphPlan hint of this run raises here
         if world == 1 and not args.no_cpu_baseline:
+            progress("cpu_baseline leg (oracle on the host cores)")
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_graphs, args.cpu_seconds, args.cpu_threads)
             res["cpu_baseline"]["cpu"] = cpu_model_string()
             res["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()

@@ -84,3 +84,19 @@ def test_real_launch_reaches_the_ranks_and_returns_their_status():
     assert p.returncode != 0
     assert "needs an MI355X" in p.stderr
     assert p.stdout.strip() == ""
+
+
+def test_cpu_legs_use_the_cpus_the_process_may_run_on_and_are_time_bounded():
+    """The configs[0] leg once took os.cpu_count() threads (the HOST's count) and a minimum of seven passes: on a GPU box
+    with a 16-CPU share it ran past seven silent minutes and the run was killed.  It takes the usable CPUs and one warm +
+    at least one timed pass now."""
+    import os
+    import time
+    import bench
+    n = bench.usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    t0 = time.perf_counter()
+    r = bench.cpu_baseline_cfg1(seconds=0.5)
+    took = time.perf_counter() - t0
+    assert r["cores"] == min(n, 32) and r["value"] > 0 and r["kind"] == "port"
+    assert took < 60, f"configs[0] leg took {took:.1f} s for a 0.5 s budget"
