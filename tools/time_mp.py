@@ -26,13 +26,13 @@ mask = (torch.rand(N, 1, device=dev, generator=g) > 0.7).float()
 flush = torch.empty(1 << 27, device=dev)     # 512 MiB write between launches: cold caches, like the real layer loop
 res = {}
 for r in range(rounds + 2):
-    for kern in ("graph", "chunk"):
+    for kern in ("graph", "graph+rowmax", "chunk"):       # "+rowmax": the inference path also writes max|out| per (node, head)
         for masked in (False, True):
             flush.fill_(float(r))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             out, alpha = ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias, node_mask=mask if masked else None,
-                                      kernel=kern)
+                                      kernel=kern.split("+")[0], want_rowmax=kern.endswith("rowmax"))
             e.record()
             torch.cuda.synchronize()
             if r >= 2:
@@ -41,5 +41,5 @@ for (kern, masked), v in sorted(res.items()):
     v = sorted(v)
     b = ops.mp_algorithmic_bytes(N, E, H, C, masked)
     med = v[len(v) // 2]
-    print(f"{kern:6s} masked={int(masked)}  median {med:7.1f} us  min {v[0]:7.1f} us  ->  {b / med / 1e3:7.1f} GB/s "
+    print(f"{kern:12s} masked={int(masked)}  median {med:7.1f} us  min {v[0]:7.1f} us  ->  {b / med / 1e3:7.1f} GB/s "
           f"({b / med / 1e3 / 8000:.3f} of 8 TB/s)")
