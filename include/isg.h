@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 7
+#define ISG_ABI_VERSION 8
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -366,9 +366,11 @@ int isg_linear_panel_multi(const void *a, int32_t a_is_f16, const uint16_t *w_fr
  * w_inv_scale from isg_split_f16x2_rows: uint16[2 * rows * Kp] (Kp = K rounded up to 32), fp32[rows].  act 0 none, 1 exact
  * GELU, 2 ReLU.  Reductions longer than 1024 run as K-chunks: a call covers columns [k_offset, k_offset + K) of a weight
  * with K_total columns (`a` points at the chunk's first column, a_rowmax holds the chunk's row maxima) and, with
- * accumulate != 0, adds to what `d` holds before bias and activation -- every chunk is its own fp32 accumulation chain. */
+ * accumulate != 0, adds to what `d` holds before bias and activation -- every chunk is its own fp32 accumulation chain.
+ * a_rowmax rows are ldp floats apart (ldp >= P): a K-chunk of a reduction whose producer left one partial maximum per
+ * 32 (or 64, ...) columns takes the slice of partials that covers its columns, no pass of its own over `a`. */
 int isg_split_f16x2_rows(const float *w, int64_t rows, int32_t K, uint16_t *planes, float *inv_scale, void *stream);
-int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int32_t P, const uint16_t *w_planes,
+int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int32_t P, int32_t ldp, const uint16_t *w_planes,
                           const float *w_inv_scale, const float *bias, float *d, float *d_rowmax, int64_t M, int32_t N,
                           int32_t K, int32_t lda, int32_t ldd, int32_t act, int32_t K_total, int32_t k_offset,
                           int32_t accumulate, void *stream);
@@ -403,10 +405,19 @@ int isg_gather_add(const float *A, const int64_t *ia, int32_t lda, const float *
  * [T, B, D] layout (row t * B + b), heads are consecutive hd-column blocks; q / k / v may be column slices of one fused
  * projection (ldq / ldk / ldv: row strides in floats).  key_bias fp32 [B, Tk] or NULL is ADDED to the scores -- the
  * reference passes the HF attention mask as a FLOAT src_key_padding_mask (question_encoder.py:35-37: +1 on real tokens,
- * padding is attended).  out fp32 rows of H * hd columns, stride ldo. */
+ * padding is attended).  out fp32 rows of H * hd columns, stride ldo.
+ * rowmax fp32 [Tq * B, H] or NULL: the largest |out| of every (row, head) -- a_rowmax (P = H) of the out_proj Linear. */
 int isg_mha_small(const float *q, int32_t ldq, const float *k, int32_t ldk, const float *v, int32_t ldv,
-                  const float *key_bias, float *out, int32_t ldo, int64_t B, int32_t H, int32_t hd, int32_t Tq, int32_t Tk,
-                  void *stream);
+                  const float *key_bias, float *out, int32_t ldo, float *rowmax, int64_t B, int32_t H, int32_t hd,
+                  int32_t Tq, int32_t Tk, void *stream);
+
+/* out = LayerNorm(x + r) over the last dimension, r optional (NULL): the post-norm step of nn.TransformerEncoderLayer /
+ * nn.TransformerDecoderLayer (question_encoder.py:20-38, question_decoder.py:25-71) with the residual add folded in;
+ * torch.nn.LayerNorm's arithmetic ((v - mean) * rstd * gamma + beta, biased variance, fp32; beta may be NULL).  rowmax
+ * fp32 [M] or NULL: max |out| per row, the a_rowmax (P = 1) of the Linear that reads `out`.  4 | D, D <= 2048, 16-byte
+ * aligned rows (ISG_EUNSUPPORTED otherwise). */
+int isg_add_layernorm(const float *x, int32_t ldx, const float *r, int32_t ldr, const float *gamma, const float *beta,
+                      float eps, float *out, int32_t ldo, float *rowmax, int64_t M, int32_t D, void *stream);
 
 #ifdef __cplusplus
 }

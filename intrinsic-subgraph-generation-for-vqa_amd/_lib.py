@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -70,8 +70,10 @@ SIGNATURES = {
                                  c_int32, c_int32, c_int32, c_void_p]),
     "isg_gather_add": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
-    "isg_mha_small": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int64,
-                              c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_mha_small": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
+                              c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_add_layernorm": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_int32,
+                                  c_void_p, c_int64, c_int32, c_void_p]),
     "isg_linear_panel_multi": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "isg_split_f16x2_frag_elems": (c_int64, [c_int64, c_int32]),
@@ -81,7 +83,7 @@ SIGNATURES = {
     "isg_gatv2_mp_fwd_rowmax": (c_int, [c_void_p] * 13 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_split_f16x2_rows": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
-    "isg_linear_f16x3_tile": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+    "isg_linear_f16x3_tile": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_row_absmax": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,

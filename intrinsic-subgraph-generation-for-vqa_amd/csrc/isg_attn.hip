@@ -17,7 +17,7 @@ namespace isg {
 
 struct MhaArgs {
   const float *q, *k, *v, *key_bias;
-  float *out;
+  float *out, *rowmax;     // rowmax [Tq*B, H] or NULL: max |out| per (row, head), the row scales of the Linear that reads out
   int B, H, hd, Tq, Tk, ldq, ldk, ldv, ldo;
   float scale;
 };
@@ -67,12 +67,78 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
     if (64 + lane < Tk) pw[64 + lane] = e1 / den;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
     if (lane < hd) {
-      float o = 0.f;
       for (int s = 0; s < Tk; ++s) o = fmaf(pw[s], Vs[s * hd + lane], o);
       a.out[qrow * a.ldo + col0 + lane] = o;
     }
+    if (a.rowmax) {
+      const float m = wave_max(fabsf(o));
+      if (lane == 0) a.rowmax[qrow * a.H + h] = m;
+    }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// out = LayerNorm(x + r) over the last dimension (r optional), torch.nn.LayerNorm's arithmetic order
+// ((v - mean) * rstd * gamma + beta, biased variance, fp32): the post-norm steps of nn.TransformerEncoderLayer /
+// DecoderLayer (question_encoder.py:20-38, question_decoder.py:25-71) with the residual add folded in, and the row's
+// largest |out| written beside it -- the row scale of the fp16 three-product Linear that reads `out` next, so that
+// Linear needs no pass of its own over its input.  Wave per row, the row in registers (NV float4 per lane), mean and
+// centred variance as two wave sums.
+template <int NV>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ r,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float eps,
+                                                            float *__restrict__ out, float *__restrict__ rowmax, int M,
+                                                            int D, int ldx, int ldr, int ldo) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nv = D >> 2;
+  float4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv) {
+      v[i] = reinterpret_cast<const float4 *>(x + (int64_t)row * ldx)[c];
+      if (r) {
+        const float4 t = reinterpret_cast<const float4 *>(r + (int64_t)row * ldr)[c];
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (lane + 64 * i < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float4 g = reinterpret_cast<const float4 *>(gamma)[c];
+      const float4 bb = beta ? reinterpret_cast<const float4 *>(beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + bb.x;
+      o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+      o.z = (v[i].z - mean) * rstd * g.z + bb.z;
+      o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+      reinterpret_cast<float4 *>(out + (int64_t)row * ldo)[c] = o;
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+    }
+  }
+  if (rowmax) {
+    mx = wave_max(mx);
+    if (lane == 0) rowmax[row] = mx;
   }
 }
 
@@ -80,15 +146,36 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
 
 using namespace isg;
 
+extern "C" int isg_add_layernorm(const float *x, int32_t ldx, const float *r, int32_t ldr, const float *gamma,
+                                 const float *beta, float eps, float *out, int32_t ldo, float *rowmax, int64_t M,
+                                 int32_t D, void *stream) {
+  if (M < 0 || D <= 0 || ldx < D || ldo < D || (r && ldr < D)) return ISG_EINVAL;
+  if (M == 0) return ISG_OK;
+  if (!x || !gamma || !out) return ISG_EINVAL;
+  auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if ((D & 3) || D > 2048 || (ldx & 3) || (ldo & 3) || (r && (ldr & 3)) || mis(x) || mis(out) || (r && mis(r)) ||
+      mis(gamma) || (beta && mis(beta)) || (M + 3) / 4 >= (1ll << 31))
+    return ISG_EUNSUPPORTED;
+  const unsigned grid = (unsigned)((M + 3) / 4);
+  hipStream_t st = as_stream(stream);
+#define ISG_LN(NV_) add_layernorm_kernel<NV_><<<grid, 256, 0, st>>>(x, r, gamma, beta, eps, out, rowmax, (int)M, D, ldx, ldr, ldo)
+  if (D <= 256) ISG_LN(1);
+  else if (D <= 512) ISG_LN(2);
+  else if (D <= 1024) ISG_LN(4);
+  else ISG_LN(8);
+#undef ISG_LN
+  return check_launch();
+}
+
 extern "C" int isg_mha_small(const float *q, int32_t ldq, const float *k, int32_t ldk, const float *v, int32_t ldv,
-                             const float *key_bias, float *out, int32_t ldo, int64_t B, int32_t H, int32_t hd, int32_t Tq,
-                             int32_t Tk, void *stream) {
+                             const float *key_bias, float *out, int32_t ldo, float *rowmax, int64_t B, int32_t H, int32_t hd,
+                             int32_t Tq, int32_t Tk, void *stream) {
   if (B < 0 || H <= 0 || hd <= 0 || Tq < 0 || Tk <= 0) return ISG_EINVAL;
   if (B == 0 || Tq == 0) return ISG_OK;
   if (!q || !k || !v || !out) return ISG_EINVAL;
   if (hd > 64 || Tk > 128 || B * H >= (1ll << 31)) return ISG_EUNSUPPORTED;
   if (ldq < H * hd || ldk < H * hd || ldv < H * hd || ldo < H * hd) return ISG_EINVAL;
-  MhaArgs a{q, k, v, key_bias, out, (int)B, H, hd, Tq, Tk, ldq, ldk, ldv, ldo, (float)(1.0 / sqrt((double)hd))};
+  MhaArgs a{q, k, v, key_bias, out, rowmax, (int)B, H, hd, Tq, Tk, ldq, ldk, ldv, ldo, (float)(1.0 / sqrt((double)hd))};
   const size_t lds = ((size_t)Tk * (2 * hd + 1) + 4 * 64 + 4 * 128) * sizeof(float);
   if (lds > 64 * 1024) return ISG_EUNSUPPORTED;
   mha_small_kernel<<<(unsigned)(B * H), 256, lds, as_stream(stream)>>>(a);

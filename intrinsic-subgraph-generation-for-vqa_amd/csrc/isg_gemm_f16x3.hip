@@ -21,6 +21,7 @@ namespace isg {
 typedef __attribute__((ext_vector_type(8))) _Float16 hf16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 hf16x4;
 typedef __attribute__((ext_vector_type(16))) float hf32x16;
+typedef __attribute__((ext_vector_type(4))) float hf32x4;
 
 constexpr int H3_BM = 64, H3_KC = 128, H3_LD = H3_KC + 8, H3_THREADS = 256;
 
@@ -283,21 +284,26 @@ __global__ void split_f16x2_rows_kernel(const float *__restrict__ w, int N, int 
 
 // ACCUM: D already holds the sum over an earlier part of K (reductions longer than 1024 are run as K-chunks, each its own
 // accumulation chain, so the fp32 chain error does not grow with K): v = this chunk + D, then bias / activation
-template <int ACT, bool XCD, bool RMAX, bool ACCUM>
+// MF: the MFMA shape.  32 = v_mfma_f32_32x32x16_f16 (2 accumulator tiles per wave, two k-halves per k-tile);
+// 16 = v_mfma_f32_16x16x32_f16 (8 accumulator tiles of 4 registers, one k-step per k-tile): the same FLOPs, LDS bytes and
+// cycles, but the chip holds a higher clock on the 16x16 shape under a dense MFMA stream (MI355X_MICROARCH.md, DVFS item
+// 7).  Its fragment reads (row = lane & 15, k = 8 * (lane >> 4)) want a 96-byte row pitch to stay conflict-free.
+template <int ACT, bool XCD, bool RMAX, bool ACCUM, int MF>
 __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *__restrict__ A,
-                                                                   const float *__restrict__ a_rowmax, int P,
+                                                                   const float *__restrict__ a_rowmax, int P, int ldp,
                                                                    const _Float16 *__restrict__ Wp,
                                                                    const float *__restrict__ w_inv,
                                                                    const float *__restrict__ bias, float *__restrict__ D,
                                                                    float *__restrict__ d_rowmax, int M, int N, int K,
                                                                    int Kp, int ldw, int lda, int ldd, int nt_store) {
+  constexpr int LD = MF == 16 ? HT_BK + 16 : HT_LD;
   struct Smem {
-    _Float16 a[2][HT_BM][HT_LD];
-    _Float16 b[2][HT_BN][HT_LD];
+    _Float16 a[2][HT_BM][LD];
+    _Float16 b[2][HT_BN][LD];
     float inv[HT_BM];
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
-  static_assert(sizeof(_Float16) * 2 * (HT_BM + HT_BN) * HT_LD >= 8 * 32 * 36 * sizeof(float), "epilogue patches must fit");
+  static_assert(sizeof(_Float16) * 2 * (HT_BM + HT_BN) * LD >= 8 * 32 * 36 * sizeof(float), "epilogue patches must fit");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   int n0, m0;
@@ -321,17 +327,22 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
     const int row = (tid + 512 * u) >> 3;
     const int gr = min(m0 + row, M - 1);
     float mx = 0.f;
-    for (int p = 0; p < P; ++p) mx = fmaxf(mx, a_rowmax[(int64_t)gr * P + p]);
+    for (int p = 0; p < P; ++p) mx = fmaxf(mx, a_rowmax[(int64_t)gr * ldp + p]);
     float inv;
     h3_scale(mx, sa[u], inv);
     if (((tid + 512 * u) & 7) == 0) sm.inv[row] = inv;
   }
 
   hf32x16 acc[2];
+  hf32x4 acc16[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc16[i][j] = hf32x4{0.f, 0.f, 0.f, 0.f};
   float4 ra0[2], ra1[2];
   hf16x8 rb0[2], rb1[2];
 #define HT_LOAD_TILE(RA, RB, k0)                                                                                 \
@@ -372,6 +383,23 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
     }                                                                                                            \
     __syncthreads();                                                                                             \
     if ((kt) + 2 < nk) HT_LOAD_TILE(RA, RB, ((kt) + 2) * HT_BK)                                                  \
+    if constexpr (MF == 16) {                                                                                    \
+      hf16x8 a[2][2];                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q)                \
+        a[i][q] = *reinterpret_cast<const hf16x8 *>(&sm.a[q][wm * 32 + i * 16 + (lane & 15)][(lane >> 4) * 8]);  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                            \
+        hf16x8 b[2];                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
+          b[q] = *reinterpret_cast<const hf16x8 *>(&sm.b[q][wn * 64 + j * 16 + (lane & 15)][(lane >> 4) * 8]);   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+          hf32x4 c = acc16[i][j];                                                                                \
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[1], c, 0, 0, 0);                                 \
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], b[0], c, 0, 0, 0);                                 \
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[0], c, 0, 0, 0);                                 \
+          acc16[i][j] = c;                                                                                       \
+        }                                                                                                        \
+      }                                                                                                          \
+    } else                                                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
       hf16x8 a[2], b[2][2];                                                                                      \
       _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                              \
@@ -398,7 +426,12 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
 
   // ---- epilogue: scale back, + bias, activation, per-wave LDS patch -> 16-byte row stores (+ the row maxima of D) ------
   float inv_a[16];
-  {
+  if constexpr (MF == 16) {      // [i * 4 + r]: row i * 16 + 4 * (lane >> 4) + r of the wave's 32
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) inv_a[i * 4 + r] = sm.inv[wm * 32 + i * 16 + 4 * (lane >> 4) + r];
+  } else {
     const int h = lane >> 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) inv_a[r] = sm.inv[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
@@ -409,10 +442,23 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int colb = n0 + wn * 64 + j * 32;
-    const int col = colb + fr;
-    const float wi = w_inv[min(col, N - 1)];
+    if constexpr (MF == 16) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + fr] = (acc[j][r] * inv_a[r]) * wi;
+      for (int jj = 0; jj < 2; ++jj) {
+        const int cin = jj * 16 + (lane & 15);
+        const float wi = w_inv[min(colb + cin, N - 1)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            patch[(i * 16 + 4 * (lane >> 4) + r) * 36 + cin] = (acc16[i][2 * j + jj][r] * inv_a[i * 4 + r]) * wi;
+      }
+    } else {
+      const int col = colb + fr;
+      const float wi = w_inv[min(col, N - 1)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + fr] = (acc[j][r] * inv_a[r]) * wi;
+    }
     __builtin_amdgcn_wave_barrier();
     const int rowb = m0 + wm * 32;
     const bool vec_ok = (ldd & 3) == 0 && colb + 32 <= N && (reinterpret_cast<uintptr_t>(D) & 15) == 0;
@@ -495,11 +541,11 @@ extern "C" int isg_split_f16x2_rows(const float *w, int64_t rows, int32_t K, uin
 // a_rowmax fp32 [M, P]: partial maxima of |a| per row (P >= 1); d_rowmax NULL or fp32 [M, ceil(N / 32)] (written).
 // k_offset / accumulate: this call covers columns [k_offset, k_offset + K) of a weight whose planes have `K_total` columns
 // (k_offset a multiple of 32); with accumulate != 0 the result is added to what `d` holds before bias and activation.
-extern "C" int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int32_t P, const uint16_t *w_planes,
-                                     const float *w_inv_scale, const float *bias, float *d, float *d_rowmax, int64_t M,
-                                     int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, int32_t K_total,
-                                     int32_t k_offset, int32_t accumulate, void *stream) {
-  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 2 || P <= 0) return ISG_EINVAL;
+extern "C" int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int32_t P, int32_t ldp,
+                                     const uint16_t *w_planes, const float *w_inv_scale, const float *bias, float *d,
+                                     float *d_rowmax, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                                     int32_t K_total, int32_t k_offset, int32_t accumulate, void *stream) {
+  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldd < N || act < 0 || act > 2 || P <= 0 || ldp < P) return ISG_EINVAL;
   if (K_total < K || k_offset < 0 || k_offset + K > K_total || (k_offset & 31)) return ISG_EINVAL;
   if (M == 0) return ISG_OK;
   if (!a || !a_rowmax || !w_planes || !w_inv_scale || !d) return ISG_EINVAL;
@@ -516,10 +562,12 @@ extern "C" int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int3
   const bool xcd = grid.x > 1;
   const _Float16 *wp = reinterpret_cast<const _Float16 *>(w_planes) + k_offset;
   hipStream_t st = as_stream(stream);
+  static const int mf = [] { const char *e = getenv("ISG_F16X3_MFMA"); return e && atoi(e) == 32 ? 32 : 16; }();
+#define ISG_HT4(ACT_, X_, R_, C_, MF_) linear_f16x3_tile_kernel<ACT_, X_, R_, C_, MF_><<<(X_) ? gridx : grid, block, 0, st>>>(a, a_rowmax, P, ldp, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, ldw, lda, ldd, nt)
 #define ISG_HT3(ACT_, R_, C_)                                                                                     \
   do {                                                                                                            \
-    if (xcd) linear_f16x3_tile_kernel<ACT_, true, R_, C_><<<gridx, block, 0, st>>>(a, a_rowmax, P, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, ldw, lda, ldd, nt); \
-    else linear_f16x3_tile_kernel<ACT_, false, R_, C_><<<grid, block, 0, st>>>(a, a_rowmax, P, wp, w_inv_scale, bias, d, d_rowmax, (int)M, N, K, Kp, ldw, lda, ldd, nt); \
+    if (xcd) { if (mf == 16) ISG_HT4(ACT_, true, R_, C_, 16); else ISG_HT4(ACT_, true, R_, C_, 32); }              \
+    else { if (mf == 16) ISG_HT4(ACT_, false, R_, C_, 16); else ISG_HT4(ACT_, false, R_, C_, 32); }                \
   } while (0)
 #define ISG_HT(ACT_, R_) do { if (accumulate) ISG_HT3(ACT_, R_, true); else ISG_HT3(ACT_, R_, false); } while (0)
   if (act == 1) { if (d_rowmax) ISG_HT(1, true); else ISG_HT(1, false); }
@@ -527,6 +575,7 @@ extern "C" int isg_linear_f16x3_tile(const float *a, const float *a_rowmax, int3
   else { if (d_rowmax) ISG_HT(0, true); else ISG_HT(0, false); }
 #undef ISG_HT
 #undef ISG_HT3
+#undef ISG_HT4
   return check_launch();
 }
 

@@ -15,7 +15,8 @@ Device work (inference): the torch modules only HOLD the parameters (so the stat
 forward pass below walks their layers itself: every projection and FFN layer is one launch of this library's bf16x6
 matrix-core kernel with bias (+ReLU) fused (ops.linear: in_proj 512->1536 as ONE GEMM, out_proj, linear1+ReLU, linear2),
 attention is isg_mha_small (csrc/isg_attn.hip: a question's K / V live in LDS, the float key-padding mask is the additive
-bias it is in the reference), residual + LayerNorm stay torch ops.  Training (autograd recording) runs the torch modules.
+bias it is in the reference), residual + LayerNorm are one launch of isg_add_layernorm.  Every producer leaves the row
+maxima of what it wrote (ops.attach_row_maxima) so the fp16 three-product Linears downstream need no pass for their scales.  Training (autograd recording) runs the torch modules.
 """
 from __future__ import annotations
 
@@ -48,16 +49,19 @@ def _attention(mha: torch.nn.MultiheadAttention, x_q: Tensor, x_kv: Tensor, B: i
         q = ops.linear(x_q, wq, bq)
         kv = ops.linear(x_kv, wkv, bkv)                                          # [S*B, 2D]
         k, v = kv[:, :D], kv[:, D:]
-    att = ops.mha_small(q, k, v, B, mha.num_heads, key_bias)
+    att = ops.mha_small(q, k, v, B, mha.num_heads, key_bias, want_rowmax=True)   # + max |att| per (row, head)
     return ops.linear(att, mha.out_proj.weight, mha.out_proj.bias)
 
 
-def _ln(norm: torch.nn.LayerNorm, x: Tensor) -> Tensor:
-    return torch.nn.functional.layer_norm(x, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
+def _ln(norm: torch.nn.LayerNorm, x: Tensor, residual: Tensor = None) -> Tensor:
+    """LayerNorm(x + residual) as one launch; the result carries its row maxima, so none of the Linears that read it
+    (in_proj, the cross-attention projections, linear1) makes a pass of its own for the fp16 planes' row scales."""
+    return ops.add_layernorm(x, residual, norm)
 
 
 def _ffn(layer, x: Tensor) -> Tensor:
-    h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, relu=True)       # ReLU is the layers' default activation
+    # ReLU is the layers' default activation; linear1's epilogue leaves one maximum per 32 columns for linear2's K-chunks
+    h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, relu=True, want_rowmax=True)
     return ops.linear(h, layer.linear2.weight, layer.linear2.bias)
 
 
@@ -111,9 +115,10 @@ class QuestionEncoder(torch.nn.Module):
         x = src.permute(1, 0, 2).reshape(T * B, D).contiguous()                          # torch's [T, B, D] row order
         key_bias = mask.float().contiguous()                                             # :36: ADDED to the scores (Q5)
         for layer in enc.layers:                                                         # post-norm encoder layers
-            x = _ln(layer.norm1, x + _attention(layer.self_attn, x, x, B, key_bias))
-            x = _ln(layer.norm2, x + _ffn(layer, x))
-        return _ln(enc.norm, x).view(T, B, D)
+            x = _ln(layer.norm1, x, _attention(layer.self_attn, x, x, B, key_bias))
+            x = _ln(layer.norm2, x, _ffn(layer, x))
+        out = _ln(enc.norm, x)
+        return ops.carry_row_maxima(out.view(T, B, D), out)      # the decoder's cross-attention reads these rows
 
 
 class QuestionDecoder(torch.nn.Module):
@@ -135,8 +140,10 @@ class QuestionDecoder(torch.nn.Module):
         n = queries.size(0)
         x = queries.reshape(n * B, D).contiguous()
         mem = memory.reshape(S * B, D).contiguous()
+        if mem.data_ptr() == memory.data_ptr():
+            ops.carry_row_maxima(mem, memory)                                            # same rows, same order
         for layer in dec.layers:                                                         # post-norm decoder layers, no masks
-            x = _ln(layer.norm1, x + _attention(layer.self_attn, x, x, B))
-            x = _ln(layer.norm2, x + _attention(layer.multihead_attn, x, mem, B, self_attn=False))
-            x = _ln(layer.norm3, x + _ffn(layer, x))
+            x = _ln(layer.norm1, x, _attention(layer.self_attn, x, x, B))
+            x = _ln(layer.norm2, x, _attention(layer.multihead_attn, x, mem, B, self_attn=False))
+            x = _ln(layer.norm3, x, _ffn(layer, x))
         return _ln(dec.norm, x).view(n, B, D)

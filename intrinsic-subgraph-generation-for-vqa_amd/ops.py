@@ -334,7 +334,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
             _lib.check(rc, "isg_gatv2_mp_fwd_rowmax")
             if timer is not None:
                 ev1.record()
-            out._isg_rowmax = rowmax
+            attach_row_maxima(out, rowmax)
             return out, alpha
     entry = lib.isg_gatv2_mp_fwd if fdt == torch.float32 else lib.isg_gatv2_mp_fwd_f16
     _lib.check(entry(
@@ -852,6 +852,55 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
     return planes
 
 
+def attach_row_maxima(x: Tensor, rowmax: Tensor) -> Tensor:
+    """Leave partial row maxima [M, P] (max |x| over P equal column blocks of every row) on `x` for the fp16 three-product
+    Linears that read it.  They are tied to x's version counter: an in-place write to x afterwards invalidates them
+    (`row_maxima` then returns None and the Linear makes its own pass) -- a stale maximum would mis-scale the fp16 planes."""
+    x._isg_rowmax = rowmax
+    x._isg_rowmax_version = x._version
+    return x
+
+
+def row_maxima(x: Tensor) -> Optional[Tensor]:
+    rm = getattr(x, "_isg_rowmax", None)
+    if rm is None or getattr(x, "_isg_rowmax_version", None) != x._version:
+        return None
+    return rm
+
+
+def carry_row_maxima(dst: Tensor, src: Tensor) -> Tensor:
+    """`dst` is a row-order-preserving view / reshape of `src` (same rows, same values): it keeps src's maxima."""
+    rm = row_maxima(src)
+    if rm is not None and dst.dim() >= 1:
+        attach_row_maxima(dst, rm)
+    return dst
+
+
+def add_layernorm(x: Tensor, residual: Optional[Tensor], norm: torch.nn.LayerNorm, want_rowmax: bool = True) -> Tensor:
+    """LayerNorm(x + residual) over the last dimension in one launch (csrc/isg_attn.hip::add_layernorm_kernel), the
+    result carrying its row maxima for the next Linear.  x / residual: fp32 [M, D] rows."""
+    lib = _lib.load()
+    M, D = x.shape
+    if residual is not None and tuple(residual.shape) != (M, D):
+        raise ValueError(f"add_layernorm: x {tuple(x.shape)} vs residual {tuple(residual.shape)}")
+    if tuple(norm.normalized_shape) != (D,) or norm.weight is None:
+        raise ValueError("add_layernorm: an affine LayerNorm over the last dimension")
+    out = torch.empty(M, D, dtype=torch.float32, device=x.device)
+    rm = torch.empty(M, 1, dtype=torch.float32, device=x.device) if want_rowmax else None
+    rc = lib.isg_add_layernorm(_chk_rows(x, "x"), x.stride(0), 0 if residual is None else _chk_rows(residual, "residual"),
+                               0 if residual is None else residual.stride(0),
+                               _chk(norm.weight.detach(), "weight", torch.float32, (D,)),
+                               _chk(None if norm.bias is None else norm.bias.detach(), "bias", torch.float32, (D,), optional=True),
+                               float(norm.eps), out.data_ptr(), D, 0 if rm is None else rm.data_ptr(), M, D, _stream())
+    if rc == ISG_EUNSUPPORTED:
+        y = x if residual is None else x + residual
+        return torch.nn.functional.layer_norm(y, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
+    _lib.check(rc, "isg_add_layernorm")
+    if rm is not None:
+        attach_row_maxima(out, rm)
+    return out
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False,
            cache_planes: bool = True, out_dtype=torch.float32, relu: bool = False, want_rowmax: bool = False) -> Tensor:
     """act(x @ weight^T + bias), x [M,K] fp32, weight [N,K] (torch Linear layout).  Uses the bf16x6 matrix-core kernel
@@ -874,40 +923,51 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         return torch.nn.functional.gelu(y) if gelu else y
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
-    a_rowmax = getattr(x, "_isg_rowmax", None)
-    f16x3_tile = GEMM_F16X3 and F16X3_TILE and GEMM_KERNEL == "auto" and K > 128 and not f16_io and M < (1 << 23)
-    if f16x3_tile and (a_rowmax is None or K > 640) and not (N >= 256 and M >= 4096):
-        f16x3_tile = False         # a pass over x for the row maxima only pays for wide Linears over many rows
-    if f16x3_tile and a_rowmax is not None and (a_rowmax.dim() != 2 or a_rowmax.size(0) != M or a_rowmax.size(1) > 64):
+    a_rowmax = row_maxima(x)
+    if a_rowmax is not None and (a_rowmax.dim() != 2 or a_rowmax.size(0) != M or a_rowmax.size(1) > 64 or
+                                 a_rowmax.stride(1) != 1):
         a_rowmax = None
+    f16x3_tile = GEMM_F16X3 and F16X3_TILE and GEMM_KERNEL == "auto" and K > 128 and not f16_io and M < (1 << 23)
+    nchunk = (K + 639) // 640              # chains of at most 640: 2.75x an fp32 GEMM's error at 1024-long chains, < 2x here
+    step = (K + nchunk - 1) // nchunk
+    step = (step + 31) // 32 * 32
+    # the producer's partial maxima serve a K-chunk when every partial covers a whole number of columns of ONE chunk
+    P = a_rowmax.size(1) if a_rowmax is not None else 0
+    per = K // P if P and K % P == 0 else 0
+    sliced = P > 0 and (nchunk == 1 or (per > 0 and step % per == 0))      # one chunk: any partition of the row serves
+    if f16x3_tile and not sliced and not (N >= 256 and M >= 4096):
+        f16x3_tile = False         # a pass over x for the row maxima only pays for wide Linears over many rows
     if f16x3_tile:
-        # fp16 three-product tile kernel.  Row scales: the producer's partial maxima, or one pass over x; reductions longer
-        # than 640 run as K-chunks that accumulate into `out` (every chunk its own fp32 chain and its own row scales)
+        # fp16 three-product tile kernel.  Row scales: the producer's partial maxima (a chunk takes the slice that covers
+        # its columns), or one pass over x which is then left on x for its other consumers; reductions longer than 640 run
+        # as K-chunks that accumulate into `out` (every chunk its own fp32 chain and its own row scales)
         planes, inv = _weight_planes(weight, cache_planes, "f16x3_rows")
         act = 2 if relu else (1 if gelu else 0)
         bptr = _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True)
         d_rowmax = torch.empty(M, (N + 31) // 32, dtype=torch.float32, device=x.device) if want_rowmax else None
         xp = _chk(x, "x", torch.float32)
-        nchunk = (K + 639) // 640          # chains of at most 640: 2.75x an fp32 GEMM's error at 1024-long chains, < 2x here
-        step = (K + nchunk - 1) // nchunk
-        step = (step + 31) // 32 * 32
         k0, c = 0, 0
         while k0 < K:
             kc = min(step, K - k0)
             last = k0 + kc >= K
-            if nchunk == 1 and a_rowmax is not None:
-                rm = a_rowmax
+            if sliced and nchunk == 1:
+                rm_ptr, rm_p, rm_ld = a_rowmax.data_ptr(), P, a_rowmax.stride(0)
+            elif sliced:
+                rm_ptr, rm_p, rm_ld = a_rowmax.data_ptr() + 4 * (k0 // per), (kc + per - 1) // per, a_rowmax.stride(0)
             else:
                 rm = torch.empty(M, 1, dtype=torch.float32, device=x.device)
                 _lib.check(lib.isg_row_absmax(xp + 4 * k0, M, kc, K, rm.data_ptr(), _stream()), "isg_row_absmax")
+                if nchunk == 1:
+                    attach_row_maxima(x, rm)          # the next Linear over the same rows does not repeat the pass
+                rm_ptr, rm_p, rm_ld = rm.data_ptr(), 1, 1
             _lib.check(lib.isg_linear_f16x3_tile(
-                xp + 4 * k0, rm.data_ptr(), rm.size(1), planes.data_ptr(), inv.data_ptr(), bptr if last else 0,
+                xp + 4 * k0, rm_ptr, rm_p, rm_ld, planes.data_ptr(), inv.data_ptr(), bptr if last else 0,
                 out.data_ptr(), d_rowmax.data_ptr() if (last and d_rowmax is not None) else 0, M, N, kc, K, N,
                 act if last else 0, K, k0, 1 if c > 0 else 0, _stream()), "isg_linear_f16x3_tile")
             k0 += kc
             c += 1
         if d_rowmax is not None:
-            out._isg_rowmax = d_rowmax
+            attach_row_maxima(out, d_rowmax)
         return out
     if _use_panel(M, N, K) and not relu and GEMM_F16X3 and K <= 128 and not f16_io:
         planes, inv = _weight_planes(weight, cache_planes, "f16x3")
@@ -969,7 +1029,8 @@ def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
     return tuple(out[i] for i in range(L))
 
 
-def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_bias: Optional[Tensor] = None) -> Tensor:
+def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_bias: Optional[Tensor] = None,
+              want_rowmax: bool = False) -> Tensor:
     """softmax(Q K^T / sqrt(hd) + key_bias) V per (batch item, head) for short sequences (csrc/isg_attn.hip).
     q [Tq*B, D], k / v [Tk*B, D] in torch's [T, B, D] row order (row t*B + b; column slices of a fused projection are
     fine), key_bias fp32 [B, Tk] additive (question_encoder.py:35-37) -> [Tq*B, D]."""
@@ -980,9 +1041,13 @@ def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_
     if H * hd != D or Tq * B != q.size(0) or Tk * B != k.size(0) or tuple(v.shape) != tuple(k.shape):
         raise ValueError(f"mha_small: q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)} vs B={B}, H={H}")
     out = torch.empty(Tq * B, D, dtype=torch.float32, device=q.device)
+    rm = torch.empty(Tq * B, H, dtype=torch.float32, device=q.device) if want_rowmax else None
     _lib.check(lib.isg_mha_small(_chk_rows(q, "q"), q.stride(0), _chk_rows(k, "k"), k.stride(0), _chk_rows(v, "v"),
                                  v.stride(0), _chk(key_bias, "key_bias", torch.float32, (B, Tk), optional=True),
-                                 out.data_ptr(), D, B, H, hd, Tq, Tk, _stream()), "isg_mha_small")
+                                 out.data_ptr(), D, 0 if rm is None else rm.data_ptr(), B, H, hd, Tq, Tk, _stream()),
+               "isg_mha_small")
+    if rm is not None:
+        attach_row_maxima(out, rm)
     return out
 
 
@@ -1010,11 +1075,11 @@ def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:   # x may be fp16 featur
             fuse = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.GELU) and mods[i + 1].approximate == "none"
             nxt = i + (2 if fuse else 1)
             more = nxt < len(mods) and hasattr(mods[nxt], "weight") and getattr(mods[nxt].weight, "dim", lambda: 0)() == 2
-            rm = getattr(x, "_isg_rowmax", None)
+            rm = row_maxima(x)
             x = x.contiguous()
             if rm is not None:
-                x._isg_rowmax = rm
-            x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more and rm is not None)
+                attach_row_maxima(x, rm)
+            x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more)      # the epilogue's maxima cost next to nothing
             i = nxt
         else:
             x = m(x)

@@ -545,6 +545,11 @@ def test_mha_small_matches_fp64_attention(dev, B, H, hd, Tq, Tk, bias):
     got = ops.mha_small(qkv_d[:, :D], kv_d[:, D:2 * D], kv_d[:, 2 * D:], B, H, None if kb is None else kb.to(dev))
     assert got.shape == (Tq * B, D)
     assert (got.cpu().double() - ref).abs().max().item() < 2e-6
+    assert ops.row_maxima(got) is None
+    got2 = ops.mha_small(qkv_d[:, :D], kv_d[:, D:2 * D], kv_d[:, 2 * D:], B, H, None if kb is None else kb.to(dev),
+                         want_rowmax=True)
+    assert torch.equal(got2, got)
+    assert torch.equal(ops.row_maxima(got2), got.view(Tq * B, H, hd).abs().amax(2))      # per (row, head), exact
 
 
 def test_linear_multi_equals_the_separate_projections(dev):
@@ -676,9 +681,9 @@ def test_linear_f16x3_tile_with_producer_row_maxima(dev, M, K, N, gelu):
         ref, f32 = torch.nn.functional.gelu(ref), torch.nn.functional.gelu(f32)
     xd = x.to(dev)
     cuts = [0, K // 5, K // 2, K - 3, K]
-    xd._isg_rowmax = torch.stack([xd[:, a:b_].abs().amax(1) for a, b_ in zip(cuts[:-1], cuts[1:])], 1).contiguous()
+    ops.attach_row_maxima(xd, torch.stack([xd[:, a:b_].abs().amax(1) for a, b_ in zip(cuts[:-1], cuts[1:])], 1).contiguous())
     got = ops.linear(xd, w.to(dev), b.to(dev), gelu=gelu, want_rowmax=True)
-    rm = got._isg_rowmax
+    rm = ops.row_maxima(got)
     err, err32 = (got.cpu().double() - ref).abs().max().item(), (f32.double() - ref).abs().max().item()
     # per-row comparison: every row has its own magnitude
     rel = ((got.cpu().double() - ref).abs().amax(1) / ((f32.double() - ref).abs().amax(1) + 1e-300))
@@ -687,3 +692,81 @@ def test_linear_f16x3_tile_with_producer_row_maxima(dev, M, K, N, gelu):
     assert rel.median().item() <= 2.0 and rel.max().item() <= 6.0
     want = torch.stack([got[:, c:c + 32].abs().amax(1) for c in range(0, N, 32)], 1)
     assert torch.equal(rm, want)
+
+
+def test_add_layernorm_matches_torch_and_leaves_exact_row_maxima(dev):
+    """isg_add_layernorm: LayerNorm(x + r) in one launch (the post-norm step of the question encoder / decoder layers,
+    question_encoder.py:20-38) against torch's fp64 LayerNorm; with and without the residual; the row maxima it leaves
+    for the next Linear are the maxima of what it wrote."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    for M, D in ((1000, 512), (37, 256), (130, 1024), (9, 2048), (64, 300)):
+        norm = torch.nn.LayerNorm(D)
+        with torch.no_grad():
+            norm.weight.copy_(1 + 0.1 * torch.randn(D, generator=gen))
+            norm.bias.copy_(0.1 * torch.randn(D, generator=gen))
+        x = torch.randn(M, D, generator=gen) * torch.logspace(-3, 3, M).unsqueeze(1)
+        r = torch.randn(M, D, generator=gen)
+        nd = norm.to(dev)
+        for res in (r, None):
+            ref = torch.nn.functional.layer_norm((x if res is None else x + res).double(), (D,), norm.weight.double().cpu(),
+                                                 norm.bias.double().cpu(), norm.eps)
+            t32 = torch.nn.functional.layer_norm(x if res is None else x + res, (D,), norm.weight.cpu(), norm.bias.cpu(), norm.eps)
+            got = ops.add_layernorm(x.to(dev), None if res is None else res.to(dev), nd)
+            err = (got.cpu().double() - ref).abs().max().item()
+            err32 = (t32.double() - ref).abs().max().item()
+            print(f"add_layernorm [{M}x{D}] residual={res is not None}: err {err:.3e}, torch fp32 {err32:.3e}")
+            assert err <= max(2.0 * err32, 2e-6)
+            rm = ops.row_maxima(got)
+            assert rm is not None and torch.equal(rm[:, 0], got.abs().amax(1))
+
+
+def test_row_maxima_are_dropped_after_an_in_place_write(dev):
+    """Row maxima left on a tensor are the scales of the fp16 planes of the Linear that reads it: after an in-place write
+    they are stale, and a stale (too small) maximum overflows fp16.  They are tied to the tensor's version counter."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(4096, 512, generator=gen).to(dev)
+    w = (torch.randn(256, 512, generator=gen) / 512 ** 0.5).to(dev)
+    y0 = ops.linear(x, w)                       # wide enough for the row pass, which leaves its maxima on x
+    assert ops.row_maxima(x) is not None
+    x.mul_(1e4)
+    assert ops.row_maxima(x) is None
+    y1 = ops.linear(x, w)
+    ref = x.double() @ w.double().t()
+    assert torch.isfinite(y1).all()
+    assert (y1.double() - ref).abs().max().item() <= 2.0 * (torch.nn.functional.linear(x, w).double() - ref).abs().max().item()
+    assert (y0.double() * 1e4 - ref).abs().max().item() < 1e-1
+
+
+def test_long_reductions_take_slices_of_the_producers_partial_maxima(dev):
+    """K = 2048 (the FFN's second Linear) runs as four K-chunks; the first Linear's epilogue left one maximum per 32
+    columns, a chunk takes the 16 that cover it: no isg_row_absmax launch, same accuracy."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    M = 4100
+    x = (torch.randn(M, 512, generator=gen) * torch.logspace(-2, 2, M).unsqueeze(1)).to(dev)
+    w1, b1 = (torch.randn(2048, 512, generator=gen) / 512 ** 0.5).to(dev), torch.randn(2048, generator=gen).to(dev)
+    w2, b2 = (torch.randn(512, 2048, generator=gen) / 2048 ** 0.5).to(dev), torch.randn(512, generator=gen).to(dev)
+    h = ops.linear(x, w1, b1, relu=True, want_rowmax=True)
+    rm = ops.row_maxima(h)
+    assert rm is not None and tuple(rm.shape) == (M, 64)
+    calls = []
+    lib = ops._lib.load()
+    real = lib.isg_row_absmax
+
+    class Spy:
+        def __call__(self, *a):
+            calls.append(a)
+            return real(*a)
+    try:
+        lib.isg_row_absmax = Spy()
+        y = ops.linear(h, w2, b2)
+    finally:
+        lib.isg_row_absmax = real
+    assert not calls, "the chunks made their own passes over h"
+    ref = h.double() @ w2.double().t() + b2.double()
+    err = (y.double() - ref).abs().max().item()
+    err32 = (torch.nn.functional.linear(h, w2, b2).double() - ref).abs().max().item()
+    print(f"K=2048 in chunks with sliced maxima: err {err:.3e}, fp32 GEMM {err32:.3e}")
+    assert err <= 2.0 * err32

@@ -24,7 +24,7 @@ for r in range(10):
         xx = x.view(M, 512)
         if f16:
             xx = x.clone() if False else x
-            xx._isg_rowmax = rm
+            ops.attach_row_maxima(xx, rm)
         elif hasattr(x, "_isg_rowmax"):
             del x._isg_rowmax
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
