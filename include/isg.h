@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 8
+#define ISG_ABI_VERSION 9
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -289,6 +289,33 @@ int isg_gatv2_mp_fwd_rowmax(const float *x_l, const float *x_r, const float *e_p
                             int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
                             const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
                             int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e, void *stream);
+
+/* GATv2 attention logits without e_proj in memory (csrc/isg_mp_logits.hip): for every CSR slot t (edge eid[t] from src[t]
+ * into dst[t]) and head h,  logits[t, h] = att_h . leaky_relu(x_l[src] + x_r[dst] + lin_edge(edge_attr[eid]))_h  with the
+ * edge mask applied before and after the leaky_relu -- MaskingGATv2Conv.message up to the softmax
+ * (mgat_v2_conv.py:243-270, lin_edge of :259-261 inside).  edge_attr fp32 rows by EDGE ID (stride lda), w_frag /
+ * w_inv_scale from isg_split_f16x2_frag(lin_edge.weight [H*C, K]), x_l / x_r fp32 rows by node id (strides ldl / ldr),
+ * eid / src / dst int32 in CSR slot order (isg_csr_build), edge_mask fp32 [E] by edge id or node_mask fp32 [N] (product of
+ * the endpoints, NodeMaskToEdgeMask) or both NULL.  logits fp32 [E, H] in SLOT order.  The product is the fp16
+ * three-term form of isg_linear_f16x3 and never leaves the accumulators.  head_stride_l / _r: distance in floats between
+ * the head slices of one node (0 = C: heads side by side in a row of H*C; N*C with ldl = C for a head-major [H][N][C]
+ * tensor, whose 512-byte rows keep a gather instruction inside a few pages).  ISG_EUNSUPPORTED unless 32 | C, K <= 128,
+ * 4 | K, H * C <= 2048, 16-byte aligned rows. */
+int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
+                          const float *x_l, int32_t ldl, int64_t head_stride_l, const float *x_r, int32_t ldr,
+                          int64_t head_stride_r, const float *att, const int32_t *eid, const int32_t *src, const int32_t *dst, const float *edge_mask,
+                          const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C, int32_t K,
+                          float negative_slope, void *stream);
+/* The rest of MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:270-279, :215-232) given those logits: softmax over
+ * every destination's in-edges (+1e-16), alpha fp32 [E, H] by edge id, out[i] = sum alpha * mask * x_l[src] + bias, rowmax
+ * (optional) as in isg_gatv2_mp_fwd_rowmax.  e_proj and x_r are not read.  Per-graph kernel only: ISG_EUNSUPPORTED for
+ * batches / widths it has no instantiation for (the caller then runs isg_linear_* + isg_gatv2_mp_fwd). */
+int isg_gatv2_mp_fwd_logits(const float *x_l, const float *logits, const float *att, const float *bias,
+                            const int32_t *rowptr, const int32_t *eid, const int32_t *src, const float *node_mask,
+                            const float *edge_mask, float *out, float *alpha, float *rowmax, int64_t N, int64_t E,
+                            int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
+                            const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
+                            int32_t emax_host, int32_t ld_l, void *stream);
 
 /* isg_gatv2_mp_fwd with the edge projection computed inside the kernel (csrc/isg_mp_fused.hip): instead of
  * e_proj = lin_edge(edge_attr) [E, H*C] (mgat_v2_conv.py:259-261) it takes edge_attr fp32 [E, K] (row stride ld_ea) and

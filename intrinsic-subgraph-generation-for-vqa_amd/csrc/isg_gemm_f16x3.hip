@@ -12,26 +12,13 @@
 // [2^13, 2^14) -- exact -- and the accumulator is scaled back in the epilogue (two exact multiplies).  A row's scale needs
 // the whole row, which is why this form exists for K <= 128 only (the row panel is staged in one piece: lin_edge,
 // lin_l | lin_r); everything else about the kernel is isg_gemm_panel.hip's A-stationary panel.
-#include "isg_common.hpp"
+#include "isg_f16x3.hpp"
 
 #include <stdlib.h>
 
 namespace isg {
 
-typedef __attribute__((ext_vector_type(8))) _Float16 hf16x8;
-typedef __attribute__((ext_vector_type(4))) _Float16 hf16x4;
-typedef __attribute__((ext_vector_type(16))) float hf32x16;
-typedef __attribute__((ext_vector_type(4))) float hf32x4;
-
 constexpr int H3_BM = 64, H3_KC = 128, H3_LD = H3_KC + 8, H3_THREADS = 256;
-
-// power of two that moves |mx| into [2^13, 2^14), and its inverse; 1 for zero / non-finite rows
-__device__ __forceinline__ void h3_scale(float mx, float &s, float &inv) {
-  const int e = (int)((__float_as_uint(mx) >> 23) & 255u);      // biased exponent
-  if (e == 0 || e == 255) { s = 1.f; inv = 1.f; return; }
-  s = __uint_as_float((unsigned)(127 + 13 + 127 - e) << 23);
-  inv = __uint_as_float((unsigned)(e - 13) << 23);
-}
 
 // Wf[q][nt][ks][lane][j] (q = hi, mid) of w[n][k] * s_n, n = nt*32 + (lane & 31), k = ks*16 + 8*(lane >> 5) + j; inv[n] = 1/s_n
 __global__ void split_f16x2_frag_kernel(const float *__restrict__ w, int N, int K, int NT, int KS, _Float16 *__restrict__ out,

@@ -253,10 +253,11 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
                   const float *edge_mask, void *out, float *alpha, int64_t N, int64_t E, int32_t H, int32_t C,
                   float negative_slope, const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst,
                   int64_t B, int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e,
-                  void *stream, int f16, float *rowmax = nullptr) {
+                  void *stream, int f16, float *rowmax = nullptr, const float *logits = nullptr) {
   if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
   if (N == 0) return ISG_OK;
-  if (!x_l || !x_r || !att || !rowptr || !out || (E > 0 && (!e_proj || !eid || !src || !alpha))) return ISG_EINVAL;
+  if (!x_l || !att || !rowptr || !out || (E > 0 && (!eid || !src || !alpha))) return ISG_EINVAL;
+  if (!logits && (!x_r || (E > 0 && !e_proj))) return ISG_EINVAL;      // with logits handed in, e_proj and x_r are not read
   if ((C & 3) != 0 || N >= (1ll << 31) || E >= (1ll << 31)) return ISG_EUNSUPPORTED;
   if (ld_l == 0) ld_l = H * C;
   if (ld_r == 0) ld_r = H * C;
@@ -274,17 +275,16 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
   a.graph_ptr = graph_ptr; a.graph_eptr = graph_eptr; a.dst = dst; a.B = (int)B; a.lrows = 0;
   a.f16 = f16;
   a.rowmax = rowmax;
-  {
-    const char *f = getenv("ISG_MP_FLAGS");   // experiment switch; default = tuned setting
-    a.flags = f ? atoi(f) : ISG_MP_DEFAULT_FLAGS;
-  }
+  a.logits = logits;
+  static const int mp_flags = [] { const char *f = getenv("ISG_MP_FLAGS"); return f ? atoi(f) : ISG_MP_DEFAULT_FLAGS; }();
+  a.flags = mp_flags;          // experiment switch, read once; default = tuned setting
   a.nchunks = 0;
   hipStream_t st = as_stream(stream);
   if (graph_ptr && graph_eptr && (dst || E == 0) && B > 0 && B < (1ll << 31) && nmax_host > 0) {
     int rc = launch_mp_graph(a, nmax_host, emax_host, st);
     if (rc != ISG_EUNSUPPORTED) return rc;   // shapes without a per-graph instantiation use the node-chunk kernel
   }
-  if (rowmax) return ISG_EUNSUPPORTED;       // the row maxima are written by the grouped per-graph kernel only
+  if (rowmax || logits) return ISG_EUNSUPPORTED;   // row maxima out / logits in: the grouped per-graph kernel only
   if (f16) return ISG_EUNSUPPORTED;          // fp16 rows exist in the per-graph kernel only
   switch (H) {
     case 1: return launch_mp<1>(a, st);
@@ -362,4 +362,20 @@ extern "C" int isg_gatv2_mp_fwd_rowmax(const float *x_l, const float *x_r, const
   if (!rowmax) return ISG_EINVAL;
   return mp_fwd(x_l, x_r, e_proj, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
                 negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, ld_r, ld_e, stream, 0, rowmax);
+}
+
+// isg_gatv2_mp_fwd with the attention logits handed in (fp32 [E, H] in CSR slot order, from isg_gatv2_edge_logits)
+// instead of e_proj and x_r: masked softmax over every destination's in-edges, alpha out, aggregation of x_l rows, bias,
+// optional row maxima of `out`.  Per-graph grouped kernel only (ISG_EUNSUPPORTED otherwise: the caller then runs the
+// un-fused pair).
+extern "C" int isg_gatv2_mp_fwd_logits(const float *x_l, const float *logits, const float *att, const float *bias,
+                                       const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                       const float *node_mask, const float *edge_mask, float *out, float *alpha,
+                                       float *rowmax, int64_t N, int64_t E, int32_t H, int32_t C, float negative_slope,
+                                       const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst, int64_t B,
+                                       int32_t nmax_host, int32_t emax_host, int32_t ld_l, void *stream) {
+  if (!logits && E > 0) return ISG_EINVAL;
+  if (E == 0) return ISG_EUNSUPPORTED;
+  return mp_fwd(x_l, nullptr, nullptr, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
+                negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, 0, 0, stream, 0, rowmax, logits);
 }

@@ -29,6 +29,8 @@ struct MpArgs {
                           // per-graph kernel: bit2 non-temporal x_l staging loads, bit5 x_r loads, bit6 alpha stores;
                           // bits 3 / 4 skip the logit / aggregation phase (ablation)
   int nchunks;
+  const float *logits;    // per-graph grouped kernel: fp32 [E, H] attention logits in CSR SLOT order (isg_gatv2_edge_logits), or
+                          // NULL.  When given, the logit phase (and with it e_proj and x_r) is skipped
   float *rowmax;          // per-graph kernel, fp32 rows: largest |out| per (node, head) [N, H], or NULL: the row scales of
                           // the fp16 three-product GEMM that consumes `out` (isg_linear_f16x3_tile) come from here
 };

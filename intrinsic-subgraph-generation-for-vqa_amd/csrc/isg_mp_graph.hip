@@ -122,6 +122,9 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
 #pragma unroll
     for (int k = 0; k < RECS; ++k)
       if (tid + k * GK_THREADS < ne) s_tab[tid + k * GK_THREADS] = rec[k];
+    if (a.logits)     // logits formed by isg_gatv2_edge_logits (slot order): this workgroup's head slice of its graph's slots
+      for (int t = tid; t < ne * HS; t += GK_THREADS)
+        s_lg[t] = a.logits[(size_t)(e0 + t / HS) * a.H + hg * HS + (t % HS)];
   }
   __syncthreads();
 
@@ -139,8 +142,8 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
   const int hd = hg * HS + grp;   // global head index of this lane group
   const float slope = a.slope;
 
-  // ---- phase B: edge-parallel logits -------------------------------------------------------------------------------
-  if (!(a.flags & 8)) {
+  // ---- phase B: edge-parallel logits (skipped when the logits were handed in) ----------------------------------------
+  if (!(a.flags & 8) && !a.logits) {
 #pragma unroll 1
     for (int tb = wave * GK_U; tb < ne; tb += GK_WAVES * GK_U) {
       typename RawQ<F16>::type epv[GK_U][P], xrv[GK_U][P];
@@ -537,6 +540,7 @@ static int launch_one(const MpArgs &a, int nmax_host, int emax_host, hipStream_t
 // then uses the node-chunk kernel).
 int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   const int Q = a.C >> 2;
+  if (a.logits && a.f16) return ISG_EUNSUPPORTED;
   if (nmax_host <= 0 || nmax_host > GK_NCAP_L || emax_host < 0 || emax_host > GK_ECAP_L) return ISG_EUNSUPPORTED;
   // heads per workgroup: the largest HS | H with a row slice of at most 1280 bytes (at least one head)
   int HS = 1;
@@ -552,7 +556,7 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   static const bool no_flat = getenv("ISG_MP_NO_FLAT") != nullptr;
   if (HS == 1 && a.H > 1 && P == 2 && Q * 10 < G * P * 7 && !force_graph) {
     // head dimension that fills < 70 % of two passes (the reference's C = 300): flat lane mapping over two heads
-    if (!no_flat && !a.rowmax) {
+    if (!no_flat && !a.rowmax && !a.logits) {
       const int rc = launch_mp_graph_flat(a, nmax_host, emax_host, st);
       if (rc != ISG_EUNSUPPORTED) return rc;
     }

@@ -1,0 +1,276 @@
+// GATv2 attention logits WITHOUT the projected edge features in memory.
+//
+// MaskingGATv2Conv (ISubGVQA/models/mgat_v2_conv.py:215-279) scores an edge e = (j -> i) per head h as
+//     logit[e, h] = att_h . leaky_relu(x_l[j] + x_r[i] + lin_edge(edge_attr[e]))_h
+// and uses e_proj = lin_edge(edge_attr) for nothing else: the message is alpha * x_l[j].  The un-fused pair writes e_proj
+// (E x H*C fp32: 420 MB per layer at BASELINE configs[1]) in isg_linear_f16x3 and streams it back in the message-passing
+// kernel -- the largest HBM stream of the step, for a tensor that only ever contributes E x H scalars.  Here the panel
+// GEMM of isg_gemm_f16x3.hip keeps its result in the accumulators and finishes the logit in its epilogue; the
+// message-passing kernel (isg_gatv2_mp_fwd_logits) then takes logits[E, H] (3 MB) instead of e_proj and x_r.
+//
+//   order      CSR SLOT order (edges sorted by destination, a graph's slots contiguous): consecutive slots share x_r[i]
+//              and draw x_l[j] from one graph's ~20 rows, so the row gathers hit L1 / L2; the logits come out in the order
+//              the message-passing kernel stages them
+//   workgroup  64 slots, 8 waves; the 64 edge_attr rows (gathered by edge id, 512 B each) are scaled per row, split into
+//              (hi, mid) fp16 planes and staged in LDS once (isg_linear_f16x3's A-stationary panel)
+//   wave       one 32-slot half of the panel and every fourth 32-channel tile of the row; a tile's product is formed
+//              TRANSPOSED -- the W fragment is the MFMA's A operand, the edge panel its B operand -- so a lane holds ONE edge
+//              (lane & 31) and 16 channels of it in its accumulator registers: the sum over channels is in-lane, and the
+//              two half-waves (channels +4) meet in one cross-lane add per head.  (With the panel as the A operand a lane
+//              holds one channel of 16 edges and every (edge, tile) needs a 32-lane reduction: that form was measured in
+//              profiles/r02_d_fused_edge.md and lost.)
+//   epilogue   per tile: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask,
+//              z * att accumulated per lane; the 2 x 4 x 16 B row gathers of a tile are issued before its MFMA loop
+// W never touches LDS (fragment-major planes from L2, one k-step ahead), exactly as in isg_linear_f16x3.
+#include "isg_f16x3.hpp"
+#include "isg_mp.hpp"
+
+#include <stdlib.h>
+
+namespace isg {
+
+constexpr int EL_BM = 64, EL_KC = 128, EL_LD = EL_KC + 8, EL_THREADS = 512;
+
+struct ElArgs {
+  const float *edge_attr;           // rows by EDGE ID, stride lda
+  const _Float16 *Wf;               // fragment-major (hi, mid) planes of lin_edge.weight [H*C, K] (isg_split_f16x2_frag)
+  const float *w_inv;               // [NT * 32]
+  const float *x_l, *x_r;           // rows by node id, strides ldl / ldr (column slices of the fused lin_l | lin_r output)
+  const float *att;                 // [H * C]
+  const int *eid, *src, *dst;       // CSR slot order
+  const float *edge_mask, *node_mask;
+  float *logits;                    // [E, H], slot order
+  int E, H, C, K, KS, NT, lda, ldl, ldr;
+  int64_t hsl, hsr;                 // distance between a row's consecutive HEAD slices in x_l / x_r (floats): C when the heads
+                                    // lie side by side in one row (row-major [N, H*C]); N * C for a head-major [H][N][C] tensor
+  float slope;
+};
+
+// DBG (ablation builds only, -DISG_EL_ABLATION, tools/ablate_edge_logits.py): bit 0 no x_l / x_r row gathers, bit 1 no MFMAs
+//
+// What was measured on the way to this form, all at BASELINE configs[1] on one MI355X, same-box A/B (first version: 4 waves,
+// a wave = 64 slots x one head, 194 VGPRs, 2 waves per SIMD: 214 us; profiles/r02_w_edge_logits.md has the tables):
+//   * ablation of the first version: 112 us without the x_l / x_r gathers, 180 without the MFMAs, 171 without the W loads
+//   * v_mfma_f32_16x16x32_f16 layout (a lane's channels contiguous, half the rows per gather instruction): 218 us
+//   * gathers issued a whole tile ahead (second register set): 226 us
+//   * the four waves on neighbouring 128-byte pieces of the same rows at the same time: 216 us
+//   * all W fragments of a tile ahead of its gathers (so that an in-order vmcnt wait for a fragment does not drain the
+//     gathers): 64 + 64 + 32 registers plus the epilogue's temporaries do not fit 256 (56-96 spilled); not run
+//   * this form (a wave = ONE 32-slot half, 8 waves, 97 VGPRs, four waves per SIMD): 217 us; its ablation: 122 us without
+//     the gathers, 232 without the MFMAs (hidden), 118 without both
+//   * x_l / x_r as column halves of [N, 2HC] (4 KB row pitch), as two dense tensors (2 KB), head-major [2H][N][C] (512-byte
+//     rows, 8 per page): 228 / 228 / 229 us, identical logits
+//   * counters: HBM fetch 508 MB per launch = 1.15x the algorithmic 442 MB; L2 hit rate 67 %; 71 M L1 line accesses (the
+//     plain lin_edge GEMM: 23 M); TCP_UTCL1_STALL_INFLIGHT_MAX 24.6 M (10.0 M)
+// So: the gathers add ~100 us to a ~118 us kernel in EVERY form -- not the address unit, not request latency, not DRAM or
+// page locality, not occupancy -- while the HBM traffic is near its minimum; what the two phases share is not identified.
+// The pair (this kernel + isg_gatv2_mp_fwd_logits) is 313-320 us against 334-350 us for isg_linear_f16x3 +
+// isg_gatv2_mp_fwd, and the configs[1] step 2.20-2.22 ms against 2.24-2.29 ms on the same box.
+template <bool MASKED, int DBG = 0>
+__global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 sA[2][EL_BM][EL_LD];   // 34,816 B
+  __shared__ float s_inv[EL_BM];
+  extern __shared__ __attribute__((aligned(16))) float s_cw[];            // att [H*C], w_inv [H*C], partial logits [4][64][H]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, tw = wave & 3;     // which 32 slots of the panel; which channel tiles (tw, tw + 4, ...)
+  const int m0 = blockIdx.x * EL_BM;
+  const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
+  const int HC = a.H * a.C;
+
+  // ---- stage the edge panel once: rows gathered by edge id -> row scale -> (hi, mid) planes -------------------------------
+  {
+    float4 ra[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + EL_THREADS * u;
+      const int row = i >> 5, c4 = i & 31;
+      const int e = a.eid[min(m0 + row, a.E - 1)];
+      const int gk = min(c4 * 4, a.K - 4);
+      ra[u] = *reinterpret_cast<const float4 *>(a.edge_attr + (int64_t)e * a.lda + gk);
+    }
+    for (int c = tid; c < HC; c += EL_THREADS) {
+      s_cw[c] = a.att[c];
+      s_cw[HC + c] = a.w_inv[c];
+    }
+    for (int c = tid; c < 4 * EL_BM * a.H; c += EL_THREADS) s_cw[2 * HC + c] = 0.f;      // the waves' partial logits
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + EL_THREADS * u;
+      const int row = i >> 5, c4 = i & 31;       // the 32 lanes of a half-wave hold one row
+      float4 v = ra[u];
+      if (m0 + row >= a.E || c4 * 4 >= a.K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      float s, inv;
+      h3_scale(mx, s, inv);
+      if (c4 == 0) s_inv[row] = inv;
+      v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+      hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+      hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
+                    (_Float16)(v.w - (float)hi[3])};
+      *reinterpret_cast<hf16x4 *>(&sA[0][row][c4 * 4]) = hi;
+      *reinterpret_cast<hf16x4 *>(&sA[1][row][c4 * 4]) = mid;
+    }
+  }
+
+  // ---- this lane's edge (slot m0 + half * 32 + fr): endpoints, mask value ------------------------------------------------
+  const int prow = half * 32 + fr;               // row of the panel
+  const int sl = min(m0 + prow, a.E - 1);
+  const int s_node = a.src[sl], d_node = a.dst[sl];
+  const int64_t xl_off = (int64_t)s_node * a.ldl + 4 * hh, xr_off = (int64_t)d_node * a.ldr + 4 * hh;
+  float me = 1.f;
+  if (MASKED) me = a.edge_mask ? a.edge_mask[a.eid[sl]] : a.node_mask[s_node] * a.node_mask[d_node];
+  __syncthreads();
+  const float sinv = s_inv[prow];
+
+  const int KS = a.KS;
+  const unsigned plane_b = (unsigned)a.NT * (unsigned)KS * 1024u;      // bytes per W plane
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.Wf), 0, (int)(2u * plane_b), 0x00020000);
+  const int voff = lane * 16;
+  const int tph = a.C >> 5;            // channel tiles per head
+  const float slope = a.slope;
+
+  // In round r the four tile-waves of a half take channel tiles 4 r .. 4 r + 3.  A wave's partial logits (its tiles of a
+  // head) go to its own LDS slots and are summed over the tile-waves in a fixed order at the end.
+  float *s_part = s_cw + 2 * HC;          // [4 tile-waves][64 slots][H]
+  float part[4];             // four partial sums (one per channel group g), added pairwise: short chains
+  int cur_hd = -1;
+  auto flush = [&](int hd) {
+    const float mine = (part[0] + part[1]) + (part[2] + part[3]);
+    const float tot = mine + __shfl_xor(mine, 32);
+    if (hh == 0) s_part[(tw * EL_BM + prow) * a.H + hd] = tot;
+  };
+#pragma unroll 1
+  for (int nt = tw; nt < a.NT; nt += 4) {
+    const int hd = nt / tph;
+    if (hd != cur_hd) {
+      if (cur_hd >= 0) flush(cur_hd);
+      cur_hd = hd;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) part[g] = 0.f;
+    }
+    const int cb = nt * 32 + 4 * hh;         // this lane's channels of the tile: cb + 8 * g + j, g = r >> 2, j = r & 3
+    const int64_t col_l = (int64_t)hd * a.hsl + (nt - hd * tph) * 32, col_r = (int64_t)hd * a.hsr + (nt - hd * tph) * 32;
+    float4 xl[4], xr[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (DBG & 1) {
+        xl[g] = make_float4(1.f, 2.f, 3.f, 4.f);
+        xr[g] = make_float4(me, sinv, 0.5f, 0.25f);
+      } else {
+        xl[g] = *reinterpret_cast<const float4 *>(a.x_l + xl_off + col_l + 8 * g);
+        xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
+      }
+    }
+    hf32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const unsigned wb = (unsigned)nt * (unsigned)KS * 1024u;
+    hf16x8 a0[2], a1[2], w0[2], w1[2];
+#define EL_LOAD_W(W, s)                                                                                          \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                  \
+      W[q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(                                   \
+          wrsrc, voff, (int)(wb + q * plane_b + (unsigned)(s) * 1024u), 0));
+#define EL_LOAD_A(Afr, ksl)                                                                                      \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                  \
+      Afr[q] = *reinterpret_cast<const hf16x8 *>(&sA[q][prow][(ksl) * 16 + fk]);
+    // transposed product: W fragment = A operand (rows = channels), edge panel = B operand (columns = edges)
+#define EL_MMA(Afr, W)                                                                                           \
+  if (DBG & 2) {                                                                                                 \
+    acc[0] += (float)W[0][0] + (float)W[1][1] + (float)Afr[0][0] + (float)Afr[1][2];                             \
+  } else {                                                                                                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[1], acc, 0, 0, 0);                                    \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[1], Afr[0], acc, 0, 0, 0);                                    \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[0], acc, 0, 0, 0);                                    \
+  }
+    EL_LOAD_W(w0, 0)
+    EL_LOAD_A(a0, 0)
+    int ks = 0;
+#pragma unroll 1
+    for (; ks + 2 <= KS; ks += 2) {
+      EL_LOAD_W(w1, ks + 1)
+      EL_LOAD_A(a1, ks + 1)
+      EL_MMA(a0, w0)
+      EL_LOAD_W(w0, min(ks + 2, KS - 1))
+      EL_LOAD_A(a0, min(ks + 2, 7))
+      EL_MMA(a1, w1)
+    }
+    if (ks < KS) { EL_MMA(a0, w0) }
+#undef EL_LOAD_W
+#undef EL_LOAD_A
+#undef EL_MMA
+    // ---- epilogue of the tile: the logit's partial sums over this lane's 16 channels ---------------------------------------
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 at4 = *reinterpret_cast<const float4 *>(&s_cw[cb + 8 * g]);
+      const float4 wi4 = *reinterpret_cast<const float4 *>(&s_cw[HC + cb + 8 * g]);
+      const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w};
+      const float lv[4] = {xl[g].x, xl[g].y, xl[g].z, xl[g].w};
+      const float rv[4] = {xr[g].x, xr[g].y, xr[g].z, xr[g].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = (acc[g * 4 + j] * sinv) * wiv[j];     // both scales are powers of two: exact
+        float z = (rv[j] + lv[j]) + e;
+        if (MASKED) z *= me;
+        z = leaky(z, slope);
+        if (MASKED) z *= me;
+        part[g] = fmaf(z, atv[j], part[g]);
+      }
+    }
+  }
+  if (cur_hd >= 0) flush(cur_hd);
+  __syncthreads();
+  for (int c = tid; c < EL_BM * a.H; c += EL_THREADS) {       // (slot, head): the tile-waves' partials in a fixed order
+    const float v = (s_part[c] + s_part[EL_BM * a.H + c]) + (s_part[2 * EL_BM * a.H + c] + s_part[3 * EL_BM * a.H + c]);
+    const int slot = m0 + c / a.H;
+    if (slot < a.E) a.logits[(int64_t)slot * a.H + (c % a.H)] = v;
+  }
+}
+
+}  // namespace isg
+
+using namespace isg;
+
+extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
+                                     const float *x_l, int32_t ldl, int64_t head_stride_l, const float *x_r, int32_t ldr,
+                                     int64_t head_stride_r, const float *att,
+                                     const int32_t *eid, const int32_t *src, const int32_t *dst, const float *edge_mask,
+                                     const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C, int32_t K,
+                                     float negative_slope, void *stream) {
+  if (head_stride_l == 0) head_stride_l = C;
+  if (head_stride_r == 0) head_stride_r = C;
+  if (E < 0 || H <= 0 || C <= 0 || K <= 0 || lda < K || ldl < C || ldr < C || head_stride_l < C || head_stride_r < C)
+    return ISG_EINVAL;
+  if ((head_stride_l == C && ldl < H * C) || (head_stride_r == C && ldr < H * C)) return ISG_EINVAL;
+  if (E == 0) return ISG_OK;
+  if (!edge_attr || !w_frag || !w_inv_scale || !x_l || !x_r || !att || !eid || !src || !dst || !logits) return ISG_EINVAL;
+  auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if ((C & 31) != 0 || H > 32 || K > EL_KC || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (head_stride_l & 3) != 0 || (head_stride_r & 3) != 0 || mis(edge_attr) ||
+      mis(x_l) || mis(x_r) || mis(att) || mis(w_inv_scale) || H * C > 2048 || E >= (1ll << 31) - EL_BM)
+    return ISG_EUNSUPPORTED;
+  ElArgs a;
+  a.edge_attr = edge_attr; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
+  a.x_l = x_l; a.x_r = x_r; a.att = att; a.eid = eid; a.src = src; a.dst = dst;
+  a.edge_mask = edge_mask; a.node_mask = node_mask; a.logits = logits;
+  a.E = (int)E; a.H = H; a.C = C; a.K = K; a.KS = (K + 15) / 16; a.NT = H * C / 32;
+  a.lda = lda; a.ldl = ldl; a.ldr = ldr; a.hsl = head_stride_l; a.hsr = head_stride_r; a.slope = negative_slope;
+  const unsigned grid = (unsigned)((E + EL_BM - 1) / EL_BM);
+  const size_t dyn = ((size_t)2 * H * C + (size_t)4 * EL_BM * H) * sizeof(float);
+  hipStream_t st = as_stream(stream);
+#ifdef ISG_EL_ABLATION
+  {
+    const char *e = getenv("ISG_EL_DBG");
+    const int dbg = e ? atoi(e) : 0;
+#define EL_ABL(D_) case D_: gatv2_edge_logits_kernel<false, D_><<<grid, EL_THREADS, dyn, st>>>(a); return check_launch();
+    switch (dbg) {
+      EL_ABL(1) EL_ABL(2) EL_ABL(3)
+      default: break;
+    }
+#undef EL_ABL
+  }
+#endif
+  if (edge_mask || node_mask) gatv2_edge_logits_kernel<true><<<grid, EL_THREADS, dyn, st>>>(a);
+  else gatv2_edge_logits_kernel<false><<<grid, EL_THREADS, dyn, st>>>(a);
+  return check_launch();
+}

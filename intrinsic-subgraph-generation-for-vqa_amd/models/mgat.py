@@ -77,8 +77,9 @@ class MGAT(torch.nn.Module):
         # every layer projects the SAME edge features (mgat.py:144-148): one launch splits each 64-row panel of
         # edge_attr into its bf16 planes once and writes one dense [E, H*C] tensor per layer (isg_linear_panel_multi)
         e_projs = None
-        fused = (edge_attr.dim() == 2 and self.convs[0].feature_dtype == torch.float32
-                 and ops.fused_edge_supported(plan, self.heads, self.convs[0].out_channels, edge_attr.size(1)))
+        fused = (edge_attr.dim() == 2 and self.convs[0].feature_dtype == torch.float32 and not torch.is_grad_enabled()
+                 and (ops.fused_edge_supported(plan, self.heads, self.convs[0].out_channels, edge_attr.size(1)) or
+                      ops.fused_logits_supported(plan, self.heads, self.convs[0].out_channels, edge_attr.size(1))))
         if (not fused and not torch.is_grad_enabled() and all(c.lin_edge is not None for c in self.convs)
                 and edge_attr.dim() == 2):
             e_projs = ops.linear_multi(edge_attr, [c.lin_edge.weight for c in self.convs],

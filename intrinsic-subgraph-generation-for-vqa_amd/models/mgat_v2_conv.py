@@ -113,6 +113,18 @@ class MaskingGATv2Conv(torch.nn.Module):
             if isinstance(return_attention_weights, bool):
                 return out, mask, (edge_index, alpha)
             return out, mask
+        if (e_proj is None and edge_attr is not None and self.lin_edge is not None and edge_attr.dim() == 2
+                and fdt == torch.float32 and not torch.is_grad_enabled()
+                and ops.fused_logits_supported(plan, H, C, edge_attr.size(1))):
+            # lin_edge folded into the logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is neither written nor read
+            res = ops.gatv2_mp_edge_logits(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att, plan, H,
+                                           bias=self.bias, node_mask=mask, negative_slope=self.negative_slope,
+                                           want_rowmax=True)                             # :215-232, :243-279
+            if res is not None:
+                out, alpha = res
+                if isinstance(return_attention_weights, bool):
+                    return out, mask, (edge_index, alpha)
+                return out, mask
         if e_proj is None:
             if edge_attr is None or self.lin_edge is None:
                 raise NotImplementedError("edge_attr=None: MGAT always passes edge features (mgat.py:147)")

@@ -34,6 +34,21 @@ class KernelTimer:
         self.meta.append(info)
         return start, end
 
+    def bracket3(self, info):
+        """A bracket around TWO consecutive launches with an event between them (info["mid"]): durations_ms() gives the
+        pair, split_ms() the two parts."""
+        start, end = self.bracket(info)
+        info["mid"] = torch.cuda.Event(enable_timing=True)
+        return start, info["mid"], end
+
+    def split_ms(self):
+        return [(s.elapsed_time(m["mid"]), m["mid"].elapsed_time(e)) for (s, e), m in zip(self.pairs, self.meta) if "mid" in m]
+
+    def drop_last(self):
+        """The bracketed launch did not happen (unsupported shape, the caller takes another path)."""
+        self.pairs.pop()
+        self.meta.pop()
+
     def durations_ms(self):
         return [s.elapsed_time(e) for s, e in self.pairs]
 
@@ -353,6 +368,103 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
     return out, alpha
 
 
+# lin_edge folded into the attention logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is never written or read
+FUSE_LOGITS = True
+
+
+def fused_logits_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
+    """Shape test of isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits (inference, fp32 rows, per-graph kernel)."""
+    return (FUSE_LOGITS and GEMM_BACKEND == "bf16x6" and GEMM_F16X3 and MP_KERNEL == "graph" and channels % 32 == 0 and
+            heads * channels <= 2048 and 0 < edge_dim <= 128 and edge_dim % 4 == 0 and plan.B > 0 and plan.nmax > 0 and
+            plan.rowptr is not None and plan.E > 0)
+
+
+def gatv2_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan", heads: int,
+                      node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
+                      negative_slope: float = 0.2) -> Optional[Tensor]:
+    """isg_gatv2_edge_logits alone: logits fp32 [E, H] in CSR SLOT order (slot t = edge plan.eid[t]); None if unsupported."""
+    lib = _lib.load()
+    plan.require_csr()
+    N, HC = x_l.shape
+    H = int(heads)
+    E, K = edge_attr.shape
+    planes, inv = _weight_planes(w_edge, True, "f16x3")
+    logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+    rc = lib.isg_gatv2_edge_logits(
+        _chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(),
+        _chk_rows(x_l, "x_l"), x_l.stride(0), 0, _chk_rows(x_r, "x_r"), x_r.stride(0), 0,
+        _chk(att.reshape(-1), "att", torch.float32, (HC,)), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(),
+        _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        logits.data_ptr(), E, H, HC // H, K, float(negative_slope), _stream())
+    if rc == ISG_EUNSUPPORTED:
+        return None
+    _lib.check(rc, "isg_gatv2_edge_logits")
+    return logits
+
+
+def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan",
+                         heads: int, bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None,
+                         edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_rowmax: bool = False):
+    """gatv2_mp(x_l, x_r, lin_edge(edge_attr), ...) as two launches that never materialise lin_edge's output
+    (mgat_v2_conv.py:243-279 with :259-261 inside): isg_gatv2_edge_logits forms the logits [E, H] in the epilogue of the
+    edge GEMM, isg_gatv2_mp_fwd_logits does softmax + aggregation.  Returns (out, alpha), or None when the per-graph kernel
+    has no instantiation for this batch / width (the caller then runs the un-fused pair)."""
+    lib = _lib.load()
+    plan.require_csr()
+    N, HC = x_l.shape
+    H = int(heads)
+    C = HC // H
+    E, K = edge_attr.shape
+    if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K) or tuple(x_r.shape) != (N, HC):
+        raise ValueError("gatv2_mp_edge_logits: operand shapes do not match the plan")
+    if x_l.dtype != torch.float32 or x_r.dtype != torch.float32 or edge_attr.dtype != torch.float32:
+        raise TypeError("gatv2_mp_edge_logits: fp32 rows")
+    planes, inv = _weight_planes(w_edge, True, "f16x3")
+    logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+    out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
+    alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+    rowmax = torch.empty(N, H, dtype=torch.float32, device=x_l.device) if want_rowmax else None
+    nm = _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True)
+    em = _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True)
+    attp = _chk(att.reshape(-1), "att", torch.float32, (HC,))
+    timer = MP_TIMER
+    if timer is not None:   # bench.py: ONE bracket around both launches -- together they are the reference's message +
+        # aggregate (plus lin_edge); the roofline keeps the un-fused algorithmic bytes of SURVEY 8(d)
+        ev0, evm, ev1 = timer.bracket3({"N": N, "E": E, "H": H, "C": C, "K": K,
+                                        "masked": node_mask is not None or edge_mask is not None, "feat_bytes": 4,
+                                        "fused_logits": True})
+        ev0.record()
+    rc = lib.isg_gatv2_edge_logits(
+        _chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(),
+        _chk_rows(x_l, "x_l"), x_l.stride(0), 0, _chk_rows(x_r, "x_r"), x_r.stride(0), 0, attp,
+        plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(), em, nm, logits.data_ptr(), E, H, C, K,
+        float(negative_slope), _stream())
+    if rc == ISG_EUNSUPPORTED:
+        if timer is not None:
+            timer.drop_last()
+        return None
+    _lib.check(rc, "isg_gatv2_edge_logits")
+    if timer is not None:
+        evm.record()
+    rc = lib.isg_gatv2_mp_fwd_logits(
+        _chk_rows(x_l, "x_l"), logits.data_ptr(), attp,
+        _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+        plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), nm, em, out.data_ptr(), alpha.data_ptr(),
+        0 if rowmax is None else rowmax.data_ptr(), N, E, H, C, float(negative_slope), plan.ptr.data_ptr(),
+        plan.eptr.data_ptr(), plan.dst.data_ptr(), plan.B, plan.nmax, plan.emax, x_l.stride(0), _stream())
+    if rc == ISG_EUNSUPPORTED:
+        if timer is not None:
+            timer.drop_last()
+        return None
+    _lib.check(rc, "isg_gatv2_mp_fwd_logits")
+    if timer is not None:
+        ev1.record()
+    if rowmax is not None:
+        attach_row_maxima(out, rowmax)
+    return out, alpha
+
+
 # lin_edge inside the message-passing kernel (csrc/isg_mp_fused.hip).  OFF by default: correct (tests) but slower than the
 # un-fused pair at configs[1] (632 us vs 377 us; profiles/r02_d_fused_edge.md says where the time goes) -- kept as the
 # starting point of that work, switchable for A/B runs
@@ -518,6 +630,18 @@ def mp_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool, feat_byte
     """bytes_mp = s*(3*N*HC + E*HC) + 4*E*H + 16*E (+4*E if edge-masked)."""
     HC = H * C
     return feat_bytes * (3 * N * HC + E * HC) + 4 * E * H + 16 * E + (4 * E if masked else 0)
+
+
+def edge_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, K: int, masked: bool) -> int:
+    """isg_gatv2_edge_logits' OWN minimum traffic: edge_attr rows (4*E*K), every x_l and x_r row once (2 * 4*N*HC), the
+    logits (4*E*H), eid / src / dst (12*E), the edge mask if any (4*E).  The W planes (4*HC*K) stay in L2."""
+    return 4 * E * K + 8 * N * H * C + 4 * E * H + 12 * E + (4 * E if masked else 0)
+
+
+def mp_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool) -> int:
+    """isg_gatv2_mp_fwd_logits' OWN minimum traffic: x_l in and out back (2 * 4*N*HC), logits in and alpha out (8*E*H),
+    the CSR (16*E as in bytes_mp), the edge mask if any (4*E)."""
+    return 8 * N * H * C + 8 * E * H + 16 * E + (4 * E if masked else 0)
 
 
 def scatter_mean(msg: Tensor, plan: GraphPlan) -> Tensor:

@@ -770,3 +770,83 @@ def test_long_reductions_take_slices_of_the_producers_partial_maxima(dev):
     err32 = (torch.nn.functional.linear(h, w2, b2).double() - ref).abs().max().item()
     print(f"K=2048 in chunks with sliced maxima: err {err:.3e}, fp32 GEMM {err32:.3e}")
     assert err <= 2.0 * err32
+
+
+@pytest.mark.parametrize("mask", [None, "node", "edge"])
+@pytest.mark.parametrize("H,C,K", [(4, 128, 128), (4, 128, 36), (4, 64, 20), (8, 32, 128), (2, 256, 64)])
+def test_edge_logits_pair_matches_the_unfused_kernels_and_the_oracle(dev, mask, H, C, K):
+    """isg_gatv2_edge_logits (lin_edge folded into the logits: transposed fp16 three-product tile, row gathers in the
+    epilogue) + isg_gatv2_mp_fwd_logits against the un-fused pair isg_linear_* + isg_gatv2_mp_fwd and against the oracle
+    (mgat_v2_conv.py:243-279): masks of both kinds, E not a multiple of the 64-slot panel, graphs with more than 64 edges,
+    an isolated target, a 1-node graph, x_l / x_r as column slices of one fused projection, odd k-step counts."""
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(70 + K + C)
+    sizes = [20, 1, 37, 5, 64, 23, 2, 30]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    src, dst, off = [], [], 0
+    for n in sizes:
+        for v in range(n):
+            if not (n == 5 and v == 4):                 # one isolated target
+                src.append(off + v); dst.append(off + v)
+        m = 0 if n == 1 else int(torch.randint(n, 4 * n, (1,), generator=gen))
+        m = min(m, 250 - n)
+        a_ = torch.randint(0, n, (m,), generator=gen); b_ = torch.randint(0, n, (m,), generator=gen)
+        if n == 5:
+            b_ = b_.clamp(max=3)
+        src += (off + a_).tolist(); dst += (off + b_).tolist()
+        off += n
+    ei = torch.tensor([src, dst])
+    ei = ei[:, torch.randperm(ei.size(1), generator=gen)]
+    N, E = batch.numel(), ei.size(1)
+    assert E % 64 != 0
+    HC = H * C
+    x_lr = torch.randn(N, 2 * HC, generator=gen)                     # the fused lin_l | lin_r output: strided halves
+    ea = torch.randn(E, K, generator=gen) * torch.logspace(-1, 1, E).unsqueeze(1)      # edge rows of different size
+    w = torch.randn(HC, K, generator=gen) / K ** 0.5
+    att, bias = torch.randn(1, H, C, generator=gen), torch.randn(HC, generator=gen)
+    nm = (torch.rand(N, generator=gen) < 0.6).float() if mask == "node" else None
+    em = (torch.rand(E, generator=gen) < 0.6).float() if mask == "edge" else None
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    assert plan.emax > 64 and ops.fused_logits_supported(plan, H, C, K)
+    t = lambda v: None if v is None else v.to(dev)
+    x_lr_d = x_lr.to(dev)
+    x_l, x_r = x_lr_d[:, :HC], x_lr_d[:, HC:]
+    wd = w.to(dev)
+    res = ops.gatv2_mp_edge_logits(x_l, x_r, t(ea), wd, t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em),
+                                   want_rowmax=True)
+    assert res is not None, "the per-graph kernel has no instantiation for this width"
+    out_f, alpha_f = res
+    e_proj = ops.linear(t(ea), wd)
+    out_u, alpha_u = ops.gatv2_mp(x_l, x_r, e_proj, t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em))
+    emask = em if em is not None else (None if nm is None else nm[ei[0]] * nm[ei[1]])
+    ref_out, ref_alpha = OM.gatv2_message_passing(x_lr[:, :HC].reshape(N, H, C), x_lr[:, HC:].reshape(N, H, C),
+                                                  (ea.double() @ w.double().t()).float().view(E, H, C), att, ei,
+                                                  None if emask is None else emask.view(E, 1), 0.2)
+    da_u, da_o = (alpha_f - alpha_u).abs().max().item(), (alpha_f.cpu() - ref_alpha).abs().max().item()
+    do_u = (out_f - out_u).abs().max().item()
+    do_o = (out_f.cpu() - (ref_out.reshape(N, HC) + bias)).abs().max().item()
+    du_o = (alpha_u.cpu() - ref_alpha).abs().max().item()
+    print(f"edge-logits pair H={H} C={C} K={K} mask={mask}: alpha vs un-fused {da_u:.2e}, vs oracle {da_o:.2e} "
+          f"(un-fused vs oracle {du_o:.2e}); out vs un-fused {do_u:.2e}, vs oracle {do_o:.2e}")
+    # the LOGITS against an fp64 evaluation of the same formula, bounded by what a plain fp32 evaluation of it loses
+    lg = ops.gatv2_edge_logits(x_l, x_r, t(ea), wd, t(att), plan, H, node_mask=t(nm), edge_mask=t(em))
+    eid, s_, d_ = plan.eid.cpu().long(), plan.src.cpu().long(), plan.dst.cpu().long()
+
+    def formula(dt):
+        ep = (ea.to(dt) @ w.to(dt).t())[eid]
+        z = (x_lr[:, HC:].to(dt)[d_] + x_lr[:, :HC].to(dt)[s_]) + ep
+        if emask is not None:
+            z = z * emask.to(dt)[eid].unsqueeze(1)
+        z = torch.nn.functional.leaky_relu(z, 0.2)
+        if emask is not None:
+            z = z * emask.to(dt)[eid].unsqueeze(1)
+        return (z.view(E, H, C) * att.to(dt).view(1, H, C)).sum(-1)
+    ref64, ref32 = formula(torch.float64), formula(torch.float32)
+    e_k, e_32 = (lg.cpu().double() - ref64).abs().max().item(), (ref32.double() - ref64).abs().max().item()
+    print(f"    logits: kernel vs fp64 {e_k:.2e}, torch fp32 vs fp64 {e_32:.2e}, max |logit| {ref64.abs().max().item():.1f}")
+    assert e_k <= 2.0 * e_32 + 1e-6
+    assert da_o <= 2.0 * du_o + 3e-6 and da_u <= 3.0 * du_o + 3e-6
+    scale = ref_out.abs().max().item()
+    assert do_u < 1e-5 * max(scale, 1.0) and do_o < 1e-5 * max(scale, 1.0)
+    assert torch.equal(ops.row_maxima(out_f), out_f.view(N, H, C).abs().amax(2))

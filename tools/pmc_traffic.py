@@ -5,7 +5,8 @@ of the message-passing kernel, corrected as MI355X_MICROARCH.md §HBM prescribes
   * FETCH_SIZE tallies the 128-B requests of wide (16 B/lane) streaming reads at 64 B -> multiply by 2; the factor is
     re-derived here from the known-size copy in the same run (1 GiB read, 1 GiB written);
   * WRITE_SIZE is exact for 16 B/lane stores (checked against the same copy).
-usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [kernel-substring]"""
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [kernel-substring[+kernel-substring]]
+A "+"-joined pair (gatv2_edge_logits+gatv2_mp_graph) sums the two kernels' per-launch averages: the edge-logits pair."""
 import collections
 import csv
 import glob
@@ -49,12 +50,23 @@ def main():
     if abs(f_scale - 2.0) > 0.1 or abs(w_scale - 1.0) > 0.05:
         raise SystemExit(f"calibration off the guide's corrections: fetch x{f_scale:.4f} (2.0), write x{w_scale:.4f} "
                          f"(1.0); copies used {copy_f} / {copy_w}")
-    kf = [v for k, vs in fetch.items() if kern in k for v in vs]
-    kw = [v for k, vs in write.items() if kern in k for v in vs]
-    name = [k for k in fetch if kern in k][0]
+    if "+" in kern:
+        parts = kern.split("+")
+        per = []
+        for tab in (fetch, write):
+            cols = [[v for k, vs in tab.items() if p_ in k for v in vs] for p_ in parts]
+            n = min(len(c) for c in cols)
+            per.append([sum(c[i] for c in cols) for i in range(n)])      # launch i of every part, in launch order
+        kf, kw = per
+        name = " + ".join(next(k.split("(")[0] for k in fetch if p_ in k) for p_ in parts) + "("
+    else:
+        kf = [v for k, vs in fetch.items() if kern in k for v in vs]
+        kw = [v for k, vs in write.items() if kern in k for v in vs]
+        name = [k for k in fetch if kern in k][0]
     half = len(kf) // 2                                      # profile_mp.py: first half unmasked, second half masked
     log = open(glob.glob(f"{fetch_dir}/../*fetch*.log")[0]).read() if glob.glob(f"{fetch_dir}/../*fetch*.log") else ""
     m = re.search(r"N=(\d+) E=(\d+) H=(\d+) C=(\d+) bytes_unmasked=(\d+) bytes_masked=(\d+)", log)
+    own = re.search(r"pair_own_bytes_unmasked=(\d+)", log)
     res = {
         "kernel": name.split("(")[0],
         "fetch_kib_raw": sum(kf[:half]) / half, "write_kib_raw": sum(kw[:half]) / half,
@@ -68,6 +80,10 @@ def main():
         res.update(N=int(m.group(1)), E=int(m.group(2)), H=int(m.group(3)), C=int(m.group(4)),
                    algorithmic_bytes=int(m.group(5)), algorithmic_bytes_masked=int(m.group(6)))
         res["traffic_over_algorithmic"] = round(res["hbm_bytes_per_launch"] / res["algorithmic_bytes"], 3)
+    if own:      # the pair never touches e_proj: its own minimum is far below the un-fused bytes_mp
+        res["pair_own_algorithmic_bytes"] = int(own.group(1))
+        res["traffic_over_own_algorithmic"] = round(res["hbm_bytes_per_launch"] / int(own.group(1)), 3)
+        res["kind"] = "logits_pair"
     json.dump(res, open(out_path, "w"), indent=1)
     print(json.dumps(res))
 

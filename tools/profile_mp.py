@@ -16,7 +16,8 @@ from isubgvqa_amd import ops, synthetic
 
 graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-ops.MP_KERNEL = sys.argv[3] if len(sys.argv) > 3 else "graph"
+mode = sys.argv[3] if len(sys.argv) > 3 else "graph"      # graph | chunk | logits (the edge-logits pair, lin_edge inside)
+ops.MP_KERNEL = "graph" if mode == "logits" else mode
 dev = torch.device("cuda:0")
 cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs})
 wl = synthetic.make_workload(cfg).to(dev)
@@ -32,10 +33,24 @@ mask = (torch.rand(N, 1, device=dev, generator=g) > 0.7).float()
 big = torch.randn(1 << 28, device=dev, generator=g)            # 1 GiB: larger than the 256 MiB Infinity Cache
 dst = torch.empty_like(big)
 torch.cuda.synchronize()
-for _ in range(reps):
-    ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias)
-for _ in range(reps):
-    ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias, node_mask=mask)
+if mode == "logits":
+    K = wl.edge_attr.size(1)
+    ea = wl.edge_attr.float().contiguous()
+    w = torch.randn(H * C, K, device=dev, generator=g) / K ** 0.5
+    x_lr = torch.cat([x_l, x_r], 1).contiguous()                 # as the model has them: halves of one projection
+    x_l, x_r = x_lr[:, :H * C], x_lr[:, H * C:]
+    ops._weight_planes(w, True, "f16x3")                         # the split of W is not part of the pair
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        ops.gatv2_mp_edge_logits(x_l, x_r, ea, w, att, plan, H, bias=bias, want_rowmax=True)
+    for _ in range(reps):
+        ops.gatv2_mp_edge_logits(x_l, x_r, ea, w, att, plan, H, bias=bias, node_mask=mask, want_rowmax=True)
+    print(f"pair_own_bytes_unmasked={ops.edge_logits_algorithmic_bytes(N, E, H, C, K, False) + ops.mp_logits_algorithmic_bytes(N, E, H, C, False)}")
+else:
+    for _ in range(reps):
+        ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias)
+    for _ in range(reps):
+        ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias, node_mask=mask)
 for _ in range(3):
     dst.copy_(big)                                              # calibration: reads 1 GiB, writes 1 GiB
 torch.cuda.synchronize()
