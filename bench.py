@@ -251,7 +251,11 @@ def load_traffic(N: int, E: int, kernel: str):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*mp_traffic.json")), reverse=True):
         try:
             t = json.load(open(path))
-            kind = t.get("kind") or ("graph" if "graph" in t.get("kernel", "") else "chunk")
+            name = t.get("kernel", "")
+            if "edge_logits" in name or "+" in name:
+                kind = "logits_pair"          # whatever else the file says: two kernels were summed
+            else:
+                kind = t.get("kind") or ("graph" if "graph" in name else "chunk")
             if t.get("N") == N and t.get("E") == E and kind == kernel:
                 return t.get("hbm_bytes_per_launch")
         except Exception:

@@ -100,3 +100,15 @@ def test_cpu_legs_use_the_cpus_the_process_may_run_on_and_are_time_bounded():
     took = time.perf_counter() - t0
     assert r["cores"] == min(n, 32) and r["value"] > 0 and r["kind"] == "port"
     assert took < 60, f"configs[0] leg took {took:.1f} s for a 0.5 s budget"
+
+
+def test_traffic_summaries_are_replayed_only_for_the_kernels_they_describe():
+    """bench.py replays committed PMC summaries into roofline.traffic.  The edge-logits pair's summary (two kernels summed,
+    874 MB) was once written without its kind and came back as the un-fused per-graph kernel's traffic (943 MB): every
+    summary is matched by what was summed, and the three committed kinds stay apart."""
+    import bench
+    N, E = 82286, 205024
+    pair, graph, chunk = (bench.load_traffic(N, E, k) for k in ("logits_pair", "graph", "chunk"))
+    assert pair is not None and graph is not None and chunk is not None and len({pair, graph, chunk}) == 3
+    assert 0.9e9 < graph < 1.0e9 and pair < graph < chunk
+    assert bench.load_traffic(N + 1, E, "graph") is None

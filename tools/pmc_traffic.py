@@ -64,7 +64,11 @@ def main():
         kw = [v for k, vs in write.items() if kern in k for v in vs]
         name = [k for k in fetch if kern in k][0]
     half = len(kf) // 2                                      # profile_mp.py: first half unmasked, second half masked
-    log = open(glob.glob(f"{fetch_dir}/../*fetch*.log")[0]).read() if glob.glob(f"{fetch_dir}/../*fetch*.log") else ""
+    # the log of THIS fetch pass (rocprofv3 ... -d <dir> ... > <dir>.log); never a sibling's: a neighbour's log once labelled
+    # the edge-logits pair's traffic as the un-fused kernel's
+    import os
+    log_path = fetch_dir.rstrip("/") + ".log"
+    log = open(log_path).read() if os.path.exists(log_path) else ""
     m = re.search(r"N=(\d+) E=(\d+) H=(\d+) C=(\d+) bytes_unmasked=(\d+) bytes_masked=(\d+)", log)
     own = re.search(r"pair_own_bytes_unmasked=(\d+)", log)
     res = {
@@ -80,10 +84,13 @@ def main():
         res.update(N=int(m.group(1)), E=int(m.group(2)), H=int(m.group(3)), C=int(m.group(4)),
                    algorithmic_bytes=int(m.group(5)), algorithmic_bytes_masked=int(m.group(6)))
         res["traffic_over_algorithmic"] = round(res["hbm_bytes_per_launch"] / res["algorithmic_bytes"], 3)
+    # what the summary describes is decided by the kernels that were summed, not by what a log happens to say
+    res["kind"] = "logits_pair" if "+" in kern else ("graph" if "graph" in name else "chunk")
+    if "+" in kern and not own:
+        raise SystemExit(f"{log_path}: no pair_own_bytes_unmasked line -- not a `profile_mp.py ... logits` run")
     if own:      # the pair never touches e_proj: its own minimum is far below the un-fused bytes_mp
         res["pair_own_algorithmic_bytes"] = int(own.group(1))
         res["traffic_over_own_algorithmic"] = round(res["hbm_bytes_per_launch"] / int(own.group(1)), 3)
-        res["kind"] = "logits_pair"
     json.dump(res, open(out_path, "w"), indent=1)
     print(json.dumps(res))
 
