@@ -160,10 +160,12 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
 
   const int nk = Kp / GM_BK;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
-  // Row-blocks walk K from different starting tiles (wrapping): with a power-of-two row stride every workgroup would
-  // otherwise touch the same 128-byte column of its rows at the same moment, i.e. the same few HBM channels
-  // ("partition camping").  Only the order of the fp32 accumulation changes, deterministically per row-block.
-  const int kshift = (int)((unsigned)(m0 / GM_BM) % (unsigned)nk);
+  // Optional (ISG_GEMM_KROT=1, flags bit 1; OFF by default): row-blocks walk K from different starting tiles (wrapping), so
+  // that workgroups do not touch the same 128-byte column of their rows at the same moment ("partition camping").  It makes
+  // the ORDER of a row's fp32 accumulation depend on where the row sits in the batch: the same graph then gives
+  // bit-different projections once it is re-batched or sharded, which breaks "a shard's result is the path run on that
+  // shard alone" (distributed.py) and can flip a near-tie in the top-k mask.  Default: every row-block starts at tile 0.
+  const int kshift = (nt_store & 2) ? (int)((unsigned)(m0 / GM_BM) % (unsigned)nk) : 0;
 #define GM_KT(t) ((((t) + kshift) >= nk ? (t) + kshift - nk : (t) + kshift))
 #define GM_STEP(RA, RB, kt)                                                                                    \
   {                                                                                                            \
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(512, 4) void linear_bf16x6_kernel(const float *__re
       } else if ((DBG & 16) ? (row < 0) : (row < M)) {
         float *dst = D + (int64_t)row * ldd + colb + c4 * 4;
         if (vec_ok) {
-          if (nt_store) {   // streaming result (see isg_linear launch): do not displace the operands in L2 / Infinity Cache
+          if (nt_store & 1) {   // streaming result (see isg_linear launch): do not displace the operands in L2 / Infinity Cache
             typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
             nt_f32x4 w4 = {v.x, v.y, v.z, v.w};
             __builtin_nontemporal_store(w4, reinterpret_cast<nt_f32x4 *>(dst));
@@ -346,7 +348,8 @@ static int linear_launch(const void *a, int a16, const uint16_t *w_planes, const
   // when they were streamed -- while the operands (A re-read per n-tile, W planes) and the small results that the very
   // next kernel reads (x_proj, MLPs: <= 84 MB) should stay resident (profiles/r01_e, r01_q / r01_x)
   static const long long nt_mb = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return e ? atoll(e) : 128ll; }();   // read once
-  const int nt = nt_mb >= 0 && (long long)M * N * (d16 ? 2 : 4) >= nt_mb * 1000000ll;
+  static const int krot = [] { const char *e = getenv("ISG_GEMM_KROT"); return e && atoi(e) != 0 ? 2 : 0; }();
+  const int nt = (nt_mb >= 0 && (long long)M * N * (d16 ? 2 : 4) >= nt_mb * 1000000ll ? 1 : 0) | krot;   // flags: bit 0 streaming stores, bit 1 K rotation
   dim3 gridx(grid.x, (grid.y + 7) / 8 * 8);
 #ifdef ISG_GEMM_ABLATION   // profiling build only (tools/build_ablation.sh): select a compile-time ablated variant by env
   const char *dv = getenv("ISG_GEMM_DBG");

@@ -1025,6 +1025,11 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], norm: torch.nn.LayerNor
     return out
 
 
+def _linear_torch(x: Tensor, weight: Tensor, bias: Optional[Tensor], gelu: bool, relu: bool) -> Tensor:
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.relu(y) if relu else (torch.nn.functional.gelu(y) if gelu else y)
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False,
            cache_planes: bool = True, out_dtype=torch.float32, relu: bool = False, want_rowmax: bool = False) -> Tensor:
     """act(x @ weight^T + bias), x [M,K] fp32, weight [N,K] (torch Linear layout).  Uses the bf16x6 matrix-core kernel
@@ -1084,10 +1089,13 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
                 if nchunk == 1:
                     attach_row_maxima(x, rm)          # the next Linear over the same rows does not repeat the pass
                 rm_ptr, rm_p, rm_ld = rm.data_ptr(), 1, 1
-            _lib.check(lib.isg_linear_f16x3_tile(
+            rc = lib.isg_linear_f16x3_tile(
                 xp + 4 * k0, rm_ptr, rm_p, rm_ld, planes.data_ptr(), inv.data_ptr(), bptr if last else 0,
                 out.data_ptr(), d_rowmax.data_ptr() if (last and d_rowmax is not None) else 0, M, N, kc, K, N,
-                act if last else 0, K, k0, 1 if c > 0 else 0, _stream()), "isg_linear_f16x3_tile")
+                act if last else 0, K, k0, 1 if c > 0 else 0, _stream())
+            if rc == ISG_EUNSUPPORTED and c == 0:       # a shape the kernel has no launch for (> 65535 row tiles): hipBLASLt
+                return _linear_torch(x, weight, bias, gelu, relu)
+            _lib.check(rc, "isg_linear_f16x3_tile")
             k0 += kc
             c += 1
         if d_rowmax is not None:
@@ -1117,10 +1125,12 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
                 out.data_ptr(), 1 if out_dtype == torch.float16 else 0, M, N, K, K, N, 1 if gelu else 0, _stream()),
                 "isg_linear_bf16x6_f16")
         return out
-    _lib.check(lib.isg_linear_bf16x6(_chk(x, "x", torch.float32), planes.data_ptr(),
-                                     _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
-                                     out.data_ptr(), M, N, K, K, N, 2 if relu else (1 if gelu else 0), _stream()),
-               "isg_linear_bf16x6")
+    rc = lib.isg_linear_bf16x6(_chk(x, "x", torch.float32), planes.data_ptr(),
+                               _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
+                               out.data_ptr(), M, N, K, K, N, 2 if relu else (1 if gelu else 0), _stream())
+    if rc == ISG_EUNSUPPORTED:                          # e.g. more than 65535 row tiles: fp32 through hipBLASLt
+        return _linear_torch(x, weight, bias, gelu, relu)
+    _lib.check(rc, "isg_linear_bf16x6")
     return out
 
 

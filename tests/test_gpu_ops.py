@@ -850,3 +850,21 @@ def test_edge_logits_pair_matches_the_unfused_kernels_and_the_oracle(dev, mask, 
     scale = ref_out.abs().max().item()
     assert do_u < 1e-5 * max(scale, 1.0) and do_o < 1e-5 * max(scale, 1.0)
     assert torch.equal(ops.row_maxima(out_f), out_f.view(N, H, C).abs().amax(2))
+
+
+@pytest.mark.parametrize("M,K,N,which", [(5000, 128, 64, "bf16x6 tile"), (40000, 128, 512, "f16x3 panel"), (5000, 512, 256, "f16x3 tile")])
+def test_a_rows_projection_does_not_depend_on_its_position_in_the_batch(dev, M, K, N, which):
+    """A shard's result is defined as the path run on that shard alone (distributed.py), and the top-k masks are asserted
+    bit-exact: the SAME row must project to the SAME bits wherever it sits in the batch.  The bf16x6 tile kernel used to
+    rotate the K-tile order with the row-block index (ISG_GEMM_KROT, now off by default): rows moved by a non-multiple of
+    the tile height then accumulated in another order."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=gen).to(dev)
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=gen).to(dev)
+    y = ops.linear(x, w, b, gelu=True)
+    for shift in (300, 128 * 7 + 1):
+        x2 = torch.cat([torch.randn(shift, K, generator=gen).to(dev) * 50.0, x], 0).contiguous()
+        y2 = ops.linear(x2, w, b, gelu=True)
+        assert torch.equal(y2[shift:], y), f"{which}: rows moved by {shift} changed by {(y2[shift:] - y).abs().max().item():.3e}"
