@@ -56,6 +56,9 @@ def parse(argv=None):
     ap.add_argument("--no-hints", action="store_true", help="let the plan read Nmax back from the device (one sync)")
     ap.add_argument("--mp-kernel", choices=["graph", "chunk"], default="graph")
     ap.add_argument("--gemm", choices=["bf16x6", "torch"], default="bf16x6")
+    ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
+                    help="graph: the step (plan build included) captured once as a hipGraph and replayed; Gumbel noise from "
+                         "torch's generator inside the graph (fresh on every replay); single GPU")
     ap.add_argument("--no-fuse-logits", action="store_true",
                     help="A/B: lin_edge as its own GEMM + the message-passing kernel streaming e_proj (the round-1 boundary)")
     ap.add_argument("--features", choices=["fp32", "fp16"], default="fp32",
@@ -361,17 +364,55 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    graph = None
+    if args.launch == "graph":
+        if world > 1:
+            raise SystemExit("--launch graph: single GPU (the all-gather stays outside a captured step)")
+        from isubgvqa_amd import synthetic as _syn
+        noise_layers = [i for i, t in enumerate(cfg.masks) if t != 1.0]
+        cap = {}
+
+        def body():
+            cap["plan"] = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=cfg.num_graphs,
+                                              max_nodes=wl.max_nodes, max_edges=wl.max_edges)
+            noises = {i: _syn.gumbel_noise((cfg.num_graphs, wl.max_nodes), dev) for i in noise_layers}
+            return model(wl, noises=noises, plan=cap["plan"])[0]
+
     with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
-        fence()
-        ops.MP_TIMER = ops.KernelTimer()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = step(args.warmup + i)
-        fence()
-        dt = time.perf_counter() - t0
-        timer, ops.MP_TIMER = ops.MP_TIMER, None
+        if args.launch == "graph":
+            for i in range(max(args.warmup, 2)):      # eager: kernel attributes, weight planes, allocator pools, hint check
+                out = body()
+            ops.check_plans()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = body()
+            graph.replay()
+            fence()
+            progress("step captured as a hipGraph")
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                graph.replay()
+            fence()
+            dt = time.perf_counter() - t0
+            cap["plan"].verify_hints()
+            # kernel durations for the roofline: EAGER steps after the timed region (events cannot sit inside a graph)
+            ops.MP_TIMER = ops.KernelTimer()
+            for i in range(10):
+                step(i)
+            fence()
+            timer, ops.MP_TIMER = ops.MP_TIMER, None
+        else:
+            for i in range(args.warmup):
+                step(i)
+            fence()
+            ops.MP_TIMER = ops.KernelTimer()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                out = step(args.warmup + i)
+            fence()
+            dt = time.perf_counter() - t0
+            timer, ops.MP_TIMER = ops.MP_TIMER, None
     assert torch.isfinite(out).all()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -432,7 +473,8 @@ def main(argv=None):
                        "nodes_per_gpu": N, "edges_per_gpu": E, "channels": cfg.channels, "heads": cfg.heads,
                        "layers": cfg.layers, "sampler": "gumbel(in-kernel Philox noise)", "k": cfg.sample_k,
                        "parallelism": f"dp{world} (graphs sharded, RCCL all-gather of logits)" if world > 1 else "dp1",
-                       "feature_rows": args.features, "launch": "eager", "edge_projection": "unfused" if args.no_fuse_logits else "folded into the logits", "dense": ("exact-split fp32 Linears on MFMA: isg_linear_f16x3 / _f16x3_tile (2 fp16 planes, 3 products, per-row scales), isg_linear_bf16x6 for the small ones" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
+                       "feature_rows": args.features,
+                       "launch": "eager" if graph is None else "hipgraph: one captured step (plan build + model) replayed; Gumbel noise from torch's generator inside the graph; the roofline's kernel durations from eager steps after the timed region", "edge_projection": "unfused" if args.no_fuse_logits else "folded into the logits", "dense": ("exact-split fp32 Linears on MFMA: isg_linear_f16x3 / _f16x3_tile (2 fp16 planes, 3 products, per-row scales), isg_linear_bf16x6 for the small ones" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
             "roofline": {"bound": "hbm",
                          "kernel": ("isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits (the reference's message + aggregate WITH "
                                     "lin_edge inside: two launches, one bracket)") if fused else

@@ -215,6 +215,12 @@ class GraphPlan:
             got = bounds.tolist()                   # one D2H sync per batch (to_dense_batch syncs per layer)
             max_nodes = got[0] if max_nodes is None else max(int(max_nodes), got[0])
             max_edges = got[1] if max_edges is None else max(int(max_edges), got[1])
+        elif torch.cuda.is_current_stream_capturing():
+            # Built inside a hipGraph capture: no pinned allocation, no event to query.  The true bounds stay on the device
+            # (every replay rewrites them); the owner of the graph calls plan.verify_hints() after replays -- one sync, outside
+            # the captured work -- and gets the same error an eager build would raise one step late.
+            plan._bounds_dev = bounds
+            plan._hints = (int(max_nodes), None if edge_index is None else int(max_edges))
         else:                                       # hinted: verify later, without a sync (see check_plans)
             if _PENDING_HINTS:
                 check_plans(block=False)
@@ -230,6 +236,18 @@ class GraphPlan:
         if plan.nmax > MAX_NODES_PER_GRAPH:
             raise _lib.IsgError(f"graphs with more than {MAX_NODES_PER_GRAPH} nodes are unsupported (got {plan.nmax})")
         return plan
+
+    def verify_hints(self) -> None:
+        """For a plan built inside a hipGraph capture: compare the hints with the bounds the LAST replay computed (one
+        device->host sync).  Raises IsgError like check_plans(); a no-op for plans built eagerly (those are verified there)."""
+        b = getattr(self, "_bounds_dev", None)
+        if b is None:
+            return
+        n_true, e_true = (int(v) for v in b.tolist())
+        hn, he = self._hints
+        if n_true > hn or (he is not None and e_true > he):
+            raise _lib.IsgError(f"GraphPlan hints understate the batch: max_nodes={hn} / max_edges={he} given, but a graph "
+                                f"has {n_true} nodes / {e_true} edges; results of that replay are invalid")
 
     @staticmethod
     def edges_only(edge_index: Tensor, num_nodes: int) -> "GraphPlan":

@@ -125,6 +125,15 @@ def make_workload(cfg: WorkloadConfig) -> Workload:
     return Workload(x, edge_index, edge_attr, batch, instr, glf, B, nmax, emax)
 
 
+def gumbel_noise(shape, device) -> Tensor:
+    """Standard Gumbel noise as the reference's sampler draws it (gumbel_scheme.py:65-69: torch.distributions.Gumbel(0, 1)
+    = TransformedDistribution(Uniform(tiny, 1 - eps), ...)): -log(-log(u)), u = tiny + rand * (1 - eps - tiny), from torch's
+    generator -- which, unlike a kernel-argument seed, advances on every replay of a captured hipGraph."""
+    tiny, eps = torch.finfo(torch.float32).tiny, torch.finfo(torch.float32).eps
+    u = tiny + torch.rand(shape, device=device) * ((1.0 - eps) - tiny)
+    return -torch.log(-torch.log(u))
+
+
 class AnswerModel(torch.nn.Module):
     """gat_seq + graph_global_attention_pooling + embedding + logit_fc, keyed like ISubGVQA."""
 

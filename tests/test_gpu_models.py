@@ -516,3 +516,51 @@ def test_text_encoder_on_own_kernels_matches_the_torch_modules(dev):
     for a, b in zip(outs[True], outs[False]):
         assert a.shape == b.shape
         assert (a - b).abs().max().item() < 2e-5, (a - b).abs().max().item()
+
+
+def test_a_step_captured_as_a_hipgraph_replays_to_the_eager_result(dev):
+    """bench.py --launch graph: the whole step (plan build, every kernel, Gumbel noise from torch's generator) captured once and
+    replayed.  With the SAME noise tensor the replay must equal the eager step bit for bit (logits and mask); a plan built
+    inside a capture keeps its true bounds on the device, and verify_hints() still catches an understated hint."""
+    from isubgvqa_amd import _lib, ops, synthetic
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": 300})
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).to(dev).eval()
+    layers = [i for i, t in enumerate(cfg.masks) if t != 1.0]
+    noise = {i: synthetic.gumbel_noise((cfg.num_graphs, wl.max_nodes), dev) for i in layers}
+    cap = {}
+
+    def body(max_nodes):
+        cap["plan"] = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=cfg.num_graphs, max_nodes=max_nodes,
+                                          max_edges=wl.max_edges)
+        return model(wl, noises=noise, plan=cap["plan"])
+
+    with torch.no_grad():
+        for _ in range(2):
+            ref = body(wl.max_nodes)
+        ops.check_plans()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = body(wl.max_nodes)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        cap["plan"].verify_hints()
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+        # fresh noise per replay when it is drawn inside the graph
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            n_in = synthetic.gumbel_noise((cfg.num_graphs, wl.max_nodes), dev)
+        g2.replay(); a = n_in.clone(); g2.replay(); torch.cuda.synchronize()
+        assert not torch.equal(a, n_in) and torch.isfinite(n_in).all()
+        # an understated hint under capture: caught by verify_hints() after the replay
+        small = max(2, wl.max_nodes // 2)
+        g3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g3):
+            plan3 = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=cfg.num_graphs, max_nodes=small,
+                                        max_edges=wl.max_edges)
+        g3.replay()
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.IsgError, match="understate"):
+            plan3.verify_hints()
