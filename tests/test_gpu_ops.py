@@ -868,3 +868,58 @@ def test_a_rows_projection_does_not_depend_on_its_position_in_the_batch(dev, M, 
         x2 = torch.cat([torch.randn(shift, K, generator=gen).to(dev) * 50.0, x], 0).contiguous()
         y2 = ops.linear(x2, w, b, gelu=True)
         assert torch.equal(y2[shift:], y), f"{which}: rows moved by {shift} changed by {(y2[shift:] - y).abs().max().item():.3e}"
+
+
+def test_edge_logits_pair_random_shapes_sweep(dev):
+    """Seeded sweep of the edge-logits pair against the un-fused kernels over the shapes the hand-picked cases do not reach:
+    E below one 64-slot panel, one-node and edge-free graphs, a single 32-channel tile per head, K = 4 (one k-step), H from 1
+    to 8, ragged last panels, both mask kinds -- 40 batches.  alpha and out must agree to fp32 rounding of the logits."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    worst = 0.0
+    for case in range(40):
+        H = [1, 2, 4, 8][ri(0, 3)]
+        C = [32, 64, 96, 128][ri(0, 3)]
+        if H * C > 1024:
+            C = 1024 // H
+        K = [4, 8, 20, 36, 64, 100, 128][ri(0, 6)]
+        B = ri(1, 6) if case % 4 else 1
+        sizes = [ri(1, 40) for _ in range(B)]
+        batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+        src, dst, off = [], [], 0
+        for n in sizes:
+            loops = [v for v in range(n) if torch.rand(1, generator=gen).item() < 0.8]      # some nodes without a self-loop
+            m = 0 if n == 1 else ri(0, min(3 * n, 200))
+            a_ = torch.randint(0, n, (m,), generator=gen)
+            b_ = torch.randint(0, n, (m,), generator=gen)
+            src += [off + v for v in loops] + (off + a_).tolist()
+            dst += [off + v for v in loops] + (off + b_).tolist()
+            off += n
+        if not src:                                    # the pair needs at least one edge (E = 0 takes the un-fused path)
+            src, dst = [0], [0]
+        ei = torch.tensor([src, dst])
+        ei = ei[:, torch.randperm(ei.size(1), generator=gen)]
+        N, E, HC = batch.numel(), ei.size(1), H * C
+        x_lr = torch.randn(N, 2 * HC, generator=gen).to(dev)
+        ea = torch.randn(E, K, generator=gen).to(dev)
+        w = (torch.randn(HC, K, generator=gen) / K ** 0.5).to(dev)
+        att, bias = torch.randn(1, H, C, generator=gen).to(dev), torch.randn(HC, generator=gen).to(dev)
+        kind = case % 3
+        nm = (torch.rand(N, generator=gen) < 0.6).float().to(dev) if kind == 1 else None
+        em = (torch.rand(E, generator=gen) < 0.6).float().to(dev) if kind == 2 else None
+        plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+        if not ops.fused_logits_supported(plan, H, C, K):
+            continue
+        x_l, x_r = x_lr[:, :HC], x_lr[:, HC:]
+        res = ops.gatv2_mp_edge_logits(x_l, x_r, ea, w, att, plan, H, bias=bias, node_mask=nm, edge_mask=em, want_rowmax=True)
+        assert res is not None, f"case {case}: H={H} C={C} K={K} unsupported by the per-graph kernel"
+        out_f, alpha_f = res
+        out_u, alpha_u = ops.gatv2_mp(x_l, x_r, ops.linear(ea, w), att, plan, H, bias=bias, node_mask=nm, edge_mask=em)
+        assert torch.isfinite(out_f).all() and torch.isfinite(alpha_f).all(), f"case {case}"
+        da, do = (alpha_f - alpha_u).abs().max().item(), (out_f - out_u).abs().max().item()
+        worst = max(worst, da)
+        scale = max(1.0, out_u.abs().max().item())
+        assert da < 2e-5 and do < 2e-5 * scale, f"case {case}: H={H} C={C} K={K} B={B} N={N} E={E} mask={kind}: alpha {da:.2e} out {do:.2e}"
+        assert torch.equal(ops.row_maxima(out_f), out_f.view(N, H, C).abs().amax(2))
+    print(f"edge-logits pair sweep: worst |alpha - alpha_unfused| = {worst:.2e}")
