@@ -99,13 +99,19 @@ class MaskingGATv2Conv(torch.nn.Module):
                              seed=seed, u_is_per_graph=True)                              # :166-168
 
         fdt = self.feature_dtype
-        if self.share_weights:
+        inference32 = (e_proj is None and edge_attr is not None and self.lin_edge is not None and edge_attr.dim() == 2
+                       and fdt == torch.float32 and not torch.is_grad_enabled())
+        fuse = inference32 and ops.fused_edge_supported(plan, H, C, edge_attr.size(1))        # opt-in experiment (off)
+        pair = inference32 and not fuse and ops.fused_logits_supported(plan, H, C, edge_attr.size(1))
+        # with the edge-logits pair, x_r = lin_r(x) can be formed inside the logit kernel too (it is used nowhere else):
+        # then only lin_l is projected here
+        xr_inside = pair and ops.FUSE_XR and not self.share_weights and x.size(1) <= 128 and x.size(1) % 4 == 0
+        if xr_inside:
+            x_l, x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt), None          # :177
+        elif self.share_weights:
             x_l = x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt)  # :177-179
         else:   # lin_l and lin_r share their input: one [N, 2*H*C] projection, x_l / x_r are its column halves
             x_l, x_r = ops.linear_fused(x, (self.lin_l, self.lin_r), out_dtype=fdt)      # :177,181
-        fuse = (e_proj is None and edge_attr is not None and self.lin_edge is not None and edge_attr.dim() == 2
-                and fdt == torch.float32 and not torch.is_grad_enabled()
-                and ops.fused_edge_supported(plan, H, C, edge_attr.size(1)))
         if fuse:      # lin_edge inside the message-passing kernel: its [E, H*C] output never exists (csrc/isg_mp_fused.hip)
             out, alpha = ops.gatv2_mp_fused_edge(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att,
                                                  plan, H, bias=self.bias, node_mask=mask,
@@ -113,18 +119,20 @@ class MaskingGATv2Conv(torch.nn.Module):
             if isinstance(return_attention_weights, bool):
                 return out, mask, (edge_index, alpha)
             return out, mask
-        if (e_proj is None and edge_attr is not None and self.lin_edge is not None and edge_attr.dim() == 2
-                and fdt == torch.float32 and not torch.is_grad_enabled()
-                and ops.fused_logits_supported(plan, H, C, edge_attr.size(1))):
-            # lin_edge folded into the logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is neither written nor read
+        if pair:
+            # lin_edge (and lin_r) folded into the logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is neither written nor read
             res = ops.gatv2_mp_edge_logits(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att, plan, H,
                                            bias=self.bias, node_mask=mask, negative_slope=self.negative_slope,
-                                           want_rowmax=True)                             # :215-232, :243-279
+                                           want_rowmax=True, x=x if xr_inside else None,
+                                           w_r=self.lin_r.weight if xr_inside else None,
+                                           b_r=self.lin_r.bias if xr_inside else None)   # :215-232, :243-279, :181
             if res is not None:
                 out, alpha = res
                 if isinstance(return_attention_weights, bool):
                     return out, mask, (edge_index, alpha)
                 return out, mask
+            if x_r is None:     # no instantiation of the pair for this batch: the un-fused kernels need x_r after all
+                x_r = ops.linear(x, self.lin_r.weight, self.lin_r.bias, out_dtype=fdt)
         if e_proj is None:
             if edge_attr is None or self.lin_edge is None:
                 raise NotImplementedError("edge_attr=None: MGAT always passes edge features (mgat.py:147)")

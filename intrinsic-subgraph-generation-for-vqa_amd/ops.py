@@ -388,6 +388,10 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
 
 # lin_edge folded into the attention logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is never written or read
 FUSE_LOGITS = True
+# ... and lin_r as well (x_r formed inside that kernel from the layer input; lin_l | lin_r shrinks to lin_l).  OFF: correct
+# (tests) but the step measured 2.255 ms with it against 2.235 ms without on the same box (profiles/r02_w_edge_logits.md):
+# the logit kernel's second W stream and product cost more than the lin_r half of the projection saves
+FUSE_XR = False
 
 
 def fused_logits_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
@@ -414,30 +418,45 @@ def gatv2_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tenso
         _chk(att.reshape(-1), "att", torch.float32, (HC,)), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(),
         _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
-        logits.data_ptr(), E, H, HC // H, K, float(negative_slope), _stream())
+        logits.data_ptr(), E, H, HC // H, K, float(negative_slope), 0, 0, 0, 0, 0, 0, _stream())
     if rc == ISG_EUNSUPPORTED:
         return None
     _lib.check(rc, "isg_gatv2_edge_logits")
     return logits
 
 
-def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan",
+def gatv2_mp_edge_logits(x_l: Tensor, x_r: Optional[Tensor], edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan",
                          heads: int, bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None,
-                         edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_rowmax: bool = False):
+                         edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_rowmax: bool = False,
+                         x: Optional[Tensor] = None, w_r: Optional[Tensor] = None, b_r: Optional[Tensor] = None):
     """gatv2_mp(x_l, x_r, lin_edge(edge_attr), ...) as two launches that never materialise lin_edge's output
     (mgat_v2_conv.py:243-279 with :259-261 inside): isg_gatv2_edge_logits forms the logits [E, H] in the epilogue of the
     edge GEMM, isg_gatv2_mp_fwd_logits does softmax + aggregation.  Returns (out, alpha), or None when the per-graph kernel
-    has no instantiation for this batch / width (the caller then runs the un-fused pair)."""
+    has no instantiation for this batch / width (the caller then runs the un-fused pair).
+    x_r=None with (x, w_r, b_r): x_r = lin_r(x) is formed inside the logit kernel from the layer input x [N, K2] (after the
+    instruction gate) and lin_r's weight / bias -- it is never written or read, the caller projects lin_l alone."""
     lib = _lib.load()
     plan.require_csr()
     N, HC = x_l.shape
     H = int(heads)
     C = HC // H
     E, K = edge_attr.shape
-    if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K) or tuple(x_r.shape) != (N, HC):
+    if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K):
         raise ValueError("gatv2_mp_edge_logits: operand shapes do not match the plan")
-    if x_l.dtype != torch.float32 or x_r.dtype != torch.float32 or edge_attr.dtype != torch.float32:
+    if x_l.dtype != torch.float32 or edge_attr.dtype != torch.float32:
         raise TypeError("gatv2_mp_edge_logits: fp32 rows")
+    if x_r is not None:
+        if tuple(x_r.shape) != (N, HC) or x_r.dtype != torch.float32:
+            raise ValueError("gatv2_mp_edge_logits: x_r must be fp32 [N, H*C]")
+        xr_args = (_chk_rows(x_r, "x_r"), x_r.stride(0), 0)
+        tail_args = (0, 0, 0, 0, 0, 0)
+    else:
+        if x is None or w_r is None or x.dim() != 2 or x.size(0) != N or tuple(w_r.shape) != (HC, x.size(1)) or x.dtype != torch.float32:
+            raise ValueError("gatv2_mp_edge_logits: without x_r, x [N, K2] and w_r [H*C, K2] are required")
+        planes_r, inv_r = _weight_planes(w_r, True, "f16x3")
+        xr_args = (0, 0, 0)
+        tail_args = (_chk_rows(x, "x"), x.stride(0), planes_r.data_ptr(), inv_r.data_ptr(),
+                     _chk(None if b_r is None else b_r.detach().reshape(-1), "b_r", torch.float32, (HC,), optional=True), x.size(1))
     planes, inv = _weight_planes(w_edge, True, "f16x3")
     logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
@@ -451,13 +470,13 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Te
         # aggregate (plus lin_edge); the roofline keeps the un-fused algorithmic bytes of SURVEY 8(d)
         ev0, evm, ev1 = timer.bracket3({"N": N, "E": E, "H": H, "C": C, "K": K,
                                         "masked": node_mask is not None or edge_mask is not None, "feat_bytes": 4,
-                                        "fused_logits": True})
+                                        "fused_logits": True, "xr_inside": x_r is None, "K2": 0 if x_r is not None else x.size(1)})
         ev0.record()
     rc = lib.isg_gatv2_edge_logits(
         _chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(),
-        _chk_rows(x_l, "x_l"), x_l.stride(0), 0, _chk_rows(x_r, "x_r"), x_r.stride(0), 0, attp,
+        _chk_rows(x_l, "x_l"), x_l.stride(0), 0, *xr_args, attp,
         plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(), em, nm, logits.data_ptr(), E, H, C, K,
-        float(negative_slope), _stream())
+        float(negative_slope), *tail_args, _stream())
     if rc == ISG_EUNSUPPORTED:
         if timer is not None:
             timer.drop_last()
@@ -650,10 +669,12 @@ def mp_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool, feat_byte
     return feat_bytes * (3 * N * HC + E * HC) + 4 * E * H + 16 * E + (4 * E if masked else 0)
 
 
-def edge_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, K: int, masked: bool) -> int:
+def edge_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, K: int, masked: bool, K2: int = 0) -> int:
     """isg_gatv2_edge_logits' OWN minimum traffic: edge_attr rows (4*E*K), every x_l and x_r row once (2 * 4*N*HC), the
-    logits (4*E*H), eid / src / dst (12*E), the edge mask if any (4*E).  The W planes (4*HC*K) stay in L2."""
-    return 4 * E * K + 8 * N * H * C + 4 * E * H + 12 * E + (4 * E if masked else 0)
+    logits (4*E*H), eid / src / dst (12*E), the edge mask if any (4*E).  The W planes (4*HC*K) stay in L2.  K2 > 0: the
+    form that computes x_r itself reads every layer-input row once (4*N*K2) instead of x_r (4*N*HC)."""
+    xr = 4 * N * K2 if K2 else 4 * N * H * C
+    return 4 * E * K + 4 * N * H * C + xr + 4 * E * H + 12 * E + (4 * E if masked else 0)
 
 
 def mp_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool) -> int:

@@ -923,3 +923,69 @@ def test_edge_logits_pair_random_shapes_sweep(dev):
         assert da < 2e-5 and do < 2e-5 * scale, f"case {case}: H={H} C={C} K={K} B={B} N={N} E={E} mask={kind}: alpha {da:.2e} out {do:.2e}"
         assert torch.equal(ops.row_maxima(out_f), out_f.view(N, H, C).abs().amax(2))
     print(f"edge-logits pair sweep: worst |alpha - alpha_unfused| = {worst:.2e}")
+
+
+@pytest.mark.parametrize("mask", [None, "node", "edge"])
+@pytest.mark.parametrize("H,C,K,K2", [(4, 128, 128, 128), (4, 128, 36, 20), (8, 32, 128, 64), (2, 256, 64, 100)])
+def test_edge_logits_pair_with_lin_r_inside(dev, mask, H, C, K, K2):
+    """The form of isg_gatv2_edge_logits that computes x_r = lin_r(x) itself (x_r == NULL: layer input rows x[dst] staged as
+    a second panel, lin_r's planes, its own accumulator and row scale, lin_r's bias): against the same pair fed with
+    x_r = isg_linear(x, W_r, b_r), against the un-fused kernels and against the oracle.  Node features and edge features of
+    very different magnitude (the reason for two row scales), odd k-step counts on both sides, a bias-free lin_r."""
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(90 + K + K2)
+    sizes = [20, 1, 37, 5, 64, 23, 2, 30]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    src, dst, off = [], [], 0
+    for n in sizes:
+        for v in range(n):
+            if not (n == 5 and v == 4):
+                src.append(off + v); dst.append(off + v)
+        m = 0 if n == 1 else int(torch.randint(n, 4 * n, (1,), generator=gen))
+        m = min(m, 250 - n)
+        a_ = torch.randint(0, n, (m,), generator=gen); b_ = torch.randint(0, n, (m,), generator=gen)
+        if n == 5:
+            b_ = b_.clamp(max=3)
+        src += (off + a_).tolist(); dst += (off + b_).tolist()
+        off += n
+    ei = torch.tensor([src, dst])
+    ei = ei[:, torch.randperm(ei.size(1), generator=gen)]
+    N, E, HC = batch.numel(), ei.size(1), H * C
+    x = torch.randn(N, K2, generator=gen) * 1e-2                      # node features 1000x smaller than the edge features
+    ea = torch.randn(E, K, generator=gen) * 10.0
+    w_e = torch.randn(HC, K, generator=gen) / K ** 0.5 * 0.1
+    w_l, b_l = torch.randn(HC, K2, generator=gen) / K2 ** 0.5 * 100, torch.randn(HC, generator=gen)
+    w_r = torch.randn(HC, K2, generator=gen) / K2 ** 0.5 * 100
+    b_r = torch.randn(HC, generator=gen) if K2 != 20 else None        # one case without a bias
+    att, bias = torch.randn(1, H, C, generator=gen), torch.randn(HC, generator=gen)
+    nm = (torch.rand(N, generator=gen) < 0.6).float() if mask == "node" else None
+    em = (torch.rand(E, generator=gen) < 0.6).float() if mask == "edge" else None
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    assert ops.fused_logits_supported(plan, H, C, K)
+    t = lambda v: None if v is None else v.to(dev)
+    xd, wld, wrd, wed = x.to(dev), w_l.to(dev), w_r.to(dev), w_e.to(dev)
+    x_l = ops.linear(xd, wld, t(b_l))
+    x_r = ops.linear(xd, wrd, t(b_r))
+    res_in = ops.gatv2_mp_edge_logits(x_l, None, t(ea), wed, t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em),
+                                      want_rowmax=True, x=xd, w_r=wrd, b_r=t(b_r))
+    res_xr = ops.gatv2_mp_edge_logits(x_l, x_r, t(ea), wed, t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em))
+    assert res_in is not None and res_xr is not None
+    out_u, alpha_u = ops.gatv2_mp(x_l, x_r, ops.linear(t(ea), wed), t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em))
+    emask = em if em is not None else (None if nm is None else nm[ei[0]] * nm[ei[1]])
+    xl64 = (x.double() @ w_l.double().t() + b_l.double()).float()
+    xr64 = (x.double() @ w_r.double().t() + (0 if b_r is None else b_r.double())).float()
+    ref_out, ref_alpha = OM.gatv2_message_passing(xl64.view(N, H, C), xr64.view(N, H, C),
+                                                  (ea.double() @ w_e.double().t()).float().view(E, H, C), att, ei,
+                                                  None if emask is None else emask.view(E, 1), 0.2)
+    d_in_xr = (res_in[1] - res_xr[1]).abs().max().item()
+    d_in_u = (res_in[1] - alpha_u).abs().max().item()
+    d_in_o = (res_in[1].cpu() - ref_alpha).abs().max().item()
+    d_u_o = (alpha_u.cpu() - ref_alpha).abs().max().item()
+    scale = max(1.0, ref_out.abs().max().item())
+    d_out = (res_in[0].cpu() - (ref_out.reshape(N, HC) + bias)).abs().max().item()
+    print(f"lin_r inside H={H} C={C} K={K} K2={K2} mask={mask}: alpha vs pair-with-x_r {d_in_xr:.2e}, vs un-fused {d_in_u:.2e}, "
+          f"vs oracle {d_in_o:.2e} (un-fused vs oracle {d_u_o:.2e}); out vs oracle {d_out:.2e} (scale {scale:.1f})")
+    assert d_in_o <= 2.0 * d_u_o + 3e-6 and d_in_u <= 3.0 * d_u_o + 3e-6 and d_in_xr <= 3.0 * d_u_o + 3e-6
+    assert d_out < 2e-5 * scale
+    assert torch.equal(ops.row_maxima(res_in[0]), res_in[0].view(N, H, C).abs().amax(2))
