@@ -468,8 +468,10 @@ static int launch_flat_sized(MpArgs a, int nmax_host, hipStream_t st) {
   if (items >= (1ll << 31)) return ISG_EUNSUPPORTED;
   const size_t row_bytes = (size_t)HS * a.C * 4;
   const size_t static_bytes = (size_t)EC * 16 + (size_t)EC * HS * 4 + (NC + 4) * 4;
-  // window: 2 workgroups per CU (16 waves); a graph's rows beyond it are read from global memory (L2)
-  const size_t budget = 78 * 1024;
+  // window: 2 workgroups per CU (16 waves); a graph's rows beyond it are read from global memory (L2).  ISG_MPF_LDS_KB: sweep
+  // switch (52 = three workgroups per CU with a 22-row window at H * C = 1200)
+  static const int flat_kb = [] { const char *e = getenv("ISG_MPF_LDS_KB"); const int v = e ? atoi(e) : 78; return v < 16 || v > 78 ? 78 : v; }();
+  const size_t budget = (size_t)flat_kb * 1024;
   if (budget < static_bytes + 8 * row_bytes) return ISG_EUNSUPPORTED;
   a.lrows = (int)((budget - static_bytes) / row_bytes);
   if (a.lrows > nmax_host) a.lrows = nmax_host;
