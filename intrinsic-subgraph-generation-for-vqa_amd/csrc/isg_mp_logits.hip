@@ -27,6 +27,15 @@
 
 #include <stdlib.h>
 
+#ifdef ISG_EL_STAMP
+// Diagnostic build (tools/stamp_edge_logits.py): every wave adds up core-clock cycles (s_memtime) per phase and writes
+// them to a buffer of its own; no output value depends on a stamp.  [workgroup * 8 + wave][8]:
+//   0 staging (kernel start -> after the panel barrier)   1 issuing a tile's gathers   2 k loop   3 wait for the gathers
+//   (s_waitcnt vmcnt(0) right after the k loop)   4 epilogue arithmetic   5 flush + final reduction   6 whole kernel   7 tiles
+static __device__ long long *g_el_stamps = nullptr;
+#define EL_T() ((long long)__builtin_amdgcn_s_memtime())
+#endif
+
 namespace isg {
 
 constexpr int EL_BM = 64, EL_KC = 128, EL_LD = EL_KC + 8, EL_THREADS = 512;
@@ -68,8 +77,12 @@ struct ElArgs {
 //     rows, 8 per page): 228 / 228 / 229 us, identical logits
 //   * counters: HBM fetch 508 MB per launch = 1.15x the algorithmic 442 MB; L2 hit rate 67 %; 71 M L1 line accesses (the
 //     plain lin_edge GEMM: 23 M); TCP_UTCL1_STALL_INFLIGHT_MAX 24.6 M (10.0 M)
-// So: the gathers add ~100 us to a ~118 us kernel in EVERY form -- not the address unit, not request latency, not DRAM or
-// page locality, not occupancy -- while the HBM traffic is near its minimum; what the two phases share is not identified.
+//   * in-kernel stamps (-DISG_EL_STAMP, tools/stamp_edge_logits.py): a wave lives 68k cycles for its 4 tiles: staging 18 %,
+//     issuing the gathers 10 % (1.8k cycles per tile: back-pressure), k loops 57 % (9.8k cycles per tile for 768 cycles of
+//     MFMA), residual gather wait after the k loop 0.1 %, epilogue 8 %: the gathers' latency under load (3-4 us per tile) is
+//     paid at the first W-fragment wait of every k loop -- vector-memory operations retire in order
+// So: the gathers add ~100 us to a ~118 us kernel in EVERY form while the HBM traffic is near its minimum: it is bound by the
+// latency-under-load of its row gathers, serialised in front of every tile's matrix work.
 // The pair (this kernel + isg_gatv2_mp_fwd_logits) is 313-320 us against 334-350 us for isg_linear_f16x3 +
 // isg_gatv2_mp_fwd, and the configs[1] step 2.20-2.22 ms against 2.24-2.29 ms on the same box.
 // XR: x_r is not an input.  lin_r(x)[dst] is used by nothing but this logit, once per slot, and slots are sorted by
@@ -89,6 +102,10 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
   const int m0 = blockIdx.x * EL_BM;
   const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
   const int HC = a.H * a.C;
+#ifdef ISG_EL_STAMP
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long st_begin = EL_T();
+#endif
 
   // ---- stage the edge panel once: rows gathered by edge id -> row scale -> (hi, mid) planes -------------------------------
   {
@@ -171,6 +188,9 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
   float me = 1.f;
   if (MASKED) me = a.edge_mask ? a.edge_mask[a.eid[sl]] : a.node_mask[s_node] * a.node_mask[d_node];
   __syncthreads();
+#ifdef ISG_EL_STAMP
+  st_acc[0] = EL_T() - st_begin;
+#endif
   const float sinv = s_inv[prow];
   const float sinv2 = XR ? s_inv2[prow] : 0.f;
   const int KS2 = a.KS2;
@@ -207,6 +227,9 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
     }
     const int cb = nt * 32 + 4 * hh;         // this lane's channels of the tile: cb + 8 * g + j, g = r >> 2, j = r & 3
     const int64_t col_l = (int64_t)hd * a.hsl + (nt - hd * tph) * 32, col_r = (int64_t)hd * a.hsr + (nt - hd * tph) * 32;
+#ifdef ISG_EL_STAMP
+    const long long st_t0 = EL_T();
+#endif
     float4 xl[4], xr[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -218,6 +241,9 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
         if constexpr (!XR) xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
       }
     }
+#ifdef ISG_EL_STAMP
+    const long long st_t1 = EL_T();
+#endif
     hf32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -290,6 +316,12 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
 #undef EL_LOAD_X
 #undef EL_MMA2
     }
+#ifdef ISG_EL_STAMP
+    asm volatile("" ::"v"(acc[0]), "v"(acc[15]));       // the k loop's results exist
+    const long long st_t2 = EL_T();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // whatever of the gathers is still in flight
+    const long long st_t3 = EL_T();
+#endif
     // ---- epilogue of the tile: the logit's partial sums over this lane's 16 channels ---------------------------------------
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -320,7 +352,15 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
         part[g] = fmaf(z, atv[j], part[g]);
       }
     }
+#ifdef ISG_EL_STAMP
+    asm volatile("" ::"v"(part[0]), "v"(part[1]), "v"(part[2]), "v"(part[3]));
+    const long long st_t4 = EL_T();
+    st_acc[1] += st_t1 - st_t0; st_acc[2] += st_t2 - st_t1; st_acc[3] += st_t3 - st_t2; st_acc[4] += st_t4 - st_t3; st_acc[7] += 1;
+#endif
   }
+#ifdef ISG_EL_STAMP
+  const long long st_t5 = EL_T();
+#endif
   if (cur_hd >= 0) flush(cur_hd);
   __syncthreads();
   for (int c = tid; c < EL_BM * a.H; c += EL_THREADS) {       // (slot, head): the tile-waves' partials in a fixed order
@@ -328,6 +368,16 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
     const int slot = m0 + c / a.H;
     if (slot < a.E) a.logits[(int64_t)slot * a.H + (c % a.H)] = v;
   }
+#ifdef ISG_EL_STAMP
+  if (g_el_stamps && lane == 0) {
+    const long long st_end = EL_T();
+    st_acc[5] = st_end - st_t5;
+    st_acc[6] = st_end - st_begin;
+    long long *dst = g_el_stamps + ((long long)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
+  }
+#endif
 }
 
 }  // namespace isg
@@ -392,3 +442,9 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   }
   return check_launch();
 }
+
+#ifdef ISG_EL_STAMP
+extern "C" int isg_el_set_stamp_buffer(long long *buf) {      // diagnostic build only: [workgroups * 8 waves][8] int64
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_el_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
