@@ -901,13 +901,16 @@ F16X3_TILE = True     # ... and 128 < K <= 1024 when the producer of the input l
 GEMM_F16X3 = True     # K <= 128 panel shapes on the fp16 three-product kernel (isg_linear_f16x3) instead of bf16x6 (A/B switch)
 
 
+PANEL_MIN_N = 256       # narrowest Linear the row-panel kernels take (A/B: tools/ab_step.py)
+
+
 def _use_panel(M: int, N: int, K: int) -> bool:
     """The row-panel kernel wins where an A panel is split once and serves many columns (K <= 128: lin_edge 182 vs 212 us,
     lin_l|lin_r 153 vs 166 us) and there are enough 64-row panels to fill the chip; the tile kernel elsewhere
     (profiles/r02_a_gemm_structures.md)."""
     if GEMM_KERNEL != "auto":
         return GEMM_KERNEL == "panel"
-    return K <= 128 and N >= 256 and M >= 32768
+    return K <= 128 and N >= PANEL_MIN_N and M >= 32768
 
 
 _DERIVED = {}   # (tag, ids of the source tensors) -> (versions, weakrefs, value): weights re-laid-out once per model

@@ -26,6 +26,9 @@ variants = [
     ("+ lin_edge folded into the logits (no e_proj in memory)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False)),
     ("+ lin_r formed inside that kernel (no x_r in memory)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, FUSE_EDGE=False, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=True)),
 ]
+if os.environ.get("AB_PANEL_N"):     # sweep the narrowest Linear the panel kernels take, on the default path
+    base = dict(variants[-2][1])
+    variants = [(f"default path, PANEL_MIN_N = {n}", {**base, "PANEL_MIN_N": n}) for n in (256, 128, 64, 256)]
 if os.environ.get("AB_LAST"):       # only the last N variants (short runs)
     variants = variants[-int(os.environ["AB_LAST"]):]
 res = {name: [] for name, _ in variants}
