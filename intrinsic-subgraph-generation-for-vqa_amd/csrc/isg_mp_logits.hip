@@ -81,8 +81,11 @@ struct ElArgs {
 //     issuing the gathers 10 % (1.8k cycles per tile: back-pressure), k loops 57 % (9.8k cycles per tile for 768 cycles of
 //     MFMA), residual gather wait after the k loop 0.1 %, epilogue 8 %: the gathers' latency under load (3-4 us per tile) is
 //     paid at the first W-fragment wait of every k loop -- vector-memory operations retire in order
-// So: the gathers add ~100 us to a ~118 us kernel in EVERY form while the HBM traffic is near its minimum: it is bound by the
-// latency-under-load of its row gathers, serialised in front of every tile's matrix work.
+//   * a 12-wave workgroup with 4 loader waves (rows as coalesced 512-byte head slices, pre-added into LDS) and 8 matrix waves
+//     that never gather -- the form that removes exactly that serialisation: 223 us against 216 us for this kernel
+// So: ten forms within 211-232 us.  The stamps show where a wave waits, but a kernel without that wait takes the same time:
+// the limit is chip-wide (per launch ~0.5 GB from HBM, 0.8-1.6 GB of W fragments and ~0.84 GB of row requests through L2);
+// the next attempt should shrink that traffic (a W tile kept in LDS across several panels), not reorder it.
 // The pair (this kernel + isg_gatv2_mp_fwd_logits) is 313-320 us against 334-350 us for isg_linear_f16x3 +
 // isg_gatv2_mp_fwd, and the configs[1] step 2.20-2.22 ms against 2.24-2.29 ms on the same box.
 // XR: x_r is not an input.  lin_r(x)[dst] is used by nothing but this logit, once per slot, and slots are sorted by
