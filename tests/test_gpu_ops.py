@@ -989,3 +989,41 @@ def test_edge_logits_pair_with_lin_r_inside(dev, mask, H, C, K, K2):
     assert d_in_o <= 2.0 * d_u_o + 3e-6 and d_in_u <= 3.0 * d_u_o + 3e-6 and d_in_xr <= 3.0 * d_u_o + 3e-6
     assert d_out < 2e-5 * scale
     assert torch.equal(ops.row_maxima(res_in[0]), res_in[0].view(N, H, C).abs().amax(2))
+
+
+def test_edge_logits_pair_is_deterministic_and_edge_order_invariant_at_full_size(dev):
+    """BASELINE configs[1] size (4096 graphs, ~82k nodes, ~205k edges), properties that need no oracle: the pair run twice
+    gives the same bits; the edges handed over in another order give the same alpha PER EDGE and the same node outputs up
+    to the summation order inside a destination's segment (the CSR sorts by destination, ties in input order)."""
+    from isubgvqa_amd import ops, synthetic
+    cfg = synthetic.CFG2
+    wl = synthetic.make_workload(cfg).to(dev)
+    N, E, H, C = wl.x.size(0), wl.edge_index.size(1), cfg.heads, cfg.channels
+    K = wl.edge_attr.size(1)
+    g = torch.Generator(device=dev).manual_seed(4)
+    x_lr = torch.randn(N, 2 * H * C, device=dev, generator=g)
+    ea = wl.edge_attr.float().contiguous()
+    w = torch.randn(H * C, K, device=dev, generator=g) / K ** 0.5
+    att, bias = torch.randn(1, H, C, device=dev, generator=g), torch.randn(H * C, device=dev, generator=g)
+    nm = (torch.rand(N, device=dev, generator=g) < 0.7).float()
+    x_l, x_r = x_lr[:, :H * C], x_lr[:, H * C:]
+    plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=cfg.num_graphs, max_nodes=wl.max_nodes, max_edges=wl.max_edges)
+    assert ops.fused_logits_supported(plan, H, C, K)
+    o1, a1 = ops.gatv2_mp_edge_logits(x_l, x_r, ea, w, att, plan, H, bias=bias, node_mask=nm)
+    o2, a2 = ops.gatv2_mp_edge_logits(x_l, x_r, ea, w, att, plan, H, bias=bias, node_mask=nm)
+    assert torch.equal(o1, o2) and torch.equal(a1, a2)
+    assert torch.isfinite(o1).all() and torch.isfinite(a1).all()
+    # softmax property at full size: alpha sums to 1 over every destination with at least one unmasked... in-edge (+1e-16)
+    dst = wl.edge_index[1]
+    seg = torch.zeros(N, H, device=dev).index_add_(0, dst, a1)
+    has = torch.zeros(N, device=dev).index_add_(0, dst, torch.ones(E, device=dev)) > 0
+    assert (seg[has] - 1.0).abs().max().item() < 1e-5
+    # another edge order
+    perm = torch.randperm(E, device=dev, generator=g)
+    ei_p = wl.edge_index[:, perm].contiguous()
+    plan_p = ops.GraphPlan.build(wl.batch, ei_p, num_graphs=cfg.num_graphs, max_nodes=wl.max_nodes, max_edges=wl.max_edges)
+    o3, a3 = ops.gatv2_mp_edge_logits(x_l, x_r, ea[perm].contiguous(), w, att, plan_p, H, bias=bias, node_mask=nm)
+    da = (a3 - a1[perm]).abs().max().item()
+    do = (o3 - o1).abs().max().item()
+    print(f"pair at configs[1] size: permuted edges: max |alpha diff| {da:.2e}, max |out diff| {do:.2e}")
+    assert da < 2e-6 and do < 2e-5

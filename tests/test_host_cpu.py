@@ -187,3 +187,24 @@ def test_reference_checkpoint_reader_roundtrip(tmp_path):
     assert not model.training
     for k, v in src.state_dict().items():
         assert torch.equal(model.state_dict()[k], v), k
+
+
+def test_docs_quote_the_headers_symbol_count_and_abi_version():
+    """README.md / DESIGN.md / INTEGRATION.md quote the number of C-ABI symbols and the ABI version; both drifted more than
+    once while entry points were added.  They are checked against include/isg.h."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "isg.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    n_sym = len(set(re.findall(r"\b(isg_[a-z0-9_]+)\s*\(", body)))
+    abi = int(re.search(r"#define ISG_ABI_VERSION (\d+)", hdr).group(1))
+    readme = open(os.path.join(root, "README.md")).read()
+    m = re.search(r"\((\d+) symbols, ABI v(\d+)\)", readme)
+    assert m, "README.md no longer states '(N symbols, ABI vM)'"
+    assert (int(m.group(1)), int(m.group(2))) == (n_sym, abi), f"README says {m.groups()}, header has {n_sym} symbols, ABI v{abi}"
+    for name in ("DESIGN.md", "INTEGRATION.md"):
+        text = open(os.path.join(root, name)).read()
+        for q in re.findall(r"(\d+) (?:`extern \"C\"` )?symbols", text):
+            if 30 <= int(q) <= 200:      # counts of the device library (the loader's 15 are quoted too)
+                assert int(q) == n_sym, f"{name} quotes {q} symbols, include/isg.h declares {n_sym}"
