@@ -1,0 +1,61 @@
+"""The RCCL calls of bench.py / distributed.py on a single-rank `nccl` group (one MI355X): two ranks cannot share a GPU under
+NCCL, so the N > 1 path is rehearsed with gloo elsewhere (tests/test_distributed_cpu.py, bench.py's ISG_BENCH_BACKEND); this
+checks that the RCCL library initialises on the box and that every collective call the multi-GPU run makes is accepted,
+asynchronous handles included.  Runs in a subprocess so that the pytest process keeps no default process group."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    assert dist.get_backend() == "nccl"
+    g = torch.Generator(device=dev).manual_seed(0)
+    logits = torch.randn(4096, 1842, device=dev, generator=g)              # one rank's answer logits (30 MB)
+    bufs = [torch.empty_like(logits) for _ in range(2)]
+    pending, sent = [], []
+    for i in range(4):                                                      # bench.py's double-buffered async pattern
+        while pending:
+            pending.pop(0)[0].wait()
+        w = dist.all_gather_into_tensor(bufs[i %% 2], logits, async_op=True)
+        pending.append((w, logits))                                         # the input stays referenced until the wait
+        sent.append(logits)
+        logits = logits + 1.0                                               # next step's producer runs beside the collective
+    while pending:
+        pending.pop(0)[0].wait()
+    torch.cuda.synchronize()
+    assert torch.equal(bufs[1], sent[3]) and torch.equal(bufs[0], sent[2]), "gathered logits differ from what was sent"
+    t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t.item()) == 1.25
+    devs = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=dev)
+    out = [torch.empty_like(devs)]
+    dist.all_gather(out, devs)
+    assert int(out[0].item()) == 0
+    dist.barrier()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    print("RCCL single-rank ok")
+""") % ROOT
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_of_the_multi_gpu_path_on_a_single_rank_group():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=300, env=env)
+    err = [l for l in res.stderr.splitlines() if l.strip() and "amdgpu.ids" not in l]
+    assert res.returncode == 0 and "RCCL single-rank ok" in res.stdout, "\n".join(err[-25:])
