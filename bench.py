@@ -17,11 +17,18 @@ are in HBM before the timed region.  With N ranks every rank owns its own 4096-g
 each step ends with the RCCL all-gather of answer logits -- the only collective of the path; it is issued asynchronously and
 overlaps the next step's kernels (the last one is waited for inside the timed region).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      message-passing kernel: algorithmic bytes / mean launch duration measured with HIP
-                events on the launch stream over the timed region, against the HBM peak
-  cpu_baseline  the CPU oracle (oracle/model.py, a port of the reference's PyG CPU path) timed on this host's
-                cores on a bounded sample of the same workload
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      the reference's message + aggregate: algorithmic bytes (e_proj included) / mean duration measured
+                with HIP events on the launch stream over the timed region, against the HBM peak.  By default that function
+                runs as TWO launches with lin_edge inside the first (isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits): the
+                bracket covers both, `parts` gives each against its own bytes, `unfused_kernel` the round-1 kernel timed in the
+                same run outside the timed region; --no-fuse-logits times the round-1 boundary as the step.  `traffic` is
+                replayed from the committed PMC summary of exactly those kernels (profiles/*_mp_traffic.json)
+  cpu_baseline  the CPU oracle (oracle/model.py, a port of the reference's PyG CPU path) timed on this host's usable
+                cores on a bounded sample of the same workload; .cfg1 = BASELINE configs[0] exactly
+  full_model    the configs[2] stand-in (full model at C = 300) timed in the same run
+  rccl          backend, world size, every rank's device index
+--launch graph replays the step as one captured hipGraph (single GPU; pays below ~500 graphs per step).
 """
 from __future__ import annotations
 
