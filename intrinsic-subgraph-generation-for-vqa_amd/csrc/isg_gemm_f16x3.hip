@@ -332,8 +332,42 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
     for (int j = 0; j < 4; ++j) acc16[i][j] = hf32x4{0.f, 0.f, 0.f, 0.f};
   float4 ra0[2], ra1[2];
   hf16x8 rb0[2], rb1[2];
+  // ISG_F16X3_APLANES (timing diagnostic build only, tools/time_f16x3_tile.py with ISG_TOOL_LIB): the bytes of A are read
+  // as if they were two fp16 planes [2][M][K] left by A's producer (same bytes, same rows per tile), staged with 16-byte LDS
+  // stores, no conversion in the loop: the upper bound of handing activations over pre-split.  The results are garbage.
+#ifdef ISG_F16X3_APLANES
+  constexpr bool APL = true;
+  // ISG_F16X3_APLANES=2: planes interleaved per k-tile, [M][K/32][hi 32 | mid 32] -- a row's k-tile is ONE 128-byte line (with
+  // two separate planes it is a 64-byte segment in each, twice the requests on the streamed operand)
+  constexpr bool APL_INTERLEAVED = ISG_F16X3_APLANES == 2;
+  // ISG_F16X3_APLANES=3: interleaved planes AND the shipped kernel's thread -> address map (8 lanes per row, one 128-byte
+  // line per row and k-tile, one instruction): global traffic identical to the fp32 path, only the conversion is gone
+  constexpr bool APL_SAMEMAP = ISG_F16X3_APLANES == 3;
+#else
+  constexpr bool APL = false;
+  constexpr bool APL_INTERLEAVED = false;
+  constexpr bool APL_SAMEMAP = false;
+#endif
+  const _Float16 *Ah = reinterpret_cast<const _Float16 *>(A);
+  const int64_t a_plane = (int64_t)M * lda;
+  hf32x4 ra0v[2], ra1v[2];      // the diagnostic paths stage in a native vector type: a whole-struct copy of HIP's float4 from
+                                // a register array into LDS left the four of them in scratch memory (80 bytes per lane)
 #define HT_LOAD_TILE(RA, RB, k0)                                                                                 \
   {                                                                                                              \
+    if constexpr (APL_SAMEMAP) {   /* the shipped kernel's (row, 16-byte chunk) map on [M][K/32][hi 32 | mid 32] */  \
+      /* both iterations written out: a loop over u left RA[u] in SCRATCH memory (80 bytes per lane) */          \
+      const int c = tid & 7, gr0 = min(m0 + (tid >> 3), M - 1), gr1 = min(m0 + ((tid + 512) >> 3), M - 1);       \
+      RA##v[0] = *reinterpret_cast<const hf32x4 *>(Ah + ((int64_t)gr0 * (lda >> 5) + ((k0) >> 5)) * 64 + c * 8);  \
+      RA##v[1] = *reinterpret_cast<const hf32x4 *>(Ah + ((int64_t)gr1 * (lda >> 5) + ((k0) >> 5)) * 64 + c * 8);  \
+    } else if constexpr (APL) {                                                                                  \
+      const int row = tid >> 2, c8 = tid & 3;                                                                    \
+      const int gr = min(m0 + row, M - 1), gk = min((k0) + c8 * 8, K - 8);                                       \
+      RA##v[0] = *reinterpret_cast<const hf32x4 *>(                                                              \
+          APL_INTERLEAVED ? Ah + ((int64_t)gr * (lda >> 5) + ((k0) >> 5)) * 64 + c8 * 8 : Ah + (int64_t)gr * lda + gk);      \
+      RA##v[1] = *reinterpret_cast<const hf32x4 *>(                                                              \
+          APL_INTERLEAVED ? Ah + ((int64_t)gr * (lda >> 5) + ((k0) >> 5)) * 64 + 32 + c8 * 8                      \
+                          : Ah + a_plane + (int64_t)gr * lda + gk);                                              \
+    } else                                                                                                       \
     _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                              \
       const int i = tid + 512 * u;                                                                               \
       const int row = i >> 3, c4 = i & 7;                                                                        \
@@ -352,6 +386,15 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
 #define HT_STEP(RA, RB, kt)                                                                                      \
   {                                                                                                              \
     if ((kt) > 0) __syncthreads();                                                                               \
+    if constexpr (APL_SAMEMAP) {                                                                                 \
+      const int c = tid & 7;                                                                                     \
+      *reinterpret_cast<hf32x4 *>(&sm.a[c >> 2][tid >> 3][(c & 3) * 8]) = RA##v[0];                              \
+      *reinterpret_cast<hf32x4 *>(&sm.a[c >> 2][(tid + 512) >> 3][(c & 3) * 8]) = RA##v[1];                      \
+    } else if constexpr (APL) {                                                                                  \
+      const int row = tid >> 2, c8 = tid & 3;                                                                    \
+      *reinterpret_cast<hf32x4 *>(&sm.a[0][row][c8 * 8]) = RA##v[0];                                             \
+      *reinterpret_cast<hf32x4 *>(&sm.a[1][row][c8 * 8]) = RA##v[1];                                             \
+    } else                                                                                                       \
     _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                              \
       const int i = tid + 512 * u;                                                                               \
       const int row = i >> 3, c4 = i & 7;                                                                        \

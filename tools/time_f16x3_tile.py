@@ -8,7 +8,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from isubgvqa_amd import ops
+from isubgvqa_amd import _lib, ops
+
+if os.environ.get("ISG_TOOL_LIB"):        # A/B against another build of the library (same box, separate processes)
+    _lib.LIB_PATH = os.path.abspath(os.environ["ISG_TOOL_LIB"])
 
 dev = torch.device("cuda:0")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
