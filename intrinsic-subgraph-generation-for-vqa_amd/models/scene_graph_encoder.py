@@ -112,7 +112,9 @@ class SceneGraphEncoder(torch.nn.Module):
         sym = gt_scene_graphs.added_sym_edge
         if plan is None:
             plan = ops.GraphPlan.build(batch, edge_index)
-        split = SPLIT_LINEARS and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        split = (SPLIT_LINEARS and self.hidden_dim % 4 == 0 and self.sg_emb_dim % 4 == 0       # isg_gather_add: float4 rows
+                 and not (torch.is_grad_enabled() and (x_embed_sum.requires_grad or
+                                                       any(p.requires_grad for p in self.parameters()))))
         if split:   # inference: no [E, 900] concatenation (forward_split); the sign of :80 rides along as a vector
             sign = torch.ones(edge_attr.numel(), dtype=torch.float32, device=edge_attr.device)
             if sym is not None and sym.numel() > 0:

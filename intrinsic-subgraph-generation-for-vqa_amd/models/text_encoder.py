@@ -30,8 +30,18 @@ from .. import ops
 FUSED_TEXT = True     # inference path on this library's kernels (A/B switch: False = torch's nn.Transformer* forward)
 
 
-def _recording(module: torch.nn.Module) -> bool:
-    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+def _recording(module: torch.nn.Module, *inputs) -> bool:
+    """True when the torch modules must run instead of the raw kernels (which have no autograd and no dropout): autograd is
+    recording through a parameter OR an input (a frozen decoder over a trainable encoder's memory), or the module is in
+    train() mode with a non-zero dropout somewhere in it."""
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters()) or
+                                    any(t is not None and t.requires_grad for t in inputs)):
+        return True
+    return module.training and any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in module.modules())
+
+
+def _kernels_fit(T_kv: int, head_dim: int) -> bool:
+    return ops.mha_small_supported(T_kv, head_dim)
 
 
 def _attention(mha: torch.nn.MultiheadAttention, x_q: Tensor, x_kv: Tensor, B: int, key_bias=None, self_attn=True) -> Tensor:
@@ -109,7 +119,10 @@ class QuestionEncoder(torch.nn.Module):
     def forward(self, src: Tensor, mask: Tensor) -> Tensor:
         src = self.text_vocab_embedding(src)                                             # :32
         enc = self.transformer_encoder
-        if not FUSED_TEXT or not src.is_cuda or _recording(self) or src.size(1) > 128 or src.size(2) // enc.layers[0].self_attn.num_heads > 64:
+        if (not FUSED_TEXT or not src.is_cuda or _recording(self, src)
+                or not _kernels_fit(src.size(1), src.size(2) // enc.layers[0].self_attn.num_heads)):
+            if src.is_cuda and not torch.is_grad_enabled():
+                ops.COUNTERS["torch_attention"] += 1
             return enc(src.permute(1, 0, 2), src_key_padding_mask=mask.float())          # :35-37
         B, T, D = src.shape
         x = src.permute(1, 0, 2).reshape(T * B, D).contiguous()                          # torch's [T, B, D] row order
@@ -134,7 +147,10 @@ class QuestionDecoder(torch.nn.Module):
         B = memory.size(1)
         queries = self.query_embed.weight.unsqueeze(1).repeat(1, B, 1)                   # :61-63
         dec = self.coarse_decoder
-        if not FUSED_TEXT or not memory.is_cuda or _recording(self) or memory.size(0) > 128 or memory.size(2) // dec.layers[0].self_attn.num_heads > 64:
+        if (not FUSED_TEXT or not memory.is_cuda or _recording(self, memory)
+                or not _kernels_fit(max(memory.size(0), queries.size(0)), memory.size(2) // dec.layers[0].self_attn.num_heads)):
+            if memory.is_cuda and not torch.is_grad_enabled():
+                ops.COUNTERS["torch_attention"] += 1
             return dec(tgt=queries, memory=memory, tgt_mask=None)                        # :64-66
         S, _, D = memory.shape
         n = queries.size(0)

@@ -19,6 +19,27 @@ from . import _lib
 
 MAX_NODES_PER_GRAPH = 1024   # LDS strip / sampler row capacity of the kernels
 
+# Launches that leave this library's own dense kernels, and extra passes a missing hand-off costs; bench.py prints them
+# per step ("no GEMM of the inference path runs on hipBLASLt" is then a number, not a sentence).
+COUNTERS = {"torch_linear": 0, "torch_layer_norm": 0, "torch_attention": 0, "row_absmax": 0}
+
+
+def reset_counters() -> None:
+    for k in COUNTERS:
+        COUNTERS[k] = 0
+
+
+def counters() -> dict:
+    return dict(COUNTERS)
+
+
+def _ver(t: Tensor):
+    """Validity stamp of a cached derivative of `t`: the autograd version counter, or -- for tensors made under
+    torch.inference_mode(), which have none (reading `._version` raises) -- a constant: an in-place write to an inference
+    tensor cannot be seen, the caches then rest on (identity, data_ptr, shape) alone.  The reference evaluates under
+    inference_mode (run_token_coo.py:49), so this path has to work there."""
+    return -1 if t.is_inference() else t._version
+
 
 class KernelTimer:
     """Optional HIP-event bracket around every launch of one named kernel (bench.py uses it for the
@@ -920,7 +941,7 @@ def derived_weight(tag: str, sources, build):
     """Cache of tensors computed from static weights (slices, concatenations): rebuilt when a source was updated in place
     (tensor._version / data_ptr) or replaced; invalidate_weight_cache() drops it."""
     key = (tag,) + tuple(id(t) for t in sources)
-    ver = tuple((t._version, t.data_ptr()) for t in sources)
+    ver = tuple((_ver(t), t.data_ptr()) for t in sources)
     hit = _DERIVED.get(key)
     if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[1], sources)):
         return hit[2]
@@ -983,7 +1004,7 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
     key = (id(weight), layout)
     hit = _PLANES.get(key) if cache else None
     # the weak reference pins the identity: a freed weight's id (and even its address) can be reused by another model
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+    if hit is not None and hit[0]() is weight and hit[1] == _ver(weight) and hit[2] == weight.data_ptr():
         return hit[3]
     lib = _lib.load()
     N, K = weight.shape
@@ -1014,7 +1035,7 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
         if len(_PLANES) > 256:
             for k in [k for k, v in _PLANES.items() if v[0]() is None]:
                 del _PLANES[k]
-        _PLANES[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), planes)
+        _PLANES[key] = (weakref.ref(weight), _ver(weight), weight.data_ptr(), planes)
     return planes
 
 
@@ -1023,13 +1044,13 @@ def attach_row_maxima(x: Tensor, rowmax: Tensor) -> Tensor:
     Linears that read it.  They are tied to x's version counter: an in-place write to x afterwards invalidates them
     (`row_maxima` then returns None and the Linear makes its own pass) -- a stale maximum would mis-scale the fp16 planes."""
     x._isg_rowmax = rowmax
-    x._isg_rowmax_version = x._version
+    x._isg_rowmax_version = (_ver(x), x.data_ptr(), tuple(x.shape))
     return x
 
 
 def row_maxima(x: Tensor) -> Optional[Tensor]:
     rm = getattr(x, "_isg_rowmax", None)
-    if rm is None or getattr(x, "_isg_rowmax_version", None) != x._version:
+    if rm is None or getattr(x, "_isg_rowmax_version", None) != (_ver(x), x.data_ptr(), tuple(x.shape)):
         return None
     return rm
 
@@ -1059,6 +1080,7 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], norm: torch.nn.LayerNor
                                _chk(None if norm.bias is None else norm.bias.detach(), "bias", torch.float32, (D,), optional=True),
                                float(norm.eps), out.data_ptr(), D, 0 if rm is None else rm.data_ptr(), M, D, _stream())
     if rc == ISG_EUNSUPPORTED:
+        COUNTERS["torch_layer_norm"] += 1
         y = x if residual is None else x + residual
         return torch.nn.functional.layer_norm(y, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
     _lib.check(rc, "isg_add_layernorm")
@@ -1068,6 +1090,7 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], norm: torch.nn.LayerNor
 
 
 def _linear_torch(x: Tensor, weight: Tensor, bias: Optional[Tensor], gelu: bool, relu: bool) -> Tensor:
+    COUNTERS["torch_linear"] += 1
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if relu else (torch.nn.functional.gelu(y) if gelu else y)
 
@@ -1084,14 +1107,15 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     if relu and (gelu or f16_io):
         raise ValueError("relu excludes gelu and fp16 rows")
     if relu and (_rec(x, weight, bias) or GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or M == 0):
-        return torch.relu(torch.nn.functional.linear(x, weight, bias))
+        return _linear_torch(x, weight, bias, False, True)
     if _rec(x, weight, bias) and GEMM_BACKEND == "bf16x6" and (K & 3) == 0 and M > 0:
         from . import autograd
         return autograd.linear(x, weight, bias, gelu)
     N = weight.size(0)
     if GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or M == 0:
-        y = torch.nn.functional.linear(x, weight, bias)
-        return torch.nn.functional.gelu(y) if gelu else y
+        if M == 0:
+            return x.new_empty(0, N)
+        return _linear_torch(x, weight, bias, gelu, False)
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
     a_rowmax = row_maxima(x)
@@ -1128,6 +1152,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
             else:
                 rm = torch.empty(M, 1, dtype=torch.float32, device=x.device)
                 _lib.check(lib.isg_row_absmax(xp + 4 * k0, M, kc, K, rm.data_ptr(), _stream()), "isg_row_absmax")
+                COUNTERS["row_absmax"] += 1
                 if nchunk == 1:
                     attach_row_maxima(x, rm)          # the next Linear over the same rows does not repeat the pass
                 rm_ptr, rm_p, rm_ld = rm.data_ptr(), 1, 1
@@ -1203,6 +1228,12 @@ def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
         _chk(x, "x", x.dtype), 1 if x.dtype == torch.float16 else 0, planes.data_ptr(), 0, out.data_ptr(),
         1 if out_dtype == torch.float16 else 0, M, L * n, K, K, n, 0, n, M * n, _stream()), "isg_linear_panel_multi")
     return tuple(out[i] for i in range(L))
+
+
+def mha_small_supported(t_kv: int, head_dim: int) -> bool:
+    """isg_mha_small's launch limits (csrc/isg_attn.hip): head_dim <= 64, <= 128 keys, and a head's K / V rows + score
+    strips within 64 KB of LDS -- at head_dim 64 that is 121 keys.  Callers ask BEFORE choosing the kernel path."""
+    return head_dim <= 64 and t_kv <= 128 and (t_kv * (2 * head_dim + 1) + 4 * 64 + 4 * 128) * 4 <= 64 * 1024
 
 
 def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_bias: Optional[Tensor] = None,
@@ -1281,7 +1312,7 @@ def linear_fused(x: Tensor, layers, out_dtype=torch.float32) -> Tuple[Tensor, ..
             o += n
         return tuple(outs)
     key = tuple(id(m.weight) for m in layers)
-    ver = tuple((m.weight._version, m.weight.data_ptr(), None if m.bias is None else m.bias._version) for m in layers)
+    ver = tuple((_ver(m.weight), m.weight.data_ptr(), None if m.bias is None else _ver(m.bias)) for m in layers)
     hit = _CAT.get(key)
     if hit is None or hit[0] != ver or any(r() is not m.weight for r, m in zip(hit[3], layers)):
         w = torch.cat([m.weight.detach() for m in layers], dim=0).contiguous()

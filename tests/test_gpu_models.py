@@ -389,6 +389,104 @@ def test_full_model_matches_the_reference_forward_golden(dev, ci):
     assert torch.allclose(gate.cpu(), case["gate"], atol=1e-5)
 
 
+def _g10_model_and_case(ci=0):
+    from isubgvqa_amd.models import build_model
+    from oracle import recipe as R
+    case = G10[ci]
+    c = case["cfg"]
+    args = _full_args(sampler_type=c["sampler"], sample_k=c["k"], mgat_layers=c["L"], mgat_masks=list(c["masks"]),
+                      interpretable_mode=c["interp"], text_vocab_size=c["text_vocab"], sg_vocab_size=c["sg_vocab"])
+    model = build_model(args, None).eval()
+    R.fill_state_dict(model, case["seed"])
+    return model, args, case
+
+
+def test_reference_layout_checkpoint_to_hip_forward_matches_the_reference_golden(dev, tmp_path):
+    """SURVEY 8(f) row 3 end to end on the GPU: a checkpoint in the reference's layout (DDP `module.` prefix on every key,
+    pickled argparse.Namespace, optimizer / scheduler / epoch entries: training/train_loop.py:84-130) holding the G10
+    recipe weights -> checkpoint.load_model (the reader behind run_token_coo.py:23-45, strict) -> HIP forward on G10's
+    inputs -> the logits and the top-k mask of the REFERENCE's own forward."""
+    from isubgvqa_amd.checkpoint import load_model
+    src, args, case = _g10_model_and_case(0)
+    del args.text_vocab_size, args.sg_vocab_size          # the reader takes them from the embedding tables
+    del args.nb_samples                                    # an older Namespace without this flag
+    args.device = "cuda"                                   # what a training run on a GPU box pickled
+    path = os.path.join(tmp_path, "checkpoint.pth")
+    torch.save({"model": {"module." + k: v for k, v in src.state_dict().items()}, "optimizer": {"state": {}},
+                "lr_scheduler": {"last_epoch": 3}, "epoch": 3, "args": args}, path)
+    del src
+    model, got_args, rest = load_model(path, device="cuda")
+    assert rest["epoch"] == 3 and got_args.nb_samples == 1 and not model.training
+    assert next(model.parameters()).is_cuda
+    t = lambda k: case[k].to(dev)
+    sg = argparse.Namespace(x_bbox=t("x_bbox"), added_sym_edge=t("added_sym_edge"))
+    noises = {i: n.to(dev) for i, n in case["noises"].items()} or None
+    with torch.no_grad():
+        logits, mask, gate, _, _ = model(t("x"), t("edge_index"), t("edge_attr"), t("batch"), t("questions"),
+                                         t("att_mask"), return_masks=True, scene_graphs=sg, noises=noises)
+    err = (logits.cpu() - case["logits"]).abs().max().item()
+    print(f"checkpoint -> HIP forward vs REFERENCE forward: max |logit diff| = {err:.3e}")
+    assert torch.equal(mask.cpu() > 0.5, case["mask"] > 0.5), "top-k node mask differs from the reference"
+    assert err < LOGIT_TOL
+
+
+def test_full_model_and_cfg2_step_run_under_inference_mode(dev):
+    """The reference evaluates under @torch.inference_mode() (run_token_coo.py:49).  Inference tensors have no version
+    counter (`._version` raises), which the row-maxima hand-off and the weight-plane caches used to read: both the full
+    model and the configs[1] step must run there and give the no_grad result bit for bit."""
+    from isubgvqa_amd import ops, synthetic
+    model, _, case = _g10_model_and_case(0)
+    model = model.to(dev)
+    t = lambda k: case[k].to(dev)
+    sg = argparse.Namespace(x_bbox=t("x_bbox"), added_sym_edge=t("added_sym_edge"))
+    noises = {i: n.to(dev) for i, n in case["noises"].items()} or None
+    call = lambda: model(t("x"), t("edge_index"), t("edge_attr"), t("batch"), t("questions"), t("att_mask"),
+                         return_masks=True, scene_graphs=sg, noises=noises)
+    with torch.no_grad():
+        want, want_mask = call()[:2]
+    ops.invalidate_weight_cache()          # the caches are rebuilt INSIDE inference mode: derived weights become inference tensors
+    with torch.inference_mode():
+        got, got_mask = call()[:2]
+        got2 = call()[0]                   # second call: cache hits on inference tensors
+    assert torch.equal(got, want) and torch.equal(got2, want) and torch.equal(got_mask, want_mask)
+    assert (got.cpu() - case["logits"]).abs().max().item() < LOGIT_TOL
+    ops.invalidate_weight_cache()
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": 96})
+    wl = synthetic.make_workload(cfg).to(dev)
+    net = synthetic.build_answer_model(cfg).to(dev).eval()
+    with torch.no_grad():
+        a = net(wl, seed=5)[0]
+    ops.invalidate_weight_cache()
+    with torch.inference_mode():
+        b = net(wl, seed=5)[0]
+        c = net(wl, seed=5)[0]
+    assert torch.equal(a, b) and torch.equal(a, c)
+    ops.invalidate_weight_cache()
+
+
+def test_long_questions_take_the_torch_attention_path_instead_of_raising(dev):
+    """isg_mha_small holds a head's K / V in 64 KB of LDS: at head_dim 64 that is 121 keys.  Sequences of 122..128 tokens
+    used to pass the Python guard (T <= 128) and raise ISG_EUNSUPPORTED; they must run (torch attention) and be counted."""
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.models import CLIPTextEmbeddings, QuestionDecoder, QuestionEncoder
+    assert ops.mha_small_supported(121, 64) and not ops.mha_small_supported(122, 64) and ops.mha_small_supported(128, 32)
+    torch.manual_seed(1)
+    enc = QuestionEncoder(CLIPTextEmbeddings(64, 512, 128), 512, 512, 8, 1024, 1, 0.1).to(dev).eval()
+    dec = QuestionDecoder(4, 512, 8, 1024, 1, 0.1).to(dev).eval()
+    for T, fused in ((121, True), (125, False)):
+        q = torch.randint(0, 64, (3, T), device=dev)
+        m = torch.ones(3, T, dtype=torch.long, device=dev)
+        ops.reset_counters()
+        with torch.no_grad():
+            e = enc(q, m)
+            d = dec(e)
+            want = dec.coarse_decoder(tgt=dec.query_embed.weight.unsqueeze(1).repeat(1, 3, 1),
+                                      memory=enc.transformer_encoder(enc.text_vocab_embedding(q).permute(1, 0, 2),
+                                                                     src_key_padding_mask=m.float()), tgt_mask=None)
+        assert (ops.counters()["torch_attention"] == 0) == fused, (T, ops.counters())
+        assert torch.allclose(d, want, atol=2e-4, rtol=1e-4), (T, (d - want).abs().max().item())
+
+
 def test_full_model_with_text_sampling(dev):
     """--text_sampling (isubgvqa.py:229-241): the SIMPLE sampler (k = mgat_layers) masks question tokens before the
     program decoder."""

@@ -1027,3 +1027,25 @@ def test_edge_logits_pair_is_deterministic_and_edge_order_invariant_at_full_size
     do = (o3 - o1).abs().max().item()
     print(f"pair at configs[1] size: permuted edges: max |alpha diff| {da:.2e}, max |out diff| {do:.2e}")
     assert da < 2e-6 and do < 2e-5
+
+
+def test_exact_split_linears_survive_rows_near_the_bottom_of_the_fp32_range(dev):
+    """h3_scale (csrc/isg_f16x3.hpp) builds 2^(140 - e) from a row's biased exponent e: for e <= 12 that does not fit an fp32
+    exponent -- at e = 12 the scale came out +inf and the row NaN, below that -0.0.  Rows (of the activation or of the
+    weight) around 3e-35 must come out as what they are: ~0, finite, and must not disturb their neighbours."""
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    for M, N, K in ((70000, 256, 128), (5000, 256, 512), (300, 64, 128)):     # panel f16x3, tile f16x3, bf16x6
+        x = torch.randn(M, K, device=dev, generator=g)
+        w = torch.randn(N, K, device=dev, generator=g) * 0.1
+        tiny = torch.tensor([3e-35, 2.5e-38, 4.6e-35, 1.2e-34, 0.0], device=dev)
+        x[:5] *= tiny[:, None]
+        w[:2] *= 3e-35
+        ops.invalidate_weight_cache()
+        y = ops.linear(x.clone(), w, None)
+        ref = (x.double() @ w.double().t()).float()
+        assert torch.isfinite(y).all(), (M, N, K)
+        assert (y[:5].abs().max() < 1e-30) and (y[:, :2].abs().max() < 1e-30)
+        scale = ref[5:, 2:].abs().max()
+        assert (y[5:, 2:] - ref[5:, 2:]).abs().max() < 2e-6 * scale * (K / 128) ** 0.5
+    ops.invalidate_weight_cache()
