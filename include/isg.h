@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 10
+#define ISG_ABI_VERSION 11
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -198,6 +198,35 @@ int isg_instr_attn_graphnorm_residual(const float *ins, const float *c, const fl
                                       double eps, const float *node_mask, float *h_out, int64_t B, int32_t C,
                                       void *stream);
 
+/* Tile plan of the fused per-layer kernels: consecutive graphs packed greedily into tiles of at most node_cap nodes (and,
+ * when eptr != NULL, edge_cap CSR slots); a graph larger than a cap gets a tile of its own (callers test the batch's bounds).
+ * tile_ptr int32[capacity + 1] receives the first graph of every tile and B behind the last; ntiles int32[1] the count (it
+ * stays on the device: kernels launch `capacity` workgroups).  isg_tile_plan_capacity() bounds the count from the sizes
+ * alone.  No reference counterpart: the reference's kernels are per-op, not per-layer. */
+int64_t isg_tile_plan_capacity(int64_t N, int64_t E, int64_t B, int32_t node_cap, int32_t edge_cap);
+int isg_tile_plan(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
+                  int32_t *tile_ptr, int32_t *ntiles, int64_t capacity, void *stream);
+
+/* The dense back half of one MGAT layer and the first line of the next as ONE launch on graph-aligned 64-row tiles
+ * (isg_tile_plan with node_cap = 64):   ISubGVQA/models/mgat.py:156-177, mgat_v2_conv.py:156-157
+ *   c = gelu(x_proj.2(gelu(x_proj.0(conv_out))));  c = scatter_attention(ins, c, c);  c = GraphNorm(c);
+ *   h_out = c + h;  h_out *= node_mask (optional);  xg_out = gelu(h_out * ins_next[batch]) (optional)
+ * conv_out fp32[N,K1] (row stride lda) with a_rowmax fp32[N,P] (row stride ldp) = partial maxima of |conv_out| per row (what
+ * isg_gatv2_mp_fwd_rowmax / _logits leave); w1 / w2: isg_split_f16x2_frag planes + inverse scales of x_proj.0.weight [MID,K1]
+ * and x_proj.2.weight [C,MID]; b1 fp32[MID], b2 fp32[C]; y_bound fp32[2] = {max_j sum_k |w1[j,k]|, max_j |b1[j]|} (the
+ * intermediate's row scales come from |x_proj.0(a)_ij| <= max_k |a_ik| * y_bound[0] + y_bound[1]); ins / ins_next fp32[B,C]; h, h_out, xg_out fp32[N,C] (h_out must not
+ * alias h); batch int64[N].  Arithmetic of the tail: isg_instr_attn_graphnorm_residual's.  ISG_EUNSUPPORTED unless
+ * K1 = 512, MID = 256, C = 128 (BASELINE configs[1]); graphs beyond 64 nodes are truncated to the tile (callers test
+ * the batch's bound first). */
+int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const float *a_rowmax, int32_t P, int32_t ldp,
+                        const uint16_t *w1_frag, const float *w1_inv_scale, const float *b1, const float *y_bound,
+                        const uint16_t *w2_frag,
+                        const float *w2_inv_scale, const float *b2, const float *ins, const float *h,
+                        const float *gn_weight, const float *gn_bias, const float *gn_mean_scale, double eps,
+                        const float *node_mask, const float *ins_next, float *h_out, float *xg_out, const int32_t *ptr,
+                        const int64_t *batch, const int32_t *tile_ptr, const int32_t *ntiles, int64_t max_tiles, int64_t N,
+                        int32_t K1, int32_t MID, int32_t C, void *stream);
+
 /* Question-conditioned softmax pooling: GlobalAttention.forward, ISubGVQA/models/att_pooling.py:63-73
  *   x = xn * node_mask;  gate = softmax_g(<x, q[g]>/sqrt(C)) (+1e-16 in the denominator);
  *   out[g,:] = sum_n gate[n] * x[n,:]
@@ -322,21 +351,6 @@ int isg_gatv2_mp_fwd_logits(const float *x_l, const float *logits, const float *
                             int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
                             const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
                             int32_t emax_host, int32_t ld_l, void *stream);
-
-/* isg_gatv2_mp_fwd with the edge projection computed inside the kernel (csrc/isg_mp_fused.hip): instead of
- * e_proj = lin_edge(edge_attr) [E, H*C] (mgat_v2_conv.py:259-261) it takes edge_attr fp32 [E, K] (row stride ld_ea) and
- * the fragment-major bf16 planes of lin_edge.weight [H*C, K] (isg_split_bf16x3_frag); a graph's e_proj tile is formed on
- * the matrix cores (same six-term bf16 arithmetic as isg_linear_panel) and consumed from registers: e_proj never exists
- * in HBM.  Same outputs as isg_gatv2_mp_fwd (alpha differs only in the summation order of the logit).  Per-graph form
- * only: graph_ptr / graph_eptr / dst and the host bounds are required.  ISG_EUNSUPPORTED (caller uses the un-fused
- * path) unless C == 128, H even, K <= 128, 4 | K, graphs within 64 nodes / 256 edges. */
-int isg_gatv2_mp_fused_edge_fwd(const float *x_l, const float *x_r, const float *edge_attr, const uint16_t *w_frag,
-                                const float *att, const float *bias, const int32_t *rowptr, const int32_t *eid,
-                                const int32_t *src, const float *node_mask, const float *edge_mask, float *out,
-                                float *alpha, int64_t N, int64_t E, int32_t H, int32_t C, int32_t K, float negative_slope,
-                                const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst, int64_t B,
-                                int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_ea,
-                                void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense projections (fp32 accuracy on the bf16 matrix cores)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -30,9 +30,6 @@ SIGNATURES = {
                                  c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_gatv2_mp_fwd_f16": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "isg_gatv2_mp_fused_edge_fwd": (c_int, [c_void_p] * 13 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p,
-                                            c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                            c_void_p]),
     "isg_graph_edge_ptr": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "isg_scatter_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
@@ -92,6 +89,10 @@ SIGNATURES = {
     "isg_linear_f16x3_tile": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_row_absmax": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "isg_tile_plan_capacity": (c_int64, [c_int64, c_int64, c_int64, c_int32, c_int32]),
+    "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "isg_mgat_dense_tail": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32] + [c_void_p] * 12 + [c_double] +
+                            [c_void_p] * 8 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

@@ -68,9 +68,57 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
 
-// exact (erf) GELU, the torch.nn.functional.gelu default used everywhere in the reference
+// exact (erf) GELU, the torch.nn.functional.gelu default used everywhere in the reference: 0.5 x (1 + erf(x / sqrt 2)).
+// GELU epilogues are VALU-bound (profiles/r03_c_dense_tail_stamps.txt: libm's erff is ~60 instructions with both of its
+// branches live in a wave), so the factor 1 + erf is formed without erf:  with t = |x| / sqrt 2 and e = erfc(t),
+//     1 + erf(x / sqrt 2) = 2 - e  (x > 0),   = e  (x <= 0)                     [no cancellation on the negative side]
+// and e = exp2(t R(t)) with ONE degree-8 polynomial R on [0, 6] (weighted minimax fit of log2 erfc, |e - erfc| < 3e-9 in exact
+// arithmetic) and the hardware exponential v_exp_f32.  Absolute accuracy is what the 1 + erf form can use: measured in fp32
+// against a float64 GELU over [-12, 12], |error| / max(|x|, 1) <= 1.2e-7 (the libm formula: 1.1e-7), <= 4 ulp for x > 0, and
+// 5x closer than the libm formula for x < 0 (which loses erf's bits in 1 + erf).  Beyond t = 6 (|x| > 8.5) e < 2e-17.
+// Written on float pairs so that the polynomial runs on v_pk_fma_f32.  -DISG_GELU_LIBM restores libm's erff (A/B).
+typedef float isg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ isg_f32x2 gelu_exact2(isg_f32x2 x) {
+#ifdef ISG_GELU_LIBM
+  return isg_f32x2{0.5f * x.x * (1.0f + erff(x.x * 0.70710678118654752440f)),
+                   0.5f * x.y * (1.0f + erff(x.y * 0.70710678118654752440f))};
+#else
+  isg_f32x2 t = isg_f32x2{fabsf(x.x), fabsf(x.y)} * 0.70710678118654752440f;
+  t = isg_f32x2{fminf(t.x, 6.0f), fminf(t.y, 6.0f)};
+  isg_f32x2 r = isg_f32x2{1.1604608516790904e-05f, 1.1604608516790904e-05f};
+  r = r * t + (-0.00015296229685191065f);
+  r = r * t + 0.0008482258417643607f;
+  r = r * t + (-0.002274767030030489f);
+  r = r * t + 8.478287054458633e-05f;
+  r = r * t + 0.02772449143230915f;
+  r = r * t + (-0.1483079195022583f);
+  r = r * t + (-0.9184429049491882f);
+  r = r * t + (-1.6279072761535645f);
+  const isg_f32x2 q = r * t;
+  const float e0 = __builtin_amdgcn_exp2f(q.x), e1 = __builtin_amdgcn_exp2f(q.y);
+  const isg_f32x2 fac = isg_f32x2{x.x > 0.f ? 2.0f - e0 : e0, x.y > 0.f ? 2.0f - e1 : e1};
+  return (x * 0.5f) * fac;
+#endif
+}
+// libm form: the node gate's scores decide the top-k masks (bit-exact vs the CPU path), one value per node: not worth a ulp
+__device__ __forceinline__ float gelu_libm(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_exact(float x) {
+#ifdef ISG_GELU_LIBM
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+#else
+  const float t = fminf(fabsf(x) * 0.70710678118654752440f, 6.0f);
+  float r = 1.1604608516790904e-05f;
+  r = fmaf(r, t, -0.00015296229685191065f);
+  r = fmaf(r, t, 0.0008482258417643607f);
+  r = fmaf(r, t, -0.002274767030030489f);
+  r = fmaf(r, t, 8.478287054458633e-05f);
+  r = fmaf(r, t, 0.02772449143230915f);
+  r = fmaf(r, t, -0.1483079195022583f);
+  r = fmaf(r, t, -0.9184429049491882f);
+  r = fmaf(r, t, -1.6279072761535645f);
+  const float e = __builtin_amdgcn_exp2f(r * t);
+  return (0.5f * x) * (x > 0.f ? 2.0f - e : e);
+#endif
 }
 
 // ---- Philox4x32-10 counter RNG (in-kernel noise when the caller passes none) ---------------------

@@ -517,7 +517,10 @@ __global__ __launch_bounds__(512, 4) void linear_f16x3_tile_kernel(const float *
         v.z += cc + 2 < N ? bias[cc + 2] : 0.f;
         v.w += cc + 3 < N ? bias[cc + 3] : 0.f;
       }
-      if (ACT == 1) { v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w); }
+      if (ACT == 1) {
+        const isg_f32x2 g0 = gelu_exact2(isg_f32x2{v.x, v.y}), g1 = gelu_exact2(isg_f32x2{v.z, v.w});
+        v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;
+      }
       if (ACT == 2) {     // ReLU (a NaN stays a NaN, as in torch)
         v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
       }

@@ -210,11 +210,8 @@ __global__ void instr_gate_kernel(const float4 *__restrict__ x, const float4 *__
   int q = (int)(idx - n * Q);
   int64_t b = batch[n];
   float4 v = x[idx], w = instr[b * Q + q];
-  v.x = gelu_exact(v.x * w.x);
-  v.y = gelu_exact(v.y * w.y);
-  v.z = gelu_exact(v.z * w.z);
-  v.w = gelu_exact(v.w * w.w);
-  out[idx] = v;
+  const isg_f32x2 g0 = gelu_exact2(isg_f32x2{v.x * w.x, v.y * w.y}), g1 = gelu_exact2(isg_f32x2{v.z * w.z, v.w * w.w});
+  out[idx] = make_float4(g0.x, g0.y, g1.x, g1.y);
 }
 
 __global__ void node_to_edge_mask_kernel(const float *__restrict__ mask, const int64_t *__restrict__ ei, int64_t E,

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void node_gate_kernel(const float4 *__restrict
     for (int c = l; c < Q; c += 16) part += dot4(xr[c], qr[c]);
   }
   const float dot = group_sum<16>(part);
-  if (n < N && l == 0) gate[n] = gelu_exact(dot / denom);
+  if (n < N && l == 0) gate[n] = gelu_libm(dot / denom);
 }
 
 // ---- row access shared by both samplers -----------------------------------------------------------------

@@ -78,25 +78,28 @@ class MGAT(torch.nn.Module):
         # edge_attr into its bf16 planes once and writes one dense [E, H*C] tensor per layer (isg_linear_panel_multi)
         e_projs = None
         fused = (edge_attr.dim() == 2 and self.convs[0].feature_dtype == torch.float32 and not torch.is_grad_enabled()
-                 and (ops.fused_edge_supported(plan, self.heads, self.convs[0].out_channels, edge_attr.size(1)) or
-                      ops.fused_logits_supported(plan, self.heads, self.convs[0].out_channels, edge_attr.size(1))))
+                 and ops.fused_logits_supported(plan, self.heads, self.convs[0].out_channels, edge_attr.size(1)))
         if (not fused and not torch.is_grad_enabled() and all(c.lin_edge is not None for c in self.convs)
                 and edge_attr.dim() == 2):
             e_projs = ops.linear_multi(edge_attr, [c.lin_edge.weight for c in self.convs],
                                        out_dtype=self.convs[0].feature_dtype)
-        for i in range(len(self.convs)):
+        L = len(self.convs)
+        wide = self.heads * self.convs[0].out_channels
+        x_gated = None        # gelu(h * ins_i[batch]) when the previous layer's fused tail has written it
+        for i in range(L):
             ins = instr_vectors[i].contiguous()
             if explainer:
                 h = expl_bypass_x if (explainer_stage - 1) == i else h                   # :140-141
+                x_gated = None
             conv_res, mask, edge_att = self.convs[i](
                 x=h, edge_index=edge_index, edge_attr=edge_attr, instruction=ins, batch=batch,
                 return_masks=return_masks, return_attention_weights=True, imle_att=glf, all_instrs=instr_vectors,
                 plan=plan, noise=None if noises is None else noises.get(i),
                 seed=None if seed is None else seed + i,
-                e_proj=None if e_projs is None else e_projs[i])                          # :144-154
+                e_proj=None if e_projs is None else e_projs[i], x_gated=x_gated)         # :144-154
+            x_gated = None
             if return_attention:
                 edge_attns.append(edge_att)
-            conv_res = ops.mlp(self.x_proj[i], conv_res)                                 # :156 (Linear+GELU fused)
             tail_mask = None
             if self.use_global_mask:                                                     # :161-162,174-175
                 global_mask = mask if global_mask is None else mask * global_mask
@@ -104,6 +107,17 @@ class MGAT(torch.nn.Module):
             elif self.interpretable_mode and mask is not None:                           # :176-177
                 tail_mask = mask
             bn = self.bns[i]
+            if (conv_res.dtype == torch.float32 and not explainer
+                    and ops.dense_tail_supported(plan, self.x_proj[i], wide, self.convs[0].out_channels)):
+                # x_proj + instruction attention + GraphNorm + residual (+ mask) + the NEXT layer's instruction gate: one
+                # launch on graph-aligned row tiles (csrc/isg_layer_tile.hip); :156-177 and mgat_v2_conv.py:156-157
+                nxt = instr_vectors[i + 1].contiguous() if i + 1 < L and self.convs[i + 1].use_instr else None
+                res = ops.mgat_dense_tail(conv_res, self.x_proj[i], ins, h, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
+                                          node_mask=tail_mask, ins_next=nxt)
+                if res is not None:
+                    h, x_gated = res
+                    continue
+            conv_res = ops.mlp(self.x_proj[i], conv_res)                                 # :156 (Linear+GELU fused)
             h = ops.mgat_layer_tail(ins, conv_res.contiguous(), h, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
                                     node_mask=tail_mask)                                 # :168-177
         if return_attention:

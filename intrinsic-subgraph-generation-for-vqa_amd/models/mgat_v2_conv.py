@@ -80,7 +80,7 @@ class MaskingGATv2Conv(torch.nn.Module):
                 instruction: Optional[Tensor] = None, imle_att: Optional[Tensor] = None,
                 return_attention_weights: bool = None, return_masks: bool = None, all_instrs=None,
                 plan: Optional[ops.GraphPlan] = None, noise: Optional[Tensor] = None, seed: Optional[int] = None,
-                e_proj: Optional[Tensor] = None):
+                e_proj: Optional[Tensor] = None, x_gated: Optional[Tensor] = None):
         H, C = self.heads, self.out_channels
         if x.dim() != 2:
             raise ValueError("x must be [N, C]")
@@ -89,9 +89,13 @@ class MaskingGATv2Conv(torch.nn.Module):
         if plan is None:
             plan = ops.GraphPlan.build(batch, edge_index,
                                        num_graphs=None if instruction is None else instruction.size(0))
-        x = x.float().contiguous()
-        if self.use_instr:
-            x = ops.instr_gate(x, instruction.contiguous(), batch, plan=plan)            # :156-157
+        if x_gated is not None and self.use_instr:
+            # gelu(x * instruction[batch]) was already written by the previous layer's fused tail (isg_mgat_dense_tail)
+            x = x_gated
+        else:
+            x = x.float().contiguous()
+            if self.use_instr:
+                x = ops.instr_gate(x, instruction.contiguous(), batch, plan=plan)        # :156-157
 
         mask = None
         if self.mask.masking_threshold != 1.0:                                           # :161
@@ -101,8 +105,7 @@ class MaskingGATv2Conv(torch.nn.Module):
         fdt = self.feature_dtype
         inference32 = (e_proj is None and edge_attr is not None and self.lin_edge is not None and edge_attr.dim() == 2
                        and fdt == torch.float32 and not torch.is_grad_enabled())
-        fuse = inference32 and ops.fused_edge_supported(plan, H, C, edge_attr.size(1))        # opt-in experiment (off)
-        pair = inference32 and not fuse and ops.fused_logits_supported(plan, H, C, edge_attr.size(1))
+        pair = inference32 and ops.fused_logits_supported(plan, H, C, edge_attr.size(1))
         # with the edge-logits pair, x_r = lin_r(x) can be formed inside the logit kernel too (it is used nowhere else):
         # then only lin_l is projected here
         xr_inside = pair and ops.FUSE_XR and not self.share_weights and x.size(1) <= 128 and x.size(1) % 4 == 0
@@ -112,13 +115,6 @@ class MaskingGATv2Conv(torch.nn.Module):
             x_l = x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt)  # :177-179
         else:   # lin_l and lin_r share their input: one [N, 2*H*C] projection, x_l / x_r are its column halves
             x_l, x_r = ops.linear_fused(x, (self.lin_l, self.lin_r), out_dtype=fdt)      # :177,181
-        if fuse:      # lin_edge inside the message-passing kernel: its [E, H*C] output never exists (csrc/isg_mp_fused.hip)
-            out, alpha = ops.gatv2_mp_fused_edge(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att,
-                                                 plan, H, bias=self.bias, node_mask=mask,
-                                                 negative_slope=self.negative_slope)    # :215-232, :259-261
-            if isinstance(return_attention_weights, bool):
-                return out, mask, (edge_index, alpha)
-            return out, mask
         if pair:
             # lin_edge (and lin_r) folded into the logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is neither written nor read
             res = ops.gatv2_mp_edge_logits(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att, plan, H,

@@ -178,6 +178,28 @@ class GraphPlan:
     edge_index: Optional[Tensor] = None      # kept for the lazily built CSR by source (backward only)
     _by_src: Optional[Tuple[Tensor, Tensor, Tensor]] = None
     _slots: Optional[Tensor] = None
+    _tiles: Optional[dict] = None
+
+    def tiles(self, node_cap: int = 64, edge_cap: int = 0) -> Tuple[Tensor, Tensor, int]:
+        """(tile_ptr int32[cap + 1], ntiles int32[1] on the device, cap): consecutive graphs packed greedily into tiles of
+        at most `node_cap` nodes (and `edge_cap` CSR slots when > 0) -- the M-tiles of the fused per-layer kernels
+        (csrc/isg_layer_tile.hip).  Tile t owns graphs tile_ptr[t] .. tile_ptr[t + 1]; the count stays on the device (no
+        sync): kernels are launched with `cap` workgroups, the ones beyond *ntiles return at once.  Built on first use."""
+        key = (int(node_cap), int(edge_cap))
+        if self._tiles is None:
+            self._tiles = {}
+        hit = self._tiles.get(key)
+        if hit is None:
+            lib = _lib.load()
+            if edge_cap > 0:
+                self.require_csr()
+            cap = int(lib.isg_tile_plan_capacity(self.N, self.E, self.B, key[0], key[1]))
+            buf = torch.empty(cap + 2, dtype=torch.int32, device=self.ptr.device)
+            _lib.check(lib.isg_tile_plan(self.ptr.data_ptr(), self.eptr.data_ptr() if edge_cap > 0 else 0, self.B, key[0],
+                                         key[1], buf.data_ptr(), buf[cap + 1:].data_ptr(), cap, _stream()), "isg_tile_plan")
+            hit = (buf[:cap + 1], buf[cap + 1:], cap)
+            self._tiles[key] = hit
+        return hit
 
     def source_csr(self) -> Tuple[Tensor, Tensor, Tensor]:
         """(rowptr_s[N+1], eid_s[E], dst_s[E]): out-edges of every node in edge-id order.  Only the backward of the
@@ -523,52 +545,7 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Optional[Tensor], edge_attr: Tensor, 
     return out, alpha
 
 
-# lin_edge inside the message-passing kernel (csrc/isg_mp_fused.hip).  OFF by default: correct (tests) but slower than the
-# un-fused pair at configs[1] (632 us vs 377 us; profiles/r02_d_fused_edge.md says where the time goes) -- kept as the
-# starting point of that work, switchable for A/B runs
-FUSE_EDGE = False
 ISG_EUNSUPPORTED = -2      # include/isg.h
-
-
-def fused_edge_supported(plan: GraphPlan, heads: int, channels: int, edge_dim: int) -> bool:
-    """Shape test of isg_gatv2_mp_fused_edge_fwd (csrc/isg_mp_fused.hip)."""
-    return (FUSE_EDGE and MP_KERNEL == "graph" and channels == 128 and heads % 2 == 0 and edge_dim <= 128 and
-            edge_dim % 4 == 0 and plan.B > 0 and 0 < plan.nmax <= 64 and plan.emax <= 256 and plan.rowptr is not None)
-
-
-def gatv2_mp_fused_edge(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: GraphPlan,
-                        heads: int, bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None,
-                        edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2) -> Tuple[Tensor, Tensor]:
-    """gatv2_mp(x_l, x_r, lin_edge(edge_attr), ...) without ever writing lin_edge's output (inference, fp32 rows;
-    mgat_v2_conv.py:243-279 with :259-261 inside).  The caller checks fused_edge_supported() first."""
-    lib = _lib.load()
-    N, HC = x_l.shape
-    H = int(heads)
-    C = HC // H
-    E, K = edge_attr.shape
-    if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K) or tuple(x_r.shape) != (N, HC):
-        raise ValueError("gatv2_mp_fused_edge: operand shapes do not match the plan")
-    planes = _weight_planes(w_edge, True, "panel")
-    out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
-    alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
-    timer = MP_TIMER
-    if timer is not None:     # bench.py: the roofline keeps the UN-fused algorithmic bytes (SURVEY §8d: do not re-base)
-        ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None,
-                                  "feat_bytes": 4, "fused_edge": True})
-        ev0.record()
-    _lib.check(lib.isg_gatv2_mp_fused_edge_fwd(
-        _chk_rows(x_l, "x_l"), _chk_rows(x_r, "x_r"), _chk_rows(edge_attr, "edge_attr") if E > 0 else 0,
-        planes.data_ptr(), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
-        _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
-        plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
-        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
-        _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
-        out.data_ptr(), alpha.data_ptr(), N, E, H, C, K, float(negative_slope), plan.ptr.data_ptr(), plan.eptr.data_ptr(),
-        plan.dst.data_ptr(), plan.B, plan.nmax, plan.emax, x_l.stride(0), x_r.stride(0), edge_attr.stride(0), _stream()),
-        "isg_gatv2_mp_fused_edge_fwd")
-    if timer is not None:
-        ev1.record()
-    return out, alpha
 
 
 def gatv2_mp_backward(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, alpha: Tensor, grad_out: Tensor,
@@ -892,6 +869,63 @@ def mgat_layer_tail(ins: Tensor, c: Tensor, h: Tensor, plan: GraphPlan, weight: 
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
         out.data_ptr(), plan.B, C, _stream()), "isg_instr_attn_graphnorm_residual")
     return out
+
+
+FUSE_DENSE_TAIL = True    # x_proj + layer tail + next instruction gate as one kernel on graph-aligned tiles (A/B switch)
+DENSE_TAIL_ROWS = 64      # nodes per tile of isg_mgat_dense_tail
+
+
+def dense_tail_supported(plan: GraphPlan, x_proj: torch.nn.Sequential, width_in: int, channels: int) -> bool:
+    """Shape test of isg_mgat_dense_tail (csrc/isg_layer_tile.hip): inference, fp32, Linear(512 -> 256) GELU Linear(256 ->
+    128) GELU (MGAT at C = 128, H = 4: BASELINE configs[1]), every graph within one 64-node tile."""
+    if not (FUSE_DENSE_TAIL and GEMM_BACKEND == "bf16x6" and GEMM_F16X3) or torch.is_grad_enabled():
+        return False
+    mods = list(x_proj)
+    if len(mods) != 4 or not all(isinstance(m, torch.nn.GELU) and m.approximate == "none" for m in (mods[1], mods[3])):
+        return False
+    l0, l2 = mods[0], mods[2]
+    if not (isinstance(l0, torch.nn.Linear) and isinstance(l2, torch.nn.Linear)) or l0.bias is None or l2.bias is None:
+        return False
+    return (width_in == 512 and channels == 128 and tuple(l0.weight.shape) == (256, 512) and
+            tuple(l2.weight.shape) == (128, 256) and plan.B > 0 and 0 < plan.nmax <= DENSE_TAIL_ROWS and plan.batch is not None)
+
+
+def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, h: Tensor, plan: GraphPlan, weight: Tensor,
+                    bias: Tensor, mean_scale: Tensor, eps: float = 1e-5, node_mask: Optional[Tensor] = None,
+                    ins_next: Optional[Tensor] = None) -> Optional[Tuple[Tensor, Optional[Tensor]]]:
+    """mgat.py:156-177 after the convolution, plus the next layer's instruction gate (mgat_v2_conv.py:156-157), as one launch:
+    x_proj (Linear GELU Linear GELU) -> scatter attention -> GraphNorm -> + h [-> * mask] -> (h', gelu(h' * ins_next[batch])).
+    conv_out must carry its row maxima (the message-passing kernels leave them); returns None when it does not (the caller
+    runs the un-fused chain).  The caller checks dense_tail_supported() first."""
+    lib = _lib.load()
+    N, K1 = conv_out.shape
+    rm = row_maxima(conv_out)
+    if rm is None or rm.dim() != 2 or rm.size(0) != N or rm.stride(1) != 1 or rm.dtype != torch.float32:
+        return None
+    l0, l2 = x_proj[0], x_proj[2]
+    C = l2.weight.size(0)
+    p1, inv1 = _weight_planes(l0.weight, True, "f16x3")
+    p2, inv2 = _weight_planes(l2.weight, True, "f16x3")
+    ybound = derived_weight("dense_tail_bound", (l0.weight, l0.bias), lambda: torch.stack(
+        [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
+    tile_ptr, ntiles, cap = plan.tiles(DENSE_TAIL_ROWS)
+    h_out = torch.empty_like(h)
+    xg = torch.empty_like(h) if ins_next is not None else None
+    rc = lib.isg_mgat_dense_tail(
+        _chk_rows(conv_out, "conv_out"), conv_out.stride(0), rm.data_ptr(), rm.size(1), rm.stride(0),
+        p1.data_ptr(), inv1.data_ptr(), _chk(l0.bias.detach(), "x_proj.0.bias", torch.float32, (l0.weight.size(0),)),
+        ybound.data_ptr(), p2.data_ptr(), inv2.data_ptr(), _chk(l2.bias.detach(), "x_proj.2.bias", torch.float32, (C,)),
+        _chk(ins, "ins", torch.float32, (plan.B, C)), _chk(h, "h", torch.float32, (plan.N, C)),
+        _chk(weight.detach(), "weight", torch.float32, (C,)), _chk(bias.detach(), "bias", torch.float32, (C,)),
+        _chk(mean_scale.detach(), "mean_scale", torch.float32, (C,)), float(eps),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        _chk(ins_next, "ins_next", torch.float32, (plan.B, C), optional=True), h_out.data_ptr(),
+        0 if xg is None else xg.data_ptr(), plan.ptr.data_ptr(), _chk(plan.batch, "batch", torch.int64, (N,)),
+        tile_ptr.data_ptr(), ntiles.data_ptr(), cap, N, K1, l0.weight.size(0), C, _stream())
+    if rc == ISG_EUNSUPPORTED:
+        return None
+    _lib.check(rc, "isg_mgat_dense_tail")
+    return h_out, xg
 
 
 def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional[Tensor] = None):

@@ -568,58 +568,6 @@ def test_linear_multi_equals_the_separate_projections(dev):
     assert ops.linear_multi(x[:100], ws) is None            # too few rows for the panel kernel: caller falls back
 
 
-@pytest.mark.parametrize("mask", [None, "node", "edge"])
-@pytest.mark.parametrize("K", [128, 36])
-def test_fused_edge_message_passing_matches_the_unfused_kernel(dev, mask, K, monkeypatch):
-    """isg_gatv2_mp_fused_edge_fwd (lin_edge on the matrix cores inside the per-graph kernel) against the un-fused pair
-    isg_linear_panel / isg_linear_bf16x6 + isg_gatv2_mp_fwd and against the oracle, incl. graphs with more than 64 edges
-    (two MFMA blocks), isolated targets, a 1-node graph and rows beyond the 22-row LDS window."""
-    from isubgvqa_amd import ops
-    from oracle import model as OM
-    gen = torch.Generator().manual_seed(50 + K)
-    sizes = [20, 1, 37, 5, 64, 23, 2, 30]
-    H, C = 4, 128
-    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
-    src, dst, off = [], [], 0
-    for n in sizes:
-        for v in range(n):
-            if not (n == 5 and v == 4):                 # one isolated target
-                src.append(off + v); dst.append(off + v)
-        m = 0 if n == 1 else int(torch.randint(n, 4 * n, (1,), generator=gen))
-        m = min(m, 250 - n)
-        a_ = torch.randint(0, n, (m,), generator=gen); b_ = torch.randint(0, n, (m,), generator=gen)
-        if n == 5:
-            b_ = b_.clamp(max=3)
-        src += (off + a_).tolist(); dst += (off + b_).tolist()
-        off += n
-    ei = torch.tensor([src, dst])
-    ei = ei[:, torch.randperm(ei.size(1), generator=gen)]
-    N, E = batch.numel(), ei.size(1)
-    x_l, x_r = torch.randn(N, H * C, generator=gen), torch.randn(N, H * C, generator=gen)
-    ea = torch.randn(E, K, generator=gen)
-    w = torch.randn(H * C, K, generator=gen) / K ** 0.5
-    att, bias = torch.randn(1, H, C, generator=gen), torch.randn(H * C, generator=gen)
-    nm = (torch.rand(N, generator=gen) < 0.6).float() if mask == "node" else None
-    em = (torch.rand(E, generator=gen) < 0.6).float() if mask == "edge" else None
-    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
-    monkeypatch.setattr(ops, "FUSE_EDGE", True)            # off by default (slower than the un-fused pair so far)
-    assert plan.emax > 64 and ops.fused_edge_supported(plan, H, C, K)
-    t = lambda v: None if v is None else v.to(dev)
-    wd = w.to(dev)
-    out_f, alpha_f = ops.gatv2_mp_fused_edge(t(x_l), t(x_r), t(ea), wd, t(att), plan, H, bias=t(bias), node_mask=t(nm),
-                                             edge_mask=t(em))
-    e_proj = ops.linear(t(ea), wd)
-    out_u, alpha_u = ops.gatv2_mp(t(x_l), t(x_r), e_proj, t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em))
-    assert torch.allclose(alpha_f, alpha_u, atol=2e-6, rtol=1e-5), (alpha_f - alpha_u).abs().max()
-    assert torch.allclose(out_f, out_u, atol=2e-5, rtol=1e-5), (out_f - out_u).abs().max()
-    emask = em if em is not None else (None if nm is None else nm[ei[0]] * nm[ei[1]])
-    ref_out, ref_alpha = OM.gatv2_message_passing(x_l.view(N, H, C), x_r.view(N, H, C),
-                                                  torch.nn.functional.linear(ea, w).view(E, H, C), att, ei,
-                                                  None if emask is None else emask.view(E, 1), 0.2)
-    assert torch.allclose(alpha_f.cpu(), ref_alpha, atol=2e-6, rtol=1e-5)
-    assert torch.allclose(out_f.cpu(), ref_out.reshape(N, H * C) + bias, atol=2e-5, rtol=1e-5)
-
-
 @pytest.mark.parametrize("scale,spread", [(1.0, 1.0), (1e-3, 1e-4), (300.0, 1e3), (1e-20, 1.0)])
 def test_linear_f16x3_keeps_fp32_accuracy_over_the_dynamic_range(dev, scale, spread, monkeypatch):
     """isg_linear_f16x3 scales every row by a power of two before the fp16 split: tiny and huge magnitudes, and rows whose
@@ -1049,3 +997,149 @@ def test_exact_split_linears_survive_rows_near_the_bottom_of_the_fp32_range(dev)
         scale = ref[5:, 2:].abs().max()
         assert (y[5:, 2:] - ref[5:, 2:]).abs().max() < 2e-6 * scale * (K / 128) ** 0.5
     ops.invalidate_weight_cache()
+
+
+# ------------------------------------------------------------------------------- graph-aligned tiles (isg_layer_tile.hip)
+def _greedy_tiles(sizes, edges, ncap, ecap, chunk=1024):
+    """Host restatement of isg_tile_plan: greedy packing, a chunk of 1024 graphs closes a tile, a graph larger than a cap is
+    a tile of its own."""
+    starts, g, B = [], 0, len(sizes)
+    while g < B:
+        end_chunk = min((g // chunk + 1) * chunk, B)
+        starts.append(g)
+        n, e, k = sizes[g], edges[g], g + 1
+        while k < end_chunk and n + sizes[k] <= ncap and (ecap <= 0 or e + edges[k] <= ecap):
+            n += sizes[k]; e += edges[k]; k += 1
+        g = k
+    return starts + [B]
+
+
+@pytest.mark.parametrize("case", ["cfg2", "tiny", "mixed", "oversize", "one", "edges"])
+def test_tile_plan_is_the_greedy_packing(dev, case):
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    if case == "cfg2":
+        sizes = torch.randint(8, 34, (4096,), generator=gen).tolist()
+    elif case == "tiny":
+        sizes = torch.randint(0, 3, (2500,), generator=gen).tolist()            # empty graphs, > 2 chunks of 1024
+    elif case == "mixed":
+        sizes = torch.randint(1, 65, (1500,), generator=gen).tolist()
+    elif case == "oversize":
+        sizes = [5, 70, 3, 64, 1, 200, 2, 2]
+    elif case == "one":
+        sizes = [17]
+    else:
+        sizes = torch.randint(4, 30, (700,), generator=gen).tolist()
+    batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5)
+    B = len(sizes)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+    ecount = torch.bincount(batch[ei[1]], minlength=B).tolist()
+    for ncap, ecap in ((64, 0),) + (((64, 160), (48, 96)) if case in ("edges", "cfg2") else ()):
+        tile_ptr, ntiles, cap = plan.tiles(ncap, ecap)
+        want = _greedy_tiles(sizes, ecount, ncap, ecap)
+        T = int(ntiles.item())
+        assert T == len(want) - 1 and T <= cap, (case, T, len(want) - 1, cap)
+        assert tile_ptr.cpu().tolist()[:T + 1] == want
+
+
+def _dense_tail_case(dev, sizes, seed, masked, with_next):
+    """The fused dense tail against the un-fused chain on the same inputs, and both against the CPU oracle's layer."""
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.models import MGAT
+    from oracle import model as OM
+    from oracle import primitives as P
+    gen = torch.Generator().manual_seed(seed)
+    H, C = 4, 128
+    batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.0)
+    N, B = batch.numel(), len(sizes)
+    torch.manual_seed(seed)
+    m = MGAT(channels=C, num_ins=1, heads=H, use_instr=True, masking_thresholds=[1.0], use_topk=True)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if "bns" in name or name.endswith(".bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    conv_out = torch.randn(N, H * C, generator=gen) * torch.rand(N, 1, generator=gen).mul(3).exp()     # rows over 3 binades
+    h = torch.randn(N, C, generator=gen)
+    ins = torch.randn(B, C, generator=gen)
+    ins_next = torch.randn(B, C, generator=gen) if with_next else None
+    mask = (torch.rand(N, generator=gen) < 0.6).float() if masked else None
+    # CPU oracle (mgat.py:156-177 + mgat_v2_conv.py:156-157)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    c = P.gelu(OM.linear(sd, "x_proj.0.0", conv_out))
+    c = P.gelu(OM.linear(sd, "x_proj.0.2", c))
+    c = OM.scatter_scaled_dot_product_attention(ins, c, c, batch, B)
+    c = P.graph_norm(c, batch, sd["bns.0.weight"], sd["bns.0.bias"], sd["bns.0.mean_scale"], 1e-5, num_graphs=B)
+    want_h = c + h
+    if masked:
+        want_h = mask[:, None] * want_h
+    want_xg = P.gelu(want_h * ins_next[batch]) if with_next else None
+    m = m.to(dev)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+    d = lambda t: None if t is None else t.to(dev)
+    co = d(conv_out)
+    rm = co.view(N, H, C).abs().amax(dim=2).contiguous()
+    bn = m.bns[0]
+    with torch.no_grad():
+        supported = ops.dense_tail_supported(plan, m.x_proj[0], H * C, C)
+        assert supported == (max(sizes) <= 64)
+        if not supported:
+            return None
+        assert ops.mgat_dense_tail(co, m.x_proj[0], d(ins), d(h), plan, bn.weight, bn.bias, bn.mean_scale, bn.eps) is None, \
+            "without row maxima on conv_out the caller must be told to run the un-fused chain"
+        ops.attach_row_maxima(co, rm)
+        got_h, got_xg = ops.mgat_dense_tail(co, m.x_proj[0], d(ins), d(h), plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
+                                            node_mask=d(mask), ins_next=d(ins_next))
+        # the un-fused chain of the same library
+        cc = ops.mlp(m.x_proj[0], co)
+        ref_h = ops.mgat_layer_tail(d(ins), cc.contiguous(), d(h), plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
+                                    node_mask=d(mask))
+        ref_xg = ops.instr_gate(ref_h, d(ins_next), batch.to(dev), plan=plan) if with_next else None
+    assert (got_xg is None) == (not with_next)
+    scale = want_h.abs().max().item()
+    e_or = (got_h.cpu() - want_h).abs().max().item()
+    e_un = (ref_h.cpu() - want_h).abs().max().item()
+    e_ch = (got_h - ref_h).abs().max().item()
+    print(f"dense tail sizes[:4]={sizes[:4]} N={N}: fused vs oracle {e_or:.2e}, un-fused vs oracle {e_un:.2e}, "
+          f"fused vs un-fused {e_ch:.2e} (|h| max {scale:.1f})")
+    # GraphNorm divides by a per-graph std: the bound is the un-fused chain's own distance from the oracle, with slack
+    assert e_or <= max(2e-5 * max(scale, 1.0), 3.0 * e_un), (e_or, e_un)
+    if with_next:
+        assert (got_xg.cpu() - want_xg).abs().max().item() <= max(2e-5 * max(scale, 1.0), 3.0 * e_un)
+        assert torch.allclose(got_xg, ref_xg, atol=5e-5 * max(scale, 1.0), rtol=0)
+    if masked:
+        assert torch.equal(got_h.cpu()[mask == 0], torch.zeros_like(got_h.cpu()[mask == 0]))
+    return e_or
+
+
+@pytest.mark.parametrize("masked,with_next", [(False, True), (True, True), (True, False)])
+def test_fused_dense_tail_matches_the_unfused_chain_and_the_oracle(dev, masked, with_next):
+    """isg_mgat_dense_tail (x_proj.0 -> GELU -> x_proj.2 -> GELU -> instruction attention -> GraphNorm -> + h -> mask ->
+    next instruction gate on graph-aligned 64-row tiles) against oracle/model.py's layer (mgat.py:156-177) on graphs of 1,
+    20, 64 nodes, ragged mixes incl. empty graphs, and a batch with a 65-node graph (-> un-fused chain)."""
+    gen = torch.Generator().manual_seed(3)
+    cases = [[1], [20], [64], [1, 1, 1, 1, 1, 1, 1], [64, 64, 1, 63, 1, 2, 62, 20, 20, 20, 5], [0, 3, 0, 0, 41, 23, 0],
+             torch.randint(8, 34, (300,), generator=gen).tolist(), torch.randint(1, 65, (150,), generator=gen).tolist()]
+    for i, sizes in enumerate(cases):
+        assert _dense_tail_case(dev, sizes, 100 + i, masked, with_next) is not None
+    assert _dense_tail_case(dev, [20, 65, 3], 99, masked, with_next) is None
+
+
+def test_model_with_and_without_the_fused_dense_tail_agree(dev, monkeypatch):
+    """configs[1]-shaped batch through AnswerModel with ops.FUSE_DENSE_TAIL on / off: same top-k masks, logits within the
+    parity tolerance of each other; and the fused path really ran (no x_proj Linear launches, no instr_gate after layer 0)."""
+    from isubgvqa_amd import ops, synthetic
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": 200})
+    wl = synthetic.make_workload(cfg).to(dev)
+    net = synthetic.build_answer_model(cfg).to(dev).eval()
+    calls = {"tail": 0, "fused": 0}
+    real_tail, real_fused = ops.mgat_layer_tail, ops.mgat_dense_tail
+    monkeypatch.setattr(ops, "mgat_layer_tail", lambda *a, **k: (calls.__setitem__("tail", calls["tail"] + 1), real_tail(*a, **k))[1])
+    monkeypatch.setattr(ops, "mgat_dense_tail", lambda *a, **k: (calls.__setitem__("fused", calls["fused"] + 1), real_fused(*a, **k))[1])
+    with torch.no_grad():
+        a, ma, _ = net(wl, seed=9)
+        assert calls == {"tail": 0, "fused": cfg.layers}
+        monkeypatch.setattr(ops, "FUSE_DENSE_TAIL", False)
+        b, mb, _ = net(wl, seed=9)
+        assert calls["tail"] == cfg.layers
+    assert torch.equal(ma, mb)
+    assert (a - b).abs().max().item() < 1e-4

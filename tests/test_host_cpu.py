@@ -205,6 +205,6 @@ def test_docs_quote_the_headers_symbol_count_and_abi_version():
     assert (int(m.group(1)), int(m.group(2))) == (n_sym, abi), f"README says {m.groups()}, header has {n_sym} symbols, ABI v{abi}"
     for name in ("DESIGN.md", "INTEGRATION.md"):
         text = open(os.path.join(root, name)).read()
-        for q in re.findall(r"(\d+) (?:`extern \"C\"` )?symbols", text):
+        for q in re.findall(r"(\d+) (?:`extern \"C\"` )?symbols", text) + re.findall(r"for all (\d+)\b", text):
             if 30 <= int(q) <= 200:      # counts of the device library (the loader's 15 are quoted too)
                 assert int(q) == n_sym, f"{name} quotes {q} symbols, include/isg.h declares {n_sym}"
