@@ -201,11 +201,12 @@ int isg_instr_attn_graphnorm_residual(const float *ins, const float *c, const fl
 /* Tile plan of the fused per-layer kernels: consecutive graphs packed greedily into tiles of at most node_cap nodes (and,
  * when eptr != NULL, edge_cap CSR slots); a graph larger than a cap gets a tile of its own (callers test the batch's bounds).
  * tile_ptr int32[capacity + 1] receives the first graph of every tile and B behind the last; ntiles int32[1] the count (it
- * stays on the device: kernels launch `capacity` workgroups).  isg_tile_plan_capacity() bounds the count from the sizes
- * alone.  No reference counterpart: the reference's kernels are per-op, not per-layer. */
+ * stays on the device: kernels launch `capacity` workgroups, or walk the tiles persistently); tile_info (optional, 16-byte
+ * aligned int32[capacity * 4]) receives {first node, nodes, first CSR slot, CSR slots} per tile, so that a workgroup learns its
+ * tile in one load.  isg_tile_plan_capacity() bounds the count from the sizes alone.  No reference counterpart: the reference's kernels are per-op, not per-layer. */
 int64_t isg_tile_plan_capacity(int64_t N, int64_t E, int64_t B, int32_t node_cap, int32_t edge_cap);
 int isg_tile_plan(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
-                  int32_t *tile_ptr, int32_t *ntiles, int64_t capacity, void *stream);
+                  int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity, void *stream);
 
 /* The dense back half of one MGAT layer and the first line of the next as ONE launch on graph-aligned 64-row tiles
  * (isg_tile_plan with node_cap = 64):   ISubGVQA/models/mgat.py:156-177, mgat_v2_conv.py:156-157
@@ -226,6 +227,22 @@ int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const float *a_rowma
                         const float *node_mask, const float *ins_next, float *h_out, float *xg_out, const int32_t *ptr,
                         const int64_t *batch, const int32_t *tile_ptr, const int32_t *ntiles, int64_t max_tiles, int64_t N,
                         int32_t K1, int32_t MID, int32_t C, void *stream);
+
+/* MaskingGATv2Conv.message + aggregate with lin_edge inside as ONE launch on graph-aligned tiles (isg_tile_plan with node_cap =
+ * 64, edge_cap = 256 and tile_info):   ISubGVQA/models/mgat_v2_conv.py:243-279 (lin_edge :259-261)
+ * Persistent workgroups (two per CU) each keep one head -- its lin_edge fragments stay in registers -- and walk tiles: the head's
+ * x_l slice of a tile's nodes is staged once in LDS and serves the logit epilogue of the edge GEMM (row gathers) and the
+ * aggregation; logits never leave LDS; the next tile's inputs are requested while the current one is finished.  Operands as
+ * isg_gatv2_edge_logits / isg_gatv2_mp_fwd_logits (x_l / x_r fp32 [N,H*C] with row strides ldl / ldr, edge_attr fp32 [E,K] by
+ * edge id, w_frag / w_inv_scale = isg_split_f16x2_frag of lin_edge.weight [H*C,K], CSR by destination); out fp32 [N,H*C] (row
+ * stride ldo), alpha fp32 [E,H] in edge-id order, rowmax fp32 [N,H] or NULL.  Results are bit-identical to that pair.
+ * ISG_EUNSUPPORTED unless C == 128, K <= 128, K % 4 == 0; graphs beyond a tile's caps are truncated (callers test the bounds). */
+int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x_r, int32_t ldr, const float *edge_attr, int32_t lda,
+                        const uint16_t *w_frag, const float *w_inv_scale, const float *att, const float *bias,
+                        const int32_t *rowptr, const int32_t *eid, const int32_t *src, const int32_t *dst,
+                        const int32_t *tile_info, const int32_t *ntiles, int64_t max_tiles, const float *node_mask,
+                        const float *edge_mask, float *out, int32_t ldo, float *alpha, float *rowmax, int64_t N, int64_t E,
+                        int32_t H, int32_t C, int32_t K, float negative_slope, void *stream);
 
 /* Question-conditioned softmax pooling: GlobalAttention.forward, ISubGVQA/models/att_pooling.py:63-73
  *   x = xn * node_mask;  gate = softmax_g(<x, q[g]>/sqrt(C)) (+1e-16 in the denominator);

@@ -90,9 +90,12 @@ SIGNATURES = {
                                       c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_row_absmax": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "isg_tile_plan_capacity": (c_int64, [c_int64, c_int64, c_int64, c_int32, c_int32]),
-    "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "isg_mgat_dense_tail": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32] + [c_void_p] * 12 + [c_double] +
                             [c_void_p] * 8 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_gatv2_tile_conv": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32] + [c_void_p] * 10 + [c_int64] +
+                            [c_void_p] * 3 + [c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_float,
+                                              c_void_p]),
     "isg_global_attn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_void_p]),
 }

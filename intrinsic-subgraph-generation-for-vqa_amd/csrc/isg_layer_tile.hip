@@ -44,7 +44,7 @@ constexpr int TP_CH = 1024;
 
 __global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict__ ptr, const int *__restrict__ eptr, int B,
                                                           int ncap, int ecap, int *__restrict__ tile_ptr,
-                                                          int *__restrict__ ntiles, int cap) {
+                                                          int *__restrict__ ntiles, int cap, int4 *__restrict__ tile_info) {
   __shared__ int s_jump[2][TP_CH];
   __shared__ int s_mark[TP_CH];
   __shared__ int s_wsum[TP_CH / 64];
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict_
       }
       nx = lo - c0 >= cn ? TP_CH : lo - c0;
     }
+    const int nx0 = nx;                  // the tile that starts at this graph ends before graph c0 + nx0 (or with the chunk)
     s_jump[0][i] = nx;
     s_mark[i] = i == 0 ? 1 : 0;
     __syncthreads();
@@ -93,7 +94,13 @@ __global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict_
     }
     if (m) {
       const int idx = off + __popcll(bal & ((1ull << lane) - 1ull));
-      if (idx < cap) tile_ptr[idx] = c0 + i;
+      if (idx < cap) {
+        tile_ptr[idx] = c0 + i;
+        if (tile_info) {       // {first node, nodes, first CSR slot, CSR slots}: one load gives a workgroup its tile
+          const int g = c0 + i, g1 = c0 + (nx0 < TP_CH ? nx0 : cn);
+          tile_info[idx] = make_int4(ptr[g], ptr[g1] - ptr[g], eptr ? eptr[g] : 0, eptr ? eptr[g1] - eptr[g] : 0);
+        }
+      }
     }
     __syncthreads();
     if (i == 0) s_base += total;
@@ -527,11 +534,13 @@ extern "C" int64_t isg_tile_plan_capacity(int64_t N, int64_t E, int64_t B, int32
 }
 
 extern "C" int isg_tile_plan(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
-                             int32_t *tile_ptr, int32_t *ntiles, int64_t capacity, void *stream) {
+                             int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity, void *stream) {
   if (B < 0 || node_cap <= 0 || capacity < 0 || !tile_ptr || !ntiles || (B > 0 && !ptr)) return ISG_EINVAL;
   if (eptr && edge_cap <= 0) return ISG_EINVAL;
   if (B >= (1ll << 31) || capacity >= (1ll << 31)) return ISG_EUNSUPPORTED;
-  tile_plan_kernel<<<1, TP_CH, 0, as_stream(stream)>>>(ptr, eptr, (int)B, node_cap, edge_cap, tile_ptr, ntiles, (int)capacity);
+  if (tile_info && (reinterpret_cast<uintptr_t>(tile_info) & 15) != 0) return ISG_EINVAL;
+  tile_plan_kernel<<<1, TP_CH, 0, as_stream(stream)>>>(ptr, eptr, (int)B, node_cap, edge_cap, tile_ptr, ntiles, (int)capacity,
+                                                       reinterpret_cast<int4 *>(tile_info));
   return check_launch();
 }
 
@@ -561,5 +570,396 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
   a.batch = reinterpret_cast<const long long *>(batch);
   a.N = (int)N; a.lda = lda; a.P = P; a.ldp = ldp; a.eps = (float)eps; a.denom = (float)sqrt((double)DT_C);
   mgat_dense_tail_kernel<<<(unsigned)max_tiles, 256, DT_SMEM_BYTES, as_stream(stream)>>>(a);
+  return check_launch();
+}
+
+// =====================================================================================================================
+// The convolution's message passing on the same tiles: edge GEMM -> logits -> softmax -> aggregation, one launch.
+//
+// Reference: MaskingGATv2Conv.message + aggregate, ISubGVQA/models/mgat_v2_conv.py:243-279 (with lin_edge, :259-261, inside).
+// The pair it replaces (isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits, csrc/isg_mp_logits.hip / isg_mp_graph.hip) gathers
+// x_l[src] and x_r[dst] per edge as 16-byte pieces from L2 -- 52 M lane accesses per launch at BASELINE configs[1], which is what
+// holds that kernel at 210 us in every ordering tried (profiles/r02_w_edge_logits.md) -- then writes the logits, and the second
+// kernel stages x_l again.  Here a workgroup owns (tile, head): the head's x_l slice of the tile's <= 64 nodes is staged ONCE
+// with coalesced 512-byte row loads and serves both the logit epilogue (row gathers from LDS) and the aggregation; the logits
+// never leave LDS.  x_r[dst] still comes from global memory: slots are sorted by destination, so a wave's 32 edges touch ~13
+// rows.  The arithmetic is the pair's, operation for operation (same MFMA sequence, same partial-sum orders, the per-graph
+// kernel's softmax and edge-id-ordered aggregation): results are bit-identical to it.
+//   block  = 8 waves: wave = (32-slot half of a 64-slot chunk, one of the head's four 32-channel tiles)
+//   LDS    = x_l slice 33 KB + edge panel planes 34 KB + CSR records / logits / partials 7 KB: two workgroups per CU
+//   grid   = tiles x heads, the heads of a tile on one XCD (block ids 8 apart): the edge rows they all stage are L2 hits
+// =====================================================================================================================
+namespace isg {
+
+constexpr int TC_ROWS = 64, TC_ECAP = 256, TC_C = 128, TC_KC = 128, TC_LDX = TC_C + 4, TC_LDA = TC_KC + 8, TC_THREADS = 256;
+constexpr int TC_SMEM_BYTES = TC_ROWS * TC_LDX * 4 + 2 * 64 * TC_LDA * 2 + TC_ECAP * 16 + TC_ECAP * 4 + 4 * 64 * 4 + 64 * 4 + 68 * 4 + 2 * TC_C * 4;
+static_assert(2 * TC_SMEM_BYTES <= 160 * 1024, "two workgroups per CU");
+
+struct TcArgs {
+  const float *x_l, *x_r;           // [N, H*C] rows (strides ldl / ldr), heads side by side
+  const float *edge_attr;           // [E, K] rows by edge id, stride lda
+  const _Float16 *Wf;               // lin_edge.weight [H*C, K] as fragment-major (hi, mid) planes
+  const float *w_inv, *att, *bias;  // [H*C]; bias may be NULL
+  const int *rowptr, *eid, *src, *dst, *ntiles;
+  const int4 *tile_info;            // {first node, nodes, first CSR slot, CSR slots} per tile (isg_tile_plan)
+  const float *edge_mask, *node_mask;
+  float *out, *alpha, *rowmax;      // [N, H*C] (stride ldo), [E, H], [N, H] or NULL
+  int N, E, H, K, KS, NT, lda, ldl, ldr, ldo;
+  float slope;
+};
+
+// PERSISTENT: the grid is two workgroups per CU; a workgroup keeps ONE head (its W fragments never leave its registers) and walks
+// tiles t = group, group + groups, ...; while it finishes a tile (softmax, aggregation) the next tile's CSR records, row pointers,
+// x_l slice and first edge rows are already in flight into registers.  A (tile, head) workgroup per launch-grid entry measured
+// 317-352 us against 330 us for the pair: every workgroup paid five dependent memory round trips for ~4.6k cycles of MFMA work at
+// two waves per SIMD (profiles/r03_l_tile_conv_stamps.txt).  Every wave leaves the loop at the same tile: the bound is uniform.
+template <bool MASKED>
+__global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
+  typedef float (*BufX)[TC_LDX];
+  typedef _Float16 (*BufP)[64][TC_LDA];
+  BufX sXl = reinterpret_cast<BufX>(tc_smem);
+  BufP sA = reinterpret_cast<BufP>(tc_smem + TC_ROWS * TC_LDX * 4);
+  int4 *s_tab = reinterpret_cast<int4 *>(tc_smem + TC_ROWS * TC_LDX * 4 + 2 * 64 * TC_LDA * 2);     // {src - r0, eid, dst - r0, mask bits}
+  float *s_lg = reinterpret_cast<float *>(s_tab + TC_ECAP);
+  float *s_part = s_lg + TC_ECAP;             // [4 tile-waves][64 slots]; after the chunks: the softmax weights
+  float *s_inv = s_part + 4 * 64;
+  int *s_rp = reinterpret_cast<int *>(s_inv + 64);
+  float *s_att = reinterpret_cast<float *>(s_rp + 68), *s_winv = s_att + TC_C;     // the head's att / inverse W scales
+
+  // workgroups 8 apart share an XCD (round-robin dispatch): the H head-workgroups of a tile group sit on one XCD, so the edge
+  // rows and CSR records they all read are L2 hits for three of them
+  const int bid = blockIdx.x;
+  const int per_xcd = gridDim.x >> 3, j = bid >> 3;
+  const int hd = j % a.H;
+  const int ngrp = gridDim.x / a.H;
+  int t = (bid & 7) * (per_xcd / a.H) + j / a.H;
+  const int T = *a.ntiles;
+  if (t >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = one of the head's four 32-channel tiles, all 64 slots
+#ifdef ISG_DT_STAMP
+  long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const long long st_begin = DT_T();
+  long long st_last = st_begin;
+#define TC_STAMP(i) { const long long now_ = DT_T(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define TC_STAMP(i)
+#endif
+  const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
+  const int hoff = hd * TC_C;
+  const int srow = tid >> 5, sc4 = tid & 31;          // staging map: 32 lanes per 512-byte row, rows srow + 8 u
+
+  // ---- W fragments of this wave's channel tile: loaded once, resident for every tile of the workgroup -----------------------
+  const int nt = hd * (TC_C / 32) + tw;
+  const int KS = a.KS;
+  const unsigned plane_b = (unsigned)a.NT * (unsigned)KS * 1024u;
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.Wf), 0, (int)(2u * plane_b), 0x00020000);
+  const unsigned wb = (unsigned)nt * (unsigned)KS * 1024u;
+  hf16x8 wq[8][2];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      wq[ks][q] = hf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ks < KS)
+        wq[ks][q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   wrsrc, lane * 16, (int)(wb + q * plane_b + (unsigned)ks * 1024u), 0));
+    }
+  if (tid < TC_C) s_att[tid] = a.att[hoff + tid];
+  else s_winv[tid - TC_C] = a.w_inv[hoff + tid - TC_C];
+  const float4 b4 = a.bias ? *reinterpret_cast<const float4 *>(a.bias + hoff + fr * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int cb = nt * 32 + 4 * hh;                  // this lane's channels of the tile: cb + 8 g + j
+  const float slope = a.slope;
+
+  // ---- a tile's inputs on their way into registers (issued a tile ahead), then into LDS -------------------------------------
+  hf32x4 ra[8];
+  // (macros, not lambdas: register arrays captured by reference end up in scratch memory)
+#define TC_REQUEST_TILE(d)                           /* d = {r0, nrows, e0, ne} */                                      \
+  {                                                                                                                  \
+    const int r0n = (d).x, nrn = min((d).y, TC_ROWS), e0n = (d).z, nen = min((d).w, TC_ECAP);                          \
+    rp_n = 0;                                                                                                        \
+    if (tid <= nrn) rp_n = a.rowptr[r0n + tid] - e0n;                                                                \
+    rec_n = make_int4(0, 0, 0, __float_as_int(1.f));                                                                 \
+    if (tid < nen) {                                                                                                 \
+      const int s_ = a.src[e0n + tid], e_ = a.eid[e0n + tid], d_ = a.dst[e0n + tid];                                 \
+      rec_n.x = min(max(s_ - r0n, 0), max(nrn - 1, 0));    /* a source outside its tile is clamped into it */        \
+      rec_n.y = e_;                                                                                                  \
+      rec_n.z = min(max(d_ - r0n, 0), max(nrn - 1, 0));                                                              \
+      sraw_n = s_;                                                                                                   \
+      draw_n = d_;                                                                                                   \
+    }                                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                  \
+      const int row = min(r0n + min(srow + 8 * u, max(nrn - 1, 0)), a.N - 1);                                        \
+      xv_n[u] = __builtin_nontemporal_load(reinterpret_cast<const hf32x4 *>(a.x_l + (int64_t)row * a.ldl + hoff + sc4 * 4)); \
+      e8[u] = nen > 0 ? a.eid[e0n + min(srow + 8 * u, nen - 1)] : 0;                                                 \
+    }                                                                                                                \
+  }
+  // chunk 0's edge rows of that tile (its edge ids have landed by now) and the mask values
+#define TC_REQUEST_ROWS0(d)                                                                                          \
+  {                                                                                                                  \
+    const int nen = min((d).w, TC_ECAP);                                                                             \
+    if (nen > 0) {                                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                                  \
+        ra[u] = *reinterpret_cast<const hf32x4 *>(a.edge_attr + (int64_t)e8[u] * a.lda + min(sc4 * 4, a.K - 4));     \
+    }                                                                                                                \
+    if (MASKED && tid < nen)                                                                                         \
+      rec_n.w = __float_as_int(a.edge_mask ? a.edge_mask[rec_n.y] : a.node_mask[sraw_n] * a.node_mask[draw_n]);      \
+  }
+#define TC_STORE_TILE(d)                                                                                             \
+  {                                                                                                                  \
+    const int nrn = min((d).y, TC_ROWS);                                                                             \
+    if (tid <= nrn) s_rp[tid] = rp_n;                                                                                \
+    s_tab[tid] = rec_n;                                                                                              \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                                    \
+      if (srow + 8 * u < nrn) *reinterpret_cast<hf32x4 *>(&sXl[srow + 8 * u][sc4 * 4]) = xv_n[u];                    \
+  }
+
+  int4 desc = a.tile_info[t];
+  {
+    int4 rec_n;
+    int rp_n, sraw_n = 0, draw_n = 0, e8[8];
+    hf32x4 xv_n[8];
+    TC_REQUEST_TILE(desc)
+    TC_REQUEST_ROWS0(desc)
+    TC_STORE_TILE(desc)
+  }
+  __syncthreads();
+  TC_STAMP(0)              // first tile's inputs (exposed once per workgroup)
+
+#pragma unroll 1
+  while (true) {
+    const int r0 = desc.x, nrows = min(desc.y, TC_ROWS), ne = min(desc.w, TC_ECAP);
+    const int t_next = t + ngrp;
+    const bool has_next = t_next < T;
+    int4 desc_n = make_int4(0, 0, 0, 0);
+    if (has_next) desc_n = a.tile_info[t_next];
+
+    // ---- 64-slot chunks: edge panel -> (hi, mid) planes, transposed product, logit epilogue (isg_mp_logits.hip) --------------
+    const int nchunk = (ne + 63) >> 6;
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+      // this lane's two edges of the chunk (slots fr and 32 + fr): their x_r[dst] pieces are requested now, used after the k loop
+      hf32x4 xr[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int dl = s_tab[min(64 * c + i * 32 + fr, ne - 1)].z;
+        const float *xr_row = a.x_r + (int64_t)(r0 + dl) * a.ldr + cb;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xr[i][g] = *reinterpret_cast<const hf32x4 *>(xr_row + 8 * g);
+      }
+      // the chunk's edge rows (requested a chunk ahead) -> row scale -> (hi, mid) planes
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = srow + 8 * u;
+        hf32x4 v = ra[u];
+        if (64 * c + row >= ne || sc4 * 4 >= a.K) v = hf32x4{0.f, 0.f, 0.f, 0.f};
+        const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        float sc, inv;
+        h3_scale(mx, sc, inv);
+        if (sc4 == 0) s_inv[row] = inv;
+        v *= sc;
+        hf16x4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        hf16x4 mid = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]), (_Float16)(v[2] - (float)hi[2]),
+                      (_Float16)(v[3] - (float)hi[3])};
+        *reinterpret_cast<hf16x4 *>(&sA[0][row][sc4 * 4]) = hi;
+        *reinterpret_cast<hf16x4 *>(&sA[1][row][sc4 * 4]) = mid;
+      }
+      __syncthreads();
+      TC_STAMP(2)            // x_r requests + panel staging + barrier
+      if (c + 1 < nchunk) {      // the next chunk's rows: in flight under this chunk's product and epilogue
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = s_tab[min(64 * (c + 1) + srow + 8 * u, ne - 1)].y;
+          ra[u] = *reinterpret_cast<const hf32x4 *>(a.edge_attr + (int64_t)e * a.lda + min(sc4 * 4, a.K - 4));
+        }
+      }
+      hf32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      {
+        // one register set of panel fragments: a k-step's LDS reads are issued behind the previous step's six MFMAs
+        hf16x8 af[2][2];          // [half][plane]
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks < KS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) af[i][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][i * 32 + fr][ks * 16 + fk]);
+            // transposed product: W fragment = A operand (rows = channels), edge panel = B operand (columns = edges)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][0], af[i][1], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][1], af[i][0], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][0], af[i][0], acc[i], 0, 0, 0);
+          }
+        }
+      }
+#ifdef ISG_DT_STAMP
+      asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][15]));
+#endif
+      TC_STAMP(3)            // k loop
+      // epilogue: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask, z * att in 4 chains
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int prow = i * 32 + fr;
+        const float sinv = s_inv[prow];
+        const int4 rec = s_tab[min(64 * c + prow, ne - 1)];
+        const float me = __int_as_float(rec.w);
+        float part[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 xl4 = *reinterpret_cast<const float4 *>(&sXl[rec.x][tw * 32 + 4 * hh + 8 * g]);
+          const float4 at4 = *reinterpret_cast<const float4 *>(&s_att[tw * 32 + 4 * hh + 8 * g]);
+          const float4 wi4 = *reinterpret_cast<const float4 *>(&s_winv[tw * 32 + 4 * hh + 8 * g]);
+          const float lv[4] = {xl4.x, xl4.y, xl4.z, xl4.w};
+          const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w};
+          part[g] = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float e = (acc[i][g * 4 + jj] * sinv) * wiv[jj];
+            float z = (xr[i][g][jj] + lv[jj]) + e;
+            if (MASKED) z *= me;
+            z = z > 0.f ? z : z * slope;
+            if (MASKED) z *= me;
+            part[g] = fmaf(z, atv[jj], part[g]);
+          }
+        }
+        const float mine = (part[0] + part[1]) + (part[2] + part[3]);
+        const float tot = mine + __shfl_xor(mine, 32);
+        if (hh == 0) s_part[tw * 64 + prow] = tot;
+      }
+      __syncthreads();
+      TC_STAMP(4)            // epilogue + barrier
+      if (tid < 64 && 64 * c + tid < ne)     // the tile-waves' partials in a fixed order
+        s_lg[64 * c + tid] = (s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]);
+    }
+    __syncthreads();
+
+    // ---- softmax + aggregation (isg_mp_graph.hip phase C: same operations in the same order) --------------------------------
+    // C1, a thread per slot: maximum and denominator of the slot's destination segment (walked in slot order), the weight; alpha
+    float *s_w = s_part;                  // the partial-logit table is free now
+    if (tid < ne) {
+      const int4 rc = s_tab[tid];
+      const int rb = s_rp[rc.z], re = min(s_rp[rc.z + 1], ne);
+      float mx = -INFINITY;
+#pragma unroll 2
+      for (int s = rb; s < re; ++s) mx = fmaxf(mx, s_lg[s]);
+      float den = 0.f;
+#pragma unroll 2
+      for (int s = rb; s < re; ++s) den += __builtin_amdgcn_exp2f((s_lg[s] - mx) * 1.4426950408889634f);
+      const float w = __builtin_amdgcn_exp2f((s_lg[tid] - mx) * 1.4426950408889634f) * __builtin_amdgcn_rcpf(den + 1e-16f);
+      a.alpha[(int64_t)rc.y * a.H + hd] = w;
+      s_w[tid] = MASKED ? __fmul_rn(w, __int_as_float(rc.w)) : w;
+    }
+    int4 rec_n;                 // the next tile's inputs: defined and consumed inside this iteration
+    int rp_n, sraw_n = 0, draw_n = 0, e8[8];
+    hf32x4 xv_n[8];
+    TC_REQUEST_TILE(desc_n)     // (unconditional: a zero descriptor requests row 0 and nothing else) the next tile's records, row pointers, x_l slice, edge ids: in flight under C2
+    __syncthreads();
+    TC_STAMP(6)              // weights
+    // C2, a half-wave per destination node, lane = float4 column: x_l rows from LDS in edge-id order, unfused mul + add
+#pragma unroll 1
+    for (int k = 2 * tw + hh; k < nrows; k += 8) {
+      const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+      for (int s = rb; s < re; ++s) {
+        const float wm = s_w[s];
+        const float4 u4 = *reinterpret_cast<const float4 *>(&sXl[s_tab[s].x][fr * 4]);
+        o.x = __fadd_rn(o.x, __fmul_rn(u4.x, wm));
+        o.y = __fadd_rn(o.y, __fmul_rn(u4.y, wm));
+        o.z = __fadd_rn(o.z, __fmul_rn(u4.z, wm));
+        o.w = __fadd_rn(o.w, __fmul_rn(u4.w, wm));
+      }
+      if (a.bias) { o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w; }
+      hf32x4 o4 = {o.x, o.y, o.z, o.w};
+      __builtin_nontemporal_store(o4, reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + fr * 4));
+      if (a.rowmax) {
+        const float rmx = group_max<32>(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        if (fr == 0) a.rowmax[(int64_t)(r0 + k) * a.H + hd] = rmx;
+      }
+    }
+    TC_STAMP(7)              // aggregation, stores
+    if (!has_next) break;
+    TC_REQUEST_ROWS0(desc_n)
+    __syncthreads();         // every wave is done with this tile's LDS image
+    TC_STORE_TILE(desc_n)
+    __syncthreads();
+    TC_STAMP(1)              // hand-over to the next tile
+    desc = desc_n;
+    t = t_next;
+  }
+#undef TC_REQUEST_TILE
+#undef TC_REQUEST_ROWS0
+#undef TC_STORE_TILE
+#ifdef ISG_DT_STAMP
+  if (g_dt_stamps && lane == 0) {
+    st_acc[12] = DT_T() - st_begin;
+    long long *dst = g_dt_stamps + ((long long)bid * 4 + tw) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[i] = st_acc[i];
+  }
+#endif
+}
+
+}  // namespace isg
+
+using namespace isg;
+
+// MaskingGATv2Conv.message + aggregate with lin_edge inside, on graph-aligned tiles (isg_tile_plan with node_cap = 64 and
+// edge_cap = 256, tile_info requested): see the kernel's header.  ISG_EUNSUPPORTED unless C == 128, K <= 128, K % 4 == 0.
+extern "C" int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x_r, int32_t ldr, const float *edge_attr,
+                                   int32_t lda, const uint16_t *w_frag, const float *w_inv_scale, const float *att,
+                                   const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                   const int32_t *dst, const int32_t *tile_info, const int32_t *ntiles, int64_t max_tiles,
+                                   const float *node_mask, const float *edge_mask, float *out, int32_t ldo, float *alpha,
+                                   float *rowmax, int64_t N, int64_t E, int32_t H, int32_t C, int32_t K, float negative_slope,
+                                   void *stream) {
+  if (N < 0 || E < 0 || H <= 0 || C <= 0 || K <= 0 || max_tiles < 0 || lda < K || ldl < H * C || ldr < H * C || ldo < H * C)
+    return ISG_EINVAL;
+  auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (C != TC_C || K > TC_KC || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (ldo & 3) != 0 || H > 64 ||
+      mis(x_l) || mis(x_r) || mis(edge_attr) || mis(att) || mis(w_inv_scale) || mis(out) || (bias && mis(bias)) || mis(tile_info) ||
+      N >= (1ll << 31) || E >= (1ll << 31))
+    return ISG_EUNSUPPORTED;
+  if (N == 0 || max_tiles == 0) return ISG_OK;
+  if (!x_l || !x_r || (E > 0 && (!edge_attr || !eid || !src || !dst || !alpha)) || !w_frag || !w_inv_scale || !att || !rowptr ||
+      !tile_info || !ntiles || !out)
+    return ISG_EINVAL;
+  TcArgs a;
+  a.x_l = x_l; a.x_r = x_r; a.edge_attr = edge_attr; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
+  a.att = att; a.bias = bias; a.rowptr = rowptr; a.eid = eid; a.src = src; a.dst = dst;
+  a.tile_info = reinterpret_cast<const int4 *>(tile_info); a.ntiles = ntiles; a.edge_mask = edge_mask; a.node_mask = node_mask;
+  a.out = out; a.alpha = alpha; a.rowmax = rowmax; a.N = (int)N; a.E = (int)E; a.H = H; a.K = K; a.KS = (K + 15) / 16;
+  a.NT = H * C / 32; a.lda = lda; a.ldl = ldl; a.ldr = ldr; a.ldo = ldo; a.slope = negative_slope;
+  // two workgroups per CU (LDS), 256 CUs: 8 XCDs x (groups per XCD) x H head-workgroups; fewer groups when there are few tiles
+  static const int gpx_max = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return cus > 0 ? cus : 256;
+  }();
+  int gpx = (2 * gpx_max / 8) / H;                       // groups per XCD
+  if (gpx < 1) gpx = 1;
+  const long long need = (max_tiles + 7) / 8;            // groups per XCD that would each get one tile
+  if (gpx > need) gpx = (int)need;
+  const unsigned grid = 8u * (unsigned)H * (unsigned)gpx;
+  hipStream_t st = as_stream(stream);
+  if (node_mask || edge_mask) {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_tile_conv_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, TC_SMEM_BYTES) == hipSuccess;
+    if (!ok) return ISG_EUNSUPPORTED;
+    gatv2_tile_conv_kernel<true><<<grid, TC_THREADS, TC_SMEM_BYTES, st>>>(a);
+  } else {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_tile_conv_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, TC_SMEM_BYTES) == hipSuccess;
+    if (!ok) return ISG_EUNSUPPORTED;
+    gatv2_tile_conv_kernel<false><<<grid, TC_THREADS, TC_SMEM_BYTES, st>>>(a);
+  }
   return check_launch();
 }

@@ -115,6 +115,16 @@ class MaskingGATv2Conv(torch.nn.Module):
             x_l = x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt)  # :177-179
         else:   # lin_l and lin_r share their input: one [N, 2*H*C] projection, x_l / x_r are its column halves
             x_l, x_r = ops.linear_fused(x, (self.lin_l, self.lin_r), out_dtype=fdt)      # :177,181
+        if pair and not xr_inside and ops.tile_conv_supported(plan, H, C, edge_attr.size(1)):
+            # edge GEMM + logits + softmax + aggregation as one launch on graph-aligned tiles (csrc/isg_layer_tile.hip)
+            res = ops.gatv2_tile_conv(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att, plan, H,
+                                      bias=self.bias, node_mask=mask, negative_slope=self.negative_slope,
+                                      want_rowmax=True)                                  # :215-232, :243-279
+            if res is not None:
+                out, alpha = res
+                if isinstance(return_attention_weights, bool):
+                    return out, mask, (edge_index, alpha)
+                return out, mask
         if pair:
             # lin_edge (and lin_r) folded into the logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is neither written nor read
             res = ops.gatv2_mp_edge_logits(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att, plan, H,

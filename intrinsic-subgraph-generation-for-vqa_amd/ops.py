@@ -180,11 +180,12 @@ class GraphPlan:
     _slots: Optional[Tensor] = None
     _tiles: Optional[dict] = None
 
-    def tiles(self, node_cap: int = 64, edge_cap: int = 0) -> Tuple[Tensor, Tensor, int]:
-        """(tile_ptr int32[cap + 1], ntiles int32[1] on the device, cap): consecutive graphs packed greedily into tiles of
+    def tiles(self, node_cap: int = 64, edge_cap: int = 0) -> Tuple[Tensor, Tensor, int, Tensor]:
+        """(tile_ptr int32[cap + 1], ntiles int32[1] on the device, cap, tile_info int32[cap, 4]): consecutive graphs packed greedily into tiles of
         at most `node_cap` nodes (and `edge_cap` CSR slots when > 0) -- the M-tiles of the fused per-layer kernels
-        (csrc/isg_layer_tile.hip).  Tile t owns graphs tile_ptr[t] .. tile_ptr[t + 1]; the count stays on the device (no
-        sync): kernels are launched with `cap` workgroups, the ones beyond *ntiles return at once.  Built on first use."""
+        (csrc/isg_layer_tile.hip).  Tile t owns graphs tile_ptr[t] .. tile_ptr[t + 1] and tile_info[t] = (first node, nodes,
+        first CSR slot, CSR slots); the count stays on the device (no sync): kernels are launched with `cap` workgroups, the ones
+        beyond *ntiles return at once, or walk the tiles persistently.  Built on first use."""
         key = (int(node_cap), int(edge_cap))
         if self._tiles is None:
             self._tiles = {}
@@ -194,10 +195,11 @@ class GraphPlan:
             if edge_cap > 0:
                 self.require_csr()
             cap = int(lib.isg_tile_plan_capacity(self.N, self.E, self.B, key[0], key[1]))
-            buf = torch.empty(cap + 2, dtype=torch.int32, device=self.ptr.device)
+            buf = torch.empty(5 * cap + 8, dtype=torch.int32, device=self.ptr.device)     # info first: 16-byte aligned
+            info, tp, nt = buf[:4 * cap], buf[4 * cap + 4:5 * cap + 5], buf[5 * cap + 5:5 * cap + 6]
             _lib.check(lib.isg_tile_plan(self.ptr.data_ptr(), self.eptr.data_ptr() if edge_cap > 0 else 0, self.B, key[0],
-                                         key[1], buf.data_ptr(), buf[cap + 1:].data_ptr(), cap, _stream()), "isg_tile_plan")
-            hit = (buf[:cap + 1], buf[cap + 1:], cap)
+                                         key[1], tp.data_ptr(), nt.data_ptr(), info.data_ptr(), cap, _stream()), "isg_tile_plan")
+            hit = (tp, nt, cap, info.view(cap, 4))
             self._tiles[key] = hit
         return hit
 
@@ -546,6 +548,68 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Optional[Tensor], edge_attr: Tensor, 
 
 
 ISG_EUNSUPPORTED = -2      # include/isg.h
+
+# message + softmax + aggregation with lin_edge inside as ONE launch on graph-aligned tiles (csrc/isg_layer_tile.hip): the
+# head's x_l slice of a tile is staged once in LDS and serves the logit epilogue's row gathers and the aggregation
+FUSE_TILE_CONV = True
+TILE_CONV_NODES, TILE_CONV_EDGES = 64, 256
+
+
+def tile_conv_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
+    """Shape test of isg_gatv2_tile_conv (inference, fp32 rows): C = 128, edge features <= 128 wide, every graph within one
+    64-node / 256-slot tile."""
+    return (FUSE_TILE_CONV and FUSE_LOGITS and GEMM_BACKEND == "bf16x6" and GEMM_F16X3 and MP_KERNEL == "graph" and
+            channels == 128 and 0 < edge_dim <= 128 and edge_dim % 4 == 0 and heads <= 64 and plan.B > 0 and
+            0 < plan.nmax <= TILE_CONV_NODES and plan.emax <= TILE_CONV_EDGES and plan.rowptr is not None and plan.E > 0)
+
+
+def gatv2_tile_conv(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan", heads: int,
+                    bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
+                    negative_slope: float = 0.2, want_rowmax: bool = False):
+    """gatv2_mp(x_l, x_r, lin_edge(edge_attr), ...) as ONE launch per layer (mgat_v2_conv.py:243-279 with :259-261 inside):
+    isg_gatv2_tile_conv.  Bit-identical to gatv2_mp_edge_logits (the two-launch pair it replaces).  Returns (out, alpha), or
+    None when the kernel has no launch for this shape (the caller then runs the pair)."""
+    lib = _lib.load()
+    plan.require_csr()
+    N, HC = x_l.shape
+    H = int(heads)
+    C = HC // H
+    E, K = edge_attr.shape
+    if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K) or tuple(x_r.shape) != (N, HC):
+        raise ValueError("gatv2_tile_conv: operand shapes do not match the plan")
+    if x_l.dtype != torch.float32 or x_r.dtype != torch.float32 or edge_attr.dtype != torch.float32:
+        raise TypeError("gatv2_tile_conv: fp32 rows")
+    planes, inv = _weight_planes(w_edge, True, "f16x3")
+    _, ntiles, cap, tile_info = plan.tiles(TILE_CONV_NODES, TILE_CONV_EDGES)
+    out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
+    alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+    rowmax = torch.empty(N, H, dtype=torch.float32, device=x_l.device) if want_rowmax else None
+    timer = MP_TIMER
+    if timer is not None:
+        ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "K": K, "masked": node_mask is not None or edge_mask is not None,
+                                  "feat_bytes": 4, "tile_conv": True})
+        ev0.record()
+    rc = lib.isg_gatv2_tile_conv(
+        _chk_rows(x_l, "x_l"), x_l.stride(0), _chk_rows(x_r, "x_r"), x_r.stride(0), _chk_rows(edge_attr, "edge_attr"),
+        edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+        _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+        plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(), tile_info.data_ptr(),
+        ntiles.data_ptr(), cap,
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
+        out.data_ptr(), HC, alpha.data_ptr(), 0 if rowmax is None else rowmax.data_ptr(), N, E, H, C, K,
+        float(negative_slope), _stream())
+    if rc == ISG_EUNSUPPORTED:
+        if timer is not None:
+            timer.drop_last()
+        return None
+    _lib.check(rc, "isg_gatv2_tile_conv")
+    if timer is not None:
+        ev1.record()
+    if rowmax is not None:
+        attach_row_maxima(out, rowmax)
+    return out, alpha
+
 
 
 def gatv2_mp_backward(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, alpha: Tensor, grad_out: Tensor,
@@ -908,7 +972,7 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
     p2, inv2 = _weight_planes(l2.weight, True, "f16x3")
     ybound = derived_weight("dense_tail_bound", (l0.weight, l0.bias), lambda: torch.stack(
         [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
-    tile_ptr, ntiles, cap = plan.tiles(DENSE_TAIL_ROWS)
+    tile_ptr, ntiles, cap, _ = plan.tiles(DENSE_TAIL_ROWS)
     h_out = torch.empty_like(h)
     xg = torch.empty_like(h) if ins_next is not None else None
     rc = lib.isg_mgat_dense_tail(

@@ -1035,11 +1035,15 @@ def test_tile_plan_is_the_greedy_packing(dev, case):
     plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
     ecount = torch.bincount(batch[ei[1]], minlength=B).tolist()
     for ncap, ecap in ((64, 0),) + (((64, 160), (48, 96)) if case in ("edges", "cfg2") else ()):
-        tile_ptr, ntiles, cap = plan.tiles(ncap, ecap)
+        tile_ptr, ntiles, cap, info = plan.tiles(ncap, ecap)
         want = _greedy_tiles(sizes, ecount, ncap, ecap)
         T = int(ntiles.item())
         assert T == len(want) - 1 and T <= cap, (case, T, len(want) - 1, cap)
         assert tile_ptr.cpu().tolist()[:T + 1] == want
+        ptr, eptr = plan.ptr.cpu().tolist(), plan.eptr.cpu().tolist()
+        want_info = [[ptr[a], ptr[b] - ptr[a], eptr[a] if ecap > 0 else 0, eptr[b] - eptr[a] if ecap > 0 else 0]
+                     for a, b in zip(want[:-1], want[1:])]
+        assert info.cpu().tolist()[:T] == want_info
 
 
 def _dense_tail_case(dev, sizes, seed, masked, with_next):
@@ -1143,3 +1147,48 @@ def test_model_with_and_without_the_fused_dense_tail_agree(dev, monkeypatch):
         assert calls["tail"] == cfg.layers
     assert torch.equal(ma, mb)
     assert (a - b).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("mask", [None, "node", "edge"])
+@pytest.mark.parametrize("K", [128, 36])
+def test_tile_conv_is_bit_identical_to_the_edge_logits_pair(dev, mask, K):
+    """isg_gatv2_tile_conv (edge GEMM + logits + softmax + aggregation per (tile, head), x_l slice in LDS) against the two-launch
+    pair it replaces (isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits): the same operations in the same order, so out, alpha and
+    the row maxima must be EQUAL; and both against the CPU oracle's message passing (mgat_v2_conv.py:243-279)."""
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(17)
+    H, C = 4, 128
+    for sizes, hub in (([1], None), ([20], None), ([64], None), ([64, 1, 63, 2, 62, 20, 20, 20, 5, 0, 3], (0, 150)),
+                       (torch.randint(8, 34, (300,), generator=gen).tolist(), (7, 60))):
+        batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=hub)
+        N, E, B = batch.numel(), ei.size(1), len(sizes)
+        x_lr = torch.randn(N, 2 * H * C, generator=gen)
+        ea = torch.randn(E, K, generator=gen) * torch.rand(E, 1, generator=gen).mul(2).exp()
+        w = torch.randn(H * C, K, generator=gen) * 0.1
+        att, bias = torch.randn(1, H, C, generator=gen), torch.randn(H * C, generator=gen)
+        nm = (torch.rand(N, generator=gen) < 0.7).float() if mask == "node" else None
+        em = (torch.rand(E, generator=gen) < 0.7).float() if mask == "edge" else None
+        d = lambda t: None if t is None else t.to(dev)
+        plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+        assert ops.tile_conv_supported(plan, H, C, K) == (plan.emax <= 256)
+        if not ops.tile_conv_supported(plan, H, C, K):
+            continue
+        xd = d(x_lr)
+        x_l, x_r, wd = xd[:, :H * C], xd[:, H * C:], d(w)
+        out_t, al_t = ops.gatv2_tile_conv(x_l, x_r, d(ea), wd, d(att), plan, H, bias=d(bias), node_mask=d(nm), edge_mask=d(em),
+                                          want_rowmax=True)
+        out_p, al_p = ops.gatv2_mp_edge_logits(x_l, x_r, d(ea), wd, d(att), plan, H, bias=d(bias), node_mask=d(nm),
+                                               edge_mask=d(em), want_rowmax=True)
+        assert torch.equal(out_t, out_p), (sizes[:4], (out_t - out_p).abs().max().item())
+        assert torch.equal(al_t, al_p)
+        assert torch.equal(ops.row_maxima(out_t), ops.row_maxima(out_p))
+        e_proj = ea @ w.t()
+        edge_mask = em if em is not None else (nm[ei[0]] * nm[ei[1]] if nm is not None else None)
+        ref_out, ref_alpha = OM.gatv2_message_passing(x_lr[:, :H * C].reshape(N, H, C), x_lr[:, H * C:].reshape(N, H, C),
+                                                      e_proj.view(E, H, C), att, ei,
+                                                      None if edge_mask is None else edge_mask.view(-1, 1), 0.2)
+        ref_out = ref_out.reshape(N, H * C) + bias
+        scale = ref_out.abs().max().item()
+        assert (out_t.cpu() - ref_out).abs().max().item() < 1e-4 * max(scale, 1.0)
+        assert (al_t.cpu() - ref_alpha).abs().max().item() < 1e-4

@@ -39,7 +39,7 @@ rm = conv_out.view(N, H, C).abs().amax(dim=2).contiguous()
 h = torch.randn(N, C, device=dev, generator=g)
 ins, ins_next = wl.instr[0].contiguous(), wl.instr[1].contiguous()
 bn = m.bns[0]
-tile_ptr, ntiles, cap = plan.tiles(64)
+tile_ptr, ntiles, cap, _ = plan.tiles(64)
 T = int(ntiles.item())
 l0, l2 = m.x_proj[0][0], m.x_proj[0][2]
 p1, inv1 = ops._weight_planes(l0.weight, True, "f16x3")

@@ -24,7 +24,7 @@ h = torch.randn(N, C, device=dev, generator=g)
 ins, ins_next = wl.instr[0].contiguous(), wl.instr[1].contiguous()
 bn = m.bns[0]
 flush = torch.empty(1 << 27, device=dev)
-tile_ptr, ntiles, cap = plan.tiles(64)
+tile_ptr, ntiles, cap, _ = plan.tiles(64)
 print(f"N={N} graphs={graphs} tiles={int(ntiles.item())} (capacity {cap}), rows/tile={N / max(int(ntiles.item()), 1):.1f}")
 
 
