@@ -112,3 +112,30 @@ def test_traffic_summaries_are_replayed_only_for_the_kernels_they_describe():
     assert pair is not None and graph is not None and chunk is not None and len({pair, graph, chunk}) == 3
     assert 0.9e9 < graph < 1.0e9 and pair < graph < chunk
     assert bench.load_traffic(N + 1, E, "graph") is None
+
+
+def test_bench_line_schema_on_the_committed_sample():
+    """The newest committed default-flag bench line of this round (profiles/r03_*bench.json) carries every object the contract
+    and the review ask for: roofline, cpu_baseline (+cfg1), fallbacks, dense_err_vs_fp32, cfg5 (with the 8-rank imbalance of
+    both partitions), full_model; a line without one of them must be rejected."""
+    import copy
+    import glob
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r03_*_bench.json")))
+    assert paths, "no committed r03 bench line under profiles/"
+    line = json.load(open(paths[-1]))
+    bench.validate_line(line)
+    assert line["metric"] == "GQA questions/sec" and line["config"]["graphs_per_gpu"] == 4096 and line["dtype"] == "f32"
+    assert line["fallbacks"]["torch_linear"] == 0 and line["fallbacks"]["torch_layer_norm"] == 0
+    assert 0 < line["dense_err_vs_fp32"]["max"] <= 2.0
+    for drop in ("cfg5", "fallbacks", "roofline"):
+        bad = copy.deepcopy(line)
+        del bad[drop]
+        try:
+            bench.validate_line(bad)
+        except KeyError:
+            continue
+        raise AssertionError(f"a line without {drop!r} passed validation")
