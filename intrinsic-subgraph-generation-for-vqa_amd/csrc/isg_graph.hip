@@ -1,6 +1,7 @@
 // Graph plan kernels: per-graph node ranges and the CSR-by-destination of a PyG COO edge_index.
 #include "isg_common.hpp"
 
+#include <algorithm>
 #include <string>
 
 namespace isg {
@@ -161,6 +162,99 @@ __global__ void csr_rank_kernel(const int64_t *__restrict__ edge_index, int E, i
   if (dst) dst[rb + rank] = d;
 }
 
+// ---- the whole plan in seven launches (isg_graph_plan_build) --------------------------------------------------------------
+// The step-by-step entry points above cost 14 launches of 4-5 us each per batch (6 % of a BASELINE configs[1] step); here the
+// independent pieces share a launch: (1) zero the degree / cursor arrays and the bounds + graph boundaries from `batch`,
+// (2) in-degree histogram + largest graph, (3) per-chunk degree sums, (4) scan: every workgroup adds up the chunk sums before
+// its own (at most a few hundred values) instead of a separate one-workgroup scan, (5) atomic fill + per-graph slot ranges and
+// the largest edge count, (6) rank by edge id inside each segment.  (7) is the tile plan (isg_tile_plan).
+__global__ void plan_init_kernel(const int64_t *__restrict__ batch, int N, int B, int *__restrict__ ptr, int *__restrict__ zero,
+                                 int nzero, int *__restrict__ bounds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nzero) zero[i] = 0;
+  if (i < 2) bounds[i] = 0;
+  if (N == 0) {
+    if (i <= B) ptr[i] = 0;
+    return;
+  }
+  if (i < N) {
+    int b = (int)batch[i];
+    const int prev = i > 0 ? (int)batch[i - 1] : -1;
+    if (b >= B) b = B - 1;
+    for (int g = prev + 1; g <= b; ++g) ptr[g] = i;
+    if (i == N - 1)
+      for (int g = b + 1; g <= B; ++g) ptr[g] = N;
+  }
+}
+
+__global__ void plan_hist_kernel(const int64_t *__restrict__ dst, int E, int N, int *__restrict__ deg, const int *__restrict__ ptr,
+                                 int B, int *__restrict__ nmax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < E) {
+    const int d = (int)dst[i];
+    if (d >= 0 && d < N) atomicAdd(&deg[d], 1);
+  }
+  int v = 0;
+  if (i < B) v = ptr[i + 1] - ptr[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(nmax, v);
+}
+
+__global__ __launch_bounds__(256) void scan_apply_self_kernel(const int *__restrict__ deg, const int *__restrict__ sums, int N,
+                                                              int nchunks, int *__restrict__ rowptr) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  int part = 0;      // sum of the chunk sums before this workgroup's chunk (and, in the last workgroup, of all of them)
+  for (int c = threadIdx.x; c < (int)blockIdx.x; c += 256) part += sums[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  __syncthreads();
+  const int base0 = s_base;
+  __syncthreads();
+  const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+  int d[4];
+  int v = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    d[u] = base + u < N ? deg[base + u] : 0;
+    v += d[u];
+  }
+  const int inc = block_inclusive_scan_256(v, s_wave);
+  int run = base0 + inc - v;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (base + u < N) rowptr[base + u] = run;
+    run += d[u];
+  }
+  if ((int)blockIdx.x == nchunks - 1 && threadIdx.x == 255) rowptr[N] = base0 + inc;      // number of valid edges
+}
+
+__global__ void plan_fill_kernel(const int64_t *__restrict__ dst, int E, int N, const int *__restrict__ rowptr,
+                                 int *__restrict__ cursor, int *__restrict__ eid_tmp, const int *__restrict__ ptr, int B,
+                                 int *__restrict__ eptr, int *__restrict__ emax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < E) {
+    const int d = (int)dst[i];
+    if (d >= 0 && d < N) {
+      const int slot = atomicAdd(&cursor[d], 1);
+      eid_tmp[rowptr[d] + slot] = i;
+    }
+  }
+  int cnt = 0;
+  if (i <= B) {
+    const int lo = rowptr[ptr[i]];
+    eptr[i] = lo;
+    if (i < B) cnt = rowptr[ptr[i + 1]] - lo;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, __shfl_xor(cnt, off, 64));
+  if ((threadIdx.x & 63) == 0 && cnt > 0) atomicMax(emax, cnt);
+}
+
 }  // namespace isg
 
 using namespace isg;
@@ -232,5 +326,39 @@ extern "C" int isg_graph_edge_ptr(const int32_t *ptr, const int32_t *rowptr, int
   hipStream_t st = as_stream(stream);
   if (emax) fill_i32_kernel<<<1, 64, 0, st>>>(emax, 1, 0);
   graph_eptr_kernel<<<(unsigned)((B + 1 + 255) / 256), 256, 0, st>>>(ptr, rowptr, (int)B, eptr, emax);
+  return check_launch();
+}
+
+
+// ptr / nmax, CSR by destination, per-graph slot ranges and the largest edge count in six launches (the tile plan is the
+// seventh): what isg_graph_ptr + isg_csr_build + isg_graph_edge_ptr compute in fourteen.  bounds int32[2] receives {largest node
+// count, largest edge count of a graph}; the other outputs as in those three; workspace: isg_csr_workspace_bytes(N, E).
+extern "C" int isg_graph_plan_build(const int64_t *batch, const int64_t *edge_index, int64_t N, int64_t E, int64_t B,
+                                    int32_t *ptr, int32_t *bounds, int32_t *rowptr, int32_t *eid, int32_t *src, int32_t *dst,
+                                    int32_t *eptr, void *workspace, size_t workspace_bytes, void *stream) {
+  if (N < 0 || E < 0 || B < 0 || !ptr || !bounds || !rowptr || !eptr || (N > 0 && !batch) || (E > 0 && (!edge_index || !eid || !src)))
+    return ISG_EINVAL;
+  if (N >= (1ll << 31) - 1024 || E >= (1ll << 31) - 1024 || B >= (1ll << 31) - 1024) return ISG_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < isg_csr_workspace_bytes(N, E)) return ISG_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  int *deg = (int *)workspace;            // N+1
+  int *cursor = deg + (N + 1);            // N+1
+  int *eid_tmp = cursor + (N + 1);        // E
+  int *chunk_sums = eid_tmp + E;          // ceil(N / SCAN_CHUNK) + 1
+  const int n = (int)N, e = (int)E, b = (int)B;
+  const int nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  const long long span1 = std::max<long long>(std::max<long long>(2ll * (n + 1), n), b + 1);
+  plan_init_kernel<<<(unsigned)((span1 + 255) / 256), 256, 0, st>>>(batch, n, b, ptr, deg, 2 * (n + 1), bounds);
+  const int span2 = std::max(e, b);
+  if (span2 > 0) plan_hist_kernel<<<(span2 + 255) / 256, 256, 0, st>>>(edge_index + E, e, n, deg, ptr, b, bounds);
+  if (nchunks > 0) {
+    scan_chunk_sums_kernel<<<nchunks, 256, 0, st>>>(deg, n, chunk_sums);
+    scan_apply_self_kernel<<<nchunks, 256, 0, st>>>(deg, chunk_sums, n, nchunks, rowptr);
+  } else {
+    fill_i32_kernel<<<1, 64, 0, st>>>(rowptr, 1, 0);
+  }
+  const int span3 = std::max(e, b + 1);
+  plan_fill_kernel<<<(span3 + 255) / 256, 256, 0, st>>>(edge_index + E, e, n, rowptr, cursor, eid_tmp, ptr, b, eptr, bounds + 1);
+  if (e > 0) csr_rank_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index, e, n, rowptr, eid_tmp, eid, src, dst);
   return check_launch();
 }

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict_
                                                           int *__restrict__ ntiles, int cap, int4 *__restrict__ tile_info) {
   __shared__ int s_jump[2][TP_CH];
   __shared__ int s_mark[TP_CH];
+  __shared__ int s_ptr[TP_CH + 1], s_eptr[TP_CH + 1];
   __shared__ int s_wsum[TP_CH / 64];
   __shared__ int s_base;
   const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
@@ -54,18 +55,24 @@ __global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict_
   __syncthreads();
   for (int c0 = 0; c0 < B; c0 += TP_CH) {
     const int cn = min(TP_CH, B - c0);
+    // the chunk's node / slot offsets in LDS: the binary search below is 11 dependent reads per graph (from global memory that
+    // was ~1 us each: most of this kernel's 21 us)
+    for (int k = i; k <= cn; k += TP_CH) {
+      s_ptr[k] = ptr[c0 + k];
+      s_eptr[k] = eptr ? eptr[c0 + k] : 0;
+    }
+    __syncthreads();
     int nx = TP_CH;
     if (i < cn) {
-      const int g = c0 + i;
-      const int nlim = ptr[g] + ncap;
-      const int elim = eptr ? eptr[g] + ecap : 0;
-      int lo = g + 1, hi = c0 + cn;      // the answer lies in [lo, hi]: the predicate is monotone, g + 1 is forced
+      const int nlim = s_ptr[i] + ncap;
+      const int elim = s_eptr[i] + ecap;
+      int lo = i + 1, hi = cn;           // the answer lies in [lo, hi]: the predicate is monotone, i + 1 is forced
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        const bool ok = ptr[mid] <= nlim && (!eptr || eptr[mid] <= elim);
+        const bool ok = s_ptr[mid] <= nlim && (!eptr || s_eptr[mid] <= elim);
         if (ok) lo = mid; else hi = mid - 1;
       }
-      nx = lo - c0 >= cn ? TP_CH : lo - c0;
+      nx = lo >= cn ? TP_CH : lo;
     }
     const int nx0 = nx;                  // the tile that starts at this graph ends before graph c0 + nx0 (or with the chunk)
     s_jump[0][i] = nx;
@@ -97,8 +104,8 @@ __global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict_
       if (idx < cap) {
         tile_ptr[idx] = c0 + i;
         if (tile_info) {       // {first node, nodes, first CSR slot, CSR slots}: one load gives a workgroup its tile
-          const int g = c0 + i, g1 = c0 + (nx0 < TP_CH ? nx0 : cn);
-          tile_info[idx] = make_int4(ptr[g], ptr[g1] - ptr[g], eptr ? eptr[g] : 0, eptr ? eptr[g1] - eptr[g] : 0);
+          const int l1 = nx0 < TP_CH ? nx0 : cn;
+          tile_info[idx] = make_int4(s_ptr[i], s_ptr[l1] - s_ptr[i], s_eptr[i], s_eptr[l1] - s_eptr[i]);
         }
       }
     }

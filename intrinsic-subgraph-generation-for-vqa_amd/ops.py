@@ -153,6 +153,9 @@ def _f32(t: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # Graph plan
 # ------------------------------------------------------------------------------------------------
+PLAN_FUSED = True     # isg_graph_plan_build (6 launches) instead of isg_graph_ptr + isg_csr_build + isg_graph_edge_ptr (14): A/B switch
+
+
 @dataclass
 class GraphPlan:
     """What every layer needs to know about one PyG Batch, computed once on the device.
@@ -232,10 +235,8 @@ class GraphPlan:
         B = int(num_graphs)
         dev = batch.device
         ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
-        bounds = torch.zeros(2, dtype=torch.int32, device=dev)     # [max nodes per graph, max edges per graph]
+        bounds = torch.empty(2, dtype=torch.int32, device=dev)     # [max nodes per graph, max edges per graph]
         nmax_dev = bounds[:1]
-        _lib.check(lib.isg_graph_ptr(batch.data_ptr(), N, B, ptr.data_ptr(), nmax_dev.data_ptr(), _stream()),
-                   "isg_graph_ptr")
         plan = GraphPlan(N=N, E=0, B=B, ptr=ptr, nmax_dev=nmax_dev, nmax=0, batch=batch)
         if edge_index is not None:
             _chk(edge_index, "edge_index", torch.int64)
@@ -244,18 +245,32 @@ class GraphPlan:
             E = edge_index.size(1)
             plan.E = E
             plan.edge_index = edge_index
-            plan.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
-            plan.eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-            plan.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-            plan.dst = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            # one allocation for the five index arrays (rows 16-byte aligned), one for the workspace
+            n1, e1 = (N + 1 + 3) // 4 * 4, (max(E, 1) + 3) // 4 * 4
+            idx = torch.empty(n1 + 3 * e1 + B + 1, dtype=torch.int32, device=dev)
+            plan.rowptr, plan.eid = idx[:N + 1], idx[n1:n1 + max(E, 1)]
+            plan.src, plan.dst = idx[n1 + e1:n1 + e1 + max(E, 1)], idx[n1 + 2 * e1:n1 + 2 * e1 + max(E, 1)]
+            plan.eptr = idx[n1 + 3 * e1:n1 + 3 * e1 + B + 1]
             ws_bytes = lib.isg_csr_workspace_bytes(N, E)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.check(lib.isg_csr_build(edge_index.data_ptr(), N, E, plan.rowptr.data_ptr(), plan.eid.data_ptr(),
-                                         plan.src.data_ptr(), plan.dst.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
-                       "isg_csr_build")
-            plan.eptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
-            _lib.check(lib.isg_graph_edge_ptr(ptr.data_ptr(), plan.rowptr.data_ptr(), B, plan.eptr.data_ptr(),
-                                              bounds[1:].data_ptr(), _stream()), "isg_graph_edge_ptr")
+            if PLAN_FUSED:
+                _lib.check(lib.isg_graph_plan_build(batch.data_ptr(), edge_index.data_ptr(), N, E, B, ptr.data_ptr(),
+                                                    bounds.data_ptr(), plan.rowptr.data_ptr(), plan.eid.data_ptr(),
+                                                    plan.src.data_ptr(), plan.dst.data_ptr(), plan.eptr.data_ptr(), ws.data_ptr(),
+                                                    ws_bytes, _stream()), "isg_graph_plan_build")
+            else:
+                bounds.zero_()
+                _lib.check(lib.isg_graph_ptr(batch.data_ptr(), N, B, ptr.data_ptr(), nmax_dev.data_ptr(), _stream()),
+                           "isg_graph_ptr")
+                _lib.check(lib.isg_csr_build(edge_index.data_ptr(), N, E, plan.rowptr.data_ptr(), plan.eid.data_ptr(),
+                                             plan.src.data_ptr(), plan.dst.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+                           "isg_csr_build")
+                _lib.check(lib.isg_graph_edge_ptr(ptr.data_ptr(), plan.rowptr.data_ptr(), B, plan.eptr.data_ptr(),
+                                                  bounds[1:].data_ptr(), _stream()), "isg_graph_edge_ptr")
+        else:
+            bounds.zero_()
+            _lib.check(lib.isg_graph_ptr(batch.data_ptr(), N, B, ptr.data_ptr(), nmax_dev.data_ptr(), _stream()),
+                       "isg_graph_ptr")
         if max_nodes is None or (edge_index is not None and max_edges is None):
             got = bounds.tolist()                   # one D2H sync per batch (to_dense_batch syncs per layer)
             max_nodes = got[0] if max_nodes is None else max(int(max_nodes), got[0])
@@ -972,7 +987,9 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
     p2, inv2 = _weight_planes(l2.weight, True, "f16x3")
     ybound = derived_weight("dense_tail_bound", (l0.weight, l0.bias), lambda: torch.stack(
         [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
-    tile_ptr, ntiles, cap, _ = plan.tiles(DENSE_TAIL_ROWS)
+    # one tile plan per batch: the convolution's (64 nodes / 256 slots) serves this kernel too when it exists
+    shared = plan._tiles is not None and (DENSE_TAIL_ROWS, TILE_CONV_EDGES) in plan._tiles
+    tile_ptr, ntiles, cap, _ = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if shared else 0)
     h_out = torch.empty_like(h)
     xg = torch.empty_like(h) if ins_next is not None else None
     rc = lib.isg_mgat_dense_tail(

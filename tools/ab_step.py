@@ -26,6 +26,14 @@ variants = [
     ("+ lin_edge folded into the logits (no e_proj in memory)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False)),
     ("+ lin_r formed inside that kernel (no x_r in memory)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=True)),
 ]
+if os.environ.get("AB_R03"):         # round 3's switches on top of round 2's default path
+    base = dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False)
+    variants = [
+        ("r02 default (edge-logits pair, un-fused tail, 14-launch plan)", {**base, "FUSE_TILE_CONV": False, "FUSE_DENSE_TAIL": False, "PLAN_FUSED": False}),
+        ("+ fused dense tail", {**base, "FUSE_TILE_CONV": False, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": False}),
+        ("+ tile conv", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": False}),
+        ("+ 6-launch plan build (r03 default)", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": True}),
+    ]
 if os.environ.get("AB_PANEL_N"):     # sweep the narrowest Linear the panel kernels take, on the default path
     base = dict(variants[-2][1])
     variants = [(f"default path, PANEL_MIN_N = {n}", {**base, "PANEL_MIN_N": n}) for n in (256, 128, 64, 256)]
@@ -38,15 +46,16 @@ with torch.no_grad():
             for k, v in sw.items():
                 setattr(ops, k, v)
             for i in range(3):
-                model(wl, seed=i)
+                model(wl, seed=i, use_hints=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(steps):
-                model(wl, seed=100 + i)
+                model(wl, seed=100 + i, use_hints=True)
             torch.cuda.synchronize()
             if r > 0:
                 res[name].append((time.perf_counter() - t0) / steps * 1e3)
-for k, v in dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False).items():
+for k, v in dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False,
+                 FUSE_TILE_CONV=True, FUSE_DENSE_TAIL=True, PLAN_FUSED=True).items():
     setattr(ops, k, v)
 for name, _ in variants:
     t = sorted(res[name])
