@@ -240,16 +240,25 @@ int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const float *a_rowma
  * Persistent workgroups (two per CU) each keep one head -- its lin_edge fragments stay in registers -- and walk tiles: the head's
  * x_l slice of a tile's nodes is staged once in LDS and serves the logit epilogue of the edge GEMM (row gathers) and the
  * aggregation; logits never leave LDS; the next tile's inputs are requested while the current one is finished.  Operands as
- * isg_gatv2_edge_logits / isg_gatv2_mp_fwd_logits (x_l / x_r fp32 [N,H*C] with row strides ldl / ldr, edge_attr fp32 [E,K] by
- * edge id, w_frag / w_inv_scale = isg_split_f16x2_frag of lin_edge.weight [H*C,K], CSR by destination); out fp32 [N,H*C] (row
+ * isg_gatv2_edge_logits / isg_gatv2_mp_fwd_logits (x_l / x_r fp32 [N,H*C] with row strides ldl / ldr, w_frag / w_inv_scale =
+ * isg_split_f16x2_frag of lin_edge.weight [H*C,K], CSR by destination) except that the edge features arrive as edge_planes /
+ * edge_inv_scale (isg_edge_planes: split once per batch, in CSR slot order, for all layers and heads); out fp32 [N,H*C] (row
  * stride ldo), alpha fp32 [E,H] in edge-id order, rowmax fp32 [N,H] or NULL.  Results are bit-identical to that pair.
  * ISG_EUNSUPPORTED unless C == 128, K <= 128, K % 4 == 0; graphs beyond a tile's caps are truncated (callers test the bounds). */
-int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x_r, int32_t ldr, const float *edge_attr, int32_t lda,
-                        const uint16_t *w_frag, const float *w_inv_scale, const float *att, const float *bias,
+int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x_r, int32_t ldr, const uint16_t *edge_planes,
+                        const float *edge_inv_scale, const uint16_t *w_frag, const float *w_inv_scale, const float *att,
+                        const float *bias,
                         const int32_t *rowptr, const int32_t *eid, const int32_t *src, const int32_t *dst,
                         const int32_t *tile_info, const int32_t *ntiles, int64_t max_tiles, const float *node_mask,
                         const float *edge_mask, float *out, int32_t ldo, float *alpha, float *rowmax, int64_t N, int64_t E,
                         int32_t H, int32_t C, int32_t K, float negative_slope, void *stream);
+
+/* Edge features as the exact-split kernels want them, once per batch: per-row power-of-two scale and (hi, mid) fp16 planes in CSR
+ * SLOT order (slot t = edge eid[t]): planes uint16 [E][2][128] (row: 128 hi values, then 128 mid values; columns beyond K zero),
+ * inv_scale fp32 [E].  edge_attr fp32 [E,K] by edge id (row stride lda).  The same edge features feed lin_edge of every layer
+ * (ISubGVQA/models/mgat.py:144-148).  ISG_EUNSUPPORTED unless K <= 128, K % 4 == 0. */
+int isg_edge_planes(const float *edge_attr, int32_t lda, const int32_t *eid, int64_t E, int32_t K, uint16_t *planes,
+                    float *inv_scale, void *stream);
 
 /* Question-conditioned softmax pooling: GlobalAttention.forward, ISubGVQA/models/att_pooling.py:63-73
  *   x = xn * node_mask;  gate = softmax_g(<x, q[g]>/sqrt(C)) (+1e-16 in the denominator);

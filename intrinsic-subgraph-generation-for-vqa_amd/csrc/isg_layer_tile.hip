@@ -604,16 +604,39 @@ static_assert(2 * TC_SMEM_BYTES <= 160 * 1024, "two workgroups per CU");
 
 struct TcArgs {
   const float *x_l, *x_r;           // [N, H*C] rows (strides ldl / ldr), heads side by side
-  const float *edge_attr;           // [E, K] rows by edge id, stride lda
+  const _Float16 *ep;               // edge features as scaled (hi, mid) fp16 planes in CSR SLOT order: [E][2][128] (isg_edge_planes)
+  const float *ep_inv;              // [E] inverse row scales, slot order
   const _Float16 *Wf;               // lin_edge.weight [H*C, K] as fragment-major (hi, mid) planes
   const float *w_inv, *att, *bias;  // [H*C]; bias may be NULL
   const int *rowptr, *eid, *src, *dst, *ntiles;
   const int4 *tile_info;            // {first node, nodes, first CSR slot, CSR slots} per tile (isg_tile_plan)
   const float *edge_mask, *node_mask;
   float *out, *alpha, *rowmax;      // [N, H*C] (stride ldo), [E, H], [N, H] or NULL
-  int N, E, H, K, KS, NT, lda, ldl, ldr, ldo;
+  int N, E, H, K, KS, NT, ldl, ldr, ldo;
   float slope;
 };
+
+// The edge features are the same for every layer and every head of a step: their row scales and (hi, mid) fp16 planes are formed
+// ONCE per batch, in CSR slot order (a tile's slots are then one contiguous 512-byte-per-slot range), instead of in every
+// (layer, head, chunk) staging pass -- that conversion was ~30 % of the tile kernel's instructions.
+__global__ __launch_bounds__(256) void edge_planes_kernel(const float *__restrict__ edge_attr, int lda, const int *__restrict__ eid,
+                                                          int E, int K, _Float16 *__restrict__ planes, float *__restrict__ inv_out) {
+  const int slot = blockIdx.x * 8 + (threadIdx.x >> 5), c4 = threadIdx.x & 31;
+  if (slot >= E) return;
+  const int e = eid[slot];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < K) v = *reinterpret_cast<const float4 *>(edge_attr + (int64_t)e * lda + c4 * 4);
+  const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  float s, inv;
+  h3_scale(mx, s, inv);
+  if (c4 == 0) inv_out[slot] = inv;
+  v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+  hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
+                (_Float16)(v.w - (float)hi[3])};
+  *reinterpret_cast<hf16x4 *>(planes + (int64_t)slot * 256 + c4 * 4) = hi;
+  *reinterpret_cast<hf16x4 *>(planes + (int64_t)slot * 256 + 128 + c4 * 4) = mid;
+}
 
 // PERSISTENT: the grid is two workgroups per CU; a workgroup keeps ONE head (its W fragments never leave its registers) and walks
 // tiles t = group, group + groups, ...; while it finishes a tile (softmax, aggregation) the next tile's CSR records, row pointers,
@@ -700,16 +723,15 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                  \
       const int row = min(r0n + min(srow + 8 * u, max(nrn - 1, 0)), a.N - 1);                                        \
       xv_n[u] = __builtin_nontemporal_load(reinterpret_cast<const hf32x4 *>(a.x_l + (int64_t)row * a.ldl + hoff + sc4 * 4)); \
-      e8[u] = nen > 0 ? a.eid[e0n + min(srow + 8 * u, nen - 1)] : 0;                                                 \
     }                                                                                                                \
   }
-  // chunk 0's edge rows of that tile (its edge ids have landed by now) and the mask values
+  // chunk 0's edge planes of that tile (slot order: one contiguous range) and the mask values
 #define TC_REQUEST_ROWS0(d)                                                                                          \
   {                                                                                                                  \
-    const int nen = min((d).w, TC_ECAP);                                                                             \
+    const int e0n = (d).z, nen = min((d).w, TC_ECAP);                                                                \
     if (nen > 0) {                                                                                                   \
       _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                                  \
-        ra[u] = *reinterpret_cast<const hf32x4 *>(a.edge_attr + (int64_t)e8[u] * a.lda + min(sc4 * 4, a.K - 4));     \
+        ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0n + min(srow + 8 * u, nen - 1)) * 256 + sc4 * 8); \
     }                                                                                                                \
     if (MASKED && tid < nen)                                                                                         \
       rec_n.w = __float_as_int(a.edge_mask ? a.edge_mask[rec_n.y] : a.node_mask[sraw_n] * a.node_mask[draw_n]);      \
@@ -726,7 +748,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
   int4 desc = a.tile_info[t];
   {
     int4 rec_n;
-    int rp_n, sraw_n = 0, draw_n = 0, e8[8];
+    int rp_n, sraw_n = 0, draw_n = 0;
     hf32x4 xv_n[8];
     TC_REQUEST_TILE(desc)
     TC_REQUEST_ROWS0(desc)
@@ -756,31 +778,18 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
 #pragma unroll
         for (int g = 0; g < 4; ++g) xr[i][g] = *reinterpret_cast<const hf32x4 *>(xr_row + 8 * g);
       }
-      // the chunk's edge rows (requested a chunk ahead) -> row scale -> (hi, mid) planes
+      // the chunk's edge planes (requested a chunk ahead): 16-byte pieces straight into the panel image
+      const int e0 = desc.z;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int row = srow + 8 * u;
-        hf32x4 v = ra[u];
-        if (64 * c + row >= ne || sc4 * 4 >= a.K) v = hf32x4{0.f, 0.f, 0.f, 0.f};
-        const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-        float sc, inv;
-        h3_scale(mx, sc, inv);
-        if (sc4 == 0) s_inv[row] = inv;
-        v *= sc;
-        hf16x4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        hf16x4 mid = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]), (_Float16)(v[2] - (float)hi[2]),
-                      (_Float16)(v[3] - (float)hi[3])};
-        *reinterpret_cast<hf16x4 *>(&sA[0][row][sc4 * 4]) = hi;
-        *reinterpret_cast<hf16x4 *>(&sA[1][row][sc4 * 4]) = mid;
-      }
+      for (int u = 0; u < 8; ++u)
+        *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 8 * u][(sc4 & 15) * 8]) = ra[u];
+      if (tid < 64) s_inv[tid] = a.ep_inv[e0 + min(64 * c + tid, ne - 1)];
       __syncthreads();
       TC_STAMP(2)            // x_r requests + panel staging + barrier
-      if (c + 1 < nchunk) {      // the next chunk's rows: in flight under this chunk's product and epilogue
+      if (c + 1 < nchunk) {      // the next chunk's planes: in flight under this chunk's product and epilogue
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int e = s_tab[min(64 * (c + 1) + srow + 8 * u, ne - 1)].y;
-          ra[u] = *reinterpret_cast<const hf32x4 *>(a.edge_attr + (int64_t)e * a.lda + min(sc4 * 4, a.K - 4));
-        }
+        for (int u = 0; u < 8; ++u)
+          ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0 + min(64 * (c + 1) + srow + 8 * u, ne - 1)) * 256 + sc4 * 8);
       }
       hf32x16 acc[2];
 #pragma unroll
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
       s_w[tid] = MASKED ? __fmul_rn(w, __int_as_float(rc.w)) : w;
     }
     int4 rec_n;                 // the next tile's inputs: defined and consumed inside this iteration
-    int rp_n, sraw_n = 0, draw_n = 0, e8[8];
+    int rp_n, sraw_n = 0, draw_n = 0;
     hf32x4 xv_n[8];
     TC_REQUEST_TILE(desc_n)     // (unconditional: a zero descriptor requests row 0 and nothing else) the next tile's records, row pointers, x_l slice, edge ids: in flight under C2
     __syncthreads();
@@ -920,31 +929,31 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
 using namespace isg;
 
 // MaskingGATv2Conv.message + aggregate with lin_edge inside, on graph-aligned tiles (isg_tile_plan with node_cap = 64 and
-// edge_cap = 256, tile_info requested): see the kernel's header.  ISG_EUNSUPPORTED unless C == 128, K <= 128, K % 4 == 0.
-extern "C" int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x_r, int32_t ldr, const float *edge_attr,
-                                   int32_t lda, const uint16_t *w_frag, const float *w_inv_scale, const float *att,
+// edge_cap = 256, tile_info requested) and on the edge features' planes (isg_edge_planes): see the kernel's header.  ISG_EUNSUPPORTED unless C == 128, K <= 128, K % 4 == 0.
+extern "C" int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x_r, int32_t ldr, const uint16_t *edge_planes,
+                                   const float *edge_inv_scale, const uint16_t *w_frag, const float *w_inv_scale, const float *att,
                                    const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
                                    const int32_t *dst, const int32_t *tile_info, const int32_t *ntiles, int64_t max_tiles,
                                    const float *node_mask, const float *edge_mask, float *out, int32_t ldo, float *alpha,
                                    float *rowmax, int64_t N, int64_t E, int32_t H, int32_t C, int32_t K, float negative_slope,
                                    void *stream) {
-  if (N < 0 || E < 0 || H <= 0 || C <= 0 || K <= 0 || max_tiles < 0 || lda < K || ldl < H * C || ldr < H * C || ldo < H * C)
+  if (N < 0 || E < 0 || H <= 0 || C <= 0 || K <= 0 || max_tiles < 0 || ldl < H * C || ldr < H * C || ldo < H * C)
     return ISG_EINVAL;
   auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (C != TC_C || K > TC_KC || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (ldo & 3) != 0 || H > 64 ||
-      mis(x_l) || mis(x_r) || mis(edge_attr) || mis(att) || mis(w_inv_scale) || mis(out) || (bias && mis(bias)) || mis(tile_info) ||
+  if (C != TC_C || K > TC_KC || (K & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (ldo & 3) != 0 || H > 64 ||
+      mis(x_l) || mis(x_r) || mis(edge_planes) || mis(att) || mis(w_inv_scale) || mis(out) || (bias && mis(bias)) || mis(tile_info) ||
       N >= (1ll << 31) || E >= (1ll << 31))
     return ISG_EUNSUPPORTED;
   if (N == 0 || max_tiles == 0) return ISG_OK;
-  if (!x_l || !x_r || (E > 0 && (!edge_attr || !eid || !src || !dst || !alpha)) || !w_frag || !w_inv_scale || !att || !rowptr ||
+  if (!x_l || !x_r || (E > 0 && (!edge_planes || !edge_inv_scale || !eid || !src || !dst || !alpha)) || !w_frag || !w_inv_scale || !att || !rowptr ||
       !tile_info || !ntiles || !out)
     return ISG_EINVAL;
   TcArgs a;
-  a.x_l = x_l; a.x_r = x_r; a.edge_attr = edge_attr; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
+  a.x_l = x_l; a.x_r = x_r; a.ep = reinterpret_cast<const _Float16 *>(edge_planes); a.ep_inv = edge_inv_scale; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
   a.att = att; a.bias = bias; a.rowptr = rowptr; a.eid = eid; a.src = src; a.dst = dst;
   a.tile_info = reinterpret_cast<const int4 *>(tile_info); a.ntiles = ntiles; a.edge_mask = edge_mask; a.node_mask = node_mask;
   a.out = out; a.alpha = alpha; a.rowmax = rowmax; a.N = (int)N; a.E = (int)E; a.H = H; a.K = K; a.KS = (K + 15) / 16;
-  a.NT = H * C / 32; a.lda = lda; a.ldl = ldl; a.ldr = ldr; a.ldo = ldo; a.slope = negative_slope;
+  a.NT = H * C / 32; a.ldl = ldl; a.ldr = ldr; a.ldo = ldo; a.slope = negative_slope;
   // two workgroups per CU (LDS), 256 CUs: 8 XCDs x (groups per XCD) x H head-workgroups; fewer groups when there are few tiles
   static const int gpx_max = [] {
     int dev = 0, cus = 256;
@@ -968,5 +977,21 @@ extern "C" int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x
     if (!ok) return ISG_EUNSUPPORTED;
     gatv2_tile_conv_kernel<false><<<grid, TC_THREADS, TC_SMEM_BYTES, st>>>(a);
   }
+  return check_launch();
+}
+
+// Edge features -> per-row power-of-two scale and (hi, mid) fp16 planes in CSR SLOT order, once per batch: planes
+// uint16 [E][2][128] (row e: the 128 hi values, then the 128 mid values; columns beyond K are zero), inv_scale fp32 [E].
+// The operand of isg_gatv2_tile_conv for every layer and head.  ISG_EUNSUPPORTED unless K <= 128, K % 4 == 0.
+extern "C" int isg_edge_planes(const float *edge_attr, int32_t lda, const int32_t *eid, int64_t E, int32_t K, uint16_t *planes,
+                               float *inv_scale, void *stream) {
+  if (E < 0 || K <= 0 || lda < K) return ISG_EINVAL;
+  if (K > 128 || (K & 3) != 0 || (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(edge_attr) & 15) != 0 ||
+      (reinterpret_cast<uintptr_t>(planes) & 15) != 0 || E >= (1ll << 31) - 8)
+    return ISG_EUNSUPPORTED;
+  if (E == 0) return ISG_OK;
+  if (!edge_attr || !eid || !planes || !inv_scale) return ISG_EINVAL;
+  edge_planes_kernel<<<(unsigned)((E + 7) / 8), 256, 0, as_stream(stream)>>>(edge_attr, lda, eid, (int)E, K,
+                                                                             reinterpret_cast<_Float16 *>(planes), inv_scale);
   return check_launch();
 }

@@ -182,6 +182,25 @@ class GraphPlan:
     _by_src: Optional[Tuple[Tensor, Tensor, Tensor]] = None
     _slots: Optional[Tensor] = None
     _tiles: Optional[dict] = None
+    _edge_planes: Optional[tuple] = None
+
+    def edge_planes(self, edge_attr: Tensor) -> Tuple[Tensor, Tensor]:
+        """(planes int16 [E, 2, 128], inv_scale fp32 [E]) of the batch's edge features in CSR slot order (isg_edge_planes): the
+        operand of isg_gatv2_tile_conv.  Every layer and head reads the same edge features (mgat.py:144-148), so the split is
+        made once per batch and kept on the plan (keyed by the tensor's identity, storage and version)."""
+        self.require_csr()
+        key = (id(edge_attr), edge_attr.data_ptr(), _ver(edge_attr), tuple(edge_attr.shape))
+        hit = self._edge_planes
+        if hit is None or hit[0] != key:
+            lib = _lib.load()
+            E, K = edge_attr.shape
+            planes = torch.empty(max(E, 1), 2, 128, dtype=torch.int16, device=edge_attr.device)
+            inv = torch.empty(max(E, 1), dtype=torch.float32, device=edge_attr.device)
+            _lib.check(lib.isg_edge_planes(_chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), self.eid.data_ptr(), E, K,
+                                           planes.data_ptr(), inv.data_ptr(), _stream()), "isg_edge_planes")
+            hit = (key, planes, inv)
+            self._edge_planes = hit
+        return hit[1], hit[2]
 
     def tiles(self, node_cap: int = 64, edge_cap: int = 0) -> Tuple[Tensor, Tensor, int, Tensor]:
         """(tile_ptr int32[cap + 1], ntiles int32[1] on the device, cap, tile_info int32[cap, 4]): consecutive graphs packed greedily into tiles of
@@ -595,6 +614,7 @@ def gatv2_tile_conv(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor,
     if x_l.dtype != torch.float32 or x_r.dtype != torch.float32 or edge_attr.dtype != torch.float32:
         raise TypeError("gatv2_tile_conv: fp32 rows")
     planes, inv = _weight_planes(w_edge, True, "f16x3")
+    ep, ep_inv = plan.edge_planes(edge_attr)
     _, ntiles, cap, tile_info = plan.tiles(TILE_CONV_NODES, TILE_CONV_EDGES)
     out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
@@ -605,8 +625,8 @@ def gatv2_tile_conv(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor,
                                   "feat_bytes": 4, "tile_conv": True})
         ev0.record()
     rc = lib.isg_gatv2_tile_conv(
-        _chk_rows(x_l, "x_l"), x_l.stride(0), _chk_rows(x_r, "x_r"), x_r.stride(0), _chk_rows(edge_attr, "edge_attr"),
-        edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+        _chk_rows(x_l, "x_l"), x_l.stride(0), _chk_rows(x_r, "x_r"), x_r.stride(0), ep.data_ptr(), ep_inv.data_ptr(),
+        planes.data_ptr(), inv.data_ptr(), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
         _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
         plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(), tile_info.data_ptr(),
         ntiles.data_ptr(), cap,

@@ -29,6 +29,7 @@ att = torch.randn(H * C, device=dev, generator=g)
 bias = torch.randn(H * C, device=dev, generator=g)
 planes, inv = ops._weight_planes(w, False, "f16x3")
 tile_ptr, ntiles, cap, tile_info = plan.tiles(64, 256)
+ep, ep_inv = plan.edge_planes(wl.edge_attr)
 T = int(ntiles.item())
 out = torch.empty(N, H * C, device=dev)
 alpha = torch.empty(E, H, device=dev)
@@ -38,8 +39,8 @@ buf = torch.zeros(nblk * 4, 16, dtype=torch.int64, device=dev)
 assert stamp.isg_dt_set_stamp_buffer(buf.data_ptr()) == 0
 for rep in range(2):
     buf.zero_()
-    rc = stamp.isg_gatv2_tile_conv(x_l.data_ptr(), x_l.stride(0), x_r.data_ptr(), x_r.stride(0), wl.edge_attr.data_ptr(),
-                                   wl.edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(), att.data_ptr(), bias.data_ptr(),
+    rc = stamp.isg_gatv2_tile_conv(x_l.data_ptr(), x_l.stride(0), x_r.data_ptr(), x_r.stride(0), ep.data_ptr(),
+                                   ep_inv.data_ptr(), planes.data_ptr(), inv.data_ptr(), att.data_ptr(), bias.data_ptr(),
                                    plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(),
                                    tile_info.data_ptr(), ntiles.data_ptr(), cap, 0, 0,
                                    out.data_ptr(), H * C, alpha.data_ptr(), rowmax.data_ptr(), N, E, H, C, C, 0.2,
