@@ -253,6 +253,21 @@ int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x_r, int32_t
                         const float *edge_mask, float *out, int32_t ldo, float *alpha, float *rowmax, int64_t N, int64_t E,
                         int32_t H, int32_t C, int32_t K, float negative_slope, void *stream);
 
+/* One MaskingGATv2Conv after its instruction gate and node mask as ONE persistent launch: lin_l | lin_r, lin_edge, logits,
+ * softmax, aggregation (ISubGVQA/models/mgat_v2_conv.py:177-181, :215-232, :243-279).  As isg_gatv2_tile_conv, but the head's x_l
+ * and x_r slices of a tile are formed inside, on the matrix cores, from the gated node rows x fp32 [N,128] (row stride ldx) and
+ * stay in LDS: neither tensor exists in memory, the logit epilogue gathers both from LDS.  wn_frag / wn_inv_scale =
+ * isg_split_f16x2_frag of cat(lin_l.weight, lin_r.weight) [2*H*C,128]; bn fp32 [2*H*C] = cat of their biases; the remaining
+ * operands as isg_gatv2_tile_conv.  Bit-identical to isg_linear_f16x3 + isg_gatv2_tile_conv.  ISG_EUNSUPPORTED unless C == 128,
+ * K_in == 128, K_edge <= 128, K_edge % 4 == 0, H <= 16. */
+int isg_gatv2_layer_conv(const float *x, int32_t ldx, const uint16_t *wn_frag, const float *wn_inv_scale, const float *bn,
+                         const uint16_t *edge_planes, const float *edge_inv_scale, const uint16_t *we_frag,
+                         const float *we_inv_scale, const float *att, const float *bias, const int32_t *rowptr,
+                         const int32_t *eid, const int32_t *src, const int32_t *dst, const int32_t *tile_info,
+                         const int32_t *ntiles, int64_t max_tiles, const float *node_mask, const float *edge_mask, float *out,
+                         int32_t ldo, float *alpha, float *rowmax, int64_t N, int64_t E, int32_t H, int32_t C, int32_t K_in,
+                         int32_t K_edge, float negative_slope, void *stream);
+
 /* Edge features as the exact-split kernels want them, once per batch: per-row power-of-two scale and (hi, mid) fp16 planes in CSR
  * SLOT order (slot t = edge eid[t]): planes uint16 [E][2][128] (row: 128 hi values, then 128 mid values; columns beyond K zero),
  * inv_scale fp32 [E].  edge_attr fp32 [E,K] by edge id (row stride lda).  The same edge features feed lin_edge of every layer

@@ -1,0 +1,428 @@
+// One MaskingGATv2Conv per launch on graph-aligned tiles: lin_l | lin_r, lin_edge, logits, softmax, aggregation.
+//
+// Reference: MaskingGATv2Conv.forward after the instruction gate and the node mask, ISubGVQA/models/mgat_v2_conv.py:177-181
+// (x_l = lin_l(x), x_r = lin_r(x)), :215-232 / :243-279 (message, softmax, aggregate) with lin_edge (:259-261) inside.
+// isg_gatv2_tile_conv (csrc/isg_layer_tile.hip) still reads x_l / x_r [N, H*C] that a separate launch (isg_linear_f16x3, 114 us per
+// layer at BASELINE configs[1], at its write floor: 337 MB) wrote just before -- 674 MB per layer of HBM traffic for two tensors
+// that are consumed once, tile by tile.  Here a persistent workgroup owns one head (as there) and forms the head's x_l / x_r slices
+// of a tile's <= 64 nodes itself, from the gated node rows x [64, 128], on the matrix cores, straight into LDS: the logit
+// epilogue gathers BOTH from LDS (no per-edge row gathers from global memory at all), the aggregation reads x_l from LDS, and
+// neither tensor ever exists in memory.  HBM per layer: x 42 MB + edge planes 105 MB in (both shared by a tile's four head
+// workgroups through L2), out 168 MB + alpha 3 MB back.
+//   block  = 8 waves, one workgroup per CU (LDS: two 33 KB row slices, one 34 KB panel image, tables), persistent
+//   wave   = node GEMM: all 64 rows x one of the head's eight 32-column tiles of [lin_l | lin_r]; edge GEMM: one 32-slot half of a
+//            64-slot chunk x one of the head's four 32-channel tiles of lin_edge (transposed product, isg_mp_logits.hip)
+//   W      = both weights' fragments of the wave's tiles live in its registers for the whole launch (128 VGPRs)
+// The arithmetic is isg_linear_f16x3's (row scale, planes, MFMA order, epilogue) followed by isg_gatv2_tile_conv's, operation
+// for operation: out / alpha / rowmax are bit-identical to the two-launch path.
+#include "isg_f16x3.hpp"
+
+#ifdef ISG_DT_STAMP
+static __device__ long long *g_lc_stamps = nullptr;
+#define LC_T() ((long long)__builtin_amdgcn_s_memtime())
+#define LC_STAMP(i) { const long long now_ = LC_T(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define LC_STAMP(i)
+#endif
+
+namespace isg {
+
+constexpr int LC_ROWS = 64, LC_ECAP = 256, LC_C = 128, LC_K = 128, LC_LDX = LC_C + 4, LC_LDA = LC_K + 8, LC_THREADS = 512;
+constexpr int LC_OFF_XR = LC_ROWS * LC_LDX * 4;                       // x_r slice behind the x_l slice
+constexpr int LC_OFF_A = 2 * LC_ROWS * LC_LDX * 4;                    // panel image: node rows, then edge chunks
+constexpr int LC_OFF_TAB = LC_OFF_A + 2 * 64 * LC_LDA * 2;
+constexpr int LC_SMEM_BYTES = LC_OFF_TAB + LC_ECAP * 16 + LC_ECAP * 4 + 4 * 64 * 4 + 64 * 4 + 68 * 4 + 2 * LC_C * 4 + 4 * LC_C * 4;
+static_assert(LC_SMEM_BYTES <= 160 * 1024, "one workgroup per CU");
+
+struct LcArgs {
+  const float *x;                   // gated node rows [N, 128] (row stride ldx): gelu(h * instruction[batch])
+  const _Float16 *Wn;               // [lin_l.weight; lin_r.weight] [2*H*C, 128] as fragment-major (hi, mid) planes
+  const float *wn_inv, *bn;         // [2*H*C] inverse scales, biases (lin_l then lin_r)
+  const _Float16 *ep;               // edge features as scaled (hi, mid) planes in CSR slot order [E][2][128] (isg_edge_planes)
+  const float *ep_inv;              // [E]
+  const _Float16 *We;               // lin_edge.weight [H*C, K] fragment planes
+  const float *we_inv, *att, *bias; // [H*C]; bias may be NULL
+  const int *rowptr, *eid, *src, *dst, *ntiles;
+  const int4 *tile_info;
+  const float *edge_mask, *node_mask;
+  float *out, *alpha, *rowmax;
+  int N, E, H, KSE, NTE, ldx, ldo;
+  float slope;
+};
+
+template <bool MASKED>
+__global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lc_smem[];
+  typedef float (*BufX)[LC_LDX];
+  typedef _Float16 (*BufP)[64][LC_LDA];
+  BufX sXl = reinterpret_cast<BufX>(lc_smem);
+  BufX sXr = reinterpret_cast<BufX>(lc_smem + LC_OFF_XR);
+  BufP sA = reinterpret_cast<BufP>(lc_smem + LC_OFF_A);
+  int4 *s_tab = reinterpret_cast<int4 *>(lc_smem + LC_OFF_TAB);        // {src - r0, eid, dst - r0, mask bits}
+  float *s_lg = reinterpret_cast<float *>(s_tab + LC_ECAP);
+  float *s_part = s_lg + LC_ECAP;             // [4 tile-waves][64 slots]; after the chunks: the softmax weights
+  float *s_inv = s_part + 4 * 64;
+  int *s_rp = reinterpret_cast<int *>(s_inv + 64);
+  float *s_att = reinterpret_cast<float *>(s_rp + 68), *s_weinv = s_att + LC_C;
+  float *s_bn = s_weinv + LC_C, *s_wninv = s_bn + 2 * LC_C;             // [x_l 128 | x_r 128] biases / inverse scales of the head
+
+  const int bid = blockIdx.x;
+  const int per_xcd = gridDim.x >> 3, jx = bid >> 3;
+  const int hd = jx % a.H;
+  const int ngrp = gridDim.x / a.H;
+  int t = (bid & 7) * (per_xcd / a.H) + jx / a.H;
+  const int T = *a.ntiles;
+  if (t >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, tw = wave & 3;      // edge GEMM: 32-slot half, 32-channel tile
+#ifdef ISG_DT_STAMP
+  long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const long long st_begin = LC_T();
+  long long st_last = st_begin;
+#endif
+  const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
+  const int hoff = hd * LC_C;
+  const int srow = tid >> 5, sc4 = tid & 31;      // staging map: 32 lanes per 512-byte row, rows srow + 16 u
+
+  // ---- resident W fragments: the wave's tile of lin_edge and its tile of [lin_l | lin_r] ---------------------------------------
+  const int KSE = a.KSE;
+  const unsigned plane_e = (unsigned)a.NTE * (unsigned)KSE * 1024u;
+  const __amdgpu_buffer_rsrc_t wrs_e =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.We), 0, (int)(2u * plane_e), 0x00020000);
+  const unsigned wb_e = (unsigned)(hd * (LC_C / 32) + tw) * (unsigned)KSE * 1024u;
+  const int NTN = 2 * a.H * (LC_C / 32);
+  const unsigned plane_n = (unsigned)NTN * 8u * 1024u;
+  const __amdgpu_buffer_rsrc_t wrs_n =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.Wn), 0, (int)(2u * plane_n), 0x00020000);
+  const int ct = wave;                             // node GEMM: column tile 0..3 = x_l channels, 4..7 = x_r channels of the head
+  const unsigned wb_n = (unsigned)((ct >> 2) * a.H * (LC_C / 32) + hd * (LC_C / 32) + (ct & 3)) * 8u * 1024u;
+  hf16x8 wq_e[8][2], wq_n[8][2];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      wq_n[ks][q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   wrs_n, lane * 16, (int)(wb_n + q * plane_n + (unsigned)ks * 1024u), 0));
+      wq_e[ks][q] = hf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ks < KSE)
+        wq_e[ks][q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     wrs_e, lane * 16, (int)(wb_e + q * plane_e + (unsigned)ks * 1024u), 0));
+    }
+  if (tid < LC_C) {
+    s_att[tid] = a.att[hoff + tid];
+    s_weinv[tid] = a.we_inv[hoff + tid];
+  } else if (tid < 3 * LC_C) {       // columns 0..127: x_l channels of the head, 128..255: x_r channels
+    const int c = tid - LC_C;
+    const int src_col = (c >> 7) * a.H * LC_C + hoff + (c & 127);
+    s_bn[c] = a.bn[src_col];
+    s_wninv[c] = a.wn_inv[src_col];
+  }
+  const float4 b4 = a.bias ? *reinterpret_cast<const float4 *>(a.bias + hoff + fr * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float slope = a.slope;
+
+  hf32x4 ra[4];            // edge planes of a chunk, requested a chunk (or a tile) ahead: rows srow + 16 u, 16-byte piece sc4
+  // (macros, not lambdas: register arrays captured by reference end up in scratch memory)
+#define LC_REQUEST_TILE(d)                           /* d = {r0, nrows, e0, ne} */                                      \
+  {                                                                                                                  \
+    const int r0n = (d).x, nrn = min((d).y, LC_ROWS), e0n = (d).z, nen = min((d).w, LC_ECAP);                          \
+    rp_n = 0;                                                                                                        \
+    if (tid <= nrn) rp_n = a.rowptr[r0n + tid] - e0n;                                                                \
+    rec_n = make_int4(0, 0, 0, __float_as_int(1.f));                                                                 \
+    if (tid < nen) {                                                                                                 \
+      const int s_ = a.src[e0n + tid], e_ = a.eid[e0n + tid], d_ = a.dst[e0n + tid];                                 \
+      rec_n.x = min(max(s_ - r0n, 0), max(nrn - 1, 0));    /* a source outside its tile is clamped into it */        \
+      rec_n.y = e_;                                                                                                  \
+      rec_n.z = min(max(d_ - r0n, 0), max(nrn - 1, 0));                                                              \
+      if (MASKED) rec_n.w = __float_as_int(a.edge_mask ? a.edge_mask[e_] : a.node_mask[s_] * a.node_mask[d_]);        \
+    }                                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
+      const int row = min(r0n + min(srow + 16 * u, max(nrn - 1, 0)), a.N - 1);                                       \
+      xv_n[u] = *reinterpret_cast<const hf32x4 *>(a.x + (int64_t)row * a.ldx + sc4 * 4);                             \
+    }                                                                                                                \
+    if (nen > 0) {                                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                  \
+        ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0n + min(srow + 16 * u, nen - 1)) * 256 + sc4 * 8); \
+    }                                                                                                                \
+  }
+  // records and row pointers into their tables; the node rows -> row scale -> (hi, mid) planes (isg_linear_f16x3's staging)
+#define LC_STORE_TILE(d)                                                                                             \
+  {                                                                                                                  \
+    const int nrn = min((d).y, LC_ROWS);                                                                             \
+    if (tid <= nrn) s_rp[tid] = rp_n;                                                                                \
+    if (tid < LC_ECAP) s_tab[tid] = rec_n;                                                                           \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
+      const int row = srow + 16 * u;                                                                                 \
+      hf32x4 v = xv_n[u];                                                                                            \
+      if (row >= nrn) v = hf32x4{0.f, 0.f, 0.f, 0.f};                                                                \
+      const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));        \
+      float sc_, inv_;                                                                                               \
+      h3_scale(mx, sc_, inv_);                                                                                       \
+      if (sc4 == 0) s_inv[row] = inv_;                                                                               \
+      v *= sc_;                                                                                                      \
+      hf16x4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};                                  \
+      hf16x4 mid = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]), (_Float16)(v[2] - (float)hi[2]), \
+                    (_Float16)(v[3] - (float)hi[3])};                                                                \
+      *reinterpret_cast<hf16x4 *>(&sA[0][row][sc4 * 4]) = hi;                                                        \
+      *reinterpret_cast<hf16x4 *>(&sA[1][row][sc4 * 4]) = mid;                                                       \
+    }                                                                                                                \
+  }
+
+  int4 desc = a.tile_info[t];
+  {
+    int4 rec_n;
+    int rp_n;
+    hf32x4 xv_n[4];
+    LC_REQUEST_TILE(desc)
+    LC_STORE_TILE(desc)
+  }
+  __syncthreads();
+  LC_STAMP(0)              // first tile's inputs (exposed once per workgroup)
+
+#pragma unroll 1
+  while (true) {
+    const int r0 = desc.x, nrows = min(desc.y, LC_ROWS), e0 = desc.z, ne = min(desc.w, LC_ECAP);
+    const int t_next = t + ngrp;
+    const bool has_next = t_next < T;
+    int4 desc_n = make_int4(0, 0, 0, 0);
+    if (has_next) desc_n = a.tile_info[t_next];
+
+    // ---- node GEMM: [64 x 128] . [lin_l | lin_r]_head^T, this wave's 32 columns (isg_linear_f16x3's product and epilogue) -----
+    {
+      hf32x16 accn[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accn[i][r] = 0.f;
+      hf16x8 an[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) an[i][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][i * 32 + fr][ks * 16 + fk]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          hf32x16 c = accn[i];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(an[i][0], wq_n[ks][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(an[i][1], wq_n[ks][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(an[i][0], wq_n[ks][0], c, 0, 0, 0);
+          accn[i] = c;
+        }
+      }
+      const float wi = s_wninv[ct * 32 + fr], bv = s_bn[ct * 32 + fr];
+      float(*dstx)[LC_LDX] = ct < 4 ? sXl : sXr;
+      const int col = (ct & 3) * 32 + fr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          dstx[rl][col] = (accn[i][r] * s_inv[rl]) * wi + bv;       // both scales are powers of two: exact
+        }
+    }
+    __syncthreads();         // x_l / x_r slices complete; the panel image is free for the edge chunks
+    LC_STAMP(1)              // node GEMM
+
+    // ---- 64-slot chunks: edge planes -> panel image, transposed product, logit epilogue (isg_mp_logits.hip) --------------------
+    const int nchunk = (ne + 63) >> 6;
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
+      if (tid < 64) s_inv[tid] = a.ep_inv[e0 + min(64 * c + tid, ne - 1)];
+      __syncthreads();
+      LC_STAMP(2)            // panel staging + barrier
+      if (c + 1 < nchunk) {      // the next chunk's planes: in flight under this chunk's product and epilogue
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0 + min(64 * (c + 1) + srow + 16 * u, ne - 1)) * 256 + sc4 * 8);
+      }
+      const int prow = half * 32 + fr;
+      hf32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      {
+        hf16x8 af[2][2];          // [stage][plane]
+#pragma unroll
+        for (int q = 0; q < 2; ++q) af[0][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][prow][fk]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks < KSE) {
+            if (ks + 1 < 8) {
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                af[(ks + 1) & 1][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][prow][(ks + 1) * 16 + fk]);
+            }
+            // transposed product: W fragment = A operand (rows = channels), edge panel = B operand (columns = edges)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][1], af[ks & 1][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][0], acc, 0, 0, 0);
+          }
+        }
+      }
+#ifdef ISG_DT_STAMP
+      asm volatile("" ::"v"(acc[0]), "v"(acc[15]));
+#endif
+      LC_STAMP(3)            // k loop
+      // epilogue: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask, z * att in 4 chains
+      {
+        const float sinv = s_inv[prow];
+        const int4 rec = s_tab[min(64 * c + prow, ne - 1)];
+        const float me = __int_as_float(rec.w);
+        float part[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cc = tw * 32 + 4 * hh + 8 * g;
+          const float4 xl4 = *reinterpret_cast<const float4 *>(&sXl[rec.x][cc]);
+          const float4 xr4 = *reinterpret_cast<const float4 *>(&sXr[rec.z][cc]);
+          const float4 at4 = *reinterpret_cast<const float4 *>(&s_att[cc]);
+          const float4 wi4 = *reinterpret_cast<const float4 *>(&s_weinv[cc]);
+          const float lv[4] = {xl4.x, xl4.y, xl4.z, xl4.w}, rv[4] = {xr4.x, xr4.y, xr4.z, xr4.w};
+          const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w};
+          part[g] = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float e = (acc[g * 4 + jj] * sinv) * wiv[jj];
+            float z = (rv[jj] + lv[jj]) + e;
+            if (MASKED) z *= me;
+            z = z > 0.f ? z : z * slope;
+            if (MASKED) z *= me;
+            part[g] = fmaf(z, atv[jj], part[g]);
+          }
+        }
+        const float mine = (part[0] + part[1]) + (part[2] + part[3]);
+        const float tot = mine + __shfl_xor(mine, 32);
+        if (hh == 0) s_part[tw * 64 + prow] = tot;
+      }
+      __syncthreads();
+      LC_STAMP(4)            // epilogue + barrier
+      if (tid < 64 && 64 * c + tid < ne)     // the tile-waves' partials in a fixed order
+        s_lg[64 * c + tid] = (s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]);
+    }
+    __syncthreads();
+
+    // ---- softmax + aggregation (isg_mp_graph.hip phase C: same operations in the same order) ----------------------------------
+    float *s_w = s_part;
+    if (tid < ne) {
+      const int4 rc = s_tab[tid];
+      const int rb = s_rp[rc.z], re = min(s_rp[rc.z + 1], ne);
+      float mx = -INFINITY;
+#pragma unroll 2
+      for (int s = rb; s < re; ++s) mx = fmaxf(mx, s_lg[s]);
+      float den = 0.f;
+#pragma unroll 2
+      for (int s = rb; s < re; ++s) den += __builtin_amdgcn_exp2f((s_lg[s] - mx) * 1.4426950408889634f);
+      const float w = __builtin_amdgcn_exp2f((s_lg[tid] - mx) * 1.4426950408889634f) * __builtin_amdgcn_rcpf(den + 1e-16f);
+      a.alpha[(int64_t)rc.y * a.H + hd] = w;
+      s_w[tid] = MASKED ? __fmul_rn(w, __int_as_float(rc.w)) : w;
+    }
+    int4 rec_n;                 // the next tile's inputs: defined and consumed inside this iteration
+    int rp_n;
+    hf32x4 xv_n[4];
+    LC_REQUEST_TILE(desc_n)     // (unconditional: a zero descriptor requests row 0 and nothing else) in flight under the aggregation
+    __syncthreads();
+    LC_STAMP(5)              // weights + the next tile's requests
+#pragma unroll 1
+    for (int k = 2 * wave + hh; k < nrows; k += 16) {
+      const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+      for (int s = rb; s < re; ++s) {
+        const float wm = s_w[s];
+        const float4 u4 = *reinterpret_cast<const float4 *>(&sXl[s_tab[s].x][fr * 4]);
+        o.x = __fadd_rn(o.x, __fmul_rn(u4.x, wm));
+        o.y = __fadd_rn(o.y, __fmul_rn(u4.y, wm));
+        o.z = __fadd_rn(o.z, __fmul_rn(u4.z, wm));
+        o.w = __fadd_rn(o.w, __fmul_rn(u4.w, wm));
+      }
+      if (a.bias) { o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w; }
+      hf32x4 o4 = {o.x, o.y, o.z, o.w};
+      __builtin_nontemporal_store(o4, reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + fr * 4));
+      if (a.rowmax) {
+        const float rmx = group_max<32>(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        if (fr == 0) a.rowmax[(int64_t)(r0 + k) * a.H + hd] = rmx;
+      }
+    }
+    LC_STAMP(6)              // aggregation, stores
+    if (!has_next) break;
+    __syncthreads();         // every wave is done with this tile's LDS image
+    LC_STORE_TILE(desc_n)
+    __syncthreads();
+    LC_STAMP(7)              // hand-over: tables, node rows -> planes
+    desc = desc_n;
+    t = t_next;
+  }
+#undef LC_REQUEST_TILE
+#undef LC_STORE_TILE
+#ifdef ISG_DT_STAMP
+  if (g_lc_stamps && lane == 0) {
+    st_acc[12] = LC_T() - st_begin;
+    long long *dst = g_lc_stamps + ((long long)bid * 8 + wave) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[i] = st_acc[i];
+  }
+#endif
+}
+
+}  // namespace isg
+
+using namespace isg;
+
+#ifdef ISG_DT_STAMP
+extern "C" int isg_lc_set_stamp_buffer(long long *buf) {      // diagnostic build only: [workgroups * 8 waves][16] int64
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_lc_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// lin_l | lin_r + MaskingGATv2Conv.message + aggregate (lin_edge inside) as one persistent launch: see the file header.
+// x fp32 [N,128] (row stride ldx) = the gated layer input; wn_frag / wn_inv_scale = isg_split_f16x2_frag of
+// cat(lin_l.weight, lin_r.weight) [2*H*C, 128], bn fp32 [2*H*C] their biases; the rest as isg_gatv2_tile_conv.
+extern "C" int isg_gatv2_layer_conv(const float *x, int32_t ldx, const uint16_t *wn_frag, const float *wn_inv_scale, const float *bn,
+                                    const uint16_t *edge_planes, const float *edge_inv_scale, const uint16_t *we_frag,
+                                    const float *we_inv_scale, const float *att, const float *bias, const int32_t *rowptr,
+                                    const int32_t *eid, const int32_t *src, const int32_t *dst, const int32_t *tile_info,
+                                    const int32_t *ntiles, int64_t max_tiles, const float *node_mask, const float *edge_mask,
+                                    float *out, int32_t ldo, float *alpha, float *rowmax, int64_t N, int64_t E, int32_t H,
+                                    int32_t C, int32_t K_in, int32_t K_edge, float negative_slope, void *stream) {
+  if (N < 0 || E < 0 || H <= 0 || C <= 0 || K_in <= 0 || K_edge <= 0 || max_tiles < 0 || ldx < K_in || ldo < H * C) return ISG_EINVAL;
+  auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (C != LC_C || K_in != LC_K || K_edge > LC_K || (K_edge & 3) != 0 || (ldx & 3) != 0 || (ldo & 3) != 0 || H > 16 || mis(x) ||
+      mis(edge_planes) || mis(out) || (bias && mis(bias)) || mis(tile_info) || N >= (1ll << 31) || E >= (1ll << 31))
+    return ISG_EUNSUPPORTED;
+  if (N == 0 || max_tiles == 0) return ISG_OK;
+  if (!x || !wn_frag || !wn_inv_scale || !bn || (E > 0 && (!edge_planes || !edge_inv_scale || !eid || !src || !dst || !alpha)) ||
+      !we_frag || !we_inv_scale || !att || !rowptr || !tile_info || !ntiles || !out)
+    return ISG_EINVAL;
+  LcArgs a;
+  a.x = x; a.Wn = reinterpret_cast<const _Float16 *>(wn_frag); a.wn_inv = wn_inv_scale; a.bn = bn;
+  a.ep = reinterpret_cast<const _Float16 *>(edge_planes); a.ep_inv = edge_inv_scale;
+  a.We = reinterpret_cast<const _Float16 *>(we_frag); a.we_inv = we_inv_scale; a.att = att; a.bias = bias; a.rowptr = rowptr;
+  a.eid = eid; a.src = src; a.dst = dst; a.ntiles = ntiles; a.tile_info = reinterpret_cast<const int4 *>(tile_info);
+  a.edge_mask = edge_mask; a.node_mask = node_mask; a.out = out; a.alpha = alpha; a.rowmax = rowmax; a.N = (int)N; a.E = (int)E;
+  a.H = H; a.KSE = (K_edge + 15) / 16; a.NTE = H * C / 32; a.ldx = ldx; a.ldo = ldo; a.slope = negative_slope;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n > 0 ? n : 256;
+  }();
+  int gpx = (cus / 8) / H;                                // groups per XCD: one workgroup per CU
+  if (gpx < 1) gpx = 1;
+  const long long need = (max_tiles + 7) / 8;
+  if (gpx > need) gpx = (int)need;
+  const unsigned grid = 8u * (unsigned)H * (unsigned)gpx;
+  hipStream_t st = as_stream(stream);
+  if (node_mask || edge_mask) {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_layer_conv_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LC_SMEM_BYTES) == hipSuccess;
+    if (!ok) return ISG_EUNSUPPORTED;
+    gatv2_layer_conv_kernel<true><<<grid, LC_THREADS, LC_SMEM_BYTES, st>>>(a);
+  } else {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_layer_conv_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LC_SMEM_BYTES) == hipSuccess;
+    if (!ok) return ISG_EUNSUPPORTED;
+    gatv2_layer_conv_kernel<false><<<grid, LC_THREADS, LC_SMEM_BYTES, st>>>(a);
+  }
+  return check_launch();
+}

@@ -109,6 +109,18 @@ class MaskingGATv2Conv(torch.nn.Module):
         # with the edge-logits pair, x_r = lin_r(x) can be formed inside the logit kernel too (it is used nowhere else):
         # then only lin_l is projected here
         xr_inside = pair and ops.FUSE_XR and not self.share_weights and x.size(1) <= 128 and x.size(1) % 4 == 0
+        if (pair and not xr_inside and not self.share_weights
+                and ops.layer_conv_supported(plan, H, C, x.size(1), edge_attr.size(1))):
+            # lin_l | lin_r, lin_edge, logits, softmax and aggregation as ONE persistent launch on graph-aligned tiles
+            # (csrc/isg_layer_conv.hip): x_l / x_r live in LDS only                       # :177-181, :215-232, :243-279
+            res = ops.gatv2_layer_conv(x, self.lin_l, self.lin_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att,
+                                       plan, H, bias=self.bias, node_mask=mask, negative_slope=self.negative_slope,
+                                       want_rowmax=True)
+            if res is not None:
+                out, alpha = res
+                if isinstance(return_attention_weights, bool):
+                    return out, mask, (edge_index, alpha)
+                return out, mask
         if xr_inside:
             x_l, x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt), None          # :177
         elif self.share_weights:

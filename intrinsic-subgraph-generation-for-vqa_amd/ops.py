@@ -597,6 +597,71 @@ def tile_conv_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: 
             0 < plan.nmax <= TILE_CONV_NODES and plan.emax <= TILE_CONV_EDGES and plan.rowptr is not None and plan.E > 0)
 
 
+FUSE_LAYER_CONV = True     # ... and lin_l | lin_r inside as well (csrc/isg_layer_conv.hip): x_l / x_r never exist in memory
+
+
+def layer_conv_supported(plan: "GraphPlan", heads: int, channels: int, in_channels: int, edge_dim: int) -> bool:
+    """Shape test of isg_gatv2_layer_conv: isg_gatv2_tile_conv's, and a 128-wide layer input."""
+    return FUSE_LAYER_CONV and in_channels == 128 and heads <= 16 and tile_conv_supported(plan, heads, channels, edge_dim)
+
+
+def gatv2_layer_conv(x: Tensor, lin_l, lin_r, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan", heads: int,
+                     bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
+                     negative_slope: float = 0.2, want_rowmax: bool = False):
+    """lin_l(x), lin_r(x), lin_edge(edge_attr), message, softmax and aggregation of one MaskingGATv2Conv as ONE launch
+    (mgat_v2_conv.py:177-181, :215-232, :243-279): isg_gatv2_layer_conv.  x = the gated layer input [N, 128].  Bit-identical to
+    linear_fused + gatv2_tile_conv.  Returns (out, alpha), or None when the kernel has no launch for this shape."""
+    lib = _lib.load()
+    plan.require_csr()
+    N, K_in = x.shape
+    H = int(heads)
+    HC = lin_l.weight.size(0)
+    C = HC // H
+    E, K = edge_attr.shape
+    if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K) or tuple(lin_r.weight.shape) != (HC, K_in) or \
+            lin_l.weight.size(1) != K_in:
+        raise ValueError("gatv2_layer_conv: operand shapes do not match the plan")
+    if x.dtype != torch.float32 or edge_attr.dtype != torch.float32:
+        raise TypeError("gatv2_layer_conv: fp32 rows")
+    cat_w = derived_weight("layer_conv_w", (lin_l.weight, lin_r.weight),
+                           lambda: torch.cat([lin_l.weight.detach(), lin_r.weight.detach()], 0).contiguous())
+    zeros = lambda m: torch.zeros(HC, dtype=torch.float32, device=x.device) if m.bias is None else m.bias.detach()
+    srcs = tuple(t for t in (lin_l.weight, lin_l.bias, lin_r.bias) if t is not None)
+    cat_b = derived_weight("layer_conv_b", srcs, lambda: torch.cat([zeros(lin_l), zeros(lin_r)]).float().contiguous())
+    wn, wn_inv = _weight_planes(cat_w, True, "f16x3")
+    we, we_inv = _weight_planes(w_edge, True, "f16x3")
+    ep, ep_inv = plan.edge_planes(edge_attr)
+    _, ntiles, cap, tile_info = plan.tiles(TILE_CONV_NODES, TILE_CONV_EDGES)
+    out = torch.empty(N, HC, dtype=torch.float32, device=x.device)
+    alpha = torch.empty(E, H, dtype=torch.float32, device=x.device)
+    rowmax = torch.empty(N, H, dtype=torch.float32, device=x.device) if want_rowmax else None
+    timer = MP_TIMER
+    if timer is not None:
+        ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "K": K, "masked": node_mask is not None or edge_mask is not None,
+                                  "feat_bytes": 4, "tile_conv": True, "layer_conv": True, "K_in": K_in})
+        ev0.record()
+    rc = lib.isg_gatv2_layer_conv(
+        _chk_rows(x, "x"), x.stride(0), wn.data_ptr(), wn_inv.data_ptr(), cat_b.data_ptr(), ep.data_ptr(), ep_inv.data_ptr(),
+        we.data_ptr(), we_inv.data_ptr(), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+        _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+        plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(), tile_info.data_ptr(),
+        ntiles.data_ptr(), cap,
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
+        out.data_ptr(), HC, alpha.data_ptr(), 0 if rowmax is None else rowmax.data_ptr(), N, E, H, C, K_in, K,
+        float(negative_slope), _stream())
+    if rc == ISG_EUNSUPPORTED:
+        if timer is not None:
+            timer.drop_last()
+        return None
+    _lib.check(rc, "isg_gatv2_layer_conv")
+    if timer is not None:
+        ev1.record()
+    if rowmax is not None:
+        attach_row_maxima(out, rowmax)
+    return out, alpha
+
+
 def gatv2_tile_conv(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan", heads: int,
                     bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
                     negative_slope: float = 0.2, want_rowmax: bool = False):

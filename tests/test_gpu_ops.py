@@ -1192,3 +1192,55 @@ def test_tile_conv_is_bit_identical_to_the_edge_logits_pair(dev, mask, K):
         scale = ref_out.abs().max().item()
         assert (out_t.cpu() - ref_out).abs().max().item() < 1e-4 * max(scale, 1.0)
         assert (al_t.cpu() - ref_alpha).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("mask", [None, "node", "edge"])
+def test_layer_conv_is_bit_identical_to_projection_plus_tile_conv(dev, mask, monkeypatch):
+    """isg_gatv2_layer_conv (lin_l | lin_r formed inside, per (tile, head), straight into LDS) against the two launches it
+    replaces (isg_linear_f16x3 over [lin_l; lin_r] + isg_gatv2_tile_conv): same operations in the same order -> EQUAL out, alpha,
+    row maxima; and against the CPU oracle (mgat_v2_conv.py:177-181, :243-279)."""
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.models.layers import GlorotLinear
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(23)
+    H, C, K = 4, 128, 128
+    monkeypatch.setattr(ops, "GEMM_KERNEL", "panel")      # the reference projection on isg_linear_f16x3 at every M (small M: tile kernel)
+    torch.manual_seed(5)
+    lin_l, lin_r = GlorotLinear(128, H * C, bias=True).to(dev), GlorotLinear(128, H * C, bias=True).to(dev)
+    with torch.no_grad():
+        lin_l.bias.add_(0.1 * torch.randn(H * C, device=dev))
+        lin_r.bias.add_(0.1 * torch.randn(H * C, device=dev))
+    for sizes, hub in (([1], None), ([64], None), ([64, 1, 63, 2, 62, 20, 20, 20, 5, 0, 3], (0, 150)),
+                       (torch.randint(8, 34, (700,), generator=gen).tolist(), (7, 60))):
+        batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=hub)
+        N, E, B = batch.numel(), ei.size(1), len(sizes)
+        x = torch.randn(N, 128, generator=gen) * torch.rand(N, 1, generator=gen).mul(3).exp()
+        ea = torch.randn(E, K, generator=gen)
+        w = torch.randn(H * C, K, generator=gen) * 0.1
+        att, bias = torch.randn(1, H, C, generator=gen), torch.randn(H * C, generator=gen)
+        nm = (torch.rand(N, generator=gen) < 0.7).float() if mask == "node" else None
+        em = (torch.rand(E, generator=gen) < 0.7).float() if mask == "edge" else None
+        d = lambda t: None if t is None else t.to(dev)
+        plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+        if not ops.layer_conv_supported(plan, H, C, 128, K):
+            assert plan.emax > 256
+            continue
+        xd, ead, wd = d(x), d(ea), d(w)
+        with torch.no_grad():
+            out_f, al_f = ops.gatv2_layer_conv(xd, lin_l, lin_r, ead, wd, d(att), plan, H, bias=d(bias), node_mask=d(nm),
+                                               edge_mask=d(em), want_rowmax=True)
+            x_l, x_r = ops.linear_fused(xd, (lin_l, lin_r))
+            out_t, al_t = ops.gatv2_tile_conv(x_l, x_r, ead, wd, d(att), plan, H, bias=d(bias), node_mask=d(nm), edge_mask=d(em),
+                                              want_rowmax=True)
+        assert torch.equal(out_f, out_t), (sizes[:4], (out_f - out_t).abs().max().item())
+        assert torch.equal(al_f, al_t)
+        assert torch.equal(ops.row_maxima(out_f), ops.row_maxima(out_t))
+        xl_ref = x @ lin_l.weight.detach().cpu().t() + lin_l.bias.detach().cpu()
+        xr_ref = x @ lin_r.weight.detach().cpu().t() + lin_r.bias.detach().cpu()
+        edge_mask = em if em is not None else (nm[ei[0]] * nm[ei[1]] if nm is not None else None)
+        ref_out, ref_alpha = OM.gatv2_message_passing(xl_ref.reshape(N, H, C), xr_ref.reshape(N, H, C), (ea @ w.t()).view(E, H, C),
+                                                      att, ei, None if edge_mask is None else edge_mask.view(-1, 1), 0.2)
+        ref_out = ref_out.reshape(N, H * C) + bias
+        scale = ref_out.abs().max().item()
+        assert (out_f.cpu() - ref_out).abs().max().item() < 1e-4 * max(scale, 1.0)
+        assert (al_f.cpu() - ref_alpha).abs().max().item() < 1e-4

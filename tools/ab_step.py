@@ -32,8 +32,11 @@ if os.environ.get("AB_R03"):         # round 3's switches on top of round 2's de
         ("r02 default (edge-logits pair, un-fused tail, 14-launch plan)", {**base, "FUSE_TILE_CONV": False, "FUSE_DENSE_TAIL": False, "PLAN_FUSED": False}),
         ("+ fused dense tail", {**base, "FUSE_TILE_CONV": False, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": False}),
         ("+ tile conv", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": False}),
-        ("+ 6-launch plan build (r03 default)", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": True}),
+        ("+ 6-launch plan build", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": True, "FUSE_LAYER_CONV": False}),
+        ("+ lin_l | lin_r inside the conv kernel (layer conv)", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": True, "FUSE_LAYER_CONV": True}),
     ]
+    for name, sw in variants[:3]:
+        sw["FUSE_LAYER_CONV"] = False
 if os.environ.get("AB_PANEL_N"):     # sweep the narrowest Linear the panel kernels take, on the default path
     base = dict(variants[-2][1])
     variants = [(f"default path, PANEL_MIN_N = {n}", {**base, "PANEL_MIN_N": n}) for n in (256, 128, 64, 256)]
