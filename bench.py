@@ -268,7 +268,9 @@ def load_traffic(N: int, E: int, kernel: str):
         try:
             t = json.load(open(path))
             name = t.get("kernel", "")
-            if "tile_conv" in name:
+            if "layer_conv" in name:
+                kind = "layer_conv"
+            elif "tile_conv" in name:
                 kind = "tile_conv"
             elif "edge_logits" in name or "+" in name:
                 kind = "logits_pair"          # whatever else the file says: two kernels were summed
@@ -606,6 +608,7 @@ def main(argv=None):
     # by it: a lower bound on what the round-1 definition would give, not comparable with a bracket of the MP kernel alone.
     fused = bool(timer.meta) and all(m.get("fused_logits") for m in timer.meta)
     tile_conv = bool(timer.meta) and all(m.get("tile_conv") for m in timer.meta)
+    layer_conv = tile_conv and all(m.get("layer_conv") for m in timer.meta)
     parts = None
     if fused:
         split = timer.split_ms()
@@ -640,9 +643,11 @@ def main(argv=None):
                        "layers": cfg.layers, "sampler": "gumbel(in-kernel Philox noise)", "k": cfg.sample_k,
                        "parallelism": f"dp{world} (graphs sharded, RCCL all-gather of logits)" if world > 1 else "dp1",
                        "feature_rows": args.features,
-                       "launch": "eager" if graph is None else "hipgraph: one captured step (plan build + model) replayed; Gumbel noise from torch's generator inside the graph; the roofline's kernel durations from eager steps after the timed region", "edge_projection": "unfused" if args.no_fuse_logits else ("inside isg_gatv2_tile_conv" if tile_conv else "folded into the logits"), "layer_tail": "isg_mgat_dense_tail (x_proj + instruction attention + GraphNorm + residual + next gate, one launch per layer)" if ops.FUSE_DENSE_TAIL else "un-fused", "dense": ("exact-split fp32 Linears on MFMA: isg_linear_f16x3 / _f16x3_tile (2 fp16 planes, 3 products, per-row scales), isg_linear_bf16x6 for the small ones" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
+                       "launch": "eager" if graph is None else "hipgraph: one captured step (plan build + model) replayed; Gumbel noise from torch's generator inside the graph; the roofline's kernel durations from eager steps after the timed region", "edge_projection": "unfused" if args.no_fuse_logits else ("inside isg_gatv2_layer_conv (with lin_l | lin_r)" if layer_conv else "inside isg_gatv2_tile_conv" if tile_conv else "folded into the logits"), "layer_tail": "isg_mgat_dense_tail (x_proj + instruction attention + GraphNorm + residual + next gate, one launch per layer)" if ops.FUSE_DENSE_TAIL else "un-fused", "dense": ("exact-split fp32 Linears on MFMA: isg_linear_f16x3 / _f16x3_tile (2 fp16 planes, 3 products, per-row scales), isg_linear_bf16x6 for the small ones" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
             "roofline": {"bound": "hbm",
-                         "kernel": ("gatv2_tile_conv_kernel (isg_gatv2_tile_conv: the reference's message + aggregate WITH lin_edge "
+                         "kernel": ("gatv2_layer_conv_kernel (isg_gatv2_layer_conv: the reference's message + aggregate WITH lin_edge AND "
+                                    "lin_l | lin_r inside as ONE persistent launch on graph-aligned tiles)") if layer_conv else
+                                   ("gatv2_tile_conv_kernel (isg_gatv2_tile_conv: the reference's message + aggregate WITH lin_edge "
                                     "inside as ONE persistent launch on graph-aligned tiles)") if tile_conv else
                                    ("isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits (the reference's message + aggregate WITH "
                                     "lin_edge inside: two launches, one bracket)") if fused else
@@ -650,22 +655,29 @@ def main(argv=None):
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
-                         "traffic": load_traffic(N, E, "tile_conv" if tile_conv else ("logits_pair" if fused else args.mp_kernel)),
+                         "traffic": load_traffic(N, E, "layer_conv" if layer_conv else ("tile_conv" if tile_conv else
+                                                                                         ("logits_pair" if fused else args.mp_kernel))),
                          "algorithmic_bytes_per_launch": int(mp_bytes),
                          "avg_launch_us": round(mp_ms * 1e3, 2), "launches_timed": len(durs)},
         }
         if tile_conv:
             m0 = timer.meta[0]
-            own = sum(4 * m["E"] * m["K"] + 12 * m["N"] * m["H"] * m["C"] + 4 * m["E"] * m["H"] + 16 * m["E"] +
+            # own minimum: edge planes + (x_l and x_r, or with lin_l | lin_r inside: the gated node rows) in, out + alpha back, CSR
+            own = sum(4 * m["E"] * m["K"] + (4 * m["N"] * m["K_in"] + 4 * m["N"] * m["H"] * m["C"] if m.get("layer_conv") else
+                                              12 * m["N"] * m["H"] * m["C"]) + 4 * m["E"] * m["H"] + 16 * m["E"] +
                       (4 * m["E"] if m["masked"] else 0) for m in timer.meta) / len(timer.meta)
-            res["roofline"]["note"] = ("bytes_mp of SURVEY 8(d) (e_proj included, which this kernel never writes or reads) over the time "
-                                       "of the ONE launch that also contains the lin_edge GEMM: a lower bound on the round-1 "
-                                       "definition; own_* = the kernel against its own minimum traffic (edge_attr + x_l + x_r in, "
-                                       "out + alpha back, CSR)")
+            res["roofline"]["note"] = ("bytes_mp of SURVEY 8(d) (x_l, x_r, e_proj included -- this kernel writes or reads none of them) "
+                                       "over the time of the ONE launch that also contains the lin_edge GEMM" +
+                                       (" and the lin_l | lin_r GEMM" if layer_conv else "") + ": a lower bound on the round-1 "
+                                       "definition, the bracket holds strictly more work; own_* = the kernel against its own minimum "
+                                       "traffic")
             res["roofline"]["own_algorithmic_bytes"] = int(own)
             res["roofline"]["own_achieved_GBps"] = round(own / (mp_ms * 1e-3) / 1e9, 1)
             res["roofline"]["own_frac"] = round(own / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-            res["roofline"]["mfma_products_TFLOPs"] = round(3 * 2.0 * m0["E"] * m0["H"] * m0["C"] * m0["K"] / (mp_ms * 1e-3) / 1e12, 1)
+            flops = 3 * 2.0 * m0["E"] * m0["H"] * m0["C"] * m0["K"]
+            if layer_conv:
+                flops += 3 * 2.0 * m0["N"] * 2 * m0["H"] * m0["C"] * m0["K_in"]
+            res["roofline"]["mfma_products_TFLOPs"] = round(flops / (mp_ms * 1e-3) / 1e12, 1)
             res["roofline"]["unfused_kernel"] = unfused
         if fused:
             res["roofline"]["note"] = ("bytes_mp of SURVEY 8(d) (e_proj included, which this pair never writes or reads) over the "

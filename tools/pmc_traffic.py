@@ -85,7 +85,7 @@ def main():
                    algorithmic_bytes=int(m.group(5)), algorithmic_bytes_masked=int(m.group(6)))
         res["traffic_over_algorithmic"] = round(res["hbm_bytes_per_launch"] / res["algorithmic_bytes"], 3)
     # what the summary describes is decided by the kernels that were summed, not by what a log happens to say
-    res["kind"] = "logits_pair" if "+" in kern else ("tile_conv" if "tile_conv" in name else ("graph" if "graph" in name else "chunk"))
+    res["kind"] = "logits_pair" if "+" in kern else ("layer_conv" if "layer_conv" in name else "tile_conv" if "tile_conv" in name else ("graph" if "graph" in name else "chunk"))
     if "+" in kern and not own:
         raise SystemExit(f"{log_path}: no pair_own_bytes_unmasked line -- not a `profile_mp.py ... logits` run")
     if own:      # the pair never touches e_proj: its own minimum is far below the un-fused bytes_mp
