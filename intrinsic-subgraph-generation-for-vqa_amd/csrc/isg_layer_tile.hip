@@ -127,8 +127,9 @@ constexpr int DT_ROWS = 64, DT_KC = 128, DT_K1 = 512, DT_MID = 256, DT_C = 128;
 constexpr int DT_LDA = DT_KC + 8, DT_LDY = DT_MID + 8, DT_LDC = DT_C + 4;
 constexpr int DT_KS1 = DT_K1 / 16, DT_KS2 = DT_MID / 16;
 constexpr int DT_BUF_BYTES = 2 * 2 * DT_ROWS * DT_LDA * 2;                 // 69,632: the two A buffers (and what aliases them)
+constexpr int DT_GPC = 128;                      // graphs of a tile whose node offsets are staged in LDS (the rest: global)
 constexpr int DT_GST = 8;                        // graphs of a tile whose instruction rows are staged in LDS (the rest: global)
-constexpr int DT_SMEM_BYTES = DT_BUF_BYTES + (3 * 64 + 4 * 64 + 64 + 64 + 64 + 2 * DT_GST * DT_C) * 4;      // 80,384
+constexpr int DT_SMEM_BYTES = DT_BUF_BYTES + (3 * 64 + 4 * 64 + 64 + 64 + 64 + 2 * DT_GST * DT_C + DT_GPC + 4) * 4;      // 80,912
 static_assert(2 * DT_ROWS * DT_LDY * 2 <= DT_BUF_BYTES && DT_ROWS * DT_LDC * 4 + 2 * 32 * DT_C * 4 <= DT_BUF_BYTES, "aliases must fit");
 static_assert(2 * DT_SMEM_BYTES <= 160 * 1024, "two workgroups per CU");
 
@@ -212,6 +213,8 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     s_mask[tid] = a.node_mask ? a.node_mask[gr] : 1.f;
   }
   const int ng = g1 - g0;
+  int *s_gp = reinterpret_cast<int *>(s_f + 2688);      // node offsets of the tile's first DT_GPC graphs: the tail's loops read these
+  if (tid <= min(ng, DT_GPC)) s_gp[tid] = a.ptr[g0 + tid] - r0;
   {   // the instruction rows of the tile's first DT_GST graphs (this layer's and the next one's): 32 lanes per row
     const int gi = tid >> 5, c4 = tid & 31;
     if (gi < min(ng, DT_GST)) {
@@ -424,8 +427,8 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   DT_STAMP(9)                  // phase A
   // phase B: softmax over a graph's nodes (the sum runs in node order), a wave per graph
   for (int gi = wave; gi < ng; gi += 4) {
-    const int nb = a.ptr[g0 + gi] - r0;
-    const int n = min(a.ptr[g0 + gi + 1] - r0, nrows) - nb;
+    const int nb = gi < DT_GPC ? s_gp[gi] : a.ptr[g0 + gi] - r0;
+    const int n = min(gi < DT_GPC ? s_gp[gi + 1] : a.ptr[g0 + gi + 1] - r0, nrows) - nb;
     if (n <= 0) continue;
     float *sa_g = s_a + nb;
     float mx = lane < n ? sa_g[lane] : -INFINITY;
@@ -451,8 +454,8 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
       const int ch = tid & (DT_C - 1);
       const float ms = a.gn_ms[ch];
       for (int gi = gb + (tid >> 7); gi < ge; gi += 2) {
-        const int nb = a.ptr[g0 + gi] - r0;
-        const int n = min(a.ptr[g0 + gi + 1] - r0, nrows) - nb;
+        const int nb = gi < DT_GPC ? s_gp[gi] : a.ptr[g0 + gi] - r0;
+        const int n = min(gi < DT_GPC ? s_gp[gi + 1] : a.ptr[g0 + gi + 1] - r0, nrows) - nb;
         if (n <= 0) continue;
         const float cnt = (float)n;
         float sum = 0.f;
