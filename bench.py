@@ -678,6 +678,14 @@ def main(argv=None):
             if layer_conv:
                 flops += 3 * 2.0 * m0["N"] * 2 * m0["H"] * m0["C"] * m0["K_in"]
             res["roofline"]["mfma_products_TFLOPs"] = round(flops / (mp_ms * 1e-3) / 1e12, 1)
+            if layer_conv:     # the launch also IS lin_l | lin_r: the bytes the reference's projection moves beside bytes_mp
+                proj = sum(4 * m["N"] * m["K_in"] + 8 * m["N"] * m["H"] * m["C"] for m in timer.meta) / len(timer.meta)
+                res["roofline"]["with_projection_bytes"] = {
+                    "what": "bytes_mp + the lin_l | lin_r projection's own traffic (x in, x_l and x_r out), the two reference steps "
+                            "this one launch performs; `frac` above counts bytes_mp only",
+                    "algorithmic_bytes": int(mp_bytes + proj),
+                    "achieved": round((mp_bytes + proj) / (mp_ms * 1e-3) / 1e9, 1),
+                    "frac": round((mp_bytes + proj) / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
             res["roofline"]["unfused_kernel"] = unfused
         if fused:
             res["roofline"]["note"] = ("bytes_mp of SURVEY 8(d) (e_proj included, which this pair never writes or reads) over the "
