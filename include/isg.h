@@ -232,8 +232,8 @@ int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const float *a_rowma
                         const float *w2_inv_scale, const float *b2, const float *ins, const float *h,
                         const float *gn_weight, const float *gn_bias, const float *gn_mean_scale, double eps,
                         const float *node_mask, const float *ins_next, float *h_out, float *xg_out, const int32_t *ptr,
-                        const int64_t *batch, const int32_t *tile_ptr, const int32_t *ntiles, int64_t max_tiles, int64_t N,
-                        int32_t K1, int32_t MID, int32_t C, void *stream);
+                        const int64_t *batch, const int32_t *tile_ptr, const int32_t *tile_info, const int32_t *ntiles,
+                        int64_t max_tiles, int64_t N, int32_t K1, int32_t MID, int32_t C, void *stream);
 
 /* MaskingGATv2Conv.message + aggregate with lin_edge inside as ONE launch on graph-aligned tiles (isg_tile_plan with node_cap =
  * 64, edge_cap = 256 and tile_info):   ISubGVQA/models/mgat_v2_conv.py:243-279 (lin_edge :259-261)

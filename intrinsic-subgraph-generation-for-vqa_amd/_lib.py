@@ -93,7 +93,7 @@ SIGNATURES = {
     "isg_tile_plan_capacity": (c_int64, [c_int64, c_int64, c_int64, c_int32, c_int32]),
     "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "isg_mgat_dense_tail": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32] + [c_void_p] * 12 + [c_double] +
-                            [c_void_p] * 8 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+                            [c_void_p] * 9 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "isg_gatv2_layer_conv": (c_int, [c_void_p, c_int32] + [c_void_p] * 15 + [c_int64] + [c_void_p] * 3 +
                              [c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "isg_edge_planes": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -146,6 +146,7 @@ struct DtArgs {
   const float *node_mask, *ins_next;
   float *h_out, *xg_out;
   const int *ptr, *tile_ptr, *ntiles;
+  const int4 *tile_info;   // {first node, nodes, ., .} per tile: the rows' loads start one round trip after the launch
   const long long *batch;
   int N, lda, P, ldp;
   float eps, denom;
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   float *s_ins = s_f + 640, *s_insn = s_f + 640 + DT_GST * DT_C;       // [DT_GST][C] each
 
   const int t = blockIdx.x;
+  const int4 tinfo = a.tile_info[t];        // requested together with the count (entries beyond it are never used)
   if (t >= *a.ntiles) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,10 +177,10 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   long long st_last = st_begin;
 #endif
   const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
-  const int g0 = a.tile_ptr[t], g1 = a.tile_ptr[t + 1];
-  const int r0 = a.ptr[g0];
-  const int nrows = min(a.ptr[g1] - r0, DT_ROWS);
+  const int r0 = tinfo.x;
+  const int nrows = min(tinfo.y, DT_ROWS);
   if (nrows <= 0) return;
+  const int g0 = a.tile_ptr[t], g1 = a.tile_ptr[t + 1];      // needed by the tail only: off the rows' critical path
 
   // ---- staging map: 8 float4 per thread and chunk; the 32 lanes of a half-wave hold one 512-byte row piece -----------------
   const int srow = tid >> 5, sc4 = tid & 31;          // rows srow + 8 u
@@ -257,14 +259,15 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  hf16x8 wq[3][2][2], af[2][2][2];
+  hf16x8 wq[4][2][2], af[2][2];      // W fragments three k-steps ahead; ONE set of panel fragments: a step's LDS reads are
+                                     // issued behind the previous step's twelve MFMAs (384 cycles of matrix-core work)
 #define DT_LOADW1(st, s)                                                                                         \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
       wq[st][j][q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(                           \
           wr1, voff, (int)(((unsigned)(2 * wave + j) * DT_KS1 + (unsigned)(s)) * 1024u + q * plane1), 0));
-#define DT_LOADA1(st, b, ksl)                                                                                    \
+#define DT_LOADA1(b, ksl)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
-      af[st][i][q] = *reinterpret_cast<const hf16x8 *>(&bufA[b][q][i * 32 + fr][(ksl) * 16 + fk]);
+      af[i][q] = *reinterpret_cast<const hf16x8 *>(&bufA[b][q][i * 32 + fr][(ksl) * 16 + fk]);
   // small terms first; the four accumulators take turns so that dependent MFMAs are four issues apart
 #define DT_MMA1(A, W)                                                                                            \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
@@ -275,23 +278,22 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][0], W[j][0], acc[i][j], 0, 0, 0);
   DT_LOADW1(0, 0)
   DT_LOADW1(1, 1)
+  DT_LOADW1(2, 2)
   __syncthreads();                    // chunk 0 is in bufA[0]
   DT_STAMP(1)                  // chunk 0 staged
-  DT_LOADA1(0, 0, 0)
 #pragma unroll
   for (int s = 0; s < DT_KS1; ++s) {
     const int c = s >> 3, ksl = s & 7;
-    if (s + 2 < DT_KS1) { DT_LOADW1((s + 2) % 3, s + 2) }
-    if (ksl < 7) { DT_LOADA1((s + 1) & 1, c & 1, ksl + 1) }
+    if (s + 3 < DT_KS1) { DT_LOADW1((s + 3) & 3, s + 3) }
+    DT_LOADA1(c & 1, ksl)
     __builtin_amdgcn_sched_barrier(0);      // the prefetches stay AHEAD of this step's MFMAs (hipcc sinks them to their use otherwise)
-    DT_MMA1(af[s & 1], wq[s % 3])
+    DT_MMA1(af, wq[s & 3])
     __builtin_amdgcn_sched_barrier(0);
     if (ksl == 7 && c < 3) {
       DT_WRITE_CHUNK((c + 1) & 1)                  // last read two chunks ago: every wave is past that barrier
       if (c + 2 < 4) { DT_LOAD_CHUNK(c + 2) }
       __syncthreads();
       DT_STAMP(2 + c)          // chunk c computed, chunk c + 1 staged
-      DT_LOADA1((s + 1) & 1, (c + 1) & 1, 0)
     }
   }
 #ifdef ISG_DT_STAMP
@@ -559,15 +561,16 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
                                    const uint16_t *w2_frag, const float *w2_inv_scale, const float *b2, const float *ins,
                                    const float *h, const float *gn_weight, const float *gn_bias, const float *gn_mean_scale,
                                    double eps, const float *node_mask, const float *ins_next, float *h_out, float *xg_out,
-                                   const int32_t *ptr, const int64_t *batch, const int32_t *tile_ptr, const int32_t *ntiles,
-                                   int64_t max_tiles, int64_t N, int32_t K1, int32_t MID, int32_t C, void *stream) {
+                                   const int32_t *ptr, const int64_t *batch, const int32_t *tile_ptr, const int32_t *tile_info,
+                                   const int32_t *ntiles, int64_t max_tiles, int64_t N, int32_t K1, int32_t MID, int32_t C,
+                                   void *stream) {
   if (N < 0 || max_tiles < 0 || lda < K1 || P <= 0 || ldp < P) return ISG_EINVAL;
   if (K1 != DT_K1 || MID != DT_MID || C != DT_C || (lda & 3) != 0 || N >= (1ll << 31) || max_tiles >= (1ll << 31) ||
       (reinterpret_cast<uintptr_t>(conv_out) & 15) != 0 || (reinterpret_cast<uintptr_t>(ins) & 15) != 0)
     return ISG_EUNSUPPORTED;
   if (N == 0 || max_tiles == 0) return ISG_OK;
   if (!conv_out || !a_rowmax || !w1_frag || !w1_inv_scale || !b1 || !y_bound || !w2_frag || !w2_inv_scale || !b2 || !ins || !h ||
-      !gn_weight || !gn_bias || !gn_mean_scale || !h_out || !ptr || !batch || !tile_ptr || !ntiles)
+      !gn_weight || !gn_bias || !gn_mean_scale || !h_out || !ptr || !batch || !tile_ptr || !tile_info || !ntiles)
     return ISG_EINVAL;
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&mgat_dense_tail_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, DT_SMEM_BYTES) == hipSuccess;
@@ -577,6 +580,7 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
   a.b1 = b1; a.y_bound = y_bound; a.w2f = reinterpret_cast<const _Float16 *>(w2_frag); a.w2_inv = w2_inv_scale; a.b2 = b2; a.ins = ins; a.h = h;
   a.gn_w = gn_weight; a.gn_b = gn_bias; a.gn_ms = gn_mean_scale; a.node_mask = node_mask; a.ins_next = ins_next;
   a.h_out = h_out; a.xg_out = xg_out; a.ptr = ptr; a.tile_ptr = tile_ptr; a.ntiles = ntiles;
+  a.tile_info = reinterpret_cast<const int4 *>(tile_info);
   a.batch = reinterpret_cast<const long long *>(batch);
   a.N = (int)N; a.lda = lda; a.P = P; a.ldp = ldp; a.eps = (float)eps; a.denom = (float)sqrt((double)DT_C);
   mgat_dense_tail_kernel<<<(unsigned)max_tiles, 256, DT_SMEM_BYTES, as_stream(stream)>>>(a);

@@ -1074,7 +1074,7 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
         [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
     # one tile plan per batch: the convolution's (64 nodes / 256 slots) serves this kernel too when it exists
     shared = plan._tiles is not None and (DENSE_TAIL_ROWS, TILE_CONV_EDGES) in plan._tiles
-    tile_ptr, ntiles, cap, _ = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if shared else 0)
+    tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if shared else 0)
     h_out = torch.empty_like(h)
     xg = torch.empty_like(h) if ins_next is not None else None
     rc = lib.isg_mgat_dense_tail(
@@ -1087,7 +1087,7 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
         _chk(ins_next, "ins_next", torch.float32, (plan.B, C), optional=True), h_out.data_ptr(),
         0 if xg is None else xg.data_ptr(), plan.ptr.data_ptr(), _chk(plan.batch, "batch", torch.int64, (N,)),
-        tile_ptr.data_ptr(), ntiles.data_ptr(), cap, N, K1, l0.weight.size(0), C, _stream())
+        tile_ptr.data_ptr(), tile_info.data_ptr(), ntiles.data_ptr(), cap, N, K1, l0.weight.size(0), C, _stream())
     if rc == ISG_EUNSUPPORTED:
         return None
     _lib.check(rc, "isg_mgat_dense_tail")

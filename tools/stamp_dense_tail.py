@@ -40,7 +40,7 @@ rm = conv_out.view(N, H, C).abs().amax(dim=2).contiguous()
 h = torch.randn(N, C, device=dev, generator=g)
 ins, ins_next = wl.instr[0].contiguous(), wl.instr[1].contiguous()
 bn = m.bns[0]
-tile_ptr, ntiles, cap, _ = plan.tiles(64)
+tile_ptr, ntiles, cap, tile_info = plan.tiles(64)
 T = int(ntiles.item())
 l0, l2 = m.x_proj[0][0], m.x_proj[0][2]
 p1, inv1 = ops._weight_planes(l0.weight, True, "f16x3")
@@ -55,7 +55,7 @@ for rep in range(2):
                                    inv1.data_ptr(), l0.bias.data_ptr(), yb.data_ptr(), p2.data_ptr(), inv2.data_ptr(), l2.bias.data_ptr(),
                                    ins.data_ptr(), h.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.mean_scale.data_ptr(),
                                    float(bn.eps), 0, ins_next.data_ptr(), h_out.data_ptr(), xg.data_ptr(), plan.ptr.data_ptr(),
-                                   wl.batch.data_ptr(), tile_ptr.data_ptr(), ntiles.data_ptr(), cap, N, 512, 256, 128,
+                                   wl.batch.data_ptr(), tile_ptr.data_ptr(), tile_info.data_ptr(), ntiles.data_ptr(), cap, N, 512, 256, 128,
                                    torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
