@@ -268,6 +268,19 @@ int isg_gatv2_layer_conv(const float *x, int32_t ldx, const uint16_t *wn_frag, c
                          int32_t ldo, float *alpha, float *rowmax, int64_t N, int64_t E, int32_t H, int32_t C, int32_t K_in,
                          int32_t K_edge, float negative_slope, void *stream);
 
+/* GlobalAttention.forward on graph-aligned 64-row tiles as one launch:   ISubGVQA/models/att_pooling.py:57-77
+ *   xn = node_nn(x) (Linear GELU Linear) * node_mask;  gate = softmax_g(<xn_n, q_g> / sqrt(C)) (+1e-16);  out_g = sum_n gate_n xn_n
+ * x fp32 [N,128] (row stride ldx); w1 / w2 = isg_split_f16x2_frag planes + inverse scales of node_nn.0 / node_nn.2 weights
+ * [128,128], b1 / b2 their biases; y_bound fp32 [2] = {max_j sum_k |w1[j,k]|, max_j |b1[j]|} (row scales of the intermediate, as
+ * in isg_mgat_dense_tail); q fp32 [B,128] = ques_nn(u); node_mask fp32 [N] or NULL; out fp32 [B,128], gate fp32 [N]; tiles from
+ * isg_tile_plan (node_cap = 64, tile_info requested).  The per-graph arithmetic is isg_global_attn_pool's.  ISG_EUNSUPPORTED
+ * unless C == 128. */
+int isg_readout_tile(const float *x, int32_t ldx, const uint16_t *w1_frag, const float *w1_inv_scale, const float *b1,
+                     const float *y_bound, const uint16_t *w2_frag, const float *w2_inv_scale, const float *b2, const float *q,
+                     const float *node_mask, float *out, float *gate, const int32_t *ptr, const int64_t *batch,
+                     const int32_t *tile_ptr, const int32_t *tile_info, const int32_t *ntiles, int64_t max_tiles, int64_t N,
+                     int32_t C, void *stream);
+
 /* Edge features as the exact-split kernels want them, once per batch: per-row power-of-two scale and (hi, mid) fp16 planes in CSR
  * SLOT order (slot t = edge eid[t]): planes uint16 [E][2][128] (row: 128 hi values, then 128 mid values; columns beyond K zero),
  * inv_scale fp32 [E].  edge_attr fp32 [E,K] by edge id (row stride lda).  The same edge features feed lin_edge of every layer

@@ -96,6 +96,7 @@ SIGNATURES = {
                             [c_void_p] * 9 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "isg_gatv2_layer_conv": (c_int, [c_void_p, c_int32] + [c_void_p] * 15 + [c_int64] + [c_void_p] * 3 +
                              [c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "isg_readout_tile": (c_int, [c_void_p, c_int32] + [c_void_p] * 16 + [c_int64, c_int64, c_int32, c_void_p]),
     "isg_edge_planes": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_gatv2_tile_conv": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p] + [c_void_p] * 10 + [c_int64] +
                             [c_void_p] * 3 + [c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_float,

@@ -37,9 +37,16 @@ class GlobalAttention(torch.nn.Module):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         if plan is None:
             plan = ops.GraphPlan.build(batch, None, num_graphs=u.size(0) if size is None else size)
-        xn = ops.mlp(self.node_nn, x)                                                    # :62
         q = ops.mlp(self.ques_nn, u)                                                     # :66
-        out, gate = ops.global_attn_pool(xn.contiguous(), q.contiguous(), plan, node_mask)   # :63-73
+        res = None
+        if x.dtype == torch.float32 and x.dim() == 2 and ops.readout_tile_supported(plan, self.node_nn, x.size(1)):
+            # node_nn, mask, per-graph softmax and pooled sum as one launch on graph-aligned tiles (csrc/isg_layer_conv.hip)
+            res = ops.readout_tile(x.contiguous(), self.node_nn, q.contiguous(), plan, node_mask)     # :62-73
+        if res is not None:
+            out, gate = res
+        else:
+            xn = ops.mlp(self.node_nn, x)                                                # :62
+            out, gate = ops.global_attn_pool(xn.contiguous(), q.contiguous(), plan, node_mask)   # :63-73
         if return_mask:
             return out, gate
         return out

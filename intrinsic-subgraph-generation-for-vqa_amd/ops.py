@@ -1094,6 +1094,50 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
     return h_out, xg
 
 
+FUSE_READOUT = True        # node_nn + mask + per-graph softmax pooling as one launch on graph-aligned tiles (A/B switch)
+
+
+def readout_tile_supported(plan: GraphPlan, node_nn: torch.nn.Sequential, width_in: int) -> bool:
+    """Shape test of isg_readout_tile: inference, fp32, node_nn = Linear(128 -> 128) GELU Linear(128 -> 128), tiles of 64 nodes."""
+    if not (FUSE_READOUT and GEMM_BACKEND == "bf16x6" and GEMM_F16X3) or torch.is_grad_enabled():
+        return False
+    mods = list(node_nn)
+    if len(mods) != 3 or not isinstance(mods[1], torch.nn.GELU) or mods[1].approximate != "none":
+        return False
+    l0, l2 = mods[0], mods[2]
+    if not (isinstance(l0, torch.nn.Linear) and isinstance(l2, torch.nn.Linear)) or l0.bias is None or l2.bias is None:
+        return False
+    return (width_in == 128 and tuple(l0.weight.shape) == (128, 128) and tuple(l2.weight.shape) == (128, 128) and plan.B > 0 and
+            0 < plan.nmax <= DENSE_TAIL_ROWS and plan.batch is not None)
+
+
+def readout_tile(x: Tensor, node_nn: torch.nn.Sequential, q: Tensor, plan: GraphPlan, node_mask: Optional[Tensor] = None):
+    """GlobalAttention.forward's device work as ONE launch (att_pooling.py:57-77): node_nn(x) * mask, per-graph softmax of
+    <xn, q>/sqrt(C), pooled sum.  Returns (out [B,C], gate [N,1]) or None when the kernel has no launch for this shape."""
+    lib = _lib.load()
+    N, C = x.shape
+    l0, l2 = node_nn[0], node_nn[2]
+    p1, inv1 = _weight_planes(l0.weight, True, "f16x3")
+    p2, inv2 = _weight_planes(l2.weight, True, "f16x3")
+    ybound = derived_weight("dense_tail_bound", (l0.weight, l0.bias), lambda: torch.stack(
+        [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
+    shared = plan._tiles is not None and (DENSE_TAIL_ROWS, TILE_CONV_EDGES) in plan._tiles
+    tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if shared else 0)
+    out = torch.empty(plan.B, C, dtype=torch.float32, device=x.device)
+    gate = torch.empty(N, 1, dtype=torch.float32, device=x.device)
+    rc = lib.isg_readout_tile(
+        _chk_rows(x, "x"), x.stride(0), p1.data_ptr(), inv1.data_ptr(), _chk(l0.bias.detach(), "node_nn.0.bias", torch.float32, (C,)),
+        ybound.data_ptr(), p2.data_ptr(), inv2.data_ptr(), _chk(l2.bias.detach(), "node_nn.2.bias", torch.float32, (C,)),
+        _chk(q, "q", torch.float32, (plan.B, C)),
+        _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+        out.data_ptr(), gate.data_ptr(), plan.ptr.data_ptr(), _chk(plan.batch, "batch", torch.int64, (N,)), tile_ptr.data_ptr(),
+        tile_info.data_ptr(), ntiles.data_ptr(), cap, N, C, _stream())
+    if rc == ISG_EUNSUPPORTED:
+        return None
+    _lib.check(rc, "isg_readout_tile")
+    return out, gate
+
+
 def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional[Tensor] = None):
     """GlobalAttention soft-max pooling (att_pooling.py:63-73).  Returns (out[B,C], gate[N,1])."""
     if _rec(xn, q, node_mask):

@@ -1244,3 +1244,45 @@ def test_layer_conv_is_bit_identical_to_projection_plus_tile_conv(dev, mask, mon
         scale = ref_out.abs().max().item()
         assert (out_f.cpu() - ref_out).abs().max().item() < 1e-4 * max(scale, 1.0)
         assert (al_f.cpu() - ref_alpha).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_readout_tile_matches_the_unfused_pooling_and_the_oracle(dev, masked):
+    """isg_readout_tile (node_nn + mask + per-graph softmax pooling on graph-aligned tiles) against ops.mlp +
+    isg_global_attn_pool and against the CPU oracle's GlobalAttention (att_pooling.py:57-77): graphs of 1, 20, 64 nodes, ragged
+    mixes with empty graphs (their pooled rows are zero), a batch with a 65-node graph (-> un-fused path)."""
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.models import GlobalAttention
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(31)
+    cases = [[1], [20], [64], [64, 64, 1, 63, 1, 2, 62, 20, 20, 20, 5], [0, 3, 0, 0, 41, 23, 0, 0],
+             torch.randint(8, 34, (300,), generator=gen).tolist(), torch.randint(1, 65, (150,), generator=gen).tolist(), [20, 65, 3]]
+    torch.manual_seed(2)
+    pool = GlobalAttention(128, 128)
+    with torch.no_grad():
+        for p in pool.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    sd = {"p." + k: v.detach().clone() for k, v in pool.state_dict().items()}
+    pool = pool.to(dev).eval()
+    for sizes in cases:
+        batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.0)
+        N, B = batch.numel(), len(sizes)
+        x = torch.randn(N, 128, generator=gen) * torch.rand(N, 1, generator=gen).mul(3).exp()
+        u = torch.randn(B, 128, generator=gen)
+        mask = (torch.rand(N, 1, generator=gen) < 0.6).float() if masked else None
+        plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+        d = lambda t: None if t is None else t.to(dev)
+        with torch.no_grad():
+            assert ops.readout_tile_supported(plan, pool.node_nn, 128) == (max(sizes) <= 64)
+            out, gate = pool(d(x), d(u), batch.to(dev), return_mask=True, node_mask=d(mask), plan=plan)
+            xn = ops.mlp(pool.node_nn, d(x))
+            ref_out, ref_gate = ops.global_attn_pool(xn.contiguous(), ops.mlp(pool.ques_nn, d(u)).contiguous(), plan, d(mask))
+            want_out, want_gate = OM.global_attention_forward(sd, "p", x, u, batch, mask, size=B)
+        scale = max(want_out.abs().max().item(), 1.0)
+        e_or, e_un = (out.cpu() - want_out).abs().max().item(), (ref_out.cpu() - want_out).abs().max().item()
+        assert e_or <= max(2e-5 * scale, 3.0 * e_un), (sizes[:4], e_or, e_un)
+        assert (gate.cpu().view(-1) - want_gate.view(-1)).abs().max().item() <= 2e-5
+        assert torch.allclose(out, ref_out, atol=1e-4 * scale, rtol=0) and torch.allclose(gate, ref_gate, atol=2e-5, rtol=0)
+        empty = torch.tensor([n == 0 for n in sizes])
+        assert torch.equal(out.cpu()[empty], torch.zeros(int(empty.sum()), 128))

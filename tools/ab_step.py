@@ -34,9 +34,12 @@ if os.environ.get("AB_R03"):         # round 3's switches on top of round 2's de
         ("+ tile conv", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": False}),
         ("+ 6-launch plan build", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": True, "FUSE_LAYER_CONV": False}),
         ("+ lin_l | lin_r inside the conv kernel (layer conv)", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": True, "FUSE_LAYER_CONV": True}),
+        ("+ read-out on tiles (r03 default)", {**base, "FUSE_TILE_CONV": True, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": True, "FUSE_LAYER_CONV": True, "FUSE_READOUT": True}),
     ]
     for name, sw in variants[:3]:
         sw["FUSE_LAYER_CONV"] = False
+    for name, sw in variants[:5]:
+        sw["FUSE_READOUT"] = False
 if os.environ.get("AB_PANEL_N"):     # sweep the narrowest Linear the panel kernels take, on the default path
     base = dict(variants[-2][1])
     variants = [(f"default path, PANEL_MIN_N = {n}", {**base, "PANEL_MIN_N": n}) for n in (256, 128, 64, 256)]
@@ -58,7 +61,7 @@ with torch.no_grad():
             if r > 0:
                 res[name].append((time.perf_counter() - t0) / steps * 1e3)
 for k, v in dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False,
-                 FUSE_TILE_CONV=True, FUSE_DENSE_TAIL=True, PLAN_FUSED=True).items():
+                 FUSE_TILE_CONV=True, FUSE_DENSE_TAIL=True, PLAN_FUSED=True, FUSE_LAYER_CONV=True, FUSE_READOUT=True).items():
     setattr(ops, k, v)
 for name, _ in variants:
     t = sorted(res[name])
