@@ -187,7 +187,10 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     int4 desc_n = make_int4(0, 0, 0, 0);
     if (has_next) desc_n = a.tile_info[t_next];
 
-    // ---- node GEMM: [64 x 128] . [lin_l | lin_r]_head^T, this wave's 32 columns (isg_linear_f16x3's product and epilogue) -----
+    // ---- node GEMM: [lin_l | lin_r]_head . x^T, this wave's 32 channels x all 64 nodes.  TRANSPOSED like the edge product (W
+    // fragment = A operand, node panel = B operand): a lane then holds ONE node and 16 channels of it in four runs of four, which
+    // go to the row-major LDS slices as 16-byte stores (with the panel as the A operand a lane holds one channel of 16 nodes:
+    // 32 four-byte stores and 32 scale reads per lane, 2.9 k cycles per tile: profiles/r03_ah_*)
     {
       hf32x16 accn[2];
 #pragma unroll
@@ -204,25 +207,36 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           hf32x16 c = accn[i];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(an[i][0], wq_n[ks][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(an[i][1], wq_n[ks][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(an[i][0], wq_n[ks][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][1], an[i][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][0], c, 0, 0, 0);
           accn[i] = c;
         }
       }
-      const float wi = s_wninv[ct * 32 + fr], bv = s_bn[ct * 32 + fr];
+#ifdef ISG_DT_STAMP
+      asm volatile("" ::"v"(accn[0][0]), "v"(accn[1][15]));
+#endif
+      LC_STAMP(8)            // node GEMM: k loop
       float(*dstx)[LC_LDX] = ct < 4 ? sXl : sXr;
-      const int col = (ct & 3) * 32 + fr;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int g = 0; g < 4; ++g) {
+        const int cc = ct * 32 + 4 * hh + 8 * g;                 // column of [x_l 128 | x_r 128]
+        const float4 wi4 = *reinterpret_cast<const float4 *>(&s_wninv[cc]);
+        const float4 bv4 = *reinterpret_cast<const float4 *>(&s_bn[cc]);
+        const float wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w}, bvv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          dstx[rl][col] = (accn[i][r] * s_inv[rl]) * wi + bv;       // both scales are powers of two: exact
+        for (int i = 0; i < 2; ++i) {
+          const float si = s_inv[i * 32 + fr];
+          hf32x4 o;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) o[jj] = (accn[i][g * 4 + jj] * si) * wiv[jj] + bvv[jj];     // both scales are powers of two
+          *reinterpret_cast<hf32x4 *>(&dstx[i * 32 + fr][(ct & 3) * 32 + 4 * hh + 8 * g]) = o;
         }
+      }
     }
+    LC_STAMP(9)              // node GEMM: epilogue
     __syncthreads();         // x_l / x_r slices complete; the panel image is free for the edge chunks
-    LC_STAMP(1)              // node GEMM
+    LC_STAMP(1)              // node GEMM: barrier
 
     // ---- 64-slot chunks: edge planes -> panel image, transposed product, logit epilogue (isg_mp_logits.hip) --------------------
     const int nchunk = (ne + 63) >> 6;
@@ -308,12 +322,27 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     if (tid < ne) {
       const int4 rc = s_tab[tid];
       const int rb = s_rp[rc.z], re = min(s_rp[rc.z + 1], ne);
+      // four slots per round, reads clamped into the segment and issued together (a wave waits for its LONGEST segment: one
+      // dependent LDS read per slot made this phase 4.8 k cycles per tile); the sum still runs in slot order, the pads add 0
       float mx = -INFINITY;
-#pragma unroll 2
-      for (int s = rb; s < re; ++s) mx = fmaxf(mx, s_lg[s]);
+#pragma unroll 1
+      for (int s = rb; s < re; s += 4) {
+        const float v0 = s_lg[s], v1 = s_lg[min(s + 1, re - 1)], v2 = s_lg[min(s + 2, re - 1)], v3 = s_lg[min(s + 3, re - 1)];
+        mx = fmaxf(fmaxf(mx, v0), fmaxf(fmaxf(v1, v2), v3));
+      }
       float den = 0.f;
-#pragma unroll 2
-      for (int s = rb; s < re; ++s) den += __builtin_amdgcn_exp2f((s_lg[s] - mx) * 1.4426950408889634f);
+#pragma unroll 1
+      for (int s = rb; s < re; s += 4) {
+        const float v0 = s_lg[s], v1 = s_lg[min(s + 1, re - 1)], v2 = s_lg[min(s + 2, re - 1)], v3 = s_lg[min(s + 3, re - 1)];
+        const float e0 = __builtin_amdgcn_exp2f((v0 - mx) * 1.4426950408889634f);
+        const float e1 = __builtin_amdgcn_exp2f((v1 - mx) * 1.4426950408889634f);
+        const float e2 = __builtin_amdgcn_exp2f((v2 - mx) * 1.4426950408889634f);
+        const float e3 = __builtin_amdgcn_exp2f((v3 - mx) * 1.4426950408889634f);
+        den += e0;
+        den += s + 1 < re ? e1 : 0.f;
+        den += s + 2 < re ? e2 : 0.f;
+        den += s + 3 < re ? e3 : 0.f;
+      }
       const float w = __builtin_amdgcn_exp2f((s_lg[tid] - mx) * 1.4426950408889634f) * __builtin_amdgcn_rcpf(den + 1e-16f);
       a.alpha[(int64_t)rc.y * a.H + hd] = w;
       s_w[tid] = MASKED ? __fmul_rn(w, __int_as_float(rc.w)) : w;
@@ -328,14 +357,28 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     for (int k = 2 * wave + hh; k < nrows; k += 16) {
       const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 2
-      for (int s = rb; s < re; ++s) {
-        const float wm = s_w[s];
-        const float4 u4 = *reinterpret_cast<const float4 *>(&sXl[s_tab[s].x][fr * 4]);
-        o.x = __fadd_rn(o.x, __fmul_rn(u4.x, wm));
-        o.y = __fadd_rn(o.y, __fmul_rn(u4.y, wm));
-        o.z = __fadd_rn(o.z, __fmul_rn(u4.z, wm));
-        o.w = __fadd_rn(o.w, __fmul_rn(u4.w, wm));
+#pragma unroll 1
+      for (int s = rb; s < re; s += 4) {      // four in-edges per round: weights, sources, then the four rows, all reads in flight
+        float wm[4];
+        int sx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = min(s + u, re - 1);
+          wm[u] = s_w[idx];
+          sx[u] = s_tab[idx].x;
+        }
+        float4 u4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) u4[u] = *reinterpret_cast<const float4 *>(&sXl[sx[u]][fr * 4]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (s + u < re) {               // edge-id order, unfused mul + add
+            o.x = __fadd_rn(o.x, __fmul_rn(u4[u].x, wm[u]));
+            o.y = __fadd_rn(o.y, __fmul_rn(u4[u].y, wm[u]));
+            o.z = __fadd_rn(o.z, __fmul_rn(u4[u].z, wm[u]));
+            o.w = __fadd_rn(o.w, __fmul_rn(u4[u].w, wm[u]));
+          }
+        }
       }
       if (a.bias) { o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w; }
       hf32x4 o4 = {o.x, o.y, o.z, o.w};
