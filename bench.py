@@ -596,6 +596,9 @@ def main(argv=None):
     else:
         rccl = {"backend": None, "world": 1, "devices": [int(devs.item())], "collective": None}
     rccl["gpu"] = torch.cuda.get_device_name(dev)
+    props = torch.cuda.get_device_properties(dev)       # the marketing string is generic on this image; the ISA name is not
+    rccl["gcn_arch"] = getattr(props, "gcnArchName", None)
+    rccl["compute_units"] = int(props.multi_processor_count)
 
     durs = timer.durations_ms()
     bytes_l = [ops.mp_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"], m.get("feat_bytes", 4)) for m in timer.meta]
