@@ -27,11 +27,17 @@ static __device__ long long *g_lc_stamps = nullptr;
 
 namespace isg {
 
+typedef __attribute__((address_space(3))) void lc_lds_t;
+typedef __attribute__((address_space(1))) void lc_glb_t;
+
 constexpr int LC_ROWS = 64, LC_ECAP = 256, LC_C = 128, LC_K = 128, LC_LDX = LC_C + 4, LC_LDA = LC_K + 8, LC_THREADS = 512;
 constexpr int LC_OFF_XR = LC_ROWS * LC_LDX * 4;                       // x_r slice behind the x_l slice
 constexpr int LC_OFF_A = 2 * LC_ROWS * LC_LDX * 4;                    // panel image: node rows, then edge chunks
 constexpr int LC_OFF_TAB = LC_OFF_A + 2 * 64 * LC_LDA * 2;
-constexpr int LC_SMEM_BYTES = LC_OFF_TAB + LC_ECAP * 16 + LC_ECAP * 4 + 4 * 64 * 4 + 64 * 4 + 68 * 4 + 2 * LC_C * 4 + 4 * LC_C * 4;
+constexpr int LC_OFF_RAW = LC_OFF_TAB + 2 * (LC_ECAP * 16 + LC_ECAP * 4 + 68 * 4) + LC_ECAP * 4 + 4 * 64 * 4 + 64 * 4 + 3 * LC_C * 4 +
+                           4 * LC_C * 4;                              // the next tile's node rows as they come from memory (fp32)
+constexpr int LC_SMEM_BYTES = LC_OFF_RAW + LC_ROWS * LC_K * 4;
+static_assert(LC_OFF_RAW % 16 == 0, "16-byte pieces");
 static_assert(LC_SMEM_BYTES <= 160 * 1024, "one workgroup per CU");
 
 struct LcArgs {
@@ -58,13 +64,15 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
   BufX sXl = reinterpret_cast<BufX>(lc_smem);
   BufX sXr = reinterpret_cast<BufX>(lc_smem + LC_OFF_XR);
   BufP sA = reinterpret_cast<BufP>(lc_smem + LC_OFF_A);
-  int4 *s_tab = reinterpret_cast<int4 *>(lc_smem + LC_OFF_TAB);        // {src - r0, eid, dst - r0, mask bits}
-  float *s_lg = reinterpret_cast<float *>(s_tab + LC_ECAP);
-  float *s_part = s_lg + LC_ECAP;             // [4 tile-waves][64 slots]; after the chunks: the softmax weights
-  float *s_inv = s_part + 4 * 64;
-  int *s_rp = reinterpret_cast<int *>(s_inv + 64);
-  float *s_att = reinterpret_cast<float *>(s_rp + 68), *s_weinv = s_att + LC_C;
-  float *s_bn = s_weinv + LC_C, *s_wninv = s_bn + 2 * LC_C;             // [x_l 128 | x_r 128] biases / inverse scales of the head
+  // per-tile tables, TWO sets: the next tile's are written while the slowest waves still aggregate the current one
+  int4 *s_tab0 = reinterpret_cast<int4 *>(lc_smem + LC_OFF_TAB);       // [2][256] {src - r0, eid, dst - r0, mask bits}
+  float *s_einv0 = reinterpret_cast<float *>(s_tab0 + 2 * LC_ECAP);     // [2][256] inverse scales of the slots' edge planes
+  int *s_rp0 = reinterpret_cast<int *>(s_einv0 + 2 * LC_ECAP);          // [2][68] row pointers relative to the tile's first slot
+  float *s_lg = reinterpret_cast<float *>(s_rp0 + 2 * 68);
+  float *s_part = s_lg + LC_ECAP;             // [4 tile-waves][64 slots]
+  float *s_inv = s_part + 4 * 64;             // inverse row scales of the node planes
+  float *s_att = s_inv + 64, *s_weinv = s_att + LC_C;
+  float *s_bias = s_weinv + LC_C, *s_bn = s_bias + LC_C, *s_wninv = s_bn + 2 * LC_C;             // [x_l 128 | x_r 128] biases / inverse scales of the head
 
   const int bid = blockIdx.x;
   const int per_xcd = gridDim.x >> 3, jx = bid >> 3;
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #endif
   const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
   const int hoff = hd * LC_C;
-  const int srow = tid >> 5, sc4 = tid & 31;      // staging map: 32 lanes per 512-byte row, rows srow + 16 u
+  const int srow = tid >> 5, scol = tid & 31, sc4 = scol;    // staging map: 32 lanes per 512-byte row, rows srow + 16 u
 
   // ---- resident W fragments: the wave's tile of lin_edge and its tile of [lin_l | lin_r] ---------------------------------------
   const int KSE = a.KSE;
@@ -112,59 +120,83 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
   if (tid < LC_C) {
     s_att[tid] = a.att[hoff + tid];
     s_weinv[tid] = a.we_inv[hoff + tid];
+    s_bias[tid] = a.bias ? a.bias[hoff + tid] : 0.f;
   } else if (tid < 3 * LC_C) {       // columns 0..127: x_l channels of the head, 128..255: x_r channels
     const int c = tid - LC_C;
     const int src_col = (c >> 7) * a.H * LC_C + hoff + (c & 127);
     s_bn[c] = a.bn[src_col];
     s_wninv[c] = a.wn_inv[src_col];
   }
-  const float4 b4 = a.bias ? *reinterpret_cast<const float4 *>(a.bias + hoff + fr * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float slope = a.slope;
 
   hf32x4 ra[4];            // edge planes of a chunk, requested a chunk (or a tile) ahead: rows srow + 16 u, 16-byte piece sc4
   // (macros, not lambdas: register arrays captured by reference end up in scratch memory)
+  // RAW values only: any arithmetic on a requested value makes the compiler wait for the load where it was issued (700 cycles each)
 #define LC_REQUEST_TILE(d)                           /* d = {r0, nrows, e0, ne} */                                      \
   {                                                                                                                  \
     const int r0n = (d).x, nrn = min((d).y, LC_ROWS), e0n = (d).z, nen = min((d).w, LC_ECAP);                          \
     rp_n = 0;                                                                                                        \
-    if (tid <= nrn) rp_n = a.rowptr[r0n + tid] - e0n;                                                                \
+    if (tid <= nrn) rp_n = a.rowptr[r0n + tid];                                                                      \
     rec_n = make_int4(0, 0, 0, __float_as_int(1.f));                                                                 \
+    einv_n = 1.f;                                                                                                    \
     if (tid < nen) {                                                                                                 \
-      const int s_ = a.src[e0n + tid], e_ = a.eid[e0n + tid], d_ = a.dst[e0n + tid];                                 \
-      rec_n.x = min(max(s_ - r0n, 0), max(nrn - 1, 0));    /* a source outside its tile is clamped into it */        \
-      rec_n.y = e_;                                                                                                  \
-      rec_n.z = min(max(d_ - r0n, 0), max(nrn - 1, 0));                                                              \
-      if (MASKED) rec_n.w = __float_as_int(a.edge_mask ? a.edge_mask[e_] : a.node_mask[s_] * a.node_mask[d_]);        \
+      rec_n.x = a.src[e0n + tid];                                                                                    \
+      rec_n.y = a.eid[e0n + tid];                                                                                    \
+      rec_n.z = a.dst[e0n + tid];                                                                                    \
+      einv_n = a.ep_inv[e0n + tid];                                                                                  \
     }                                                                                                                \
+    /* node rows: memory -> LDS directly (a wave instruction lands 1 KB = its two rows srow, 16 bytes per lane): sixteen */ \
+    /* registers less across the chunk epilogue, which is where the allocator ran out and evicted W fragments          */ \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
       const int row = min(r0n + min(srow + 16 * u, max(nrn - 1, 0)), a.N - 1);                                       \
-      xv_n[u] = *reinterpret_cast<const hf32x4 *>(a.x + (int64_t)row * a.ldx + sc4 * 4);                             \
+      __builtin_amdgcn_global_load_lds((lc_glb_t *)(a.x + (int64_t)row * a.ldx + sc4 * 4),                           \
+                                       (lc_lds_t *)(lc_smem + LC_OFF_RAW + (2 * wave + 16 * u) * (LC_K * 4)), 16, 0, 0); \
     }                                                                                                                \
+  }
+  // second stage, a phase later (the ids have arrived): the masks behind them
+#define LC_REQUEST_MASKS(d)                                                                                          \
+  {                                                                                                                  \
+    if (MASKED && tid < min((d).w, LC_ECAP))                                                                         \
+      rec_n.w = __float_as_int(a.edge_mask ? a.edge_mask[rec_n.y] : a.node_mask[rec_n.x] * a.node_mask[rec_n.z]);      \
+  }
+  // the tile's first chunk of edge planes: requested AFTER the aggregation (16 registers that phase needs), still a node GEMM
+  // ahead of its use
+#define LC_REQUEST_PLANES(d)                                                                                         \
+  {                                                                                                                  \
+    const int e0n = (d).z, nen = min((d).w, LC_ECAP);                                                                \
     if (nen > 0) {                                                                                                   \
       _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                  \
         ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0n + min(srow + 16 * u, nen - 1)) * 256 + sc4 * 8); \
     }                                                                                                                \
   }
-  // records and row pointers into their tables; the node rows -> row scale -> (hi, mid) planes (isg_linear_f16x3's staging)
-#define LC_STORE_TILE(d)                                                                                             \
+  // records, scales and row pointers into table set `b`; the node rows -> row scale -> (hi, mid) planes (isg_linear_f16x3's staging)
+#define LC_STORE_TILE(d, b)                                                                                          \
   {                                                                                                                  \
-    const int nrn = min((d).y, LC_ROWS);                                                                             \
-    if (tid <= nrn) s_rp[tid] = rp_n;                                                                                \
-    if (tid < LC_ECAP) s_tab[tid] = rec_n;                                                                           \
+    const int r0n = (d).x, nrn = min((d).y, LC_ROWS), e0n = (d).z;                                                   \
+    if (tid <= nrn) s_rp0[(b) * 68 + tid] = rp_n - e0n;                                                              \
+    if (tid < LC_ECAP) {                              /* a source outside its tile is clamped into it */             \
+      rec_n.x = min(max(rec_n.x - r0n, 0), max(nrn - 1, 0));                                                         \
+      rec_n.z = min(max(rec_n.z - r0n, 0), max(nrn - 1, 0));                                                         \
+      s_tab0[(b) * LC_ECAP + tid] = rec_n;                                                                           \
+      s_einv0[(b) * LC_ECAP + tid] = einv_n;                                                                         \
+    }                                                                                                                \
+    int srl = srow, scl = scol;                      /* laundered like the node GEMM's store addresses */            \
+    asm volatile("" : "+v"(srl), "+v"(scl));                                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* the rows this wave asked for have landed (long ago) */      \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
-      const int row = srow + 16 * u;                                                                                 \
-      hf32x4 v = xv_n[u];                                                                                            \
+      const int row = srl + 16 * u;                                                                                  \
+      hf32x4 v = *reinterpret_cast<const hf32x4 *>(lc_smem + LC_OFF_RAW + (row * LC_K + scl * 4) * 4);               \
       if (row >= nrn) v = hf32x4{0.f, 0.f, 0.f, 0.f};                                                                \
       const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));        \
       float sc_, inv_;                                                                                               \
       h3_scale(mx, sc_, inv_);                                                                                       \
-      if (sc4 == 0) s_inv[row] = inv_;                                                                               \
+      if (scl == 0) s_inv[row] = inv_;                                                                               \
       v *= sc_;                                                                                                      \
       hf16x4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};                                  \
       hf16x4 mid = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]), (_Float16)(v[2] - (float)hi[2]), \
                     (_Float16)(v[3] - (float)hi[3])};                                                                \
-      *reinterpret_cast<hf16x4 *>(&sA[0][row][sc4 * 4]) = hi;                                                        \
-      *reinterpret_cast<hf16x4 *>(&sA[1][row][sc4 * 4]) = mid;                                                       \
+      *reinterpret_cast<hf16x4 *>(&sA[0][row][scl * 4]) = hi;                                                        \
+      *reinterpret_cast<hf16x4 *>(&sA[1][row][scl * 4]) = mid;                                                       \
     }                                                                                                                \
   }
 
@@ -172,20 +204,26 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
   {
     int4 rec_n;
     int rp_n;
-    hf32x4 xv_n[4];
+    float einv_n;
     LC_REQUEST_TILE(desc)
-    LC_STORE_TILE(desc)
+    LC_REQUEST_MASKS(desc)
+    LC_REQUEST_PLANES(desc)
+    LC_STORE_TILE(desc, 0)
   }
   __syncthreads();
   LC_STAMP(0)              // first tile's inputs (exposed once per workgroup)
+  int cur = 0;             // table set of the tile in hand
 
 #pragma unroll 1
   while (true) {
     const int r0 = desc.x, nrows = min(desc.y, LC_ROWS), e0 = desc.z, ne = min(desc.w, LC_ECAP);
     const int t_next = t + ngrp;
     const bool has_next = t_next < T;
-    int4 desc_n = make_int4(0, 0, 0, 0);
-    if (has_next) desc_n = a.tile_info[t_next];
+    int4 dn = a.tile_info[min(t_next, T - 1)];       // the next tile's descriptor: on its way under the node GEMM, read after
+                                                     // it (unconditional: a conditional load is waited for where it is issued)
+    const int4 *s_tab = s_tab0 + cur * LC_ECAP;
+    const float *s_einv = s_einv0 + cur * LC_ECAP;
+    const int *s_rp = s_rp0 + cur * 68;
 
     // ---- node GEMM: [lin_l | lin_r]_head . x^T, this wave's 32 channels x all 64 nodes.  TRANSPOSED like the edge product (W
     // fragment = A operand, node panel = B operand): a lane then holds ONE node and 16 channels of it in four runs of four, which
@@ -218,25 +256,36 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #endif
       LC_STAMP(8)            // node GEMM: k loop
       float(*dstx)[LC_LDX] = ct < 4 ? sXl : sXr;
+      int frl = fr, hhl = hh;          // laundered: the addresses below, hoisted out of the tile loop, were spilled and came back
+      asm volatile("" : "+v"(frl), "+v"(hhl));       // from scratch one dependent load at a time (700 cycles per tile)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int cc = ct * 32 + 4 * hh + 8 * g;                 // column of [x_l 128 | x_r 128]
+        const int cc = ct * 32 + 4 * hhl + 8 * g;                // column of [x_l 128 | x_r 128]
         const float4 wi4 = *reinterpret_cast<const float4 *>(&s_wninv[cc]);
         const float4 bv4 = *reinterpret_cast<const float4 *>(&s_bn[cc]);
         const float wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w}, bvv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const float si = s_inv[i * 32 + fr];
+          const float si = s_inv[i * 32 + frl];
           hf32x4 o;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) o[jj] = (accn[i][g * 4 + jj] * si) * wiv[jj] + bvv[jj];     // both scales are powers of two
-          *reinterpret_cast<hf32x4 *>(&dstx[i * 32 + fr][(ct & 3) * 32 + 4 * hh + 8 * g]) = o;
+          *reinterpret_cast<hf32x4 *>(&dstx[i * 32 + frl][(ct & 3) * 32 + 4 * hhl + 8 * g]) = o;
         }
       }
     }
     LC_STAMP(9)              // node GEMM: epilogue
     __syncthreads();         // x_l / x_r slices complete; the panel image is free for the edge chunks
     LC_STAMP(1)              // node GEMM: barrier
+    // The next tile's rows, records and scales are requested in the LAST chunk, behind the last request for edge planes: any
+    // earlier and the chunks' waits for their planes (counted from the youngest request) wait for these too; any later (before the
+    // aggregation loop) and the compiler drains every request at the loop's entry, 800 cycles per tile.
+    asm volatile("" : "+v"(dn.x), "+v"(dn.y), "+v"(dn.z), "+v"(dn.w)::"memory");
+    const int4 desc_n = make_int4(has_next ? __builtin_amdgcn_readfirstlane(dn.x) : 0, has_next ? __builtin_amdgcn_readfirstlane(dn.y) : 0,
+                                  has_next ? __builtin_amdgcn_readfirstlane(dn.z) : 0, has_next ? __builtin_amdgcn_readfirstlane(dn.w) : 0);
+    int4 rec_n;                 // defined and consumed inside this iteration (a zero descriptor requests row 0 and nothing else)
+    int rp_n;
+    float einv_n;
 
     // ---- 64-slot chunks: edge planes -> panel image, transposed product, logit epilogue (isg_mp_logits.hip) --------------------
     const int nchunk = (ne + 63) >> 6;
@@ -245,9 +294,9 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
-      if (tid < 64) s_inv[tid] = a.ep_inv[e0 + min(64 * c + tid, ne - 1)];
       __syncthreads();
       LC_STAMP(2)            // panel staging + barrier
+      if (c + 1 == nchunk) LC_REQUEST_TILE(desc_n)
       if (c + 1 < nchunk) {      // the next chunk's planes: in flight under this chunk's product and epilogue
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -280,10 +329,12 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       asm volatile("" ::"v"(acc[0]), "v"(acc[15]));
 #endif
       LC_STAMP(3)            // k loop
+      if (MASKED && c + 1 == nchunk) LC_REQUEST_MASKS(desc_n)      // the ids they hang on were requested a k loop ago
       // epilogue: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask, z * att in 4 chains
       {
-        const float sinv = s_inv[prow];
-        const int4 rec = s_tab[min(64 * c + prow, ne - 1)];
+        const int slot = min(64 * c + prow, ne - 1);
+        const float sinv = s_einv[slot];
+        const int4 rec = s_tab[slot];
         const float me = __int_as_float(rec.w);
         float part[4];
 #pragma unroll
@@ -305,6 +356,9 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
             if (MASKED) z *= me;
             part[g] = fmaf(z, atv[jj], part[g]);
           }
+          // two groups at a time: all four groups' x_l / x_r / att / scale reads in flight at once are 64 registers, which the
+          // allocator took from the resident W fragments (scratch reloads in the node GEMM, each waited for)
+          if (g < 3) __builtin_amdgcn_sched_barrier(0);
         }
         const float mine = (part[0] + part[1]) + (part[2] + part[3]);
         const float tot = mine + __shfl_xor(mine, 32);
@@ -318,21 +372,58 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     __syncthreads();
 
     // ---- softmax + aggregation (isg_mp_graph.hip phase C: same operations in the same order) ----------------------------------
-    float *s_w = s_part;
-    if (tid < ne) {
-      const int4 rc = s_tab[tid];
-      const int rb = s_rp[rc.z], re = min(s_rp[rc.z + 1], ne);
-      // four slots per round, reads clamped into the segment and issued together (a wave waits for its LONGEST segment: one
-      // dependent LDS read per slot made this phase 4.8 k cycles per tile); the sum still runs in slot order, the pads add 0
-      float mx = -INFINITY;
+    // One pass per destination node, 32 lanes x 16 bytes of its output row: every lane repeats the segment's max / denominator /
+    // weights (the logits are broadcast reads), so no weight table and no barrier between the softmax and the aggregation; the
+    // first four in-edges (most segments) are read once and stay in registers for all three uses.
+    if (nchunk == 0) {          // a tile without edges: nothing hid the requests
+      LC_REQUEST_TILE(desc_n)
+      LC_REQUEST_MASKS(desc_n)
+    }
+    LC_STORE_TILE(desc_n, cur ^ 1)      // panel image and scales are free since the last chunk's barrier; tables: the other set
+    LC_STAMP(5)              // last logit sums + barrier; the next tile's planes and tables
+    // 16 lanes per node (two 16-byte pieces each, 256 contiguous bytes per instruction): a wave aggregates FOUR nodes at a time,
+    // two passes cover the tile -- this phase is a chain of dependent LDS reads (pointers -> records -> rows), so its time is the
+    // number of passes (with 32 lanes per node: four passes, 6 k cycles per tile)
+    const int q4 = lane >> 4, j16 = lane & 15;
+    int rbp[2], rep[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {       // both passes' segment bounds in one round trip
+      const int k = min(4 * wave + q4 + 32 * ps, LC_ROWS - 1);
+      rbp[ps] = s_rp[k];
+      rep[ps] = s_rp[k + 1];
+    }
 #pragma unroll 1
-      for (int s = rb; s < re; s += 4) {
+    for (int ps = 0; ps < 2; ++ps) {
+      const int k = 4 * wave + q4 + 32 * ps;
+      if (k >= nrows) break;
+      const int rb = ps ? rbp[1] : rbp[0], re = min(ps ? rep[1] : rep[0], ne);
+      float lg4[4], e4[4];
+      int4 rc4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = max(min(rb + u, re - 1), 0);
+        lg4[u] = s_lg[idx];
+        rc4[u] = s_tab[idx];
+      }
+      float4 u4[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) u4[u][m] = *reinterpret_cast<const float4 *>(&sXl[rc4[u].x][64 * m + j16 * 4]);
+      float mx = fmaxf(fmaxf(-INFINITY, lg4[0]), fmaxf(fmaxf(lg4[1], lg4[2]), lg4[3]));
+#pragma unroll 1
+      for (int s = rb + 4; s < re; s += 4) {
         const float v0 = s_lg[s], v1 = s_lg[min(s + 1, re - 1)], v2 = s_lg[min(s + 2, re - 1)], v3 = s_lg[min(s + 3, re - 1)];
         mx = fmaxf(fmaxf(mx, v0), fmaxf(fmaxf(v1, v2), v3));
       }
-      float den = 0.f;
+      float den = 0.f;          // in slot order, like the per-edge loop of the kernels this replaces
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        e4[u] = __builtin_amdgcn_exp2f((lg4[u] - mx) * 1.4426950408889634f);
+        den += rb + u < re ? e4[u] : 0.f;
+      }
 #pragma unroll 1
-      for (int s = rb; s < re; s += 4) {
+      for (int s = rb + 4; s < re; s += 4) {
         const float v0 = s_lg[s], v1 = s_lg[min(s + 1, re - 1)], v2 = s_lg[min(s + 2, re - 1)], v3 = s_lg[min(s + 3, re - 1)];
         const float e0 = __builtin_amdgcn_exp2f((v0 - mx) * 1.4426950408889634f);
         const float e1 = __builtin_amdgcn_exp2f((v1 - mx) * 1.4426950408889634f);
@@ -343,61 +434,67 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
         den += s + 2 < re ? e2 : 0.f;
         den += s + 3 < re ? e3 : 0.f;
       }
-      const float w = __builtin_amdgcn_exp2f((s_lg[tid] - mx) * 1.4426950408889634f) * __builtin_amdgcn_rcpf(den + 1e-16f);
-      a.alpha[(int64_t)rc.y * a.H + hd] = w;
-      s_w[tid] = MASKED ? __fmul_rn(w, __int_as_float(rc.w)) : w;
-    }
-    int4 rec_n;                 // the next tile's inputs: defined and consumed inside this iteration
-    int rp_n;
-    hf32x4 xv_n[4];
-    LC_REQUEST_TILE(desc_n)     // (unconditional: a zero descriptor requests row 0 and nothing else) in flight under the aggregation
-    __syncthreads();
-    LC_STAMP(5)              // weights + the next tile's requests
+      const float rden = __builtin_amdgcn_rcpf(den + 1e-16f);
+      float4 o[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+      int s = rb;
 #pragma unroll 1
-    for (int k = 2 * wave + hh; k < nrows; k += 16) {
-      const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-      for (int s = rb; s < re; s += 4) {      // four in-edges per round: weights, sources, then the four rows, all reads in flight
-        float wm[4];
-        int sx[4];
+      while (true) {            // four in-edges per round, edge-id order, mul + add as the kernels this replaces compile them
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (s + u < re) {
+            const float w = e4[u] * rden;
+            if (j16 == u) a.alpha[(int64_t)rc4[u].y * a.H + hd] = w;
+            const float wm = MASKED ? __fmul_rn(w, __int_as_float(rc4[u].w)) : w;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              o[m].x = __fadd_rn(o[m].x, __fmul_rn(u4[u][m].x, wm));
+              o[m].y = __fadd_rn(o[m].y, __fmul_rn(u4[u][m].y, wm));
+              o[m].z = __fadd_rn(o[m].z, __fmul_rn(u4[u][m].z, wm));
+              o[m].w = __fadd_rn(o[m].w, __fmul_rn(u4[u][m].w, wm));
+            }
+          }
+        }
+        s += 4;
+        if (s >= re) break;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int idx = min(s + u, re - 1);
-          wm[u] = s_w[idx];
-          sx[u] = s_tab[idx].x;
+          e4[u] = __builtin_amdgcn_exp2f((s_lg[idx] - mx) * 1.4426950408889634f);
+          rc4[u] = s_tab[idx];
         }
-        float4 u4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) u4[u] = *reinterpret_cast<const float4 *>(&sXl[sx[u]][fr * 4]);
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (s + u < re) {               // edge-id order, unfused mul + add
-            o.x = __fadd_rn(o.x, __fmul_rn(u4[u].x, wm[u]));
-            o.y = __fadd_rn(o.y, __fmul_rn(u4[u].y, wm[u]));
-            o.z = __fadd_rn(o.z, __fmul_rn(u4[u].z, wm[u]));
-            o.w = __fadd_rn(o.w, __fmul_rn(u4[u].w, wm[u]));
-          }
-        }
+          for (int m = 0; m < 2; ++m) u4[u][m] = *reinterpret_cast<const float4 *>(&sXl[rc4[u].x][64 * m + j16 * 4]);
       }
-      if (a.bias) { o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w; }
-      hf32x4 o4 = {o.x, o.y, o.z, o.w};
-      __builtin_nontemporal_store(o4, reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + fr * 4));
+      float rmx = 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (a.bias) {
+          const float4 b4 = *reinterpret_cast<const float4 *>(&s_bias[64 * m + j16 * 4]);
+          o[m].x += b4.x; o[m].y += b4.y; o[m].z += b4.z; o[m].w += b4.w;
+        }
+        hf32x4 o4 = {o[m].x, o[m].y, o[m].z, o[m].w};
+        __builtin_nontemporal_store(o4, reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + 64 * m + j16 * 4));
+        rmx = fmaxf(rmx, fmaxf(fmaxf(fabsf(o[m].x), fabsf(o[m].y)), fmaxf(fabsf(o[m].z), fabsf(o[m].w))));
+      }
       if (a.rowmax) {
-        const float rmx = group_max<32>(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
-        if (fr == 0) a.rowmax[(int64_t)(r0 + k) * a.H + hd] = rmx;
+        rmx = group_max<16>(rmx);
+        if (j16 == 0) a.rowmax[(int64_t)(r0 + k) * a.H + hd] = rmx;
       }
     }
-    LC_STAMP(6)              // aggregation, stores
+    LC_STAMP(6)              // softmax + aggregation, stores
     if (!has_next) break;
-    __syncthreads();         // every wave is done with this tile's LDS image
-    LC_STORE_TILE(desc_n)
-    __syncthreads();
-    LC_STAMP(7)              // hand-over: tables, node rows -> planes
+    LC_REQUEST_PLANES(desc_n)
+    __syncthreads();         // every wave is done with this tile's slices; the next tile's planes and tables are complete
+    LC_STAMP(7)              // hand-over barrier
     desc = desc_n;
     t = t_next;
+    cur ^= 1;
   }
 #undef LC_REQUEST_TILE
+#undef LC_REQUEST_PLANES
+#undef LC_REQUEST_MASKS
 #undef LC_STORE_TILE
 #ifdef ISG_DT_STAMP
   if (g_lc_stamps && lane == 0) {

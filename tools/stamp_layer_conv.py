@@ -49,8 +49,8 @@ for rep in range(2):
 s = buf.double().cpu()
 s = s[s[:, 12] > 0]
 names = ["first tile's inputs (once)", "node GEMM: barrier", "chunks: panel staging + barrier", "chunks: k loops",
-         "chunks: epilogue + barrier", "C1 softmax weights, alpha, next tile's requests", "C2 aggregation, stores",
-         "hand-over: tables, node rows -> planes (2 barriers)", "node GEMM: k loop", "node GEMM: epilogue (LDS writes)"]
+         "chunks: epilogue + barrier", "last logit sums + barrier; next tile: planes, tables", "softmax + aggregation per node, stores",
+         "hand-over barrier", "node GEMM: k loop", "node GEMM: epilogue (LDS writes)"]
 tot = s[:, 12].mean().item()
 nwg = s.size(0) // 8
 print(f"{T} tiles x {H} heads on {nwg} persistent workgroups of 8 waves; a wave lives {tot:.0f} cycles = {tot * nwg / max(T * H, 1):.0f} per (tile, head)")
