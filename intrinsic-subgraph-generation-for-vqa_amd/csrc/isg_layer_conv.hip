@@ -182,7 +182,8 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     }                                                                                                                \
     int srl = srow, scl = scol;                      /* laundered like the node GEMM's store addresses */            \
     asm volatile("" : "+v"(srl), "+v"(scl));                                                                         \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* the rows this wave asked for have landed (long ago) */      \
+    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): the rows this wave asked for have landed (a builtin, not asm: the */ \
+                                          /* compiler must SEE the LDS-DMA retired or it drains every later request early) */ \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
       const int row = srl + 16 * u;                                                                                  \
       hf32x4 v = *reinterpret_cast<const hf32x4 *>(lc_smem + LC_OFF_RAW + (row * LC_K + scl * 4) * 4);               \
@@ -289,19 +290,26 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 
     // ---- 64-slot chunks: edge planes -> panel image, transposed product, logit epilogue (isg_mp_logits.hip) --------------------
     const int nchunk = (ne + 63) >> 6;
+    const int creq = max(nchunk - 2, 0);       // two chunks of lead: one chunk (4 k cycles) did not cover the requests' latency
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
+      LC_STAMP(10)           // panel staging: the wait for the planes, LDS writes
       __syncthreads();
       LC_STAMP(2)            // panel staging + barrier
-      if (c + 1 == nchunk) LC_REQUEST_TILE(desc_n)
+      if (c == creq) LC_REQUEST_TILE(desc_n)
       if (c + 1 < nchunk) {      // the next chunk's planes: in flight under this chunk's product and epilogue
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0 + min(64 * (c + 1) + srow + 16 * u, ne - 1)) * 256 + sc4 * 8);
       }
+#ifdef LC_LAT_PROBE          // diagnostic: how long does the request just made take when nothing hides it?
+      LC_STAMP(13)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      LC_STAMP(14)
+#endif
       const int prow = half * 32 + fr;
       hf32x16 acc;
 #pragma unroll
@@ -375,12 +383,14 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     // One pass per destination node, 32 lanes x 16 bytes of its output row: every lane repeats the segment's max / denominator /
     // weights (the logits are broadcast reads), so no weight table and no barrier between the softmax and the aggregation; the
     // first four in-edges (most segments) are read once and stay in registers for all three uses.
+    LC_STAMP(11)             // last logit sums + barrier
     if (nchunk == 0) {          // a tile without edges: nothing hid the requests
       LC_REQUEST_TILE(desc_n)
       LC_REQUEST_MASKS(desc_n)
     }
     LC_STORE_TILE(desc_n, cur ^ 1)      // panel image and scales are free since the last chunk's barrier; tables: the other set
-    LC_STAMP(5)              // last logit sums + barrier; the next tile's planes and tables
+    LC_REQUEST_PLANES(desc_n)
+    LC_STAMP(5)              // the next tile's planes and tables
     // 16 lanes per node (two 16-byte pieces each, 256 contiguous bytes per instruction): a wave aggregates FOUR nodes at a time,
     // two passes cover the tile -- this phase is a chain of dependent LDS reads (pointers -> records -> rows), so its time is the
     // number of passes (with 32 lanes per node: four passes, 6 k cycles per tile)
@@ -485,7 +495,6 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     }
     LC_STAMP(6)              // softmax + aggregation, stores
     if (!has_next) break;
-    LC_REQUEST_PLANES(desc_n)
     __syncthreads();         // every wave is done with this tile's slices; the next tile's planes and tables are complete
     LC_STAMP(7)              // hand-over barrier
     desc = desc_n;

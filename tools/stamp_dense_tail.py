@@ -15,6 +15,7 @@ OUT = os.path.join(ROOT, "tools", "_build", "libisg_dt_stamp.so")
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DISG_DT_STAMP",
+                           *[a for a in sys.argv[1:] if a.startswith("-D")],
                            os.path.join(CSRC, "isg_layer_tile.hip"), os.path.join(CSRC, "isg_layer_conv.hip"), os.path.join(CSRC, "isg_graph.hip"),
                            "-o", OUT])
     print("built", OUT)

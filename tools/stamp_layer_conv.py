@@ -48,9 +48,9 @@ for rep in range(2):
     torch.cuda.synchronize()
 s = buf.double().cpu()
 s = s[s[:, 12] > 0]
-names = ["first tile's inputs (once)", "node GEMM: barrier", "chunks: panel staging + barrier", "chunks: k loops",
-         "chunks: epilogue + barrier", "last logit sums + barrier; next tile: planes, tables", "softmax + aggregation per node, stores",
-         "hand-over barrier", "node GEMM: k loop", "node GEMM: epilogue (LDS writes)"]
+names = ["first tile's inputs (once)", "node GEMM: barrier", "chunks: staging barrier", "chunks: k loops",
+         "chunks: epilogue + barrier", "next tile: rows -> planes, tables", "softmax + aggregation per node, stores",
+         "hand-over barrier", "node GEMM: k loop", "node GEMM: epilogue (LDS writes)", "chunks: wait for the planes, LDS writes", "last logit sums + barrier", "(total)", "(probe) other", "(probe) exposed latency of a chunk request"]
 tot = s[:, 12].mean().item()
 nwg = s.size(0) // 8
 print(f"{T} tiles x {H} heads on {nwg} persistent workgroups of 8 waves; a wave lives {tot:.0f} cycles = {tot * nwg / max(T * H, 1):.0f} per (tile, head)")
