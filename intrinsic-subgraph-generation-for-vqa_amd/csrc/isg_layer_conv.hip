@@ -56,7 +56,9 @@ struct LcArgs {
   float slope;
 };
 
-template <bool MASKED>
+// KSE_T: 16-column steps of the edge product when known at compile time (8 = the 128 edge features of the model: no branch between
+// the MFMAs), 0 = read it from the arguments
+template <bool MASKED, int KSE_T>
 __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lc_smem[];
   typedef float (*BufX)[LC_LDX];
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
   const int srow = tid >> 5, scol = tid & 31, sc4 = scol;    // staging map: 32 lanes per 512-byte row, rows srow + 16 u
 
   // ---- resident W fragments: the wave's tile of lin_edge and its tile of [lin_l | lin_r] ---------------------------------------
-  const int KSE = a.KSE;
+  const int KSE = KSE_T ? KSE_T : a.KSE;
   const unsigned plane_e = (unsigned)a.NTE * (unsigned)KSE * 1024u;
   const __amdgpu_buffer_rsrc_t wrs_e =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.We), 0, (int)(2u * plane_e), 0x00020000);
@@ -289,8 +291,48 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     float einv_n;
 
     // ---- 64-slot chunks: edge planes -> panel image, transposed product, logit epilogue (isg_mp_logits.hip) --------------------
+    // (Running the two 32-slot halves of a chunk one phase apart -- waves 0-3 in chunk c's product while waves 4-7 are in chunk
+    // c - 1's epilogue -- did not overlap the matrix and the vector pipe: 304 vs 302 us, profiles/r03_aw_*.)
     const int nchunk = (ne + 63) >> 6;
     const int creq = max(nchunk - 2, 0);       // two chunks of lead: one chunk (4 k cycles) did not cover the requests' latency
+    const int prow = half * 32 + fr;
+    hf32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // epilogue of chunk `ch`: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask, z * att in
+    // 4 chains (one group of reads at a time: all four in flight are 64 registers, which the allocator took from the resident W)
+#define LC_EPILOGUE(ch)                                                                                              \
+  {                                                                                                                  \
+    const int slot = min(64 * (ch) + prow, ne - 1);                                                                  \
+    const float sinv = s_einv[slot];                                                                                 \
+    const int4 rec = s_tab[slot];                                                                                    \
+    const float me = __int_as_float(rec.w);                                                                          \
+    float part[4];                                                                                                   \
+    int cb = tw * 32 + 4 * hh;       /* laundered: hoisted out of the chunk loop, the 16 addresses below cost 16 registers */ \
+    asm volatile("" : "+v"(cb));                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                  \
+      const int cc = cb + 8 * g;                                                                                     \
+      const float4 xl4 = *reinterpret_cast<const float4 *>(&sXl[rec.x][cc]);                                         \
+      const float4 xr4 = *reinterpret_cast<const float4 *>(&sXr[rec.z][cc]);                                         \
+      const float4 at4 = *reinterpret_cast<const float4 *>(&s_att[cc]);                                              \
+      const float4 wi4 = *reinterpret_cast<const float4 *>(&s_weinv[cc]);                                            \
+      const float lv[4] = {xl4.x, xl4.y, xl4.z, xl4.w}, rv[4] = {xr4.x, xr4.y, xr4.z, xr4.w};                        \
+      const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w};                      \
+      part[g] = 0.f;                                                                                                 \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                             \
+        const float e = (acc[g * 4 + jj] * sinv) * wiv[jj];                                                          \
+        float z = (rv[jj] + lv[jj]) + e;                                                                             \
+        if (MASKED) z *= me;                                                                                         \
+        z = z > 0.f ? z : z * slope;                                                                                 \
+        if (MASKED) z *= me;                                                                                         \
+        part[g] = fmaf(z, atv[jj], part[g]);                                                                         \
+      }                                                                                                              \
+      if (g < 3) __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }                                                                                                                \
+    const float mine = (part[0] + part[1]) + (part[2] + part[3]);                                                    \
+    const float tot = mine + __shfl_xor(mine, 32);                                                                   \
+    if (hh == 0) s_part[tw * 64 + prow] = tot;                                                                       \
+  }
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
@@ -298,7 +340,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
         *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
       LC_STAMP(10)           // panel staging: the wait for the planes, LDS writes
       __syncthreads();
-      LC_STAMP(2)            // panel staging + barrier
+      LC_STAMP(2)            // staging barrier
       if (c == creq) LC_REQUEST_TILE(desc_n)
       if (c + 1 < nchunk) {      // the next chunk's planes: in flight under this chunk's product and epilogue
 #pragma unroll
@@ -310,11 +352,9 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       __builtin_amdgcn_s_waitcnt(0x0F70);
       LC_STAMP(14)
 #endif
-      const int prow = half * 32 + fr;
-      hf32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         hf16x8 af[2][2];          // [stage][plane]
 #pragma unroll
         for (int q = 0; q < 2; ++q) af[0][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][prow][fk]);
@@ -338,45 +378,13 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #endif
       LC_STAMP(3)            // k loop
       if (MASKED && c + 1 == nchunk) LC_REQUEST_MASKS(desc_n)      // the ids they hang on were requested a k loop ago
-      // epilogue: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask, z * att in 4 chains
-      {
-        const int slot = min(64 * c + prow, ne - 1);
-        const float sinv = s_einv[slot];
-        const int4 rec = s_tab[slot];
-        const float me = __int_as_float(rec.w);
-        float part[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cc = tw * 32 + 4 * hh + 8 * g;
-          const float4 xl4 = *reinterpret_cast<const float4 *>(&sXl[rec.x][cc]);
-          const float4 xr4 = *reinterpret_cast<const float4 *>(&sXr[rec.z][cc]);
-          const float4 at4 = *reinterpret_cast<const float4 *>(&s_att[cc]);
-          const float4 wi4 = *reinterpret_cast<const float4 *>(&s_weinv[cc]);
-          const float lv[4] = {xl4.x, xl4.y, xl4.z, xl4.w}, rv[4] = {xr4.x, xr4.y, xr4.z, xr4.w};
-          const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w};
-          part[g] = 0.f;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const float e = (acc[g * 4 + jj] * sinv) * wiv[jj];
-            float z = (rv[jj] + lv[jj]) + e;
-            if (MASKED) z *= me;
-            z = z > 0.f ? z : z * slope;
-            if (MASKED) z *= me;
-            part[g] = fmaf(z, atv[jj], part[g]);
-          }
-          // two groups at a time: all four groups' x_l / x_r / att / scale reads in flight at once are 64 registers, which the
-          // allocator took from the resident W fragments (scratch reloads in the node GEMM, each waited for)
-          if (g < 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        const float mine = (part[0] + part[1]) + (part[2] + part[3]);
-        const float tot = mine + __shfl_xor(mine, 32);
-        if (hh == 0) s_part[tw * 64 + prow] = tot;
-      }
+      LC_EPILOGUE(c)
       __syncthreads();
       LC_STAMP(4)            // epilogue + barrier
       if (tid < 64 && 64 * c + tid < ne)     // the tile-waves' partials in a fixed order
         s_lg[64 * c + tid] = (s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]);
     }
+#undef LC_EPILOGUE
     __syncthreads();
 
     // ---- softmax + aggregation (isg_mp_graph.hip phase C: same operations in the same order) ----------------------------------
@@ -562,17 +570,20 @@ extern "C" int isg_gatv2_layer_conv(const float *x, int32_t ldx, const uint16_t 
   if (gpx > need) gpx = (int)need;
   const unsigned grid = 8u * (unsigned)H * (unsigned)gpx;
   hipStream_t st = as_stream(stream);
-  if (node_mask || edge_mask) {
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_layer_conv_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LC_SMEM_BYTES) == hipSuccess;
-    if (!ok) return ISG_EUNSUPPORTED;
-    gatv2_layer_conv_kernel<true><<<grid, LC_THREADS, LC_SMEM_BYTES, st>>>(a);
-  } else {
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_layer_conv_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LC_SMEM_BYTES) == hipSuccess;
-    if (!ok) return ISG_EUNSUPPORTED;
-    gatv2_layer_conv_kernel<false><<<grid, LC_THREADS, LC_SMEM_BYTES, st>>>(a);
+#define LC_LAUNCH(M, KT)                                                                                             \
+  {                                                                                                                  \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_layer_conv_kernel<M, KT>),      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LC_SMEM_BYTES) == hipSuccess; \
+    if (!ok) return ISG_EUNSUPPORTED;                                                                                \
+    gatv2_layer_conv_kernel<M, KT><<<grid, LC_THREADS, LC_SMEM_BYTES, st>>>(a);                                      \
   }
+  const bool masked = node_mask || edge_mask;
+  if (a.KSE == 8) {
+    if (masked) LC_LAUNCH(true, 8) else LC_LAUNCH(false, 8)
+  } else {
+    if (masked) LC_LAUNCH(true, 0) else LC_LAUNCH(false, 0)
+  }
+#undef LC_LAUNCH
   return check_launch();
 }
 
