@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 11
+#define ISG_ABI_VERSION 12
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -87,6 +87,13 @@ int isg_csr_build(const int64_t *edge_index, int64_t N, int64_t E, int32_t *rowp
  * x,out fp32[N,C]; instr fp32[B,C]; batch int64[N].  out may alias x. */
 int isg_instr_gate(const float *x, const float *instr, const int64_t *batch, float *out, int64_t N,
                    int32_t C, void *stream);
+
+/* The same gate written as isg_gatv2_layer_conv reads its input:   ISubGVQA/models/mgat_v2_conv.py:156-157
+ * planes uint16 [N][2][128] = gelu(x * instr[batch]) as per-row-scaled (hi, mid) fp16 planes (row: 128 hi values, then 128 mid
+ * values; the row scale / split of isg_edge_planes), inv_scale fp32 [N]; out fp32 [N,128] or NULL (the fp32 rows as well: a
+ * masked layer's node gate reads them).  ISG_EUNSUPPORTED unless C == 128. */
+int isg_instr_gate_planes(const float *x, const float *instr, const int64_t *batch, float *out, uint16_t *planes,
+                          float *inv_scale, int64_t N, int32_t C, void *stream);
 
 /* edge_mask[e] = mask[src[e]] * mask[dst[e]]        ISubGVQA/sampling/node_edge_masks.py:7-10
  * mask fp32[N]; edge_index int64[2,E]; out fp32[E]. */
@@ -218,7 +225,8 @@ int isg_tile_plan(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t no
 /* The dense back half of one MGAT layer and the first line of the next as ONE launch on graph-aligned 64-row tiles
  * (isg_tile_plan with node_cap = 64):   ISubGVQA/models/mgat.py:156-177, mgat_v2_conv.py:156-157
  *   c = gelu(x_proj.2(gelu(x_proj.0(conv_out))));  c = scatter_attention(ins, c, c);  c = GraphNorm(c);
- *   h_out = c + h;  h_out *= node_mask (optional);  xg_out = gelu(h_out * ins_next[batch]) (optional)
+ *   h_out = c + h;  h_out *= node_mask (optional);  xg = gelu(h_out * ins_next[batch]) (optional: xg_out fp32 [N,C] and / or
+ *   xp_out uint16 [N][2][128] + xinv_out fp32 [N] = the same rows as the scaled (hi, mid) planes isg_gatv2_layer_conv reads)
  * conv_out fp32[N,K1] (row stride lda) with a_rowmax fp32[N,P] (row stride ldp) = partial maxima of |conv_out| per row (what
  * isg_gatv2_mp_fwd_rowmax / _logits leave); w1 / w2: isg_split_f16x2_frag planes + inverse scales of x_proj.0.weight [MID,K1]
  * and x_proj.2.weight [C,MID]; b1 fp32[MID], b2 fp32[C]; y_bound fp32[2] = {max_j sum_k |w1[j,k]|, max_j |b1[j]|} (the
@@ -231,9 +239,10 @@ int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const float *a_rowma
                         const uint16_t *w2_frag,
                         const float *w2_inv_scale, const float *b2, const float *ins, const float *h,
                         const float *gn_weight, const float *gn_bias, const float *gn_mean_scale, double eps,
-                        const float *node_mask, const float *ins_next, float *h_out, float *xg_out, const int32_t *ptr,
-                        const int64_t *batch, const int32_t *tile_ptr, const int32_t *tile_info, const int32_t *ntiles,
-                        int64_t max_tiles, int64_t N, int32_t K1, int32_t MID, int32_t C, void *stream);
+                        const float *node_mask, const float *ins_next, float *h_out, float *xg_out, uint16_t *xp_out,
+                        float *xinv_out, const int32_t *ptr, const int64_t *batch, const int32_t *tile_ptr,
+                        const int32_t *tile_info, const int32_t *ntiles, int64_t max_tiles, int64_t N, int32_t K1, int32_t MID,
+                        int32_t C, void *stream);
 
 /* MaskingGATv2Conv.message + aggregate with lin_edge inside as ONE launch on graph-aligned tiles (isg_tile_plan with node_cap =
  * 64, edge_cap = 256 and tile_info):   ISubGVQA/models/mgat_v2_conv.py:243-279 (lin_edge :259-261)
@@ -255,12 +264,15 @@ int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x_r, int32_t
 
 /* One MaskingGATv2Conv after its instruction gate and node mask as ONE persistent launch: lin_l | lin_r, lin_edge, logits,
  * softmax, aggregation (ISubGVQA/models/mgat_v2_conv.py:177-181, :215-232, :243-279).  As isg_gatv2_tile_conv, but the head's x_l
- * and x_r slices of a tile are formed inside, on the matrix cores, from the gated node rows x fp32 [N,128] (row stride ldx) and
+ * and x_r slices of a tile are formed inside, on the matrix cores, from the gated node rows -- which arrive as scaled (hi, mid)
+ * planes x_planes uint16 [N][2][128] + x_inv_scale fp32 [N] (isg_instr_gate_planes, isg_mgat_dense_tail's xp_out, or
+ * isg_edge_planes with eid = NULL on fp32 rows: the split is made once per row, not once per tile and head) -- and
  * stay in LDS: neither tensor exists in memory, the logit epilogue gathers both from LDS.  wn_frag / wn_inv_scale =
  * isg_split_f16x2_frag of cat(lin_l.weight, lin_r.weight) [2*H*C,128]; bn fp32 [2*H*C] = cat of their biases; the remaining
  * operands as isg_gatv2_tile_conv.  Bit-identical to isg_linear_f16x3 + isg_gatv2_tile_conv.  ISG_EUNSUPPORTED unless C == 128,
  * K_in == 128, K_edge <= 128, K_edge % 4 == 0, H <= 16. */
-int isg_gatv2_layer_conv(const float *x, int32_t ldx, const uint16_t *wn_frag, const float *wn_inv_scale, const float *bn,
+int isg_gatv2_layer_conv(const uint16_t *x_planes, const float *x_inv_scale, const uint16_t *wn_frag, const float *wn_inv_scale,
+                         const float *bn,
                          const uint16_t *edge_planes, const float *edge_inv_scale, const uint16_t *we_frag,
                          const float *we_inv_scale, const float *att, const float *bias, const int32_t *rowptr,
                          const int32_t *eid, const int32_t *src, const int32_t *dst, const int32_t *tile_info,
@@ -284,7 +296,8 @@ int isg_readout_tile(const float *x, int32_t ldx, const uint16_t *w1_frag, const
 /* Edge features as the exact-split kernels want them, once per batch: per-row power-of-two scale and (hi, mid) fp16 planes in CSR
  * SLOT order (slot t = edge eid[t]): planes uint16 [E][2][128] (row: 128 hi values, then 128 mid values; columns beyond K zero),
  * inv_scale fp32 [E].  edge_attr fp32 [E,K] by edge id (row stride lda).  The same edge features feed lin_edge of every layer
- * (ISubGVQA/models/mgat.py:144-148).  ISG_EUNSUPPORTED unless K <= 128, K % 4 == 0. */
+ * (ISubGVQA/models/mgat.py:144-148).  eid == NULL: rows in their own order (any fp32 [E,K] matrix, e.g. node rows for
+ * isg_gatv2_layer_conv).  ISG_EUNSUPPORTED unless K <= 128, K % 4 == 0. */
 int isg_edge_planes(const float *edge_attr, int32_t lda, const int32_t *eid, int64_t E, int32_t K, uint16_t *planes,
                     float *inv_scale, void *stream);
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -93,8 +93,9 @@ SIGNATURES = {
     "isg_tile_plan_capacity": (c_int64, [c_int64, c_int64, c_int64, c_int32, c_int32]),
     "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "isg_mgat_dense_tail": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32] + [c_void_p] * 12 + [c_double] +
-                            [c_void_p] * 9 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
-    "isg_gatv2_layer_conv": (c_int, [c_void_p, c_int32] + [c_void_p] * 15 + [c_int64] + [c_void_p] * 3 +
+                            [c_void_p] * 11 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_instr_gate_planes": (c_int, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
+    "isg_gatv2_layer_conv": (c_int, [c_void_p, c_void_p] + [c_void_p] * 15 + [c_int64] + [c_void_p] * 3 +
                              [c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "isg_readout_tile": (c_int, [c_void_p, c_int32] + [c_void_p] * 16 + [c_int64, c_int64, c_int32, c_void_p]),
     "isg_edge_planes": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -41,7 +41,8 @@ static_assert(LC_OFF_RAW % 16 == 0, "16-byte pieces");
 static_assert(LC_SMEM_BYTES <= 160 * 1024, "one workgroup per CU");
 
 struct LcArgs {
-  const float *x;                   // gated node rows [N, 128] (row stride ldx): gelu(h * instruction[batch])
+  const _Float16 *xp;               // gated node rows gelu(h * instruction[batch]) as scaled (hi, mid) planes [N][2][128]
+  const float *xinv;                // [N] inverse row scales (isg_instr_gate_planes / isg_mgat_dense_tail / isg_edge_planes write both)
   const _Float16 *Wn;               // [lin_l.weight; lin_r.weight] [2*H*C, 128] as fragment-major (hi, mid) planes
   const float *wn_inv, *bn;         // [2*H*C] inverse scales, biases (lin_l then lin_r)
   const _Float16 *ep;               // edge features as scaled (hi, mid) planes in CSR slot order [E][2][128] (isg_edge_planes)
@@ -52,9 +53,33 @@ struct LcArgs {
   const int4 *tile_info;
   const float *edge_mask, *node_mask;
   float *out, *alpha, *rowmax;
-  int N, E, H, KSE, NTE, ldx, ldo;
+  int N, E, H, KSE, NTE, ldo;
   float slope;
 };
+
+// gelu(x * instr[batch]) -> fp32 rows (optional) + scaled (hi, mid) planes + inverse row scale: 32 lanes x 4 channels per row
+__global__ __launch_bounds__(256) void instr_gate_planes_kernel(const float *__restrict__ x, const float *__restrict__ instr,
+                                                                const int64_t *__restrict__ batch, float *__restrict__ out,
+                                                                _Float16 *__restrict__ planes, float *__restrict__ inv_out, int N) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), c4 = threadIdx.x & 31;
+  if (row >= N) return;
+  const int64_t b = batch[row];
+  const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)row * LC_K + c4 * 4);
+  const float4 w = *reinterpret_cast<const float4 *>(instr + b * LC_K + c4 * 4);
+  const isg_f32x2 g0 = gelu_exact2(isg_f32x2{v.x * w.x, v.y * w.y}), g1 = gelu_exact2(isg_f32x2{v.z * w.z, v.w * w.w});
+  hf32x4 g = {g0.x, g0.y, g1.x, g1.y};
+  if (out) *reinterpret_cast<hf32x4 *>(out + (int64_t)row * LC_K + c4 * 4) = g;
+  const float mx = group_max<32>(fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3]))));
+  float sc, inv;
+  h3_scale(mx, sc, inv);
+  if (c4 == 0) inv_out[row] = inv;
+  g *= sc;
+  hf16x4 hi = {(_Float16)g[0], (_Float16)g[1], (_Float16)g[2], (_Float16)g[3]};
+  hf16x4 mid = {(_Float16)(g[0] - (float)hi[0]), (_Float16)(g[1] - (float)hi[1]), (_Float16)(g[2] - (float)hi[2]),
+                (_Float16)(g[3] - (float)hi[3])};
+  *reinterpret_cast<hf16x4 *>(planes + (int64_t)row * 256 + c4 * 4) = hi;
+  *reinterpret_cast<hf16x4 *>(planes + (int64_t)row * 256 + 128 + c4 * 4) = mid;
+}
 
 // KSE_T: 16-column steps of the edge product when known at compile time (8 = the 128 edge features of the model: no branch between
 // the MFMAs), 0 = read it from the arguments
@@ -147,12 +172,18 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       rec_n.z = a.dst[e0n + tid];                                                                                    \
       einv_n = a.ep_inv[e0n + tid];                                                                                  \
     }                                                                                                                \
-    /* node rows: memory -> LDS directly (a wave instruction lands 1 KB = its two rows srow, 16 bytes per lane): sixteen */ \
-    /* registers less across the chunk epilogue, which is where the allocator ran out and evicted W fragments          */ \
+    xinv_n = 1.f;                                                                                                    \
+    if (tid < nrn) xinv_n = a.xinv[r0n + tid];                                                                       \
+    /* node planes: memory -> LDS directly, no registers (sixteen held across the chunk epilogue is where the allocator */ \
+    /* ran out and evicted W fragments).  A wave instruction lands 1 KB = its two rows (srow, srow + 1), 16 bytes per   */ \
+    /* lane, rows 512 bytes apart: the 16-byte pieces of a 256-byte plane row sit at position p ^ (row & 15), applied   */ \
+    /* HERE, on the source address, so that the node GEMM's B fragments (32 rows x one piece) spread over the banks     */ \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
-      const int row = min(r0n + min(srow + 16 * u, max(nrn - 1, 0)), a.N - 1);                                       \
-      __builtin_amdgcn_global_load_lds((lc_glb_t *)(a.x + (int64_t)row * a.ldx + sc4 * 4),                           \
-                                       (lc_lds_t *)(lc_smem + LC_OFF_RAW + (2 * wave + 16 * u) * (LC_K * 4)), 16, 0, 0); \
+      const int lrow = srow + 16 * u;                                                                                \
+      const int row = min(r0n + min(lrow, max(nrn - 1, 0)), a.N - 1);                                                \
+      const int piece = (sc4 & 15) ^ (lrow & 15);                                                                    \
+      __builtin_amdgcn_global_load_lds((lc_glb_t *)(a.xp + (int64_t)row * 256 + (sc4 >> 4) * 128 + piece * 8),      \
+                                       (lc_lds_t *)(lc_smem + LC_OFF_RAW + (2 * wave + 16 * u) * 512), 16, 0, 0);    \
     }                                                                                                                \
   }
   // second stage, a phase later (the ids have arrived): the masks behind them
@@ -171,7 +202,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
         ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0n + min(srow + 16 * u, nen - 1)) * 256 + sc4 * 8); \
     }                                                                                                                \
   }
-  // records, scales and row pointers into table set `b`; the node rows -> row scale -> (hi, mid) planes (isg_linear_f16x3's staging)
+  // records, scales and row pointers into table set `b`; the node planes' scales
 #define LC_STORE_TILE(d, b)                                                                                          \
   {                                                                                                                  \
     const int r0n = (d).x, nrn = min((d).y, LC_ROWS), e0n = (d).z;                                                   \
@@ -182,32 +213,17 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       s_tab0[(b) * LC_ECAP + tid] = rec_n;                                                                           \
       s_einv0[(b) * LC_ECAP + tid] = einv_n;                                                                         \
     }                                                                                                                \
-    int srl = srow, scl = scol;                      /* laundered like the node GEMM's store addresses */            \
-    asm volatile("" : "+v"(srl), "+v"(scl));                                                                         \
-    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): the rows this wave asked for have landed (a builtin, not asm: the */ \
-                                          /* compiler must SEE the LDS-DMA retired or it drains every later request early) */ \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
-      const int row = srl + 16 * u;                                                                                  \
-      hf32x4 v = *reinterpret_cast<const hf32x4 *>(lc_smem + LC_OFF_RAW + (row * LC_K + scl * 4) * 4);               \
-      if (row >= nrn) v = hf32x4{0.f, 0.f, 0.f, 0.f};                                                                \
-      const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));        \
-      float sc_, inv_;                                                                                               \
-      h3_scale(mx, sc_, inv_);                                                                                       \
-      if (scl == 0) s_inv[row] = inv_;                                                                               \
-      v *= sc_;                                                                                                      \
-      hf16x4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};                                  \
-      hf16x4 mid = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]), (_Float16)(v[2] - (float)hi[2]), \
-                    (_Float16)(v[3] - (float)hi[3])};                                                                \
-      *reinterpret_cast<hf16x4 *>(&sA[0][row][scl * 4]) = hi;                                                        \
-      *reinterpret_cast<hf16x4 *>(&sA[1][row][scl * 4]) = mid;                                                       \
-    }                                                                                                                \
+    if (tid < LC_ROWS) s_inv[tid] = xinv_n;                                                                          \
+    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): the planes this wave asked for have landed, long ago (a builtin, */ \
+                                          /* not asm: the compiler must SEE the LDS-DMA retired or it drains every     */ \
+                                          /* later request early)                                                      */ \
   }
 
   int4 desc = a.tile_info[t];
   {
     int4 rec_n;
     int rp_n;
-    float einv_n;
+    float einv_n, xinv_n;
     LC_REQUEST_TILE(desc)
     LC_REQUEST_MASKS(desc)
     LC_REQUEST_PLANES(desc)
@@ -244,7 +260,8 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int q = 0; q < 2; ++q) an[i][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][i * 32 + fr][ks * 16 + fk]);
+          for (int q = 0; q < 2; ++q)
+            an[i][q] = *reinterpret_cast<const hf16x8 *>(lc_smem + LC_OFF_RAW + (i * 32 + fr) * 512 + q * 256 + (((ks * 2 + hh) ^ (fr & 15)) << 4));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           hf32x16 c = accn[i];
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
                                   has_next ? __builtin_amdgcn_readfirstlane(dn.z) : 0, has_next ? __builtin_amdgcn_readfirstlane(dn.w) : 0);
     int4 rec_n;                 // defined and consumed inside this iteration (a zero descriptor requests row 0 and nothing else)
     int rp_n;
-    float einv_n;
+    float einv_n, xinv_n;
 
     // ---- 64-slot chunks: edge planes -> panel image, transposed product, logit epilogue (isg_mp_logits.hip) --------------------
     // (Running the two 32-slot halves of a chunk one phase apart -- waves 0-3 in chunk c's product while waves 4-7 are in chunk
@@ -533,32 +550,51 @@ extern "C" int isg_lc_set_stamp_buffer(long long *buf) {      // diagnostic buil
 }
 #endif
 
+// gelu(x * instr[batch]) (mgat_v2_conv.py:156-157, isg_instr_gate) written as the (hi, mid) planes + inverse row scales that
+// isg_gatv2_layer_conv reads, and as fp32 rows too when `out` is given (the masked layer's node gate reads those): the same row
+// scale / split as isg_linear_f16x3's staging, done once per row here instead of once per (tile, head) in the layer kernel.
+extern "C" int isg_instr_gate_planes(const float *x, const float *instr, const int64_t *batch, float *out, uint16_t *planes,
+                                     float *inv_scale, int64_t N, int32_t C, void *stream) {
+  if (N < 0 || C <= 0) return ISG_EINVAL;
+  if (C != LC_K || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(instr) & 15) != 0 ||
+      (out && (reinterpret_cast<uintptr_t>(out) & 15) != 0) || (reinterpret_cast<uintptr_t>(planes) & 15) != 0 || N >= (1ll << 31))
+    return ISG_EUNSUPPORTED;
+  if (N == 0) return ISG_OK;
+  if (!x || !instr || !batch || !planes || !inv_scale) return ISG_EINVAL;
+  instr_gate_planes_kernel<<<(unsigned)((N + 7) / 8), 256, 0, as_stream(stream)>>>(x, instr, batch, out, reinterpret_cast<_Float16 *>(planes),
+                                                                                   inv_scale, (int)N);
+  return check_launch();
+}
+
 // lin_l | lin_r + MaskingGATv2Conv.message + aggregate (lin_edge inside) as one persistent launch: see the file header.
-// x fp32 [N,128] (row stride ldx) = the gated layer input; wn_frag / wn_inv_scale = isg_split_f16x2_frag of
-// cat(lin_l.weight, lin_r.weight) [2*H*C, 128], bn fp32 [2*H*C] their biases; the rest as isg_gatv2_tile_conv.
-extern "C" int isg_gatv2_layer_conv(const float *x, int32_t ldx, const uint16_t *wn_frag, const float *wn_inv_scale, const float *bn,
-                                    const uint16_t *edge_planes, const float *edge_inv_scale, const uint16_t *we_frag,
+// x_planes [N][2][128] fp16 + x_inv_scale [N] = the gated layer input gelu(h * instruction[batch]) as scaled (hi, mid) planes
+// (isg_instr_gate_planes, isg_mgat_dense_tail's xp_out, or isg_edge_planes with eid = NULL on fp32 rows); wn_frag / wn_inv_scale =
+// isg_split_f16x2_frag of cat(lin_l.weight, lin_r.weight) [2*H*C, 128], bn fp32 [2*H*C] their biases; the rest as isg_gatv2_tile_conv.
+extern "C" int isg_gatv2_layer_conv(const uint16_t *x_planes, const float *x_inv_scale, const uint16_t *wn_frag, const float *wn_inv_scale,
+                                    const float *bn, const uint16_t *edge_planes, const float *edge_inv_scale, const uint16_t *we_frag,
                                     const float *we_inv_scale, const float *att, const float *bias, const int32_t *rowptr,
                                     const int32_t *eid, const int32_t *src, const int32_t *dst, const int32_t *tile_info,
                                     const int32_t *ntiles, int64_t max_tiles, const float *node_mask, const float *edge_mask,
                                     float *out, int32_t ldo, float *alpha, float *rowmax, int64_t N, int64_t E, int32_t H,
                                     int32_t C, int32_t K_in, int32_t K_edge, float negative_slope, void *stream) {
-  if (N < 0 || E < 0 || H <= 0 || C <= 0 || K_in <= 0 || K_edge <= 0 || max_tiles < 0 || ldx < K_in || ldo < H * C) return ISG_EINVAL;
+  if (N < 0 || E < 0 || H <= 0 || C <= 0 || K_in <= 0 || K_edge <= 0 || max_tiles < 0 || ldo < H * C) return ISG_EINVAL;
   auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (C != LC_C || K_in != LC_K || K_edge > LC_K || (K_edge & 3) != 0 || (ldx & 3) != 0 || (ldo & 3) != 0 || H > 16 || mis(x) ||
+  if (C != LC_C || K_in != LC_K || K_edge > LC_K || (K_edge & 3) != 0 || (ldo & 3) != 0 || H > 16 || mis(x_planes) ||
       mis(edge_planes) || mis(out) || (bias && mis(bias)) || mis(tile_info) || N >= (1ll << 31) || E >= (1ll << 31))
     return ISG_EUNSUPPORTED;
   if (N == 0 || max_tiles == 0) return ISG_OK;
-  if (!x || !wn_frag || !wn_inv_scale || !bn || (E > 0 && (!edge_planes || !edge_inv_scale || !eid || !src || !dst || !alpha)) ||
-      !we_frag || !we_inv_scale || !att || !rowptr || !tile_info || !ntiles || !out)
+  if (!x_planes || !x_inv_scale || !wn_frag || !wn_inv_scale || !bn ||
+      (E > 0 && (!edge_planes || !edge_inv_scale || !eid || !src || !dst || !alpha)) || !we_frag || !we_inv_scale || !att || !rowptr ||
+      !tile_info || !ntiles || !out)
     return ISG_EINVAL;
   LcArgs a;
-  a.x = x; a.Wn = reinterpret_cast<const _Float16 *>(wn_frag); a.wn_inv = wn_inv_scale; a.bn = bn;
+  a.xp = reinterpret_cast<const _Float16 *>(x_planes); a.xinv = x_inv_scale;
+  a.Wn = reinterpret_cast<const _Float16 *>(wn_frag); a.wn_inv = wn_inv_scale; a.bn = bn;
   a.ep = reinterpret_cast<const _Float16 *>(edge_planes); a.ep_inv = edge_inv_scale;
   a.We = reinterpret_cast<const _Float16 *>(we_frag); a.we_inv = we_inv_scale; a.att = att; a.bias = bias; a.rowptr = rowptr;
   a.eid = eid; a.src = src; a.dst = dst; a.ntiles = ntiles; a.tile_info = reinterpret_cast<const int4 *>(tile_info);
   a.edge_mask = edge_mask; a.node_mask = node_mask; a.out = out; a.alpha = alpha; a.rowmax = rowmax; a.N = (int)N; a.E = (int)E;
-  a.H = H; a.KSE = (K_edge + 15) / 16; a.NTE = H * C / 32; a.ldx = ldx; a.ldo = ldo; a.slope = negative_slope;
+  a.H = H; a.KSE = (K_edge + 15) / 16; a.NTE = H * C / 32; a.ldo = ldo; a.slope = negative_slope;
   static const int cus = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;

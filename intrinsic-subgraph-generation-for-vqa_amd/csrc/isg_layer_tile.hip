@@ -144,7 +144,8 @@ struct DtArgs {
   const float *ins, *h;    // [B, 128], [N, 128]
   const float *gn_w, *gn_b, *gn_ms;
   const float *node_mask, *ins_next;
-  float *h_out, *xg_out;
+  float *h_out, *xg_out, *xinv_out;
+  _Float16 *xp_out;                 // the gated rows as scaled (hi, mid) planes [N][2][128] for isg_gatv2_layer_conv (optional)
   const int *ptr, *tile_ptr, *ntiles;
   const int4 *tile_info;   // {first node, nodes, ., .} per tile: the rows' loads start one round trip after the launch
   const long long *batch;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
           if (a.node_mask) y = __fmul_rn(mk, y);
           y4[j] = y;
         }
-        if (a.xg_out) {
+        if (a.xg_out || a.xp_out) {
           const isg_f32x2 ga = gelu_exact2(isg_f32x2{y4[0] * xv[0], y4[1] * xv[1]});
           const isg_f32x2 gb2 = gelu_exact2(isg_f32x2{y4[2] * xv[2], y4[3] * xv[3]});
           g4 = hf32x4{ga.x, ga.y, gb2.x, gb2.y};
@@ -510,6 +511,18 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
         const int64_t at = (int64_t)(r0 + row) * DT_C + sc4 * 4;
         *reinterpret_cast<hf32x4 *>(a.h_out + at) = y4;
         if (a.xg_out) *reinterpret_cast<hf32x4 *>(a.xg_out + at) = g4;
+        if (a.xp_out) {          // row scale + (hi, mid) split once per row here, not once per (tile, head) in the layer kernel
+          const float mx = group_max<32>(fmaxf(fmaxf(fabsf(g4[0]), fabsf(g4[1])), fmaxf(fabsf(g4[2]), fabsf(g4[3]))));
+          float sc, inv;
+          h3_scale(mx, sc, inv);
+          if (sc4 == 0) a.xinv_out[r0 + row] = inv;
+          g4 *= sc;
+          hf16x4 hi = {(_Float16)g4[0], (_Float16)g4[1], (_Float16)g4[2], (_Float16)g4[3]};
+          hf16x4 mid = {(_Float16)(g4[0] - (float)hi[0]), (_Float16)(g4[1] - (float)hi[1]), (_Float16)(g4[2] - (float)hi[2]),
+                        (_Float16)(g4[3] - (float)hi[3])};
+          *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + sc4 * 4) = hi;
+          *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + 128 + sc4 * 4) = mid;
+        }
       }
     }
     if (gb + 32 < ng) __syncthreads();
@@ -561,16 +574,17 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
                                    const uint16_t *w2_frag, const float *w2_inv_scale, const float *b2, const float *ins,
                                    const float *h, const float *gn_weight, const float *gn_bias, const float *gn_mean_scale,
                                    double eps, const float *node_mask, const float *ins_next, float *h_out, float *xg_out,
-                                   const int32_t *ptr, const int64_t *batch, const int32_t *tile_ptr, const int32_t *tile_info,
-                                   const int32_t *ntiles, int64_t max_tiles, int64_t N, int32_t K1, int32_t MID, int32_t C,
-                                   void *stream) {
+                                   uint16_t *xp_out, float *xinv_out, const int32_t *ptr, const int64_t *batch,
+                                   const int32_t *tile_ptr, const int32_t *tile_info, const int32_t *ntiles, int64_t max_tiles,
+                                   int64_t N, int32_t K1, int32_t MID, int32_t C, void *stream) {
   if (N < 0 || max_tiles < 0 || lda < K1 || P <= 0 || ldp < P) return ISG_EINVAL;
   if (K1 != DT_K1 || MID != DT_MID || C != DT_C || (lda & 3) != 0 || N >= (1ll << 31) || max_tiles >= (1ll << 31) ||
       (reinterpret_cast<uintptr_t>(conv_out) & 15) != 0 || (reinterpret_cast<uintptr_t>(ins) & 15) != 0)
     return ISG_EUNSUPPORTED;
   if (N == 0 || max_tiles == 0) return ISG_OK;
   if (!conv_out || !a_rowmax || !w1_frag || !w1_inv_scale || !b1 || !y_bound || !w2_frag || !w2_inv_scale || !b2 || !ins || !h ||
-      !gn_weight || !gn_bias || !gn_mean_scale || !h_out || !ptr || !batch || !tile_ptr || !tile_info || !ntiles)
+      !gn_weight || !gn_bias || !gn_mean_scale || !h_out || !ptr || !batch || !tile_ptr || !tile_info || !ntiles ||
+      ((xg_out || xp_out) && !ins_next) || (xp_out && !xinv_out))
     return ISG_EINVAL;
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&mgat_dense_tail_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, DT_SMEM_BYTES) == hipSuccess;
@@ -579,7 +593,7 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
   a.a = conv_out; a.a_rowmax = a_rowmax; a.w1f = reinterpret_cast<const _Float16 *>(w1_frag); a.w1_inv = w1_inv_scale;
   a.b1 = b1; a.y_bound = y_bound; a.w2f = reinterpret_cast<const _Float16 *>(w2_frag); a.w2_inv = w2_inv_scale; a.b2 = b2; a.ins = ins; a.h = h;
   a.gn_w = gn_weight; a.gn_b = gn_bias; a.gn_ms = gn_mean_scale; a.node_mask = node_mask; a.ins_next = ins_next;
-  a.h_out = h_out; a.xg_out = xg_out; a.ptr = ptr; a.tile_ptr = tile_ptr; a.ntiles = ntiles;
+  a.h_out = h_out; a.xg_out = xg_out; a.xp_out = reinterpret_cast<_Float16 *>(xp_out); a.xinv_out = xinv_out; a.ptr = ptr; a.tile_ptr = tile_ptr; a.ntiles = ntiles;
   a.tile_info = reinterpret_cast<const int4 *>(tile_info);
   a.batch = reinterpret_cast<const long long *>(batch);
   a.N = (int)N; a.lda = lda; a.P = P; a.ldp = ldp; a.eps = (float)eps; a.denom = (float)sqrt((double)DT_C);
@@ -630,7 +644,7 @@ __global__ __launch_bounds__(256) void edge_planes_kernel(const float *__restric
                                                           int E, int K, _Float16 *__restrict__ planes, float *__restrict__ inv_out) {
   const int slot = blockIdx.x * 8 + (threadIdx.x >> 5), c4 = threadIdx.x & 31;
   if (slot >= E) return;
-  const int e = eid[slot];
+  const int e = eid ? eid[slot] : slot;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 * 4 < K) v = *reinterpret_cast<const float4 *>(edge_attr + (int64_t)e * lda + c4 * 4);
   const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
@@ -997,7 +1011,7 @@ extern "C" int isg_edge_planes(const float *edge_attr, int32_t lda, const int32_
       (reinterpret_cast<uintptr_t>(planes) & 15) != 0 || E >= (1ll << 31) - 8)
     return ISG_EUNSUPPORTED;
   if (E == 0) return ISG_OK;
-  if (!edge_attr || !eid || !planes || !inv_scale) return ISG_EINVAL;
+  if (!edge_attr || !planes || !inv_scale) return ISG_EINVAL;
   edge_planes_kernel<<<(unsigned)((E + 7) / 8), 256, 0, as_stream(stream)>>>(edge_attr, lda, eid, (int)E, K,
                                                                              reinterpret_cast<_Float16 *>(planes), inv_scale);
   return check_launch();

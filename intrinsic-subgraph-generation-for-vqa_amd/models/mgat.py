@@ -85,19 +85,19 @@ class MGAT(torch.nn.Module):
                                        out_dtype=self.convs[0].feature_dtype)
         L = len(self.convs)
         wide = self.heads * self.convs[0].out_channels
-        x_gated = None        # gelu(h * ins_i[batch]) when the previous layer's fused tail has written it
+        x_gated = x_planes = None     # gelu(h * ins_i[batch]) when the previous layer's fused tail has written it: fp32 rows, planes
         for i in range(L):
             ins = instr_vectors[i].contiguous()
             if explainer:
                 h = expl_bypass_x if (explainer_stage - 1) == i else h                   # :140-141
-                x_gated = None
+                x_gated = x_planes = None
             conv_res, mask, edge_att = self.convs[i](
                 x=h, edge_index=edge_index, edge_attr=edge_attr, instruction=ins, batch=batch,
                 return_masks=return_masks, return_attention_weights=True, imle_att=glf, all_instrs=instr_vectors,
                 plan=plan, noise=None if noises is None else noises.get(i),
                 seed=None if seed is None else seed + i,
-                e_proj=None if e_projs is None else e_projs[i], x_gated=x_gated)         # :144-154
-            x_gated = None
+                e_proj=None if e_projs is None else e_projs[i], x_gated=x_gated, x_planes=x_planes)      # :144-154
+            x_gated = x_planes = None
             if return_attention:
                 edge_attns.append(edge_att)
             tail_mask = None
@@ -112,10 +112,18 @@ class MGAT(torch.nn.Module):
                 # x_proj + instruction attention + GraphNorm + residual (+ mask) + the NEXT layer's instruction gate: one
                 # launch on graph-aligned row tiles (csrc/isg_layer_tile.hip); :156-177 and mgat_v2_conv.py:156-157
                 nxt = instr_vectors[i + 1].contiguous() if i + 1 < L and self.convs[i + 1].use_instr else None
+                # the next layer's gated input: as planes when it runs as isg_gatv2_layer_conv, as fp32 rows when anything else
+                # reads it (a masked layer's node gate, the un-fused convolution)
+                want_planes = want_rows = False
+                if nxt is not None:
+                    cn = self.convs[i + 1]
+                    want_planes = cn.layer_conv_ready(plan, h.size(1), edge_attr,
+                                                      None if e_projs is None else e_projs[i + 1])
+                    want_rows = (not want_planes) or cn.mask.masking_threshold != 1.0
                 res = ops.mgat_dense_tail(conv_res, self.x_proj[i], ins, h, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
-                                          node_mask=tail_mask, ins_next=nxt)
+                                          node_mask=tail_mask, ins_next=nxt, want_rows=want_rows, want_planes=want_planes)
                 if res is not None:
-                    h, x_gated = res
+                    h, x_gated, x_planes = res
                     continue
             conv_res = ops.mlp(self.x_proj[i], conv_res)                                 # :156 (Linear+GELU fused)
             h = ops.mgat_layer_tail(ins, conv_res.contiguous(), h, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,

@@ -76,11 +76,23 @@ class MaskingGATv2Conv(torch.nn.Module):
         if self.bias is not None:
             torch.nn.init.zeros_(self.bias)
 
+    def layer_conv_ready(self, plan, in_channels: int, edge_attr, e_proj=None) -> bool:
+        """Will forward() run this layer as isg_gatv2_layer_conv?  (Then its gated input is wanted as ops.NodePlanes: MGAT asks
+        before it lets the previous layer's fused tail write them.)"""
+        if (e_proj is not None or edge_attr is None or self.lin_edge is None or edge_attr.dim() != 2
+                or self.feature_dtype != torch.float32 or torch.is_grad_enabled() or self.share_weights or plan is None):
+            return False
+        H, C = self.heads, self.out_channels
+        pair = ops.fused_logits_supported(plan, H, C, edge_attr.size(1))
+        xr_inside = pair and ops.FUSE_XR and in_channels <= 128 and in_channels % 4 == 0
+        return bool(pair and not xr_inside and ops.layer_conv_supported(plan, H, C, in_channels, edge_attr.size(1)))
+
     def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, edge_attr: Optional[Tensor] = None,
                 instruction: Optional[Tensor] = None, imle_att: Optional[Tensor] = None,
                 return_attention_weights: bool = None, return_masks: bool = None, all_instrs=None,
                 plan: Optional[ops.GraphPlan] = None, noise: Optional[Tensor] = None, seed: Optional[int] = None,
-                e_proj: Optional[Tensor] = None, x_gated: Optional[Tensor] = None):
+                e_proj: Optional[Tensor] = None, x_gated: Optional[Tensor] = None,
+                x_planes: Optional["ops.NodePlanes"] = None):
         H, C = self.heads, self.out_channels
         if x.dim() != 2:
             raise ValueError("x must be [N, C]")
@@ -89,12 +101,19 @@ class MaskingGATv2Conv(torch.nn.Module):
         if plan is None:
             plan = ops.GraphPlan.build(batch, edge_index,
                                        num_graphs=None if instruction is None else instruction.size(0))
-        if x_gated is not None and self.use_instr:
+        masked = self.mask.masking_threshold != 1.0
+        layer_conv = self.layer_conv_ready(plan, x.size(1), edge_attr, e_proj)
+        planes = None          # gelu(x * instruction[batch]) as the planes isg_gatv2_layer_conv reads (fp32 rows only where needed)
+        if (x_gated is not None or x_planes is not None) and self.use_instr:
             # gelu(x * instruction[batch]) was already written by the previous layer's fused tail (isg_mgat_dense_tail)
-            x = x_gated
+            x, planes = x_gated, x_planes
+            if x is None and (masked or not layer_conv):
+                raise RuntimeError("the previous layer's tail left no fp32 rows of the gated input, and this layer needs them")
         else:
             x = x.float().contiguous()
-            if self.use_instr:
+            if self.use_instr and layer_conv:
+                x, planes = ops.instr_gate_planes(x, instruction.contiguous(), batch, want_rows=masked)   # :156-157
+            elif self.use_instr:
                 x = ops.instr_gate(x, instruction.contiguous(), batch, plan=plan)        # :156-157
 
         mask = None
@@ -103,24 +122,26 @@ class MaskingGATv2Conv(torch.nn.Module):
                              seed=seed, u_is_per_graph=True)                              # :166-168
 
         fdt = self.feature_dtype
+        if layer_conv:
+            # lin_l | lin_r, lin_edge, logits, softmax and aggregation as ONE persistent launch on graph-aligned tiles
+            # (csrc/isg_layer_conv.hip): x_l / x_r live in LDS only                       # :177-181, :215-232, :243-279
+            res = ops.gatv2_layer_conv(planes if planes is not None else x, self.lin_l, self.lin_r, edge_attr.float().contiguous(),
+                                       self.lin_edge.weight, self.att, plan, H, bias=self.bias, node_mask=mask,
+                                       negative_slope=self.negative_slope, want_rowmax=True)
+            if res is not None:
+                out, alpha = res
+                if isinstance(return_attention_weights, bool):
+                    return out, mask, (edge_index, alpha)
+                return out, mask
+            if x is None:
+                raise RuntimeError("isg_gatv2_layer_conv refused a shape layer_conv_supported() accepted, and the gated input "
+                                   "exists only as planes")
         inference32 = (e_proj is None and edge_attr is not None and self.lin_edge is not None and edge_attr.dim() == 2
                        and fdt == torch.float32 and not torch.is_grad_enabled())
         pair = inference32 and ops.fused_logits_supported(plan, H, C, edge_attr.size(1))
         # with the edge-logits pair, x_r = lin_r(x) can be formed inside the logit kernel too (it is used nowhere else):
         # then only lin_l is projected here
         xr_inside = pair and ops.FUSE_XR and not self.share_weights and x.size(1) <= 128 and x.size(1) % 4 == 0
-        if (pair and not xr_inside and not self.share_weights
-                and ops.layer_conv_supported(plan, H, C, x.size(1), edge_attr.size(1))):
-            # lin_l | lin_r, lin_edge, logits, softmax and aggregation as ONE persistent launch on graph-aligned tiles
-            # (csrc/isg_layer_conv.hip): x_l / x_r live in LDS only                       # :177-181, :215-232, :243-279
-            res = ops.gatv2_layer_conv(x, self.lin_l, self.lin_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att,
-                                       plan, H, bias=self.bias, node_mask=mask, negative_slope=self.negative_slope,
-                                       want_rowmax=True)
-            if res is not None:
-                out, alpha = res
-                if isinstance(return_attention_weights, bool):
-                    return out, mask, (edge_index, alpha)
-                return out, mask
         if xr_inside:
             x_l, x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt), None          # :177
         elif self.share_weights:

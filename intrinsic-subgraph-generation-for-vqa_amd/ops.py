@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import weakref
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import NamedTuple, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -605,15 +605,55 @@ def layer_conv_supported(plan: "GraphPlan", heads: int, channels: int, in_channe
     return FUSE_LAYER_CONV and in_channels == 128 and heads <= 16 and tile_conv_supported(plan, heads, channels, edge_dim)
 
 
-def gatv2_layer_conv(x: Tensor, lin_l, lin_r, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan", heads: int,
+class NodePlanes(NamedTuple):
+    """Node rows as isg_gatv2_layer_conv reads them: per-row power-of-two scale, (hi, mid) fp16 planes int16 [N, 2, 128] and the
+    inverse scales fp32 [N] (the staging of the exact-split Linears, made once per row by the kernel that produces the rows)."""
+    planes: Tensor
+    inv: Tensor
+
+
+def node_planes(x: Tensor) -> NodePlanes:
+    """fp32 rows [N, 128] -> NodePlanes (isg_edge_planes in row order): for callers that hold the gated rows only as fp32."""
+    lib = _lib.load()
+    N, K = x.shape
+    planes = torch.empty(max(N, 1), 2, 128, dtype=torch.int16, device=x.device)
+    inv = torch.empty(max(N, 1), dtype=torch.float32, device=x.device)
+    _lib.check(lib.isg_edge_planes(_chk_rows(x, "x"), x.stride(0), 0, N, K, planes.data_ptr(), inv.data_ptr(), _stream()),
+               "isg_edge_planes")
+    return NodePlanes(planes, inv)
+
+
+def instr_gate_planes(x: Tensor, instr: Tensor, batch: Tensor, want_rows: bool = False) -> Tuple[Optional[Tensor], NodePlanes]:
+    """gelu(x * instr[batch]) (mgat_v2_conv.py:156-157) as NodePlanes for gatv2_layer_conv, plus the fp32 rows when a masked
+    layer's node gate needs them: isg_instr_gate_planes.  Inference only (C = 128)."""
+    lib = _lib.load()
+    N, C = x.shape
+    rows = torch.empty_like(x) if want_rows else None
+    planes = torch.empty(max(N, 1), 2, 128, dtype=torch.int16, device=x.device)
+    inv = torch.empty(max(N, 1), dtype=torch.float32, device=x.device)
+    _lib.check(lib.isg_instr_gate_planes(_chk(x, "x", torch.float32), _chk(instr, "instr", torch.float32, (instr.size(0), C)),
+                                         _chk(batch, "batch", torch.int64, (N,)), 0 if rows is None else rows.data_ptr(),
+                                         planes.data_ptr(), inv.data_ptr(), N, C, _stream()), "isg_instr_gate_planes")
+    return rows, NodePlanes(planes, inv)
+
+
+def gatv2_layer_conv(x, lin_l, lin_r, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan", heads: int,
                      bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
                      negative_slope: float = 0.2, want_rowmax: bool = False):
     """lin_l(x), lin_r(x), lin_edge(edge_attr), message, softmax and aggregation of one MaskingGATv2Conv as ONE launch
-    (mgat_v2_conv.py:177-181, :215-232, :243-279): isg_gatv2_layer_conv.  x = the gated layer input [N, 128].  Bit-identical to
-    linear_fused + gatv2_tile_conv.  Returns (out, alpha), or None when the kernel has no launch for this shape."""
+    (mgat_v2_conv.py:177-181, :215-232, :243-279): isg_gatv2_layer_conv.  x = the gated layer input [N, 128], as NodePlanes (from
+    instr_gate_planes / mgat_dense_tail) or as fp32 rows (split here, one more launch).  Bit-identical to linear_fused +
+    gatv2_tile_conv.  Returns (out, alpha), or None when the kernel has no launch for this shape."""
     lib = _lib.load()
     plan.require_csr()
-    N, K_in = x.shape
+    if not isinstance(x, NodePlanes):
+        if x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != 128:
+            raise TypeError("gatv2_layer_conv: fp32 rows [N, 128] or NodePlanes")
+        x = node_planes(x)
+    N, K_in = plan.N, 128
+    if x.planes.size(0) < N or x.inv.size(0) < N:
+        raise ValueError("gatv2_layer_conv: node planes shorter than the plan's node count")
+    dev = x.planes.device
     H = int(heads)
     HC = lin_l.weight.size(0)
     C = HC // H
@@ -621,27 +661,27 @@ def gatv2_layer_conv(x: Tensor, lin_l, lin_r, edge_attr: Tensor, w_edge: Tensor,
     if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K) or tuple(lin_r.weight.shape) != (HC, K_in) or \
             lin_l.weight.size(1) != K_in:
         raise ValueError("gatv2_layer_conv: operand shapes do not match the plan")
-    if x.dtype != torch.float32 or edge_attr.dtype != torch.float32:
-        raise TypeError("gatv2_layer_conv: fp32 rows")
+    if edge_attr.dtype != torch.float32:
+        raise TypeError("gatv2_layer_conv: fp32 edge rows")
     cat_w = derived_weight("layer_conv_w", (lin_l.weight, lin_r.weight),
                            lambda: torch.cat([lin_l.weight.detach(), lin_r.weight.detach()], 0).contiguous())
-    zeros = lambda m: torch.zeros(HC, dtype=torch.float32, device=x.device) if m.bias is None else m.bias.detach()
+    zeros = lambda m: torch.zeros(HC, dtype=torch.float32, device=dev) if m.bias is None else m.bias.detach()
     srcs = tuple(t for t in (lin_l.weight, lin_l.bias, lin_r.bias) if t is not None)
     cat_b = derived_weight("layer_conv_b", srcs, lambda: torch.cat([zeros(lin_l), zeros(lin_r)]).float().contiguous())
     wn, wn_inv = _weight_planes(cat_w, True, "f16x3")
     we, we_inv = _weight_planes(w_edge, True, "f16x3")
     ep, ep_inv = plan.edge_planes(edge_attr)
     _, ntiles, cap, tile_info = plan.tiles(TILE_CONV_NODES, TILE_CONV_EDGES)
-    out = torch.empty(N, HC, dtype=torch.float32, device=x.device)
-    alpha = torch.empty(E, H, dtype=torch.float32, device=x.device)
-    rowmax = torch.empty(N, H, dtype=torch.float32, device=x.device) if want_rowmax else None
+    out = torch.empty(N, HC, dtype=torch.float32, device=dev)
+    alpha = torch.empty(E, H, dtype=torch.float32, device=dev)
+    rowmax = torch.empty(N, H, dtype=torch.float32, device=dev) if want_rowmax else None
     timer = MP_TIMER
     if timer is not None:
         ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "K": K, "masked": node_mask is not None or edge_mask is not None,
                                   "feat_bytes": 4, "tile_conv": True, "layer_conv": True, "K_in": K_in})
         ev0.record()
     rc = lib.isg_gatv2_layer_conv(
-        _chk_rows(x, "x"), x.stride(0), wn.data_ptr(), wn_inv.data_ptr(), cat_b.data_ptr(), ep.data_ptr(), ep_inv.data_ptr(),
+        x.planes.data_ptr(), x.inv.data_ptr(), wn.data_ptr(), wn_inv.data_ptr(), cat_b.data_ptr(), ep.data_ptr(), ep_inv.data_ptr(),
         we.data_ptr(), we_inv.data_ptr(), _chk(att.reshape(-1), "att", torch.float32, (HC,)),
         _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
         plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(), tile_info.data_ptr(),
@@ -1056,9 +1096,11 @@ def dense_tail_supported(plan: GraphPlan, x_proj: torch.nn.Sequential, width_in:
 
 def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, h: Tensor, plan: GraphPlan, weight: Tensor,
                     bias: Tensor, mean_scale: Tensor, eps: float = 1e-5, node_mask: Optional[Tensor] = None,
-                    ins_next: Optional[Tensor] = None) -> Optional[Tuple[Tensor, Optional[Tensor]]]:
+                    ins_next: Optional[Tensor] = None, want_rows: bool = True, want_planes: bool = False
+                    ) -> Optional[Tuple[Tensor, Optional[Tensor], Optional["NodePlanes"]]]:
     """mgat.py:156-177 after the convolution, plus the next layer's instruction gate (mgat_v2_conv.py:156-157), as one launch:
-    x_proj (Linear GELU Linear GELU) -> scatter attention -> GraphNorm -> + h [-> * mask] -> (h', gelu(h' * ins_next[batch])).
+    x_proj (Linear GELU Linear GELU) -> scatter attention -> GraphNorm -> + h [-> * mask] -> (h', xg, xg planes) with
+    xg = gelu(h' * ins_next[batch]) as fp32 rows (want_rows) and / or as NodePlanes for gatv2_layer_conv (want_planes).
     conv_out must carry its row maxima (the message-passing kernels leave them); returns None when it does not (the caller
     runs the un-fused chain).  The caller checks dense_tail_supported() first."""
     lib = _lib.load()
@@ -1076,7 +1118,11 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
     shared = plan._tiles is not None and (DENSE_TAIL_ROWS, TILE_CONV_EDGES) in plan._tiles
     tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if shared else 0)
     h_out = torch.empty_like(h)
-    xg = torch.empty_like(h) if ins_next is not None else None
+    xg = torch.empty_like(h) if ins_next is not None and want_rows else None
+    xp = None
+    if ins_next is not None and want_planes:
+        xp = NodePlanes(torch.empty(max(N, 1), 2, 128, dtype=torch.int16, device=h.device),
+                        torch.empty(max(N, 1), dtype=torch.float32, device=h.device))
     rc = lib.isg_mgat_dense_tail(
         _chk_rows(conv_out, "conv_out"), conv_out.stride(0), rm.data_ptr(), rm.size(1), rm.stride(0),
         p1.data_ptr(), inv1.data_ptr(), _chk(l0.bias.detach(), "x_proj.0.bias", torch.float32, (l0.weight.size(0),)),
@@ -1086,12 +1132,13 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
         _chk(mean_scale.detach(), "mean_scale", torch.float32, (C,)), float(eps),
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
         _chk(ins_next, "ins_next", torch.float32, (plan.B, C), optional=True), h_out.data_ptr(),
-        0 if xg is None else xg.data_ptr(), plan.ptr.data_ptr(), _chk(plan.batch, "batch", torch.int64, (N,)),
+        0 if xg is None else xg.data_ptr(), 0 if xp is None else xp.planes.data_ptr(), 0 if xp is None else xp.inv.data_ptr(),
+        plan.ptr.data_ptr(), _chk(plan.batch, "batch", torch.int64, (N,)),
         tile_ptr.data_ptr(), tile_info.data_ptr(), ntiles.data_ptr(), cap, N, K1, l0.weight.size(0), C, _stream())
     if rc == ISG_EUNSUPPORTED:
         return None
     _lib.check(rc, "isg_mgat_dense_tail")
-    return h_out, xg
+    return h_out, xg, xp
 
 
 FUSE_READOUT = True        # node_nn + mask + per-graph softmax pooling as one launch on graph-aligned tiles (A/B switch)

@@ -1091,14 +1091,22 @@ def _dense_tail_case(dev, sizes, seed, masked, with_next):
         assert ops.mgat_dense_tail(co, m.x_proj[0], d(ins), d(h), plan, bn.weight, bn.bias, bn.mean_scale, bn.eps) is None, \
             "without row maxima on conv_out the caller must be told to run the un-fused chain"
         ops.attach_row_maxima(co, rm)
-        got_h, got_xg = ops.mgat_dense_tail(co, m.x_proj[0], d(ins), d(h), plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
-                                            node_mask=d(mask), ins_next=d(ins_next))
+        got_h, got_xg, got_xp = ops.mgat_dense_tail(co, m.x_proj[0], d(ins), d(h), plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
+                                                    node_mask=d(mask), ins_next=d(ins_next), want_rows=True, want_planes=True)
         # the un-fused chain of the same library
         cc = ops.mlp(m.x_proj[0], co)
         ref_h = ops.mgat_layer_tail(d(ins), cc.contiguous(), d(h), plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
                                     node_mask=d(mask))
         ref_xg = ops.instr_gate(ref_h, d(ins_next), batch.to(dev), plan=plan) if with_next else None
-    assert (got_xg is None) == (not with_next)
+    assert (got_xg is None) == (not with_next) and (got_xp is None) == (not with_next)
+    if with_next:
+        # the planes the layer kernel reads are the split of exactly the fp32 rows written beside them
+        ref_xp = ops.node_planes(got_xg)
+        assert torch.equal(got_xp.planes[:N], ref_xp.planes[:N]) and torch.equal(got_xp.inv[:N], ref_xp.inv[:N])
+        with torch.no_grad():
+            only_p = ops.mgat_dense_tail(co, m.x_proj[0], d(ins), d(h), plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
+                                         node_mask=d(mask), ins_next=d(ins_next), want_rows=False, want_planes=True)
+        assert only_p[1] is None and torch.equal(only_p[2].planes[:N], got_xp.planes[:N]) and torch.equal(only_p[0], got_h)
     scale = want_h.abs().max().item()
     e_or = (got_h.cpu() - want_h).abs().max().item()
     e_un = (ref_h.cpu() - want_h).abs().max().item()
@@ -1113,6 +1121,29 @@ def _dense_tail_case(dev, sizes, seed, masked, with_next):
     if masked:
         assert torch.equal(got_h.cpu()[mask == 0], torch.zeros_like(got_h.cpu()[mask == 0]))
     return e_or
+
+
+def test_instr_gate_planes_is_the_gate_followed_by_the_row_split(dev):
+    """isg_instr_gate_planes = isg_instr_gate, then the per-row scale / (hi, mid) split of isg_edge_planes in row order: bit for
+    bit, with and without the fp32 rows beside the planes; and the planes decode back to the rows within the split's 2^-22."""
+    from isubgvqa_amd import ops
+    g = torch.Generator().manual_seed(11)
+    sizes = [1, 7, 64, 3, 29]
+    N, B, C = sum(sizes), len(sizes), 128
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes)).to(dev)
+    x = (torch.randn(N, C, generator=g) * torch.logspace(-3, 2, N).unsqueeze(1)).to(dev)
+    x[5] = 0.0                                         # an all-zero row: scale 1, zero planes
+    ins = torch.randn(B, C, generator=g).to(dev)
+    rows, xp = ops.instr_gate_planes(x, ins, batch, want_rows=True)
+    none, xp2 = ops.instr_gate_planes(x, ins, batch, want_rows=False)
+    ref = ops.instr_gate(x, ins, batch)
+    refp = ops.node_planes(ref)
+    assert none is None and torch.equal(rows, ref)
+    assert torch.equal(xp.planes[:N], refp.planes[:N]) and torch.equal(xp.inv[:N], refp.inv[:N])
+    assert torch.equal(xp2.planes[:N], xp.planes[:N]) and torch.equal(xp2.inv[:N], xp.inv[:N])
+    dec = (xp.planes[:N, 0].view(torch.float16).float() + xp.planes[:N, 1].view(torch.float16).float()) * xp.inv[:N, None]
+    assert (dec - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().amax(dim=1).clamp_min(1e-30).max().item()
+    assert torch.equal(dec[5], torch.zeros(C, device=dev))
 
 
 @pytest.mark.parametrize("masked,with_next", [(False, True), (True, True), (True, False)])

@@ -26,7 +26,7 @@ with torch.no_grad():
     for rep in range(5):
         out, _ = ops.gatv2_layer_conv(x, conv.lin_l, conv.lin_r, wl.edge_attr, conv.lin_edge.weight, conv.att, plan, H, bias=conv.bias,
                                       want_rowmax=True)
-        h, xg = ops.mgat_dense_tail(out, m.x_proj[0], ins, x, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps, ins_next=ins_next)
+        h, xg, _ = ops.mgat_dense_tail(out, m.x_proj[0], ins, x, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps, ins_next=ins_next)
         ops.readout_tile(h, net.graph_global_attention_pooling.node_nn, wl.glf, plan)
 torch.cuda.synchronize()
 print("ok")

@@ -47,7 +47,8 @@ l0, l2 = m.x_proj[0][0], m.x_proj[0][2]
 p1, inv1 = ops._weight_planes(l0.weight, True, "f16x3")
 p2, inv2 = ops._weight_planes(l2.weight, True, "f16x3")
 yb = torch.stack([l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous()
-h_out, xg = torch.empty_like(h), torch.empty_like(h)
+h_out = torch.empty_like(h)      # the next layer's input as planes, as the model runs it
+xp, xinv = torch.empty(N, 2, 128, dtype=torch.int16, device=dev), torch.empty(N, device=dev)
 buf = torch.zeros(cap * 4, 16, dtype=torch.int64, device=dev)
 assert stamp.isg_dt_set_stamp_buffer(buf.data_ptr()) == 0
 for rep in range(2):
@@ -55,7 +56,7 @@ for rep in range(2):
     rc = stamp.isg_mgat_dense_tail(conv_out.data_ptr(), conv_out.stride(0), rm.data_ptr(), rm.size(1), rm.stride(0), p1.data_ptr(),
                                    inv1.data_ptr(), l0.bias.data_ptr(), yb.data_ptr(), p2.data_ptr(), inv2.data_ptr(), l2.bias.data_ptr(),
                                    ins.data_ptr(), h.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.mean_scale.data_ptr(),
-                                   float(bn.eps), 0, ins_next.data_ptr(), h_out.data_ptr(), xg.data_ptr(), plan.ptr.data_ptr(),
+                                   float(bn.eps), 0, ins_next.data_ptr(), h_out.data_ptr(), 0, xp.data_ptr(), xinv.data_ptr(), plan.ptr.data_ptr(),
                                    wl.batch.data_ptr(), tile_ptr.data_ptr(), tile_info.data_ptr(), ntiles.data_ptr(), cap, N, 512, 256, 128,
                                    torch.cuda.current_stream().cuda_stream)
     assert rc == 0

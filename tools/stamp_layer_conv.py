@@ -34,12 +34,13 @@ T = int(ntiles.item())
 out = torch.empty(N, H * C, device=dev)
 alpha = torch.empty(E, H, device=dev)
 rowmax = torch.empty(N, H, device=dev)
+xp = ops.node_planes(x)
 buf = torch.zeros(4096 * 8, 16, dtype=torch.int64, device=dev)
 assert stamp.isg_lc_set_stamp_buffer(buf.data_ptr()) == 0
 att = conv.att.detach().reshape(-1).contiguous()
 for rep in range(2):
     buf.zero_()
-    rc = stamp.isg_gatv2_layer_conv(x.data_ptr(), x.stride(0), wn.data_ptr(), wn_inv.data_ptr(), cat_b.data_ptr(), ep.data_ptr(),
+    rc = stamp.isg_gatv2_layer_conv(xp.planes.data_ptr(), xp.inv.data_ptr(), wn.data_ptr(), wn_inv.data_ptr(), cat_b.data_ptr(), ep.data_ptr(),
                                     ep_inv.data_ptr(), we.data_ptr(), we_inv.data_ptr(), att.data_ptr(), conv.bias.data_ptr(),
                                     plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(),
                                     tile_info.data_ptr(), ntiles.data_ptr(), cap, 0, 0, out.data_ptr(), H * C, alpha.data_ptr(),

@@ -30,7 +30,7 @@ print(f"N={N} graphs={graphs} tiles={int(ntiles.item())} (capacity {cap}), rows/
 
 def fused():
     ops.attach_row_maxima(conv_out, rm)
-    return ops.mgat_dense_tail(conv_out, m.x_proj[0], ins, h, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps, ins_next=ins_next)
+    return ops.mgat_dense_tail(conv_out, m.x_proj[0], ins, h, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps, ins_next=ins_next)[:2]
 
 
 def chain():

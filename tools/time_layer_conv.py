@@ -17,12 +17,13 @@ conv = net.gat_seq.convs[0]
 N, E, H, C = wl.x.size(0), wl.edge_index.size(1), cfg.heads, cfg.channels
 plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=graphs, max_nodes=wl.max_nodes, max_edges=wl.max_edges)
 x = wl.x.contiguous()
+xp = ops.node_planes(x)       # the layer kernel's input as its producers (instruction gate / previous tail) write it
 flush = torch.empty(1 << 27, device=dev)
 w, att, bias = conv.lin_edge.weight, conv.att, conv.bias
 
 
 def fused():
-    return ops.gatv2_layer_conv(x, conv.lin_l, conv.lin_r, wl.edge_attr, w, att, plan, H, bias=bias, want_rowmax=True)
+    return ops.gatv2_layer_conv(xp, conv.lin_l, conv.lin_r, wl.edge_attr, w, att, plan, H, bias=bias, want_rowmax=True)
 
 
 def two():
