@@ -55,10 +55,12 @@ int isg_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t *ptr, int3
 
 /* The whole plan of a batch in six launches: ptr / bounds[0] as isg_graph_ptr, rowptr / eid / src / dst as isg_csr_build, eptr /
  * bounds[1] as isg_graph_edge_ptr (those three entry points together take fourteen launches of 4-5 us: 6 % of a BASELINE
- * configs[1] step).  bounds int32[2] = {largest node count, largest edge count of a graph}; workspace as isg_csr_build. */
+ * configs[1] step).  bounds int32[2] = {largest node count, largest edge count of a graph}; bounds_host: NULL, or int32[2] in
+ * pinned host memory the device can address (hipHostMalloc): the last kernel stores the bounds there too, so a caller that only
+ * verifies size hints later needs no device->host copy in the stream (4 us + two engine switches); workspace as isg_csr_build. */
 int isg_graph_plan_build(const int64_t *batch, const int64_t *edge_index, int64_t N, int64_t E, int64_t B, int32_t *ptr,
-                         int32_t *bounds, int32_t *rowptr, int32_t *eid, int32_t *src, int32_t *dst, int32_t *eptr,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         int32_t *bounds, int32_t *bounds_host, int32_t *rowptr, int32_t *eid, int32_t *src, int32_t *dst,
+                         int32_t *eptr, void *workspace, size_t workspace_bytes, void *stream);
 
 /* eptr[g] = rowptr[ptr[g]] for g = 0..B: the CSR-slot range of graph g when its nodes are contiguous and its edges
  * stay inside it (PyG Batch layout).  Lets the per-graph message-passing kernel read a graph's node range and edge

@@ -30,7 +30,7 @@ SIGNATURES = {
                                  c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_gatv2_mp_fwd_f16": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "isg_graph_plan_build": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64] + [c_void_p] * 8 + [c_size_t, c_void_p]),
+    "isg_graph_plan_build": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64] + [c_void_p] * 9 + [c_size_t, c_void_p]),
     "isg_graph_edge_ptr": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "isg_scatter_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p]),

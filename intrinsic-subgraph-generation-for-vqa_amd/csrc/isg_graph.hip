@@ -146,8 +146,13 @@ __global__ void csr_fill_kernel(const int64_t *__restrict__ dst, int E, int N, c
 // segment so the final order is ascending edge id (= torch_scatter's CPU accumulation order).
 __global__ void csr_rank_kernel(const int64_t *__restrict__ edge_index, int E, int N,
                                 const int *__restrict__ rowptr, const int *__restrict__ eid_tmp,
-                                int *__restrict__ eid, int *__restrict__ src, int *__restrict__ dst) {
+                                int *__restrict__ eid, int *__restrict__ src, int *__restrict__ dst,
+                                const int *__restrict__ bounds = nullptr, int *bounds_host = nullptr) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bounds_host && t < 2) {           // the plan's last launch: the bounds are final (isg_graph_plan_build)
+    bounds_host[t] = bounds[t];
+    __threadfence_system();
+  }
   int total = rowptr[N];
   if (t >= total) return;
   int e = eid_tmp[t];
@@ -168,6 +173,10 @@ __global__ void csr_rank_kernel(const int64_t *__restrict__ edge_index, int E, i
 // (2) in-degree histogram + largest graph, (3) per-chunk degree sums, (4) scan: every workgroup adds up the chunk sums before
 // its own (at most a few hundred values) instead of a separate one-workgroup scan, (5) atomic fill + per-graph slot ranges and
 // the largest edge count, (6) rank by edge id inside each segment.  (7) is the tile plan (isg_tile_plan).
+__global__ void copy_bounds_kernel(const int *__restrict__ bounds, int *bounds_host) {
+  if (threadIdx.x < 2) bounds_host[threadIdx.x] = bounds[threadIdx.x];
+  __threadfence_system();
+}
 __global__ void plan_init_kernel(const int64_t *__restrict__ batch, int N, int B, int *__restrict__ ptr, int *__restrict__ zero,
                                  int nzero, int *__restrict__ bounds) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -334,8 +343,9 @@ extern "C" int isg_graph_edge_ptr(const int32_t *ptr, const int32_t *rowptr, int
 // seventh): what isg_graph_ptr + isg_csr_build + isg_graph_edge_ptr compute in fourteen.  bounds int32[2] receives {largest node
 // count, largest edge count of a graph}; the other outputs as in those three; workspace: isg_csr_workspace_bytes(N, E).
 extern "C" int isg_graph_plan_build(const int64_t *batch, const int64_t *edge_index, int64_t N, int64_t E, int64_t B,
-                                    int32_t *ptr, int32_t *bounds, int32_t *rowptr, int32_t *eid, int32_t *src, int32_t *dst,
-                                    int32_t *eptr, void *workspace, size_t workspace_bytes, void *stream) {
+                                    int32_t *ptr, int32_t *bounds, int32_t *bounds_host, int32_t *rowptr, int32_t *eid,
+                                    int32_t *src, int32_t *dst, int32_t *eptr, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
   if (N < 0 || E < 0 || B < 0 || !ptr || !bounds || !rowptr || !eptr || (N > 0 && !batch) || (E > 0 && (!edge_index || !eid || !src)))
     return ISG_EINVAL;
   if (N >= (1ll << 31) - 1024 || E >= (1ll << 31) - 1024 || B >= (1ll << 31) - 1024) return ISG_EUNSUPPORTED;
@@ -359,6 +369,9 @@ extern "C" int isg_graph_plan_build(const int64_t *batch, const int64_t *edge_in
   }
   const int span3 = std::max(e, b + 1);
   plan_fill_kernel<<<(span3 + 255) / 256, 256, 0, st>>>(edge_index + E, e, n, rowptr, cursor, eid_tmp, ptr, b, eptr, bounds + 1);
-  if (e > 0) csr_rank_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index, e, n, rowptr, eid_tmp, eid, src, dst);
+  if (e > 0)
+    csr_rank_kernel<<<(e + 255) / 256, 256, 0, st>>>(edge_index, e, n, rowptr, eid_tmp, eid, src, dst, bounds, bounds_host);
+  else if (bounds_host)
+    copy_bounds_kernel<<<1, 64, 0, st>>>(bounds, bounds_host);
   return check_launch();
 }

@@ -154,6 +154,7 @@ def _f32(t: Tensor) -> Tensor:
 # Graph plan
 # ------------------------------------------------------------------------------------------------
 PLAN_FUSED = True     # isg_graph_plan_build (6 launches) instead of isg_graph_ptr + isg_csr_build + isg_graph_edge_ptr (14): A/B switch
+BOUNDS_TO_HOST = True    # isg_graph_plan_build writes the batch's true bounds into pinned host memory (hint check without a copy)
 
 
 @dataclass
@@ -257,6 +258,7 @@ class GraphPlan:
         bounds = torch.empty(2, dtype=torch.int32, device=dev)     # [max nodes per graph, max edges per graph]
         nmax_dev = bounds[:1]
         plan = GraphPlan(N=N, E=0, B=B, ptr=ptr, nmax_dev=nmax_dev, nmax=0, batch=batch)
+        host_bounds = None
         if edge_index is not None:
             _chk(edge_index, "edge_index", torch.int64)
             if edge_index.dim() != 2 or edge_index.size(0) != 2:
@@ -273,8 +275,13 @@ class GraphPlan:
             ws_bytes = lib.isg_csr_workspace_bytes(N, E)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             if PLAN_FUSED:
+                # hinted and eager: the plan's last kernel stores the bounds into pinned host memory itself (no copy in the stream)
+                if (max_nodes is not None and max_edges is not None and BOUNDS_TO_HOST
+                        and not torch.cuda.is_current_stream_capturing()):
+                    host_bounds = torch.empty(2, dtype=torch.int32, pin_memory=True)
                 _lib.check(lib.isg_graph_plan_build(batch.data_ptr(), edge_index.data_ptr(), N, E, B, ptr.data_ptr(),
-                                                    bounds.data_ptr(), plan.rowptr.data_ptr(), plan.eid.data_ptr(),
+                                                    bounds.data_ptr(), 0 if host_bounds is None else host_bounds.data_ptr(),
+                                                    plan.rowptr.data_ptr(), plan.eid.data_ptr(),
                                                     plan.src.data_ptr(), plan.dst.data_ptr(), plan.eptr.data_ptr(), ws.data_ptr(),
                                                     ws_bytes, _stream()), "isg_graph_plan_build")
             else:
@@ -303,8 +310,11 @@ class GraphPlan:
         else:                                       # hinted: verify later, without a sync (see check_plans)
             if _PENDING_HINTS:
                 check_plans(block=False)
-            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-            host.copy_(bounds, non_blocking=True)
+            if host_bounds is not None:
+                host = host_bounds
+            else:
+                host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+                host.copy_(bounds, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             _PENDING_HINTS.append((ev, host, int(max_nodes), None if edge_index is None else int(max_edges)))

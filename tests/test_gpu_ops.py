@@ -505,6 +505,18 @@ def test_understated_plan_hints_raise(dev):
     # a partial hint goes through the synchronous path and can only widen
     plan = ops.GraphPlan.build(batch, ei, num_graphs=3, max_nodes=4)
     assert plan.nmax == 9 and plan.emax == 9
+    # a batch without edges (the plan's last kernel is then a two-thread copy of the bounds), and the copy-in-stream arm
+    ei0 = torch.zeros(2, 0, dtype=torch.long, device=dev)
+    ops.GraphPlan.build(batch, ei0, num_graphs=3, max_nodes=8, max_edges=0)
+    with pytest.raises(_lib.IsgError, match="understate"):
+        ops.check_plans()
+    ops.BOUNDS_TO_HOST = False
+    try:
+        ops.GraphPlan.build(batch, ei, num_graphs=3, max_nodes=9, max_edges=8)
+        with pytest.raises(_lib.IsgError, match="understate"):
+            ops.check_plans()
+    finally:
+        ops.BOUNDS_TO_HOST = True
 
 
 def test_invalidate_weight_cache_after_a_write_through_data(dev):
