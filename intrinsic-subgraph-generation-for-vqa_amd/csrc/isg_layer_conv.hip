@@ -25,6 +25,10 @@ static __device__ long long *g_lc_stamps = nullptr;
 #define LC_STAMP(i)
 #endif
 
+#ifndef LC_ABL
+#define LC_ABL 0   // ablation builds only (tools/ablate_layer_conv.sh): 1 no logit epilogue, 2 no edge MFMAs, 4 no node MFMAs, 8 no aggregation
+#endif
+
 namespace isg {
 
 typedef __attribute__((address_space(3))) void lc_lds_t;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     // fragment = A operand, node panel = B operand): a lane then holds ONE node and 16 channels of it in four runs of four, which
     // go to the row-major LDS slices as 16-byte stores (with the panel as the A operand a lane holds one channel of 16 nodes:
     // 32 four-byte stores and 32 scale reads per lane, 2.9 k cycles per tile: profiles/r03_ah_*)
-    {
+    if (!(LC_ABL & 16)) {
       hf32x16 accn[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -265,9 +269,13 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           hf32x16 c = accn[i];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][1], an[i][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][0], c, 0, 0, 0);
+          if (!(LC_ABL & 4)) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][1], an[i][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][0], c, 0, 0, 0);
+          } else {
+            c[0] += (float)an[i][0][0] + (float)an[i][1][0];
+          }
           accn[i] = c;
         }
       }
@@ -352,14 +360,16 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
   }
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
+      if (!(LC_ABL & 32)) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
+        for (int u = 0; u < 4; ++u)
+          *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
+      }
       LC_STAMP(10)           // panel staging: the wait for the planes, LDS writes
       __syncthreads();
       LC_STAMP(2)            // staging barrier
-      if (c == creq) LC_REQUEST_TILE(desc_n)
-      if (c + 1 < nchunk) {      // the next chunk's planes: in flight under this chunk's product and epilogue
+      if (c == creq && !(LC_ABL & 64)) LC_REQUEST_TILE(desc_n)
+      if (c + 1 < nchunk && !(LC_ABL & 32)) {      // the next chunk's planes: in flight under this chunk's product and epilogue
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0 + min(64 * (c + 1) + srow + 16 * u, ne - 1)) * 256 + sc4 * 8);
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       __builtin_amdgcn_s_waitcnt(0x0F70);
       LC_STAMP(14)
 #endif
-      {
+      if (!(LC_ABL & 32)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         hf16x8 af[2][2];          // [stage][plane]
@@ -384,9 +394,13 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
                 af[(ks + 1) & 1][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][prow][(ks + 1) * 16 + fk]);
             }
             // transposed product: W fragment = A operand (rows = channels), edge panel = B operand (columns = edges)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][1], af[ks & 1][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][0], acc, 0, 0, 0);
+            if (!(LC_ABL & 2)) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][1], af[ks & 1][0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][0], acc, 0, 0, 0);
+            } else {
+              acc[0] += (float)af[ks & 1][0][0] + (float)af[ks & 1][1][0];
+            }
           }
         }
       }
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #endif
       LC_STAMP(3)            // k loop
       if (MASKED && c + 1 == nchunk) LC_REQUEST_MASKS(desc_n)      // the ids they hang on were requested a k loop ago
-      LC_EPILOGUE(c)
+      if (!(LC_ABL & 1)) LC_EPILOGUE(c) else if (hh == 0) s_part[tw * 64 + prow] = acc[0];
       __syncthreads();
       LC_STAMP(4)            // epilogue + barrier
       if (tid < 64 && 64 * c + tid < ne)     // the tile-waves' partials in a fixed order
@@ -409,12 +423,14 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     // weights (the logits are broadcast reads), so no weight table and no barrier between the softmax and the aggregation; the
     // first four in-edges (most segments) are read once and stay in registers for all three uses.
     LC_STAMP(11)             // last logit sums + barrier
-    if (nchunk == 0) {          // a tile without edges: nothing hid the requests
+    if (nchunk == 0 && !(LC_ABL & 64)) {          // a tile without edges: nothing hid the requests
       LC_REQUEST_TILE(desc_n)
       LC_REQUEST_MASKS(desc_n)
     }
-    LC_STORE_TILE(desc_n, cur ^ 1)      // panel image and scales are free since the last chunk's barrier; tables: the other set
-    LC_REQUEST_PLANES(desc_n)
+    if (!(LC_ABL & 64)) {
+      LC_STORE_TILE(desc_n, cur ^ 1)      // panel image and scales are free since the last chunk's barrier; tables: the other set
+      LC_REQUEST_PLANES(desc_n)
+    }
     LC_STAMP(5)              // the next tile's planes and tables
     // 16 lanes per node (two 16-byte pieces each, 256 contiguous bytes per instruction): a wave aggregates FOUR nodes at a time,
     // two passes cover the tile -- this phase is a chain of dependent LDS reads (pointers -> records -> rows), so its time is the
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #pragma unroll 1
     for (int ps = 0; ps < 2; ++ps) {
       const int k = 4 * wave + q4 + 32 * ps;
-      if (k >= nrows) break;
+      if (k >= nrows || (LC_ABL & 8)) break;
       const int rb = ps ? rbp[1] : rbp[0], re = min(ps ? rep[1] : rep[0], ne);
       float lg4[4], e4[4];
       int4 rc4[4];
@@ -474,19 +490,24 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       int s = rb;
 #pragma unroll 1
       while (true) {            // four in-edges per round, edge-id order, mul + add as the kernels this replaces compile them
+        {       // alpha: ONE store instruction per round, lane u of a node's sixteen writes in-edge u (four single-lane stores with
+                // their own address arithmetic and exec masks cost ~10 us per launch)
+          const float wsel = (j16 & 2) ? ((j16 & 1) ? e4[3] : e4[2]) : ((j16 & 1) ? e4[1] : e4[0]);
+          const int esel = (j16 & 2) ? ((j16 & 1) ? rc4[3].y : rc4[2].y) : ((j16 & 1) ? rc4[1].y : rc4[0].y);
+          if (j16 < 4 && s + j16 < re && !(LC_ABL & 1024)) a.alpha[(int64_t)esel * a.H + hd] = wsel * rden;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          if (s + u < re) {
-            const float w = e4[u] * rden;
-            if (j16 == u) a.alpha[(int64_t)rc4[u].y * a.H + hd] = w;
-            const float wm = MASKED ? __fmul_rn(w, __int_as_float(rc4[u].w)) : w;
+          // slots past the segment's end carry weight 0 instead of a branch each: their rows are copies of the last slot's
+          // (finite), and x + 0 * r = x exactly
+          const float w = s + u < re ? e4[u] * rden : 0.f;
+          const float wm = MASKED ? __fmul_rn(w, __int_as_float(rc4[u].w)) : w;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              o[m].x = __fadd_rn(o[m].x, __fmul_rn(u4[u][m].x, wm));
-              o[m].y = __fadd_rn(o[m].y, __fmul_rn(u4[u][m].y, wm));
-              o[m].z = __fadd_rn(o[m].z, __fmul_rn(u4[u][m].z, wm));
-              o[m].w = __fadd_rn(o[m].w, __fmul_rn(u4[u][m].w, wm));
-            }
+          for (int m = 0; m < 2; ++m) {
+            o[m].x = __fadd_rn(o[m].x, __fmul_rn(u4[u][m].x, wm));
+            o[m].y = __fadd_rn(o[m].y, __fmul_rn(u4[u][m].y, wm));
+            o[m].z = __fadd_rn(o[m].z, __fmul_rn(u4[u][m].z, wm));
+            o[m].w = __fadd_rn(o[m].w, __fmul_rn(u4[u][m].w, wm));
           }
         }
         s += 4;
@@ -510,6 +531,11 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
           o[m].x += b4.x; o[m].y += b4.y; o[m].z += b4.z; o[m].w += b4.w;
         }
         hf32x4 o4 = {o[m].x, o[m].y, o[m].z, o[m].w};
+        if (LC_ABL & 256) {
+          if (o4[0] == 1.2345e30f) *reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + 64 * m + j16 * 4) = o4;
+        } else if (LC_ABL & 512) {
+          *reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + 64 * m + j16 * 4) = o4;
+        } else
         __builtin_nontemporal_store(o4, reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + 64 * m + j16 * 4));
         rmx = fmaxf(rmx, fmaxf(fmaxf(fabsf(o[m].x), fabsf(o[m].y)), fmaxf(fabsf(o[m].z), fabsf(o[m].w))));
       }
