@@ -269,14 +269,17 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #define DT_LOADA1(b, ksl)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
       af[i][q] = *reinterpret_cast<const hf16x8 *>(&bufA[b][q][i * 32 + fr][(ksl) * 16 + fk]);
-  // small terms first; the four accumulators take turns so that dependent MFMAs are four issues apart
+  // small terms first; the four accumulators take turns so that dependent MFMAs are four issues apart.  TRANSPOSED (W fragment =
+  // the MFMA's A operand, the panel fragment its B operand; the fragments are the same either way): a lane then holds ONE row and
+  // 16 columns of it in four runs of four, so the epilogue writes 8-byte plane pieces and reads a row's scales once -- with the
+  // panel as the A operand a lane holds one column of 16 rows: 128 two-byte LDS stores and 64 scale reads per lane
 #define DT_MMA1(A, W)                                                                                            \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][0], W[j][1], acc[i][j], 0, 0, 0);                  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[j][1], A[i][0], acc[i][j], 0, 0, 0);                  \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][1], W[j][0], acc[i][j], 0, 0, 0);                  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[j][0], A[i][1], acc[i][j], 0, 0, 0);                  \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][0], W[j][0], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[j][0], A[i][0], acc[i][j], 0, 0, 0);
   DT_LOADW1(0, 0)
   DT_LOADW1(1, 1)
   DT_LOADW1(2, 2)
@@ -309,28 +312,38 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 
   // ---- epilogue 1: scale back, + bias, GELU -> the intermediate's (hi, mid) planes (row scales: see the tile header) ----------
   {
-    float wi[2], bv[2];
+    // this lane's 2 x 4 runs of four columns: their W scales and biases (L2; the registers of the W fragments are free now)
+    hf32x4 wi4[2][4], bv4[2][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = (2 * wave + j) * 32 + fr;
-      wi[j] = a.w1_inv[col];
-      bv[j] = a.b1[col];
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = (2 * wave + j) * 32 + 8 * g + 4 * hh;
+        wi4[j][g] = *reinterpret_cast<const hf32x4 *>(a.w1_inv + col);
+        bv4[j][g] = *reinterpret_cast<const hf32x4 *>(a.b1 + col);
+      }
     __syncthreads();          // every wave is done with the A buffers: the planes may overwrite them
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 32 + fr;
+      const float si = s_inv1[row], s2 = s_scale2[row];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float si = s_inv1[row], s2 = s_scale2[row];
-        // both scales are powers of two: exact
-        const isg_f32x2 v2 = gelu_exact2(isg_f32x2{(acc[i][0][r] * si) * wi[0] + bv[0], (acc[i][1][r] * si) * wi[1] + bv[1]}) * s2;
-        const _Float16 h0 = (_Float16)v2.x, h1 = (_Float16)v2.y;
-        sY[0][row][(2 * wave) * 32 + fr] = h0;
-        sY[0][row][(2 * wave + 1) * 32 + fr] = h1;
-        sY[1][row][(2 * wave) * 32 + fr] = (_Float16)(v2.x - (float)h0);
-        sY[1][row][(2 * wave + 1) * 32 + fr] = (_Float16)(v2.y - (float)h1);
-      }
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          // both scales are powers of two: exact
+          const isg_f32x2 va = gelu_exact2(isg_f32x2{(acc[i][j][4 * g] * si) * wi4[j][g][0] + bv4[j][g][0],
+                                                     (acc[i][j][4 * g + 1] * si) * wi4[j][g][1] + bv4[j][g][1]}) * s2;
+          const isg_f32x2 vb = gelu_exact2(isg_f32x2{(acc[i][j][4 * g + 2] * si) * wi4[j][g][2] + bv4[j][g][2],
+                                                     (acc[i][j][4 * g + 3] * si) * wi4[j][g][3] + bv4[j][g][3]}) * s2;
+          const hf16x4 hi = {(_Float16)va.x, (_Float16)va.y, (_Float16)vb.x, (_Float16)vb.y};
+          const hf16x4 mid = {(_Float16)(va.x - (float)hi[0]), (_Float16)(va.y - (float)hi[1]), (_Float16)(vb.x - (float)hi[2]),
+                              (_Float16)(vb.y - (float)hi[3])};
+          const int col = (2 * wave + j) * 32 + 8 * g + 4 * hh;
+          *reinterpret_cast<hf16x4 *>(&sY[0][row][col]) = hi;
+          *reinterpret_cast<hf16x4 *>(&sY[1][row][col]) = mid;
+        }
+    }
   }
   __syncthreads();
   DT_STAMP(6)                  // epilogue 1: GELU, row maxima, planes of the intermediate
@@ -373,34 +386,41 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        acc2[kh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[s & 1][i][0], w2[s & 3][1], acc2[kh][i], 0, 0, 0);
+        acc2[kh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s & 3][1], a2[s & 1][i][0], acc2[kh][i], 0, 0, 0);       // transposed,
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        acc2[kh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[s & 1][i][1], w2[s & 3][0], acc2[kh][i], 0, 0, 0);
+        acc2[kh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s & 3][0], a2[s & 1][i][1], acc2[kh][i], 0, 0, 0);       // as GEMM1
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        acc2[kh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[s & 1][i][0], w2[s & 3][0], acc2[kh][i], 0, 0, 0);
+        acc2[kh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s & 3][0], a2[s & 1][i][0], acc2[kh][i], 0, 0, 0);
     }
 #undef DT_LOADW2
 #undef DT_LOADA2
   }
-  const int col2 = wave * 32 + fr;
-  const float wi2 = a.w2_inv[col2], bv2 = a.b2[col2];
+  hf32x4 wi2[4], bv2[4];     // this lane's four runs of four columns
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    wi2[g] = *reinterpret_cast<const hf32x4 *>(a.w2_inv + wave * 32 + 8 * g + 4 * hh);
+    bv2[g] = *reinterpret_cast<const hf32x4 *>(a.b2 + wave * 32 + 8 * g + 4 * hh);
+  }
 #ifdef ISG_DT_STAMP
   asm volatile("" ::"v"(acc2[0][0][0]), "v"(acc2[1][1][15]));
 #endif
   DT_STAMP(7)                  // GEMM2
   __syncthreads();          // every wave is done with the planes of the intermediate: c may overwrite them
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + fr;
+    const float si2 = s_inv2[row];
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;        // r even: r + 1 is the next row
-      const isg_f32x2 v2 = gelu_exact2(isg_f32x2{((acc2[0][i][r] + acc2[1][i][r]) * s_inv2[row]) * wi2 + bv2,
-                                                 ((acc2[0][i][r + 1] + acc2[1][i][r + 1]) * s_inv2[row + 1]) * wi2 + bv2});
-      sC[row][col2] = v2.x;
-      sC[row + 1][col2] = v2.y;
+    for (int g = 0; g < 4; ++g) {
+      const isg_f32x2 va = gelu_exact2(isg_f32x2{((acc2[0][i][4 * g] + acc2[1][i][4 * g]) * si2) * wi2[g][0] + bv2[g][0],
+                                                 ((acc2[0][i][4 * g + 1] + acc2[1][i][4 * g + 1]) * si2) * wi2[g][1] + bv2[g][1]});
+      const isg_f32x2 vb = gelu_exact2(isg_f32x2{((acc2[0][i][4 * g + 2] + acc2[1][i][4 * g + 2]) * si2) * wi2[g][2] + bv2[g][2],
+                                                 ((acc2[0][i][4 * g + 3] + acc2[1][i][4 * g + 3]) * si2) * wi2[g][3] + bv2[g][3]});
+      *reinterpret_cast<hf32x4 *>(&sC[row][wave * 32 + 8 * g + 4 * hh]) = hf32x4{va.x, va.y, vb.x, vb.y};
     }
+  }
   __syncthreads();
   DT_STAMP(8)                  // epilogue 2
 
@@ -579,7 +599,9 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
                                    int64_t N, int32_t K1, int32_t MID, int32_t C, void *stream) {
   if (N < 0 || max_tiles < 0 || lda < K1 || P <= 0 || ldp < P) return ISG_EINVAL;
   if (K1 != DT_K1 || MID != DT_MID || C != DT_C || (lda & 3) != 0 || N >= (1ll << 31) || max_tiles >= (1ll << 31) ||
-      (reinterpret_cast<uintptr_t>(conv_out) & 15) != 0 || (reinterpret_cast<uintptr_t>(ins) & 15) != 0)
+      (reinterpret_cast<uintptr_t>(conv_out) & 15) != 0 || (reinterpret_cast<uintptr_t>(ins) & 15) != 0 ||
+      ((reinterpret_cast<uintptr_t>(w1_inv_scale) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(w2_inv_scale) |
+        reinterpret_cast<uintptr_t>(b2)) & 15) != 0)          // the epilogues read them as 16-byte runs
     return ISG_EUNSUPPORTED;
   if (N == 0 || max_tiles == 0) return ISG_OK;
   if (!conv_out || !a_rowmax || !w1_frag || !w1_inv_scale || !b1 || !y_bound || !w2_frag || !w2_inv_scale || !b2 || !ins || !h ||
