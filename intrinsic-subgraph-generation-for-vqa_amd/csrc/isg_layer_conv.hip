@@ -753,7 +753,6 @@ __global__ __launch_bounds__(256, 2) void readout_tile_kernel(RoArgs a) {
     }
   }
   __syncthreads();
-  const int col = wave * 32 + fr;
 
   // ---- GEMM1 [64 x 128] . W1^T (this wave's 32 columns), GELU, planes of the intermediate into the second image ------------
   {
@@ -770,11 +769,11 @@ __global__ __launch_bounds__(256, 2) void readout_tile_kernel(RoArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) af[i][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][i * 32 + fr][ks * 16 + fk]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wq[ks][1], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][1], af[i][0], acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], wq[ks][0], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][0], af[i][1], acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wq[ks][0], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][0], af[i][0], acc[i], 0, 0, 0);
     }
     // the second weight's fragments take over the registers while the epilogue runs
 #pragma unroll
@@ -783,20 +782,29 @@ __global__ __launch_bounds__(256, 2) void readout_tile_kernel(RoArgs a) {
       for (int q = 0; q < 2; ++q)
         wq[ks][q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                                    wr2, lane * 16, (int)(((unsigned)wave * 8u + (unsigned)ks) * 1024u + q * plane), 0));
-    const float wi = a.w1_inv[col], bv = a.b1[col];
+    // transposed products (W fragment = A operand, as in isg_mgat_dense_tail): a lane holds ONE row and four runs of four columns
+    hf32x4 wi4[4], bv4[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < 4; ++g) {
+      wi4[g] = *reinterpret_cast<const hf32x4 *>(a.w1_inv + wave * 32 + 8 * g + 4 * hh);
+      bv4[g] = *reinterpret_cast<const hf32x4 *>(a.b1 + wave * 32 + 8 * g + 4 * hh);
+    }
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const isg_f32x2 v2 = gelu_exact2(isg_f32x2{(acc[i][r] * s_inv1[row]) * wi + bv, (acc[i][r + 1] * s_inv1[row + 1]) * wi + bv});
-        const float y0 = v2.x * s_scale2[row], y1 = v2.y * s_scale2[row + 1];
-        const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
-        sB[0][row][col] = h0;
-        sB[0][row + 1][col] = h1;
-        sB[1][row][col] = (_Float16)(y0 - (float)h0);
-        sB[1][row + 1][col] = (_Float16)(y1 - (float)h1);
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 32 + fr;
+      const float si = s_inv1[row], s2 = s_scale2[row];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const isg_f32x2 va = gelu_exact2(isg_f32x2{(acc[i][4 * g] * si) * wi4[g][0] + bv4[g][0], (acc[i][4 * g + 1] * si) * wi4[g][1] + bv4[g][1]});
+        const isg_f32x2 vb = gelu_exact2(isg_f32x2{(acc[i][4 * g + 2] * si) * wi4[g][2] + bv4[g][2], (acc[i][4 * g + 3] * si) * wi4[g][3] + bv4[g][3]});
+        const float y0 = va.x * s2, y1 = va.y * s2, y2 = vb.x * s2, y3 = vb.y * s2;
+        const hf16x4 hi = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+        const hf16x4 mid = {(_Float16)(y0 - (float)hi[0]), (_Float16)(y1 - (float)hi[1]), (_Float16)(y2 - (float)hi[2]), (_Float16)(y3 - (float)hi[3])};
+        const int c0 = wave * 32 + 8 * g + 4 * hh;
+        *reinterpret_cast<hf16x4 *>(&sB[0][row][c0]) = hi;
+        *reinterpret_cast<hf16x4 *>(&sB[1][row][c0]) = mid;
       }
+    }
   }
   __syncthreads();          // the intermediate is complete; every wave is done with the first image (xn will overwrite it)
 
@@ -815,21 +823,33 @@ __global__ __launch_bounds__(256, 2) void readout_tile_kernel(RoArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) af[i][q] = *reinterpret_cast<const hf16x8 *>(&sB[q][i * 32 + fr][ks * 16 + fk]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wq[ks][1], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][1], af[i][0], acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], wq[ks][0], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][0], af[i][1], acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wq[ks][0], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][0], af[i][0], acc[i], 0, 0, 0);
     }
-    const float wi = a.w2_inv[col], bv = a.b2[col];
+    hf32x4 wi4[4], bv4[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < 4; ++g) {
+      wi4[g] = *reinterpret_cast<const hf32x4 *>(a.w2_inv + wave * 32 + 8 * g + 4 * hh);
+      bv4[g] = *reinterpret_cast<const hf32x4 *>(a.b2 + wave * 32 + 8 * g + 4 * hh);
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float v = (acc[i][r] * s_inv2[row]) * wi + bv;
-        sC[row][col] = a.node_mask ? __fmul_rn(v, s_mask[row]) : v;      // att_pooling.py:63: x = node_nn(x) * node_mask
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 32 + fr;
+      const float si = s_inv2[row], mk = s_mask[row];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        hf32x4 v;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float t = (acc[i][4 * g + jj] * si) * wi4[g][jj] + bv4[g][jj];
+          v[jj] = a.node_mask ? __fmul_rn(t, mk) : t;      // att_pooling.py:63: x = node_nn(x) * node_mask
+        }
+        *reinterpret_cast<hf32x4 *>(&sC[row][wave * 32 + 8 * g + 4 * hh]) = v;
       }
+    }
   }
   __syncthreads();
 
@@ -900,6 +920,8 @@ extern "C" int isg_readout_tile(const float *x, int32_t ldx, const uint16_t *w1_
                                 int64_t max_tiles, int64_t N, int32_t C, void *stream) {
   if (N < 0 || max_tiles < 0 || ldx < C || C <= 0) return ISG_EINVAL;
   if (C != isg::RO_C || (ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(q) & 15) != 0 ||
+      ((reinterpret_cast<uintptr_t>(w1_inv_scale) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(w2_inv_scale) |
+        reinterpret_cast<uintptr_t>(b2)) & 15) != 0 ||          // the epilogues read them as 16-byte runs
       N >= (1ll << 31) || max_tiles >= (1ll << 31))
     return ISG_EUNSUPPORTED;
   if (max_tiles == 0) return ISG_OK;
