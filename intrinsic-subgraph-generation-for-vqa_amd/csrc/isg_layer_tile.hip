@@ -32,6 +32,15 @@ static __device__ long long *g_dt_stamps = nullptr;
 #define DT_STAMP(i)
 #endif
 
+#ifndef DT_ABL
+#define DT_ABL 0   // ablation builds only: 1 no GEMM1 MFMAs, 2 no GELU in epilogue 1, 4 no GEMM2 MFMAs, 8 no GELU in epilogue 2, 16 no phases A / B,
+                   // 32 no GraphNorm statistics, 64 no gate GELU, 128 no plane split of the gated rows, 256 multiply by 1/std instead of dividing
+#endif
+
+#define DT_GELU1(...) ((DT_ABL & 2) ? (__VA_ARGS__) : gelu_exact2(__VA_ARGS__))
+#define DT_GELU2(...) ((DT_ABL & 8) ? (__VA_ARGS__) : gelu_exact2(__VA_ARGS__))
+#define DT_GELU3(...) ((DT_ABL & 64) ? (__VA_ARGS__) : gelu_exact2(__VA_ARGS__))
+
 namespace isg {
 
 // =====================================================================================================================
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                \
     const int row = srow + 8 * u;                                                                                \
     const int gr = min(r0 + min(row, nrows - 1), a.N - 1);                                                       \
-    ra[u] = *reinterpret_cast<const float4 *>(a.a + (int64_t)gr * a.lda + (c) * DT_KC + sc4 * 4);                \
+    { const hf32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const hf32x4 *>(a.a + (int64_t)gr * a.lda + (c) * DT_KC + sc4 * 4)); ra[u] = make_float4(t_[0], t_[1], t_[2], t_[3]); } \
   }
   float4 ra[8];
   DT_LOAD_CHUNK(0)               // in flight under the tile's bookkeeping
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     if (s + 3 < DT_KS1) { DT_LOADW1((s + 3) & 3, s + 3) }
     DT_LOADA1(c & 1, ksl)
     __builtin_amdgcn_sched_barrier(0);      // the prefetches stay AHEAD of this step's MFMAs (hipcc sinks them to their use otherwise)
-    DT_MMA1(af, wq[s & 3])
+    if (!(DT_ABL & 1)) { DT_MMA1(af, wq[s & 3]) } else { acc[0][0][0] += (float)af[0][0][0] + (float)wq[s & 3][0][0][0]; acc[1][1][1] += (float)af[1][1][0] + (float)wq[s & 3][1][1][0]; }
     __builtin_amdgcn_sched_barrier(0);
     if (ksl == 7 && c < 3) {
       DT_WRITE_CHUNK((c + 1) & 1)                  // last read two chunks ago: every wave is past that barrier
@@ -332,9 +341,9 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           // both scales are powers of two: exact
-          const isg_f32x2 va = gelu_exact2(isg_f32x2{(acc[i][j][4 * g] * si) * wi4[j][g][0] + bv4[j][g][0],
+          const isg_f32x2 va = DT_GELU1(isg_f32x2{(acc[i][j][4 * g] * si) * wi4[j][g][0] + bv4[j][g][0],
                                                      (acc[i][j][4 * g + 1] * si) * wi4[j][g][1] + bv4[j][g][1]}) * s2;
-          const isg_f32x2 vb = gelu_exact2(isg_f32x2{(acc[i][j][4 * g + 2] * si) * wi4[j][g][2] + bv4[j][g][2],
+          const isg_f32x2 vb = DT_GELU1(isg_f32x2{(acc[i][j][4 * g + 2] * si) * wi4[j][g][2] + bv4[j][g][2],
                                                      (acc[i][j][4 * g + 3] * si) * wi4[j][g][3] + bv4[j][g][3]}) * s2;
           const hf16x4 hi = {(_Float16)va.x, (_Float16)va.y, (_Float16)vb.x, (_Float16)vb.y};
           const hf16x4 mid = {(_Float16)(va.x - (float)hi[0]), (_Float16)(va.y - (float)hi[1]), (_Float16)(vb.x - (float)hi[2]),
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int gr = min(r0 + min(srow + 8 * u, nrows - 1), a.N - 1);
-    rh[u] = *reinterpret_cast<const hf32x4 *>(a.h + (int64_t)gr * DT_C + sc4 * 4);
+    rh[u] = __builtin_nontemporal_load(reinterpret_cast<const hf32x4 *>(a.h + (int64_t)gr * DT_C + sc4 * 4));      // read once
   }
   hf32x16 acc2[2][2];        // [k half][row block]
 #pragma unroll
@@ -384,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
       if (s + 3 < DT_KS2) { DT_LOADW2((s + 3) & 3, s + 3) }
       if (s + 1 < DT_KS2) { DT_LOADA2((s + 1) & 1, s + 1) }
       __builtin_amdgcn_sched_barrier(0);
+      if (DT_ABL & 4) { acc2[kh][0][0] += (float)w2[s & 3][1][0] + (float)a2[s & 1][0][0][0] + (float)a2[s & 1][1][1][0]; continue; }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         acc2[kh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s & 3][1], a2[s & 1][i][0], acc2[kh][i], 0, 0, 0);       // transposed,
@@ -414,9 +424,9 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     const float si2 = s_inv2[row];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const isg_f32x2 va = gelu_exact2(isg_f32x2{((acc2[0][i][4 * g] + acc2[1][i][4 * g]) * si2) * wi2[g][0] + bv2[g][0],
+      const isg_f32x2 va = DT_GELU2(isg_f32x2{((acc2[0][i][4 * g] + acc2[1][i][4 * g]) * si2) * wi2[g][0] + bv2[g][0],
                                                  ((acc2[0][i][4 * g + 1] + acc2[1][i][4 * g + 1]) * si2) * wi2[g][1] + bv2[g][1]});
-      const isg_f32x2 vb = gelu_exact2(isg_f32x2{((acc2[0][i][4 * g + 2] + acc2[1][i][4 * g + 2]) * si2) * wi2[g][2] + bv2[g][2],
+      const isg_f32x2 vb = DT_GELU2(isg_f32x2{((acc2[0][i][4 * g + 2] + acc2[1][i][4 * g + 2]) * si2) * wi2[g][2] + bv2[g][2],
                                                  ((acc2[0][i][4 * g + 3] + acc2[1][i][4 * g + 3]) * si2) * wi2[g][3] + bv2[g][3]});
       *reinterpret_cast<hf32x4 *>(&sC[row][wave * 32 + 8 * g + 4 * hh]) = hf32x4{va.x, va.y, vb.x, vb.y};
     }
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   // ---- the layer tail on the tile's graphs (isg_norm_pool.hip::graph_tail_kernel<2>, same arithmetic, rows from LDS) --------
   // phase A: a_n = <ins_g, c_n> / sqrt(C).  A half-wave per node, one float4 per lane, the 32-lane butterfly -- the same bits as
   // graph_tail_kernel's 64-lane wave_sum, whose upper half adds zeros; eight nodes per wave and iteration (independent chains)
-  for (int kb = 8 * wave; kb < nrows; kb += 32) {
+  for (int kb = 8 * wave; kb < ((DT_ABL & 16) ? 0 : nrows); kb += 32) {
     float part[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   __syncthreads();
   DT_STAMP(9)                  // phase A
   // phase B: softmax over a graph's nodes (the sum runs in node order), a wave per graph
-  for (int gi = wave; gi < ng; gi += 4) {
+  for (int gi = wave; gi < ((DT_ABL & 16) ? 0 : ng); gi += 4) {
     const int nb = gi < DT_GPC ? s_gp[gi] : a.ptr[g0 + gi] - r0;
     const int n = min(gi < DT_GPC ? s_gp[gi + 1] : a.ptr[g0 + gi + 1] - r0, nrows) - nb;
     if (n <= 0) continue;
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     {
       const int ch = tid & (DT_C - 1);
       const float ms = a.gn_ms[ch];
-      for (int gi = gb + (tid >> 7); gi < ge; gi += 2) {
+      for (int gi = gb + (tid >> 7); gi < ((DT_ABL & 32) ? 0 : ge); gi += 2) {
         const int nb = gi < DT_GPC ? s_gp[gi] : a.ptr[g0 + gi] - r0;
         const int n = min(gi < DT_GPC ? s_gp[gi + 1] : a.ptr[g0 + gi + 1] - r0, nrows) - nb;
         if (n <= 0) continue;
@@ -518,20 +528,20 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float o = __fsub_rn(__fmul_rn(an, cv[j]), mv[j]);
-          float y = __fadd_rn(__fmul_rn(wv[j], o) / dv[j], bv[j]);
+          float y = (DT_ABL & 256) ? __fadd_rn(__fmul_rn(wv[j], o) * __builtin_amdgcn_rcpf(dv[j]), bv[j]) : __fadd_rn(__fmul_rn(wv[j], o) / dv[j], bv[j]);
           y = __fadd_rn(y, rh[u][j]);
           if (a.node_mask) y = __fmul_rn(mk, y);
           y4[j] = y;
         }
         if (a.xg_out || a.xp_out) {
-          const isg_f32x2 ga = gelu_exact2(isg_f32x2{y4[0] * xv[0], y4[1] * xv[1]});
-          const isg_f32x2 gb2 = gelu_exact2(isg_f32x2{y4[2] * xv[2], y4[3] * xv[3]});
+          const isg_f32x2 ga = DT_GELU3(isg_f32x2{y4[0] * xv[0], y4[1] * xv[1]});
+          const isg_f32x2 gb2 = DT_GELU3(isg_f32x2{y4[2] * xv[2], y4[3] * xv[3]});
           g4 = hf32x4{ga.x, ga.y, gb2.x, gb2.y};
         }
         const int64_t at = (int64_t)(r0 + row) * DT_C + sc4 * 4;
         *reinterpret_cast<hf32x4 *>(a.h_out + at) = y4;
         if (a.xg_out) *reinterpret_cast<hf32x4 *>(a.xg_out + at) = g4;
-        if (a.xp_out) {          // row scale + (hi, mid) split once per row here, not once per (tile, head) in the layer kernel
+        if (a.xp_out && !(DT_ABL & 128)) {          // row scale + (hi, mid) split once per row here, not once per (tile, head) in the layer kernel
           const float mx = group_max<32>(fmaxf(fmaxf(fabsf(g4[0]), fabsf(g4[1])), fmaxf(fabsf(g4[2]), fabsf(g4[3]))));
           float sc, inv;
           h3_scale(mx, sc, inv);
