@@ -1238,7 +1238,8 @@ def test_tile_conv_is_bit_identical_to_the_edge_logits_pair(dev, mask, K):
 
 
 @pytest.mark.parametrize("mask", [None, "node", "edge"])
-def test_layer_conv_is_bit_identical_to_projection_plus_tile_conv(dev, mask, monkeypatch):
+@pytest.mark.parametrize("H,K", [(4, 128), (4, 36), (2, 128), (1, 100)])
+def test_layer_conv_is_bit_identical_to_projection_plus_tile_conv(dev, mask, H, K, monkeypatch):
     """isg_gatv2_layer_conv (lin_l | lin_r formed inside, per (tile, head), straight into LDS) against the two launches it
     replaces (isg_linear_f16x3 over [lin_l; lin_r] + isg_gatv2_tile_conv): same operations in the same order -> EQUAL out, alpha,
     row maxima; and against the CPU oracle (mgat_v2_conv.py:177-181, :243-279)."""
@@ -1246,15 +1247,16 @@ def test_layer_conv_is_bit_identical_to_projection_plus_tile_conv(dev, mask, mon
     from isubgvqa_amd.models.layers import GlorotLinear
     from oracle import model as OM
     gen = torch.Generator().manual_seed(23)
-    H, C, K = 4, 128, 128
+    C = 128           # (K = 128: the kernel's compile-time edge width; other K: its run-time form; H: the head <-> workgroup map)
     monkeypatch.setattr(ops, "GEMM_KERNEL", "panel")      # the reference projection on isg_linear_f16x3 at every M (small M: tile kernel)
     torch.manual_seed(5)
     lin_l, lin_r = GlorotLinear(128, H * C, bias=True).to(dev), GlorotLinear(128, H * C, bias=True).to(dev)
     with torch.no_grad():
         lin_l.bias.add_(0.1 * torch.randn(H * C, device=dev))
         lin_r.bias.add_(0.1 * torch.randn(H * C, device=dev))
-    for sizes, hub in (([1], None), ([64], None), ([64, 1, 63, 2, 62, 20, 20, 20, 5, 0, 3], (0, 150)),
-                       (torch.randint(8, 34, (700,), generator=gen).tolist(), (7, 60))):
+    cases = (([1], None), ([64], None), ([64, 1, 63, 2, 62, 20, 20, 20, 5, 0, 3], (0, 150)),
+             (torch.randint(8, 34, (700 if (H, K) == (4, 128) else 150,), generator=gen).tolist(), (7, 60)))
+    for sizes, hub in cases:
         batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=hub)
         N, E, B = batch.numel(), ei.size(1), len(sizes)
         x = torch.randn(N, 128, generator=gen) * torch.rand(N, 1, generator=gen).mul(3).exp()
