@@ -26,7 +26,8 @@ static __device__ long long *g_lc_stamps = nullptr;
 #endif
 
 #ifndef LC_ABL
-#define LC_ABL 0   // ablation builds only (tools/ablate_layer_conv.sh): 1 no logit epilogue, 2 no edge MFMAs, 4 no node MFMAs, 8 no aggregation
+#define LC_ABL 0   // ablation builds only (profiles/r03_bg_*): 1 no logit epilogue, 2 no edge MFMAs, 4 no node MFMAs, 8 no aggregation, 16 no node
+                   // GEMM, 32 no chunk data path, 64 no next-tile requests, 1024 no alpha stores
 #endif
 
 namespace isg {
@@ -432,116 +433,115 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       LC_REQUEST_PLANES(desc_n)
     }
     LC_STAMP(5)              // the next tile's planes and tables
-    // 16 lanes per node (two 16-byte pieces each, 256 contiguous bytes per instruction): a wave aggregates FOUR nodes at a time,
-    // two passes cover the tile -- this phase is a chain of dependent LDS reads (pointers -> records -> rows), so its time is the
-    // number of passes (with 32 lanes per node: four passes, 6 k cycles per tile)
-    const int q4 = lane >> 4, j16 = lane & 15;
-    int rbp[2], rep[2];
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {       // both passes' segment bounds in one round trip
-      const int k = min(4 * wave + q4 + 32 * ps, LC_ROWS - 1);
-      rbp[ps] = s_rp[k];
-      rep[ps] = s_rp[k + 1];
-    }
-#pragma unroll 1
-    for (int ps = 0; ps < 2; ++ps) {
-      const int k = 4 * wave + q4 + 32 * ps;
-      if (k >= nrows || (LC_ABL & 8)) break;
-      const int rb = ps ? rbp[1] : rbp[0], re = min(ps ? rep[1] : rep[0], ne);
-      float lg4[4], e4[4];
-      int4 rc4[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = max(min(rb + u, re - 1), 0);
-        lg4[u] = s_lg[idx];
-        rc4[u] = s_tab[idx];
-      }
-      float4 u4[4][2];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) u4[u][m] = *reinterpret_cast<const float4 *>(&sXl[rc4[u].x][64 * m + j16 * 4]);
-      float mx = fmaxf(fmaxf(-INFINITY, lg4[0]), fmaxf(fmaxf(lg4[1], lg4[2]), lg4[3]));
-#pragma unroll 1
-      for (int s = rb + 4; s < re; s += 4) {
-        const float v0 = s_lg[s], v1 = s_lg[min(s + 1, re - 1)], v2 = s_lg[min(s + 2, re - 1)], v3 = s_lg[min(s + 3, re - 1)];
-        mx = fmaxf(fmaxf(mx, v0), fmaxf(fmaxf(v1, v2), v3));
-      }
-      float den = 0.f;          // in slot order, like the per-edge loop of the kernels this replaces
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        e4[u] = __builtin_amdgcn_exp2f((lg4[u] - mx) * 1.4426950408889634f);
-        den += rb + u < re ? e4[u] : 0.f;
-      }
-#pragma unroll 1
-      for (int s = rb + 4; s < re; s += 4) {
-        const float v0 = s_lg[s], v1 = s_lg[min(s + 1, re - 1)], v2 = s_lg[min(s + 2, re - 1)], v3 = s_lg[min(s + 3, re - 1)];
-        const float e0 = __builtin_amdgcn_exp2f((v0 - mx) * 1.4426950408889634f);
-        const float e1 = __builtin_amdgcn_exp2f((v1 - mx) * 1.4426950408889634f);
-        const float e2 = __builtin_amdgcn_exp2f((v2 - mx) * 1.4426950408889634f);
-        const float e3 = __builtin_amdgcn_exp2f((v3 - mx) * 1.4426950408889634f);
-        den += e0;
-        den += s + 1 < re ? e1 : 0.f;
-        den += s + 2 < re ? e2 : 0.f;
-        den += s + 3 < re ? e3 : 0.f;
-      }
-      const float rden = __builtin_amdgcn_rcpf(den + 1e-16f);
-      float4 o[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-      int s = rb;
-#pragma unroll 1
-      while (true) {            // four in-edges per round, edge-id order, mul + add as the kernels this replaces compile them
-        {       // alpha: ONE store instruction per round, lane u of a node's sixteen writes in-edge u (four single-lane stores with
-                // their own address arithmetic and exec masks cost ~10 us per launch)
-          const float wsel = (j16 & 2) ? ((j16 & 1) ? e4[3] : e4[2]) : ((j16 & 1) ? e4[1] : e4[0]);
-          const int esel = (j16 & 2) ? ((j16 & 1) ? rc4[3].y : rc4[2].y) : ((j16 & 1) ? rc4[1].y : rc4[0].y);
-          if (j16 < 4 && s + j16 < re && !(LC_ABL & 1024)) a.alpha[(int64_t)esel * a.H + hd] = wsel * rden;
-        }
+    // 8 lanes per node (four 16-byte pieces each, 128 contiguous bytes per instruction): a wave aggregates EIGHT nodes at a time,
+    // ONE pass covers the tile.  The phase is issue-bound on its per-node bookkeeping (bounds, records, softmax, stores), which a
+    // pass does once per instruction whatever the lane count per node: 16 lanes per node needed two passes, 32 lanes four.
+    {
+      const int q8 = lane >> 3, j8 = lane & 7;
+      const int k = 8 * wave + q8;
+      if (k < nrows && !(LC_ABL & 8)) {
+        const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
+        float lg4[4], e4[4];
+        int4 rc4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          // slots past the segment's end carry weight 0 instead of a branch each: their rows are copies of the last slot's
-          // (finite), and x + 0 * r = x exactly
-          const float w = s + u < re ? e4[u] * rden : 0.f;
-          const float wm = MASKED ? __fmul_rn(w, __int_as_float(rc4[u].w)) : w;
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            o[m].x = __fadd_rn(o[m].x, __fmul_rn(u4[u][m].x, wm));
-            o[m].y = __fadd_rn(o[m].y, __fmul_rn(u4[u][m].y, wm));
-            o[m].z = __fadd_rn(o[m].z, __fmul_rn(u4[u][m].z, wm));
-            o[m].w = __fadd_rn(o[m].w, __fmul_rn(u4[u][m].w, wm));
-          }
-        }
-        s += 4;
-        if (s >= re) break;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int idx = min(s + u, re - 1);
-          e4[u] = __builtin_amdgcn_exp2f((s_lg[idx] - mx) * 1.4426950408889634f);
+          const int idx = max(min(rb + u, re - 1), 0);
+          lg4[u] = s_lg[idx];
           rc4[u] = s_tab[idx];
         }
+        float4 u2[2][4];          // the rows of two in-edges at a time (four would be 64 registers)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) u4[u][m] = *reinterpret_cast<const float4 *>(&sXl[rc4[u].x][64 * m + j16 * 4]);
-      }
-      float rmx = 0.f;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if (a.bias) {
-          const float4 b4 = *reinterpret_cast<const float4 *>(&s_bias[64 * m + j16 * 4]);
-          o[m].x += b4.x; o[m].y += b4.y; o[m].z += b4.z; o[m].w += b4.w;
+          for (int m = 0; m < 4; ++m) u2[u][m] = *reinterpret_cast<const float4 *>(&sXl[rc4[u].x][32 * m + j8 * 4]);
+        float mx = fmaxf(fmaxf(-INFINITY, lg4[0]), fmaxf(fmaxf(lg4[1], lg4[2]), lg4[3]));
+#pragma unroll 1
+        for (int s = rb + 4; s < re; s += 4) {
+          const float v0 = s_lg[s], v1 = s_lg[min(s + 1, re - 1)], v2 = s_lg[min(s + 2, re - 1)], v3 = s_lg[min(s + 3, re - 1)];
+          mx = fmaxf(fmaxf(mx, v0), fmaxf(fmaxf(v1, v2), v3));
         }
-        hf32x4 o4 = {o[m].x, o[m].y, o[m].z, o[m].w};
-        if (LC_ABL & 256) {
-          if (o4[0] == 1.2345e30f) *reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + 64 * m + j16 * 4) = o4;
-        } else if (LC_ABL & 512) {
-          *reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + 64 * m + j16 * 4) = o4;
-        } else
-        __builtin_nontemporal_store(o4, reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + 64 * m + j16 * 4));
-        rmx = fmaxf(rmx, fmaxf(fmaxf(fabsf(o[m].x), fabsf(o[m].y)), fmaxf(fabsf(o[m].z), fabsf(o[m].w))));
-      }
-      if (a.rowmax) {
-        rmx = group_max<16>(rmx);
-        if (j16 == 0) a.rowmax[(int64_t)(r0 + k) * a.H + hd] = rmx;
+        float den = 0.f;          // in slot order, like the per-edge loop of the kernels this replaces
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          e4[u] = __builtin_amdgcn_exp2f((lg4[u] - mx) * 1.4426950408889634f);
+          den += rb + u < re ? e4[u] : 0.f;
+        }
+#pragma unroll 1
+        for (int s = rb + 4; s < re; s += 4) {
+          const float v0 = s_lg[s], v1 = s_lg[min(s + 1, re - 1)], v2 = s_lg[min(s + 2, re - 1)], v3 = s_lg[min(s + 3, re - 1)];
+          const float e0 = __builtin_amdgcn_exp2f((v0 - mx) * 1.4426950408889634f);
+          const float e1 = __builtin_amdgcn_exp2f((v1 - mx) * 1.4426950408889634f);
+          const float e2 = __builtin_amdgcn_exp2f((v2 - mx) * 1.4426950408889634f);
+          const float e3 = __builtin_amdgcn_exp2f((v3 - mx) * 1.4426950408889634f);
+          den += e0;
+          den += s + 1 < re ? e1 : 0.f;
+          den += s + 2 < re ? e2 : 0.f;
+          den += s + 3 < re ? e3 : 0.f;
+        }
+        const float rden = __builtin_amdgcn_rcpf(den + 1e-16f);
+        float4 o[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) o[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = rb;
+#pragma unroll 1
+        while (true) {          // four in-edges per round (two and two), edge-id order, mul + add as the kernels this replaces compile them
+          {     // alpha: ONE store instruction per round, lane u of a node's eight writes in-edge u
+            const float wsel = (j8 & 2) ? ((j8 & 1) ? e4[3] : e4[2]) : ((j8 & 1) ? e4[1] : e4[0]);
+            const int esel = (j8 & 2) ? ((j8 & 1) ? rc4[3].y : rc4[2].y) : ((j8 & 1) ? rc4[1].y : rc4[0].y);
+            if (j8 < 4 && s + j8 < re && !(LC_ABL & 1024)) a.alpha[(int64_t)esel * a.H + hd] = wsel * rden;
+          }
+#pragma unroll
+          for (int hp = 0; hp < 2; ++hp) {
+            if (hp == 1) {      // the second pair's rows: only when some node of the wave has a third in-edge in this round
+              if (!__any(s + 2 < re)) break;
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) u2[u][m] = *reinterpret_cast<const float4 *>(&sXl[rc4[2 + u].x][32 * m + j8 * 4]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              // slots past the segment's end carry weight 0 instead of a branch each: their rows are copies of the last slot's
+              // (finite), and x + 0 * r = x exactly
+              const float w = s + 2 * hp + u < re ? e4[2 * hp + u] * rden : 0.f;
+              const float wm = MASKED ? __fmul_rn(w, __int_as_float(rc4[2 * hp + u].w)) : w;
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                o[m].x = __fadd_rn(o[m].x, __fmul_rn(u2[u][m].x, wm));
+                o[m].y = __fadd_rn(o[m].y, __fmul_rn(u2[u][m].y, wm));
+                o[m].z = __fadd_rn(o[m].z, __fmul_rn(u2[u][m].z, wm));
+                o[m].w = __fadd_rn(o[m].w, __fmul_rn(u2[u][m].w, wm));
+              }
+            }
+          }
+          s += 4;
+          if (s >= re) break;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = min(s + u, re - 1);
+            e4[u] = __builtin_amdgcn_exp2f((s_lg[idx] - mx) * 1.4426950408889634f);
+            rc4[u] = s_tab[idx];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) u2[u][m] = *reinterpret_cast<const float4 *>(&sXl[rc4[u].x][32 * m + j8 * 4]);
+        }
+        float rmx = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if (a.bias) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(&s_bias[32 * m + j8 * 4]);
+            o[m].x += b4.x; o[m].y += b4.y; o[m].z += b4.z; o[m].w += b4.w;
+          }
+          hf32x4 o4 = {o[m].x, o[m].y, o[m].z, o[m].w};
+          __builtin_nontemporal_store(o4, reinterpret_cast<hf32x4 *>(a.out + (int64_t)(r0 + k) * a.ldo + hoff + 32 * m + j8 * 4));
+          rmx = fmaxf(rmx, fmaxf(fmaxf(fabsf(o[m].x), fabsf(o[m].y)), fmaxf(fabsf(o[m].z), fabsf(o[m].w))));
+        }
+        if (a.rowmax) {
+          rmx = group_max<8>(rmx);
+          if (j8 == 0) a.rowmax[(int64_t)(r0 + k) * a.H + hd] = rmx;
+        }
       }
     }
     LC_STAMP(6)              // softmax + aggregation, stores
