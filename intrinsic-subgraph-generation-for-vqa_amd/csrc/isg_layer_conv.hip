@@ -380,7 +380,10 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       __builtin_amdgcn_s_waitcnt(0x0F70);
       LC_STAMP(14)
 #endif
-      if (!(LC_ABL & 32)) {
+      // a chunk's upper 32 slots are often past the tile's end (its last chunk holds ne mod 64 slots): the four waves of that half
+      // then skip product and epilogue, and the other four have their SIMDs to themselves
+      const bool live = half == 0 || 64 * c + 32 < ne;
+      if (!(LC_ABL & 32) && live) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         hf16x8 af[2][2];          // [stage][plane]
@@ -410,7 +413,9 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #endif
       LC_STAMP(3)            // k loop
       if (MASKED && c + 1 == nchunk) LC_REQUEST_MASKS(desc_n)      // the ids they hang on were requested a k loop ago
-      if (!(LC_ABL & 1)) LC_EPILOGUE(c) else if (hh == 0) s_part[tw * 64 + prow] = acc[0];
+      if (live) {
+        if (!(LC_ABL & 1)) LC_EPILOGUE(c) else if (hh == 0) s_part[tw * 64 + prow] = acc[0];
+      }
       __syncthreads();
       LC_STAMP(4)            // epilogue + barrier
       if (tid < 64 && 64 * c + tid < ne)     // the tile-waves' partials in a fixed order
