@@ -5,16 +5,22 @@
 // isg_gatv2_tile_conv (csrc/isg_layer_tile.hip) still reads x_l / x_r [N, H*C] that a separate launch (isg_linear_f16x3, 114 us per
 // layer at BASELINE configs[1], at its write floor: 337 MB) wrote just before -- 674 MB per layer of HBM traffic for two tensors
 // that are consumed once, tile by tile.  Here a persistent workgroup owns one head (as there) and forms the head's x_l / x_r slices
-// of a tile's <= 64 nodes itself, from the gated node rows x [64, 128], on the matrix cores, straight into LDS: the logit
-// epilogue gathers BOTH from LDS (no per-edge row gathers from global memory at all), the aggregation reads x_l from LDS, and
-// neither tensor ever exists in memory.  HBM per layer: x 42 MB + edge planes 105 MB in (both shared by a tile's four head
-// workgroups through L2), out 168 MB + alpha 3 MB back.
-//   block  = 8 waves, one workgroup per CU (LDS: two 33 KB row slices, one 34 KB panel image, tables), persistent
+// of a tile's <= 64 nodes itself, from the gated node rows, on the matrix cores, straight into LDS: the logit epilogue gathers
+// BOTH from LDS (no per-edge row gathers from global memory at all), the aggregation reads x_l from LDS, and neither tensor ever
+// exists in memory.  The node rows arrive as the scaled (hi, mid) planes their PRODUCER wrote (isg_instr_gate_planes, the previous
+// layer's isg_mgat_dense_tail): the row split is done once per row, not once per (tile, head).  HBM per layer: node planes 42 MB +
+// edge planes 105 MB in (both shared by a tile's four head workgroups through L2), out 168 MB + alpha 3 MB back.
+//   block  = 8 waves, one workgroup per CU, persistent.  LDS: two 33 KB row slices (x_l, x_r), one 34 KB panel image (edge chunks,
+//            padded rows), one 32 KB panel of node planes filled by LDS-DMA (swizzled on the source address), two sets of tables
 //   wave   = node GEMM: all 64 rows x one of the head's eight 32-column tiles of [lin_l | lin_r]; edge GEMM: one 32-slot half of a
-//            64-slot chunk x one of the head's four 32-channel tiles of lin_edge (transposed product, isg_mp_logits.hip)
+//            64-slot chunk x one of the head's four 32-channel tiles of lin_edge (transposed products, isg_mp_logits.hip);
+//            softmax + aggregation: eight destination nodes per wave instruction (8 lanes x 64 bytes of a node's row)
 //   W      = both weights' fragments of the wave's tiles live in its registers for the whole launch (128 VGPRs)
+//   ahead  = the next tile's tables (raw values in registers), node planes (DMA) and first edge planes are requested two chunks /
+//            one phase before their use; the hand-over between tiles is one barrier
 // The arithmetic is isg_linear_f16x3's (row scale, planes, MFMA order, epilogue) followed by isg_gatv2_tile_conv's, operation
-// for operation: out / alpha / rowmax are bit-identical to the two-launch path.
+// for operation: out / alpha / rowmax are bit-identical to the two-launch path.  What bounds the kernel (it is the sum of its
+// phases) and what was tried: DESIGN.md 9.1, profiles/r03_bg_layer_conv_ablation.md.
 #include "isg_f16x3.hpp"
 
 #ifdef ISG_DT_STAMP
