@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void instr_gate_planes_kernel(const float *__r
 
 // KSE_T: 16-column steps of the edge product when known at compile time (8 = the 128 edge features of the model: no branch between
 // the MFMAs), 0 = read it from the arguments
-template <bool MASKED, int KSE_T>
+// SL01: 0 <= negative_slope <= 1 (the reference's 0.2): leaky_relu(z) = max(z, slope z), one instruction less per value
+template <bool MASKED, int KSE_T, bool SL01>
 __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lc_smem[];
   typedef float (*BufX)[LC_LDX];
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // epilogue of chunk `ch`: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask, z * att in
     // 4 chains (one group of reads at a time: all four in flight are 64 registers, which the allocator took from the resident W)
-#define LC_EPILOGUE(ch)                                                                                              \
+#define LC_EPILOGUE_(ch, SL01)                                                                                       \
   {                                                                                                                  \
     const int slot = min(64 * (ch) + prow, ne - 1);                                                                  \
     const float sinv = s_einv[slot];                                                                                 \
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
         const float e = (acc[g * 4 + jj] * sinv) * wiv[jj];                                                          \
         float z = (rv[jj] + lv[jj]) + e;                                                                             \
         if (MASKED) z *= me;                                                                                         \
-        z = z > 0.f ? z : z * slope;                                                                                 \
+        z = (SL01) ? fmaxf(z, z * slope) : (z > 0.f ? z : z * slope);   /* 0 <= slope <= 1: max(z, slope z), same bits */ \
         if (MASKED) z *= me;                                                                                         \
         part[g] = fmaf(z, atv[jj], part[g]);                                                                         \
       }                                                                                                              \
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     const float tot = mine + __shfl_xor(mine, 32);                                                                   \
     if (hh == 0) s_part[tw * 64 + prow] = tot;                                                                       \
   }
+#define LC_EPILOGUE(ch) LC_EPILOGUE_(ch, SL01)
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
       if (!(LC_ABL & 32)) {
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
         s_lg[64 * c + tid] = (s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]);
     }
 #undef LC_EPILOGUE
+#undef LC_EPILOGUE_
     __syncthreads();
 
     // ---- softmax + aggregation (isg_mp_graph.hip phase C: same operations in the same order) ----------------------------------
@@ -643,18 +646,21 @@ extern "C" int isg_gatv2_layer_conv(const uint16_t *x_planes, const float *x_inv
   if (gpx > need) gpx = (int)need;
   const unsigned grid = 8u * (unsigned)H * (unsigned)gpx;
   hipStream_t st = as_stream(stream);
-#define LC_LAUNCH(M, KT)                                                                                             \
+#define LC_LAUNCH(M, KT, SL)                                                                                         \
   {                                                                                                                  \
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_layer_conv_kernel<M, KT>),      \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_layer_conv_kernel<M, KT, SL>),  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LC_SMEM_BYTES) == hipSuccess; \
     if (!ok) return ISG_EUNSUPPORTED;                                                                                \
-    gatv2_layer_conv_kernel<M, KT><<<grid, LC_THREADS, LC_SMEM_BYTES, st>>>(a);                                      \
+    gatv2_layer_conv_kernel<M, KT, SL><<<grid, LC_THREADS, LC_SMEM_BYTES, st>>>(a);                                  \
   }
   const bool masked = node_mask || edge_mask;
-  if (a.KSE == 8) {
-    if (masked) LC_LAUNCH(true, 8) else LC_LAUNCH(false, 8)
+  const bool sl01 = negative_slope >= 0.f && negative_slope <= 1.f;
+  if (a.KSE == 8 && sl01) {
+    if (masked) LC_LAUNCH(true, 8, true) else LC_LAUNCH(false, 8, true)
+  } else if (sl01) {
+    if (masked) LC_LAUNCH(true, 0, true) else LC_LAUNCH(false, 0, true)
   } else {
-    if (masked) LC_LAUNCH(true, 0) else LC_LAUNCH(false, 0)
+    if (masked) LC_LAUNCH(true, 0, false) else LC_LAUNCH(false, 0, false)
   }
 #undef LC_LAUNCH
   return check_launch();

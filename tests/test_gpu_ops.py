@@ -1280,6 +1280,13 @@ def test_layer_conv_is_bit_identical_to_projection_plus_tile_conv(dev, mask, H, 
         assert torch.equal(out_f, out_t), (sizes[:4], (out_f - out_t).abs().max().item())
         assert torch.equal(al_f, al_t)
         assert torch.equal(ops.row_maxima(out_f), ops.row_maxima(out_t))
+        if K == 128 and H == 4:      # a slope outside [0, 1]: leaky_relu is not max(z, slope z) there (the kernel's other form)
+            with torch.no_grad():
+                o1, a1 = ops.gatv2_layer_conv(xd, lin_l, lin_r, ead, wd, d(att), plan, H, bias=d(bias), node_mask=d(nm),
+                                              edge_mask=d(em), negative_slope=1.5)
+                o2, a2 = ops.gatv2_tile_conv(x_l, x_r, ead, wd, d(att), plan, H, bias=d(bias), node_mask=d(nm), edge_mask=d(em),
+                                             negative_slope=1.5)
+            assert torch.equal(o1, o2) and torch.equal(a1, a2) and not torch.equal(a1, al_f)
         xl_ref = x @ lin_l.weight.detach().cpu().t() + lin_l.bias.detach().cpu()
         xr_ref = x @ lin_r.weight.detach().cpu().t() + lin_r.bias.detach().cpu()
         edge_mask = em if em is not None else (nm[ei[0]] * nm[ei[1]] if nm is not None else None)
