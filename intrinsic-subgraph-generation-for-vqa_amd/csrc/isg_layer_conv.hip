@@ -338,7 +338,8 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
   {                                                                                                                  \
     const int slot = min(64 * (ch) + prow, ne - 1);                                                                  \
     const float sinv = s_einv[slot];                                                                                 \
-    const int4 rec = s_tab[slot];                                                                                    \
+    int4 rec = s_tab[slot];                                                                                          \
+    if (LC_ABL & 2048) { rec.x = 0; rec.z = 0; }     /* ablation: no scattered row gathers */                        \
     const float me = __int_as_float(rec.w);                                                                          \
     float part[4];                                                                                                   \
     int cb = tw * 32 + 4 * hh;       /* laundered: hoisted out of the chunk loop, the 16 addresses below cost 16 registers */ \
