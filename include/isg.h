@@ -155,6 +155,17 @@ int isg_scatter_mean(const float *msg, const int32_t *rowptr, const int32_t *eid
 int isg_node_gate(const float *xn, const float *q, const int64_t *batch, int32_t double_index, float *gate,
                   int64_t N, int32_t C, void *stream);
 
+/* The same gate with node_nn inside, from the layer input as planes:   ISubGVQA/models/masking.py:137, 151-155
+ *   gate[n] = gelu( < gelu(node_nn.0(x))[n,:], q[r(n),:] > / sqrt(C) )
+ * x_planes uint16 [N][2][128] + x_inv_scale fp32 [N]: the gated layer input as isg_gatv2_layer_conv reads it (isg_instr_gate_planes,
+ * isg_mgat_dense_tail's xp_out); w_frag / w_inv_scale = isg_split_f16x2_frag of node_nn.0.weight [128,128], b fp32 [128] its bias;
+ * q, batch, double_index, gate as isg_node_gate.  The Linear runs on the fp16 three-product form (isg_linear_f16x3's arithmetic),
+ * the reduction against q is isg_node_gate's; neither gelu(node_nn(x)) [N,128] nor an fp32 copy of x exists in memory.
+ * ISG_EUNSUPPORTED unless C == 128. */
+int isg_node_gate_planes(const uint16_t *x_planes, const float *x_inv_scale, const uint16_t *w_frag, const float *w_inv_scale,
+                         const float *b, const float *q, const int64_t *batch, int32_t double_index, float *gate, int64_t N,
+                         int32_t C, void *stream);
+
 /* Row layout shared by the samplers.  Row b has `Nmax` slots:
  *   ragged input  (ptr != NULL): slot j < n_b reads scores[ptr[b]+j], slots n_b..Nmax-1 are the
  *                 0.0 pads of to_dense_batch (masking.py:162) and DO compete; outputs are written

@@ -92,6 +92,116 @@ __global__ __launch_bounds__(256) void instr_gate_planes_kernel(const float *__r
   *reinterpret_cast<hf16x4 *>(planes + (int64_t)row * 256 + 128 + c4 * 4) = mid;
 }
 
+// The masked layer's node gate from the layer input's PLANES (masking.py:137, 151-155):
+//   gate_n = gelu( < gelu(node_nn(x))_n , q[r(n)] > / sqrt(C) ),   r(n) = batch[n] or batch[batch[n]] (quirk Q3)
+// 64 rows per workgroup (no graph alignment needed), 4 waves: the planes -- the same ones isg_gatv2_layer_conv reads -- go to LDS as
+// they are, node_nn is one transposed product per wave (32 columns x 64 rows, isg_linear_f16x3's arithmetic), its GELU'd result
+// stays in LDS as fp32 rows and is reduced against q exactly as node_gate_kernel does it (16 lanes per node, two float4 per lane,
+// the same butterfly).  The [N, 128] intermediate is neither written nor read back, and the fp32 copy of the gated rows that the
+// un-fused node_nn needed is not written by the previous layer's tail either.
+constexpr int NG_ROWS = 64, NG_C = 128, NG_LDA = NG_C + 8, NG_LDC = NG_C + 4;
+__global__ __launch_bounds__(256, 3) void node_gate_planes_kernel(const _Float16 *__restrict__ xp, const float *__restrict__ xinv,
+                                                                  const _Float16 *__restrict__ wf, const float *__restrict__ w_inv,
+                                                                  const float *__restrict__ bias, const float *__restrict__ q,
+                                                                  const long long *__restrict__ batch, int dbl,
+                                                                  float *__restrict__ gate, int N, float denom) {
+  __shared__ __attribute__((aligned(16))) unsigned char ng_smem[2 * NG_ROWS * NG_LDA * 2];
+  __shared__ float s_inv[NG_ROWS];
+  __shared__ int s_b[NG_ROWS];
+  typedef _Float16 (*BufP)[NG_ROWS][NG_LDA];
+  BufP sA = reinterpret_cast<BufP>(ng_smem);
+  float(*sC)[NG_LDC] = reinterpret_cast<float(*)[NG_LDC]>(ng_smem);       // aliases the planes once every wave is done with them
+  static_assert(NG_ROWS * NG_LDC * 4 <= 2 * NG_ROWS * NG_LDA * 2, "xn aliases the plane image");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
+  const int r0 = blockIdx.x * NG_ROWS, nrows = min(NG_ROWS, N - r0);
+  // the wave's 32-column tile of node_nn.0's fragments: requested first
+  constexpr unsigned plane = (unsigned)(NG_C / 32) * 8u * 1024u;
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wf), 0, (int)(2u * plane), 0x00020000);
+  hf16x8 wq[8][2];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      wq[ks][p] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 wr, lane * 16, (int)(((unsigned)wave * 8u + (unsigned)ks) * 1024u + p * plane), 0));
+  {
+    const int srow = tid >> 5, sc4 = tid & 31;       // 32 lanes x 16 bytes = one row's 512 bytes of (hi, mid) planes
+    hf32x4 pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int gr = min(r0 + srow + 8 * u, N - 1);
+      pv[u] = *reinterpret_cast<const hf32x4 *>(xp + (int64_t)gr * 256 + sc4 * 8);
+    }
+    if (tid < NG_ROWS) {
+      const int gr = min(r0 + tid, N - 1);
+      s_inv[tid] = xinv[gr];
+      long long b = batch[gr];
+      if (dbl) b = batch[min(b, (long long)N - 1)];          // batch[batch[n]] (quirk Q3)
+      s_b[tid] = (int)b;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 8 * u][(sc4 & 15) * 8]) = pv[u];
+  }
+  hf32x4 wi4[4], bv4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    wi4[g] = *reinterpret_cast<const hf32x4 *>(w_inv + wave * 32 + 8 * g + 4 * hh);
+    bv4[g] = *reinterpret_cast<const hf32x4 *>(bias + wave * 32 + 8 * g + 4 * hh);
+  }
+  __syncthreads();
+  hf32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  {
+    hf16x8 af[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) af[i][p] = *reinterpret_cast<const hf16x8 *>(&sA[p][i * 32 + fr][ks * 16 + fk]);
+      // transposed (W fragment = A operand): a lane holds ONE row and four runs of four columns
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][1], af[i][0], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][0], af[i][1], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks][0], af[i][0], acc[i], 0, 0, 0);
+    }
+  }
+  __syncthreads();          // every wave is done with the planes: xn may overwrite them
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + fr;
+    const float si = s_inv[row];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const isg_f32x2 va = gelu_exact2(isg_f32x2{(acc[i][4 * g] * si) * wi4[g][0] + bv4[g][0], (acc[i][4 * g + 1] * si) * wi4[g][1] + bv4[g][1]});
+      const isg_f32x2 vb = gelu_exact2(isg_f32x2{(acc[i][4 * g + 2] * si) * wi4[g][2] + bv4[g][2], (acc[i][4 * g + 3] * si) * wi4[g][3] + bv4[g][3]});
+      *reinterpret_cast<hf32x4 *>(&sC[row][wave * 32 + 8 * g + 4 * hh]) = hf32x4{va.x, va.y, vb.x, vb.y};
+    }
+  }
+  __syncthreads();
+  // node_gate_kernel's reduction: 16 lanes per node, lane l covers float4 columns l and l + 16
+  const int grp = lane >> 4, l = lane & 15;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int n = wave * 16 + it * 4 + grp;
+    float part = 0.f;
+    if (n < nrows) {
+      const float *qr = q + (int64_t)s_b[n] * NG_C;
+      part += dot4(*reinterpret_cast<const float4 *>(&sC[n][4 * l]), *reinterpret_cast<const float4 *>(qr + 4 * l));
+      part += dot4(*reinterpret_cast<const float4 *>(&sC[n][4 * (l + 16)]), *reinterpret_cast<const float4 *>(qr + 4 * (l + 16)));
+    }
+    const float dot = group_sum<16>(part);
+    if (n < nrows && l == 0) gate[r0 + n] = gelu_libm(dot / denom);
+  }
+}
+
 // KSE_T: 16-column steps of the edge product when known at compile time (8 = the 128 edge features of the model: no branch between
 // the MFMAs), 0 = read it from the arguments
 // SL01: 0 <= negative_slope <= 1 (the reference's 0.2): leaky_relu(z) = max(z, slope z), one instruction less per value
@@ -604,6 +714,24 @@ extern "C" int isg_instr_gate_planes(const float *x, const float *instr, const i
   if (!x || !instr || !batch || !planes || !inv_scale) return ISG_EINVAL;
   instr_gate_planes_kernel<<<(unsigned)((N + 7) / 8), 256, 0, as_stream(stream)>>>(x, instr, batch, out, reinterpret_cast<_Float16 *>(planes),
                                                                                    inv_scale, (int)N);
+  return check_launch();
+}
+
+// The masked layer's node gate (masking.py:137, 151-155) from the layer input's planes, node_nn inside: see node_gate_planes_kernel.
+// x_planes / x_inv_scale as isg_gatv2_layer_conv's; w_frag / w_inv_scale = isg_split_f16x2_frag of node_nn.0.weight [128,128], b its
+// bias; q fp32 [Bq,128] = ques_nn(u); gate fp32 [N] = isg_node_gate(gelu(node_nn(x)), q, ...) with the Linear on the fp16 three-
+// product form.  ISG_EUNSUPPORTED unless C == 128.
+extern "C" int isg_node_gate_planes(const uint16_t *x_planes, const float *x_inv_scale, const uint16_t *w_frag, const float *w_inv_scale,
+                                    const float *b, const float *q, const int64_t *batch, int32_t double_index, float *gate,
+                                    int64_t N, int32_t C, void *stream) {
+  if (N < 0 || C <= 0) return ISG_EINVAL;
+  auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (C != NG_C || mis(x_planes) || mis(w_inv_scale) || mis(b) || mis(q) || N >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  if (N == 0) return ISG_OK;
+  if (!x_planes || !x_inv_scale || !w_frag || !w_inv_scale || !b || !q || !batch || !gate) return ISG_EINVAL;
+  node_gate_planes_kernel<<<(unsigned)((N + NG_ROWS - 1) / NG_ROWS), 256, 0, as_stream(stream)>>>(
+      reinterpret_cast<const _Float16 *>(x_planes), x_inv_scale, reinterpret_cast<const _Float16 *>(w_frag), w_inv_scale, b, q,
+      reinterpret_cast<const long long *>(batch), double_index, gate, (int)N, sqrtf((float)C));   // torch.sqrt(torch.tensor(C)): fp32
   return check_launch();
 }
 

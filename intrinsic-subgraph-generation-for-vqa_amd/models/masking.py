@@ -62,23 +62,33 @@ class MaskingModel(torch.nn.Module):
                 if hasattr(m, "reset_parameters"):
                     m.reset_parameters()
 
-    def gate_scores(self, x: Tensor, u: Tensor, batch: Tensor, u_is_per_graph: bool = False, plan=None) -> Tensor:
+    def planes_ready(self, u: Tensor) -> bool:
+        """Will gate_scores() run on the layer input's planes (isg_node_gate_planes)?  Then no fp32 copy of the input is needed."""
+        return (u is not None and u.dim() == 2 and u.size(1) == self.dim_questions == 128 and self.dim_nodes == 128
+                and u.dtype == torch.float32 and ops.node_gate_planes_supported(self.node_nn, u))
+
+    def gate_scores(self, x: Tensor, u: Tensor, batch: Tensor, u_is_per_graph: bool = False, plan=None,
+                    x_planes=None) -> Tensor:
         """masking.py:137,151-155 -> [N,1].  ``u_is_per_graph``: u is [B,C] and the caller would have passed
         u[batch]; the reference then indexes ques_nn(u[batch]) with batch AGAIN (quirk Q3), which equals
         ques_nn(u)[batch[batch]] row for row -- computed here without the N-row GEMM."""
-        xn = ops.mlp(self.node_nn, x)
         q = ops.mlp(self.ques_nn, u)
+        if x_planes is not None and self.planes_ready(u):
+            # node_nn + the reduction against q as one launch on the planes the convolution reads anyway
+            return ops.node_gate_planes(x_planes, self.node_nn, q.contiguous(), batch, double_index=u_is_per_graph)
+        xn = ops.mlp(self.node_nn, x)
         return ops.node_gate(xn.contiguous(), q.contiguous(), batch, double_index=u_is_per_graph,
                              plan=plan)
 
     def forward(self, x, u, batch, edge_index, size=None, use_all_instrs=True, plan: Optional[ops.GraphPlan] = None,
-                noise: Optional[Tensor] = None, seed: Optional[int] = None, u_is_per_graph: bool = False):
+                noise: Optional[Tensor] = None, seed: Optional[int] = None, u_is_per_graph: bool = False, x_planes=None):
         if use_all_instrs:
             raise NotImplementedError("use_all_instrs=True (masking.py:141-149) is off by default and outside this path")
-        x = x.unsqueeze(-1) if x.dim() == 1 else x
+        if x is not None:
+            x = x.unsqueeze(-1) if x.dim() == 1 else x
         if plan is None:
             plan = ops.GraphPlan.build(batch, None, num_graphs=size)
-        gate = self.gate_scores(x, u, batch, u_is_per_graph, plan)
+        gate = self.gate_scores(x, u, batch, u_is_per_graph, plan, x_planes=x_planes)
         if not self.use_topk:                                               # masking.py:195-198
             gate = F.dropout(gate, p=self.gate_dropout, training=self.training)
             return (torch.sigmoid(gate) > 0.5).to(dtype=gate.dtype)

@@ -119,7 +119,7 @@ class MGAT(torch.nn.Module):
                     cn = self.convs[i + 1]
                     want_planes = cn.layer_conv_ready(plan, h.size(1), edge_attr,
                                                       None if e_projs is None else e_projs[i + 1])
-                    want_rows = (not want_planes) or cn.mask.masking_threshold != 1.0
+                    want_rows = cn.needs_rows(plan, h.size(1), edge_attr, None if e_projs is None else e_projs[i + 1], glf)
                 res = ops.mgat_dense_tail(conv_res, self.x_proj[i], ins, h, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps,
                                           node_mask=tail_mask, ins_next=nxt, want_rows=want_rows, want_planes=want_planes)
                 if res is not None:

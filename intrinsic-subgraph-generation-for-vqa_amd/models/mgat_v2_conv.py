@@ -87,6 +87,13 @@ class MaskingGATv2Conv(torch.nn.Module):
         xr_inside = pair and ops.FUSE_XR and in_channels <= 128 and in_channels % 4 == 0
         return bool(pair and not xr_inside and ops.layer_conv_supported(plan, H, C, in_channels, edge_attr.size(1)))
 
+    def needs_rows(self, plan, in_channels: int, edge_attr, e_proj=None, imle_att=None) -> bool:
+        """Does forward() read the gated layer input as fp32 ROWS (beside, or instead of, its planes)?  Only the un-fused
+        convolution and a node gate that cannot run on the planes do."""
+        if not self.layer_conv_ready(plan, in_channels, edge_attr, e_proj):
+            return True
+        return self.mask.masking_threshold != 1.0 and not self.mask.planes_ready(imle_att)
+
     def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, edge_attr: Optional[Tensor] = None,
                 instruction: Optional[Tensor] = None, imle_att: Optional[Tensor] = None,
                 return_attention_weights: bool = None, return_masks: bool = None, all_instrs=None,
@@ -101,25 +108,25 @@ class MaskingGATv2Conv(torch.nn.Module):
         if plan is None:
             plan = ops.GraphPlan.build(batch, edge_index,
                                        num_graphs=None if instruction is None else instruction.size(0))
-        masked = self.mask.masking_threshold != 1.0
         layer_conv = self.layer_conv_ready(plan, x.size(1), edge_attr, e_proj)
+        need_rows = self.needs_rows(plan, x.size(1), edge_attr, e_proj, imle_att)
         planes = None          # gelu(x * instruction[batch]) as the planes isg_gatv2_layer_conv reads (fp32 rows only where needed)
         if (x_gated is not None or x_planes is not None) and self.use_instr:
             # gelu(x * instruction[batch]) was already written by the previous layer's fused tail (isg_mgat_dense_tail)
             x, planes = x_gated, x_planes
-            if x is None and (masked or not layer_conv):
+            if x is None and need_rows:
                 raise RuntimeError("the previous layer's tail left no fp32 rows of the gated input, and this layer needs them")
         else:
             x = x.float().contiguous()
             if self.use_instr and layer_conv:
-                x, planes = ops.instr_gate_planes(x, instruction.contiguous(), batch, want_rows=masked)   # :156-157
+                x, planes = ops.instr_gate_planes(x, instruction.contiguous(), batch, want_rows=need_rows)   # :156-157
             elif self.use_instr:
                 x = ops.instr_gate(x, instruction.contiguous(), batch, plan=plan)        # :156-157
 
         mask = None
         if self.mask.masking_threshold != 1.0:                                           # :161
             mask = self.mask(x, imle_att, batch, edge_index, use_all_instrs=False, plan=plan, noise=noise,
-                             seed=seed, u_is_per_graph=True)                              # :166-168
+                             seed=seed, u_is_per_graph=True, x_planes=planes)             # :166-168
 
         fdt = self.feature_dtype
         if layer_conv:

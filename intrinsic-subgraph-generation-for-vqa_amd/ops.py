@@ -928,6 +928,35 @@ def node_gate(xn: Tensor, q: Tensor, batch: Tensor, double_index: bool, plan: Op
     return gate
 
 
+FUSE_GATE = True           # the masked layer's node gate from the layer input's planes, node_nn inside (A/B switch)
+
+
+def node_gate_planes_supported(node_nn: torch.nn.Sequential, q: Tensor) -> bool:
+    """Shape test of isg_node_gate_planes: inference, node_nn = Linear(128 -> 128) + exact GELU, 128-wide question rows."""
+    if not (FUSE_GATE and GEMM_BACKEND == "bf16x6" and GEMM_F16X3) or torch.is_grad_enabled():
+        return False
+    mods = list(node_nn)
+    if len(mods) != 2 or not isinstance(mods[0], torch.nn.Linear) or not isinstance(mods[1], torch.nn.GELU) \
+            or mods[1].approximate != "none" or mods[0].bias is None:
+        return False
+    return tuple(mods[0].weight.shape) == (128, 128) and q.dim() == 2 and q.size(1) == 128 and q.dtype == torch.float32
+
+
+def node_gate_planes(x: "NodePlanes", node_nn: torch.nn.Sequential, q: Tensor, batch: Tensor, double_index: bool) -> Tensor:
+    """gelu(<gelu(node_nn(x))_n, q[r(n)]>/sqrt(C)) -> [N,1] (masking.py:137, 151-155) from the layer input as NodePlanes:
+    isg_node_gate_planes.  The caller checks node_gate_planes_supported() first."""
+    lib = _lib.load()
+    N = batch.numel()
+    l0 = node_nn[0]
+    wp, w_inv = _weight_planes(l0.weight, True, "f16x3")
+    gate = torch.empty(N, 1, dtype=torch.float32, device=q.device)
+    _lib.check(lib.isg_node_gate_planes(x.planes.data_ptr(), x.inv.data_ptr(), wp.data_ptr(), w_inv.data_ptr(),
+                                        _chk(l0.bias.detach(), "node_nn.0.bias", torch.float32, (128,)),
+                                        _chk(q, "q", torch.float32, (q.size(0), 128)), _chk(batch, "batch", torch.int64, (N,)),
+                                        1 if double_index else 0, gate.data_ptr(), N, 128, _stream()), "isg_node_gate_planes")
+    return gate
+
+
 def _rows(scores: Tensor, plan: Optional[GraphPlan]):
     """(ptr, B, nmax_host, nmax_dev, out) for the ragged (plan) or dense ([B,Nmax]) row layout."""
     if plan is not None:

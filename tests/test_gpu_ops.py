@@ -1135,6 +1135,36 @@ def _dense_tail_case(dev, sizes, seed, masked, with_next):
     return e_or
 
 
+def test_node_gate_planes_matches_node_nn_plus_node_gate(dev):
+    """isg_node_gate_planes (node_nn + GELU + the reduction against q, from the layer input's planes) against the chain it
+    replaces (ops.mlp(node_nn) + isg_node_gate on fp32 rows) and against a float64 restatement of masking.py:137, 151-155; both
+    index forms (quirk Q3), ragged last block, a zero row."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(31)
+    for sizes in ([5], [64], [64, 1, 63, 2, 20, 20, 7], torch.randint(8, 34, (300,), generator=gen).tolist()):
+        N, B, C = sum(sizes), len(sizes), 128
+        batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes)).to(dev)
+        x = (torch.randn(N, C, generator=gen) * torch.rand(N, 1, generator=gen).mul(3).exp()).to(dev)
+        x[N // 2] = 0.0
+        node_nn = torch.nn.Sequential(torch.nn.Linear(C, C), torch.nn.GELU()).to(dev)
+        q = torch.randn(B, C, generator=gen).to(dev)
+        with torch.no_grad():
+            assert ops.node_gate_planes_supported(node_nn, q)
+            xp = ops.node_planes(x)
+            for dbl in (False, True):
+                if dbl and N <= B:
+                    continue
+                got = ops.node_gate_planes(xp, node_nn, q, batch, double_index=dbl)
+                ref = ops.node_gate(ops.mlp(node_nn, x).contiguous(), q, batch, double_index=dbl)
+                rows = batch[batch.clamp(max=N - 1)] if dbl else batch
+                xn64 = torch.nn.functional.gelu(x.double() @ node_nn[0].weight.double().t() + node_nn[0].bias.double())
+                want = torch.nn.functional.gelu((xn64 * q.double()[rows]).sum(1) / math.sqrt(C)).float().view(N, 1)
+                scale = want.abs().max().item()
+                e_got, e_ref = (got - want).abs().max().item(), (ref - want).abs().max().item()
+                assert got.shape == ref.shape == (N, 1)
+                assert e_got <= max(3e-6 * max(scale, 1.0), 3.0 * e_ref), (sizes[:3], dbl, e_got, e_ref)
+
+
 def test_instr_gate_planes_is_the_gate_followed_by_the_row_split(dev):
     """isg_instr_gate_planes = isg_instr_gate, then the per-row scale / (hi, mid) split of isg_edge_planes in row order: bit for
     bit, with and without the fp32 rows beside the planes; and the planes decode back to the rows within the split's 2^-22."""
