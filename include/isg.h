@@ -97,6 +97,11 @@ int isg_instr_gate(const float *x, const float *instr, const int64_t *batch, flo
 int isg_instr_gate_planes(const float *x, const float *instr, const int64_t *batch, float *out, uint16_t *planes,
                           float *inv_scale, int64_t N, int32_t C, void *stream);
 
+/* out = cat((a, b, a * b), dim=1), rowmax[m] = max |out[m,:]|      ISubGVQA/models/isubgvqa.py:288-291 (the classifier head's
+ * input; the maxima are the row scales' input of the exact-split Linear that reads it).  a, b fp32 [M,C]; out fp32 [M,3C];
+ * rowmax fp32 [M].  ISG_EUNSUPPORTED unless C % 4 == 0. */
+int isg_cat_mul_rowmax(const float *a, const float *b, float *out, float *rowmax, int64_t M, int32_t C, void *stream);
+
 /* edge_mask[e] = mask[src[e]] * mask[dst[e]]        ISubGVQA/sampling/node_edge_masks.py:7-10
  * mask fp32[N]; edge_index int64[2,E]; out fp32[E]. */
 int isg_node_to_edge_mask(const float *node_mask, const int64_t *edge_index, int64_t E, float *out,

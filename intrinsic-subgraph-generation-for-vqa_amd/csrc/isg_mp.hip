@@ -214,6 +214,31 @@ __global__ void instr_gate_kernel(const float4 *__restrict__ x, const float4 *__
   out[idx] = make_float4(g0.x, g0.y, g1.x, g1.y);
 }
 
+// cat((a, b, a * b), dim=1) with the row maxima of the result beside it (isubgvqa.py:288-291: the classifier head's input).
+// 32 lanes per row, float4 pieces; the maxima feed the row scales of the Linear that reads the result (isg_linear_f16x3_tile),
+// which would otherwise make its own pass over it.
+__global__ __launch_bounds__(256) void cat_mul_rowmax_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                             float *__restrict__ out, float *__restrict__ rowmax, int M, int Q) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  if (row >= M) return;
+  const float4 *ar = reinterpret_cast<const float4 *>(a) + (size_t)row * Q;
+  const float4 *br = reinterpret_cast<const float4 *>(b) + (size_t)row * Q;
+  float4 *o = reinterpret_cast<float4 *>(out) + (size_t)row * 3 * Q;
+  float mx = 0.f;
+  for (int c = l; c < Q; c += 32) {
+    const float4 x = ar[c], y = br[c];
+    const float4 p = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+    o[c] = x;
+    o[Q + c] = y;
+    o[2 * Q + c] = p;
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))),
+                         fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))));
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), fabsf(p.w))));
+  }
+  mx = group_max<32>(mx);
+  if (l == 0) rowmax[row] = mx;
+}
+
 __global__ void node_to_edge_mask_kernel(const float *__restrict__ mask, const int64_t *__restrict__ ei, int64_t E,
                                          float *__restrict__ out) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -324,6 +349,17 @@ extern "C" int isg_instr_gate(const float *x, const float *instr, const int64_t 
   if ((total + 255) / 256 >= (1ll << 31)) return ISG_EUNSUPPORTED;
   instr_gate_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(
       (const float4 *)x, (const float4 *)instr, batch, (float4 *)out, total, Q);
+  return check_launch();
+}
+
+extern "C" int isg_cat_mul_rowmax(const float *a, const float *b, float *out, float *rowmax, int64_t M, int32_t C, void *stream) {
+  if (M < 0 || C <= 0) return ISG_EINVAL;
+  if ((C & 3) != 0 || M >= (1ll << 31) || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                                            reinterpret_cast<uintptr_t>(out)) & 15) != 0)
+    return ISG_EUNSUPPORTED;
+  if (M == 0) return ISG_OK;
+  if (!a || !b || !out || !rowmax) return ISG_EINVAL;
+  cat_mul_rowmax_kernel<<<(unsigned)((M + 7) / 8), 256, 0, as_stream(stream)>>>(a, b, out, rowmax, (int)M, C >> 2);
   return check_launch();
 }
 

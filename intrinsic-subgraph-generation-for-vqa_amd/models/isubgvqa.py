@@ -103,7 +103,7 @@ class ISubGVQA(torch.nn.Module):
             explainer_stage=explainer_stage, expl_bypass_x=expl_bypass_x, plan=plan, noises=noises, seed=seed)
         embed, gate = self.graph_global_attention_pooling(x=x_mgat, u=glf, batch=batch, size=None,
                                                           return_mask=True, node_mask=imle_mask, plan=plan)
-        feats = ops.mlp(self.embedding, torch.cat((embed, glf, embed * glf), dim=1))     # :288-291
+        feats = ops.mlp(self.embedding, ops.cat_mul(embed, glf), want_rowmax=True)       # :288-291 (row maxima: for logit_fc)
         return ops.linear(feats, self.logit_fc.weight, self.logit_fc.bias), imle_mask, gate, node_logits_layers   # :292
 
     def forward(self, node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask,

@@ -1602,8 +1602,27 @@ def linear_wgrad(grad_out: Tensor, x: Tensor) -> Tensor:
     return part.sum(0) if splits > 1 else part[0]
 
 
-def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:   # x may be fp16 feature rows; the output is fp32
-    """Run an nn.Sequential of Linear / GELU / Dropout(eval) modules with every Linear(+GELU) pair as one launch."""
+def cat_mul(a: Tensor, b: Tensor) -> Tensor:
+    """cat((a, b, a * b), dim=1) (isubgvqa.py:288-291).  Inference on fp32 rows: one launch that also leaves the result's row
+    maxima on it for the Linear that follows (isg_cat_mul_rowmax); otherwise the torch ops."""
+    if (_rec(a, b) or a.dtype != torch.float32 or b.dtype != torch.float32 or a.dim() != 2 or a.shape != b.shape
+            or a.size(1) % 4 != 0 or not a.is_cuda):
+        return torch.cat((a, b, a * b), dim=1)
+    lib = _lib.load()
+    M, C = a.shape
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty(M, 3 * C, dtype=torch.float32, device=a.device)
+    rm = torch.empty(M, 1, dtype=torch.float32, device=a.device)
+    rc = lib.isg_cat_mul_rowmax(a.data_ptr(), b.data_ptr(), out.data_ptr(), rm.data_ptr(), M, C, _stream())
+    if rc == ISG_EUNSUPPORTED:
+        return torch.cat((a, b, a * b), dim=1)
+    _lib.check(rc, "isg_cat_mul_rowmax")
+    return attach_row_maxima(out, rm)
+
+
+def mlp(seq: torch.nn.Sequential, x: Tensor, want_rowmax: bool = False) -> Tensor:   # x may be fp16 feature rows; the output is fp32
+    """Run an nn.Sequential of Linear / GELU / Dropout(eval) modules with every Linear(+GELU) pair as one launch.
+    ``want_rowmax``: the caller feeds the result to another Linear (the last launch's epilogue leaves its row maxima on it)."""
     mods = list(seq)
     i = 0
     while i < len(mods):
@@ -1616,7 +1635,7 @@ def mlp(seq: torch.nn.Sequential, x: Tensor) -> Tensor:   # x may be fp16 featur
             x = x.contiguous()
             if rm is not None:
                 attach_row_maxima(x, rm)
-            x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more)      # the epilogue's maxima cost next to nothing
+            x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more or (want_rowmax and nxt >= len(mods)))      # the epilogue's maxima cost next to nothing
             i = nxt
         else:
             x = m(x)

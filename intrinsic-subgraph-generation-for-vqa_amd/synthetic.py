@@ -163,7 +163,7 @@ class AnswerModel(torch.nn.Module):
         embed, gate = self.graph_global_attention_pooling(x=h, u=wl.glf, batch=wl.batch, size=None, return_mask=True,
                                                           node_mask=mask, plan=plan)
         from . import ops as _ops
-        feats = _ops.mlp(self.embedding, torch.cat((embed, wl.glf, embed * wl.glf), dim=1))
+        feats = _ops.mlp(self.embedding, _ops.cat_mul(embed, wl.glf), want_rowmax=True)
         return _ops.linear(feats, self.logit_fc.weight, self.logit_fc.bias), mask, gate
 
 

@@ -1135,6 +1135,32 @@ def _dense_tail_case(dev, sizes, seed, masked, with_next):
     return e_or
 
 
+def test_cat_mul_leaves_the_row_maxima_for_the_next_linear(dev):
+    """isg_cat_mul_rowmax = torch.cat((a, b, a * b), 1) bit for bit, with max |row| beside it; a Linear over the result then makes
+    no pass of its own (COUNTERS['row_absmax'] stays put) and returns the bits it returns after its own pass."""
+    from isubgvqa_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for M, C in ((1, 128), (37, 128), (4096, 128), (100, 36)):
+        a = (torch.randn(M, C, generator=g) * torch.rand(M, 1, generator=g).mul(4).exp()).to(dev)
+        b = torch.randn(M, C, generator=g).to(dev)
+        a[M // 2] = 0.0
+        with torch.no_grad():
+            got = ops.cat_mul(a, b)
+        want = torch.cat((a, b, a * b), dim=1)
+        assert torch.equal(got, want)
+        rm = ops.row_maxima(got)
+        assert rm is not None and torch.equal(rm.view(-1), want.abs().amax(dim=1))
+    lin = torch.nn.Linear(3 * 128, 512).to(dev)
+    a, b = torch.randn(4096, 128, generator=g).to(dev), torch.randn(4096, 128, generator=g).to(dev)
+    with torch.no_grad():
+        ops.reset_counters()
+        y1 = ops.linear(ops.cat_mul(a, b), lin.weight, lin.bias, gelu=True)
+        assert ops.counters()["row_absmax"] == 0
+        y2 = ops.linear(torch.cat((a, b, a * b), dim=1), lin.weight, lin.bias, gelu=True)
+        assert ops.counters()["row_absmax"] == 1
+    assert torch.equal(y1, y2)
+
+
 def test_node_gate_planes_matches_node_nn_plus_node_gate(dev):
     """isg_node_gate_planes (node_nn + GELU + the reduction against q, from the layer input's planes) against the chain it
     replaces (ops.mlp(node_nn) + isg_node_gate on fp32 rows) and against a float64 restatement of masking.py:137, 151-155; both
