@@ -1635,7 +1635,9 @@ def mlp(seq: torch.nn.Sequential, x: Tensor, want_rowmax: bool = False) -> Tenso
             x = x.contiguous()
             if rm is not None:
                 attach_row_maxima(x, rm)
-            x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more or (want_rowmax and nxt >= len(mods)))      # the epilogue's maxima cost next to nothing
+            tail = want_rowmax and not any(hasattr(t, "weight") and getattr(t.weight, "dim", lambda: 0)() == 2 for t in mods[nxt:]) \
+                and all(isinstance(t, torch.nn.Dropout) and not t.training for t in mods[nxt:])   # only identities follow
+            x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more or tail)      # the epilogue's maxima cost next to nothing
             i = nxt
         else:
             x = m(x)
