@@ -319,6 +319,14 @@ int isg_readout_tile(const float *x, int32_t ldx, const uint16_t *w1_frag, const
 int isg_edge_planes(const float *edge_attr, int32_t lda, const int32_t *eid, int64_t E, int32_t K, uint16_t *planes,
                     float *inv_scale, void *stream);
 
+/* isg_tile_plan and isg_edge_planes as ONE launch: both depend on the graph plan only, and the tile plan is a single workgroup
+ * (22 us at 4096 graphs) that otherwise has the chip to itself; here it is workgroup 0 of the launch that splits the edge rows.
+ * Operands and results exactly as the two entry points'. */
+int isg_tile_plan_edge_planes(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
+                              int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity, const float *edge_attr,
+                              int32_t lda, const int32_t *eid, int64_t E, int32_t K, uint16_t *planes, float *inv_scale,
+                              void *stream);
+
 /* Question-conditioned softmax pooling: GlobalAttention.forward, ISubGVQA/models/att_pooling.py:63-73
  *   x = xn * node_mask;  gate = softmax_g(<x, q[g]>/sqrt(C)) (+1e-16 in the denominator);
  *   out[g,:] = sum_n gate[n] * x[n,:]

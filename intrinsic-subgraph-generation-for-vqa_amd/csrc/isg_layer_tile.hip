@@ -51,9 +51,9 @@ namespace isg {
 // =====================================================================================================================
 constexpr int TP_CH = 1024;
 
-__global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict__ ptr, const int *__restrict__ eptr, int B,
-                                                          int ncap, int ecap, int *__restrict__ tile_ptr,
-                                                          int *__restrict__ ntiles, int cap, int4 *__restrict__ tile_info) {
+__device__ __forceinline__ void tile_plan_body(const int *__restrict__ ptr, const int *__restrict__ eptr, int B, int ncap, int ecap,
+                                               int *__restrict__ tile_ptr, int *__restrict__ ntiles, int cap,
+                                               int4 *__restrict__ tile_info) {
   __shared__ int s_jump[2][TP_CH];
   __shared__ int s_mark[TP_CH];
   __shared__ int s_ptr[TP_CH + 1], s_eptr[TP_CH + 1];
@@ -127,6 +127,12 @@ __global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict_
     tile_ptr[T] = B;
     *ntiles = T;
   }
+}
+
+__global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict__ ptr, const int *__restrict__ eptr, int B,
+                                                          int ncap, int ecap, int *__restrict__ tile_ptr,
+                                                          int *__restrict__ ntiles, int cap, int4 *__restrict__ tile_info) {
+  tile_plan_body(ptr, eptr, B, ncap, ecap, tile_ptr, ntiles, cap, tile_info);
 }
 
 // =====================================================================================================================
@@ -672,9 +678,8 @@ struct TcArgs {
 // The edge features are the same for every layer and every head of a step: their row scales and (hi, mid) fp16 planes are formed
 // ONCE per batch, in CSR slot order (a tile's slots are then one contiguous 512-byte-per-slot range), instead of in every
 // (layer, head, chunk) staging pass -- that conversion was ~30 % of the tile kernel's instructions.
-__global__ __launch_bounds__(256) void edge_planes_kernel(const float *__restrict__ edge_attr, int lda, const int *__restrict__ eid,
-                                                          int E, int K, _Float16 *__restrict__ planes, float *__restrict__ inv_out) {
-  const int slot = blockIdx.x * 8 + (threadIdx.x >> 5), c4 = threadIdx.x & 31;
+__device__ __forceinline__ void edge_planes_row(const float *__restrict__ edge_attr, int lda, const int *__restrict__ eid, int E, int K,
+                                                _Float16 *__restrict__ planes, float *__restrict__ inv_out, int slot, int c4) {
   if (slot >= E) return;
   const int e = eid ? eid[slot] : slot;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -689,6 +694,26 @@ __global__ __launch_bounds__(256) void edge_planes_kernel(const float *__restric
                 (_Float16)(v.w - (float)hi[3])};
   *reinterpret_cast<hf16x4 *>(planes + (int64_t)slot * 256 + c4 * 4) = hi;
   *reinterpret_cast<hf16x4 *>(planes + (int64_t)slot * 256 + 128 + c4 * 4) = mid;
+}
+
+__global__ __launch_bounds__(256) void edge_planes_kernel(const float *__restrict__ edge_attr, int lda, const int *__restrict__ eid,
+                                                          int E, int K, _Float16 *__restrict__ planes, float *__restrict__ inv_out) {
+  edge_planes_row(edge_attr, lda, eid, E, K, planes, inv_out, blockIdx.x * 8 + (threadIdx.x >> 5), threadIdx.x & 31);
+}
+
+// The tile plan (ONE workgroup, 22 us of barriers and LDS latency) and the edge planes (every CU, 36 us) depend on the graph plan
+// only, not on each other: as one launch -- workgroup 0 plans the tiles, the others split 32 edge rows each -- the tile plan runs
+// beside the planes instead of alone on the chip.
+__global__ __launch_bounds__(TP_CH) void tile_plan_edge_planes_kernel(const int *__restrict__ ptr, const int *__restrict__ eptr, int B,
+                                                                      int ncap, int ecap, int *__restrict__ tile_ptr,
+                                                                      int *__restrict__ ntiles, int cap, int4 *__restrict__ tile_info,
+                                                                      const float *__restrict__ edge_attr, int lda,
+                                                                      const int *__restrict__ eid, int E, int K,
+                                                                      _Float16 *__restrict__ planes, float *__restrict__ inv_out) {
+  if (blockIdx.x == 0)
+    tile_plan_body(ptr, eptr, B, ncap, ecap, tile_ptr, ntiles, cap, tile_info);
+  else
+    edge_planes_row(edge_attr, lda, eid, E, K, planes, inv_out, (blockIdx.x - 1) * 32 + (threadIdx.x >> 5), threadIdx.x & 31);
 }
 
 // PERSISTENT: the grid is two workgroups per CU; a workgroup keeps ONE head (its W fragments never leave its registers) and walks
@@ -1046,5 +1071,23 @@ extern "C" int isg_edge_planes(const float *edge_attr, int32_t lda, const int32_
   if (!edge_attr || !planes || !inv_scale) return ISG_EINVAL;
   edge_planes_kernel<<<(unsigned)((E + 7) / 8), 256, 0, as_stream(stream)>>>(edge_attr, lda, eid, (int)E, K,
                                                                              reinterpret_cast<_Float16 *>(planes), inv_scale);
+  return check_launch();
+}
+
+// isg_tile_plan + isg_edge_planes as ONE launch (see tile_plan_edge_planes_kernel): same operands, same results.
+extern "C" int isg_tile_plan_edge_planes(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
+                                         int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity,
+                                         const float *edge_attr, int32_t lda, const int32_t *eid, int64_t E, int32_t K,
+                                         uint16_t *planes, float *inv_scale, void *stream) {
+  if (B < 0 || node_cap <= 0 || capacity < 0 || !tile_ptr || !ntiles || (B > 0 && !ptr) || E < 0 || K <= 0 || lda < K) return ISG_EINVAL;
+  if (eptr && edge_cap <= 0) return ISG_EINVAL;
+  if (B >= (1ll << 31) || capacity >= (1ll << 31) || K > 128 || (K & 3) != 0 || (lda & 3) != 0 ||
+      (reinterpret_cast<uintptr_t>(edge_attr) & 15) != 0 || (reinterpret_cast<uintptr_t>(planes) & 15) != 0 || E >= (1ll << 31) - 1024)
+    return ISG_EUNSUPPORTED;
+  if (tile_info && (reinterpret_cast<uintptr_t>(tile_info) & 15) != 0) return ISG_EINVAL;
+  if (E > 0 && (!edge_attr || !planes || !inv_scale)) return ISG_EINVAL;
+  tile_plan_edge_planes_kernel<<<(unsigned)(1 + (E + 31) / 32), TP_CH, 0, as_stream(stream)>>>(
+      ptr, eptr, (int)B, node_cap, edge_cap, tile_ptr, ntiles, (int)capacity, reinterpret_cast<int4 *>(tile_info), edge_attr, lda, eid,
+      (int)E, K, reinterpret_cast<_Float16 *>(planes), inv_scale);
   return check_launch();
 }

@@ -203,6 +203,35 @@ class GraphPlan:
             self._edge_planes = hit
         return hit[1], hit[2]
 
+    def tiles_and_edge_planes(self, edge_attr: Tensor, node_cap: int, edge_cap: int):
+        """(tiles(node_cap, edge_cap), edge_planes(edge_attr)); when neither exists yet they are made by ONE launch
+        (isg_tile_plan_edge_planes: the one-workgroup tile plan runs beside the row split instead of alone on the chip)."""
+        key = (int(node_cap), int(edge_cap))
+        ekey = (id(edge_attr), edge_attr.data_ptr(), _ver(edge_attr), tuple(edge_attr.shape))
+        have_t = self._tiles is not None and key in self._tiles
+        have_e = self._edge_planes is not None and self._edge_planes[0] == ekey
+        if PLAN_FUSED and not have_t and not have_e and edge_cap > 0 and edge_attr.dim() == 2 and edge_attr.size(1) <= 128 \
+                and edge_attr.size(1) % 4 == 0 and edge_attr.dtype == torch.float32:
+            lib = _lib.load()
+            self.require_csr()
+            E, K = edge_attr.shape
+            cap = int(lib.isg_tile_plan_capacity(self.N, self.E, self.B, key[0], key[1]))
+            buf = torch.empty(5 * cap + 8, dtype=torch.int32, device=self.ptr.device)     # info first: 16-byte aligned
+            info, tp, nt = buf[:4 * cap], buf[4 * cap + 4:5 * cap + 5], buf[5 * cap + 5:5 * cap + 6]
+            planes = torch.empty(max(E, 1), 2, 128, dtype=torch.int16, device=edge_attr.device)
+            inv = torch.empty(max(E, 1), dtype=torch.float32, device=edge_attr.device)
+            rc = lib.isg_tile_plan_edge_planes(self.ptr.data_ptr(), self.eptr.data_ptr(), self.B, key[0], key[1], tp.data_ptr(),
+                                               nt.data_ptr(), info.data_ptr(), cap, _chk_rows(edge_attr, "edge_attr"),
+                                               edge_attr.stride(0), self.eid.data_ptr(), E, K, planes.data_ptr(), inv.data_ptr(),
+                                               _stream())
+            if rc != ISG_EUNSUPPORTED:
+                _lib.check(rc, "isg_tile_plan_edge_planes")
+                if self._tiles is None:
+                    self._tiles = {}
+                self._tiles[key] = (tp, nt, cap, info.view(cap, 4))
+                self._edge_planes = (ekey, planes, inv)
+        return self.tiles(node_cap, edge_cap), self.edge_planes(edge_attr)
+
     def tiles(self, node_cap: int = 64, edge_cap: int = 0) -> Tuple[Tensor, Tensor, int, Tensor]:
         """(tile_ptr int32[cap + 1], ntiles int32[1] on the device, cap, tile_info int32[cap, 4]): consecutive graphs packed greedily into tiles of
         at most `node_cap` nodes (and `edge_cap` CSR slots when > 0) -- the M-tiles of the fused per-layer kernels
@@ -680,8 +709,7 @@ def gatv2_layer_conv(x, lin_l, lin_r, edge_attr: Tensor, w_edge: Tensor, att: Te
     cat_b = derived_weight("layer_conv_b", srcs, lambda: torch.cat([zeros(lin_l), zeros(lin_r)]).float().contiguous())
     wn, wn_inv = _weight_planes(cat_w, True, "f16x3")
     we, we_inv = _weight_planes(w_edge, True, "f16x3")
-    ep, ep_inv = plan.edge_planes(edge_attr)
-    _, ntiles, cap, tile_info = plan.tiles(TILE_CONV_NODES, TILE_CONV_EDGES)
+    (_, ntiles, cap, tile_info), (ep, ep_inv) = plan.tiles_and_edge_planes(edge_attr, TILE_CONV_NODES, TILE_CONV_EDGES)
     out = torch.empty(N, HC, dtype=torch.float32, device=dev)
     alpha = torch.empty(E, H, dtype=torch.float32, device=dev)
     rowmax = torch.empty(N, H, dtype=torch.float32, device=dev) if want_rowmax else None

@@ -1135,6 +1135,28 @@ def _dense_tail_case(dev, sizes, seed, masked, with_next):
     return e_or
 
 
+def test_tile_plan_and_edge_planes_as_one_launch_equal_the_two(dev):
+    """GraphPlan.tiles_and_edge_planes (isg_tile_plan_edge_planes: workgroup 0 plans the tiles beside the row split) against
+    isg_tile_plan + isg_edge_planes on a second plan of the same batch: every output equal; and what is cached is reused."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(41)
+    for sizes, K in (([1], 128), ([64, 1, 63, 2, 62, 20, 20, 20, 5, 0, 3], 36), (torch.randint(1, 40, (2500,), generator=gen).tolist(), 128)):
+        batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5)
+        B, E = len(sizes), ei.size(1)
+        ea = torch.randn(E, K, generator=gen).to(dev)
+        p1 = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+        p2 = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+        (tp1, nt1, cap1, info1), (pl1, inv1) = p1.tiles_and_edge_planes(ea, 64, 256)
+        tp2, nt2, cap2, info2 = p2.tiles(64, 256)
+        pl2, inv2 = p2.edge_planes(ea)
+        T = int(nt1.item())
+        assert T == int(nt2.item()) and cap1 == cap2
+        assert torch.equal(tp1[:T + 1], tp2[:T + 1]) and torch.equal(info1[:T], info2[:T])
+        assert torch.equal(pl1[:E], pl2[:E]) and torch.equal(inv1[:E], inv2[:E])
+        again = p1.tiles_and_edge_planes(ea, 64, 256)
+        assert again[0][0] is tp1 and again[1][0] is pl1
+
+
 def test_cat_mul_leaves_the_row_maxima_for_the_next_linear(dev):
     """isg_cat_mul_rowmax = torch.cat((a, b, a * b), 1) bit for bit, with max |row| beside it; a Linear over the result then makes
     no pass of its own (COUNTERS['row_absmax'] stays put) and returns the bits it returns after its own pass."""
