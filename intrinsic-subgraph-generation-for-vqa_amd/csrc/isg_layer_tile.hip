@@ -34,7 +34,8 @@ static __device__ long long *g_dt_stamps = nullptr;
 
 #ifndef DT_ABL
 #define DT_ABL 0   // ablation builds only: 1 no GEMM1 MFMAs, 2 no GELU in epilogue 1, 4 no GEMM2 MFMAs, 8 no GELU in epilogue 2, 16 no phases A / B,
-                   // 32 no GraphNorm statistics, 64 no gate GELU, 128 no plane split of the gated rows, 256 multiply by 1/std instead of dividing
+                   // 32 no GraphNorm statistics, 64 no gate GELU, 128 no plane split of the gated rows, 256 multiply by 1/std instead of dividing,
+                   // 512 conv_out always from row 0 (no HBM stream), 1024 W0 fragments always the same 1 KB (no L2 stream), 2048 no stores
 #endif
 
 #define DT_GELU1(...) ((DT_ABL & 2) ? (__VA_ARGS__) : gelu_exact2(__VA_ARGS__))
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #define DT_LOAD_CHUNK(c)                                                                                         \
   _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                \
     const int row = srow + 8 * u;                                                                                \
-    const int gr = min(r0 + min(row, nrows - 1), a.N - 1);                                                       \
+    const int gr = (DT_ABL & 512) ? 0 : min(r0 + min(row, nrows - 1), a.N - 1);                                   \
     { const hf32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const hf32x4 *>(a.a + (int64_t)gr * a.lda + (c) * DT_KC + sc4 * 4)); ra[u] = make_float4(t_[0], t_[1], t_[2], t_[3]); } \
   }
   float4 ra[8];
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #define DT_LOADW1(st, s)                                                                                         \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
       wq[st][j][q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(                           \
-          wr1, voff, (int)(((unsigned)(2 * wave + j) * DT_KS1 + (unsigned)(s)) * 1024u + q * plane1), 0));
+          wr1, voff, (DT_ABL & 1024) ? 0 : (int)(((unsigned)(2 * wave + j) * DT_KS1 + (unsigned)(s)) * 1024u + q * plane1), 0));
 #define DT_LOADA1(b, ksl)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
       af[i][q] = *reinterpret_cast<const hf16x8 *>(&bufA[b][q][i * 32 + fr][(ksl) * 16 + fk]);
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
           g4 = hf32x4{ga.x, ga.y, gb2.x, gb2.y};
         }
         const int64_t at = (int64_t)(r0 + row) * DT_C + sc4 * 4;
-        *reinterpret_cast<hf32x4 *>(a.h_out + at) = y4;
+        if (!(DT_ABL & 2048) || y4[0] == 1.2345e30f) *reinterpret_cast<hf32x4 *>(a.h_out + at) = y4;
         if (a.xg_out) *reinterpret_cast<hf32x4 *>(a.xg_out + at) = g4;
         if (a.xp_out && !(DT_ABL & 128)) {          // row scale + (hi, mid) split once per row here, not once per (tile, head) in the layer kernel
           const float mx = group_max<32>(fmaxf(fmaxf(fabsf(g4[0]), fabsf(g4[1])), fmaxf(fabsf(g4[2]), fabsf(g4[3]))));
@@ -556,8 +557,8 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
           hf16x4 hi = {(_Float16)g4[0], (_Float16)g4[1], (_Float16)g4[2], (_Float16)g4[3]};
           hf16x4 mid = {(_Float16)(g4[0] - (float)hi[0]), (_Float16)(g4[1] - (float)hi[1]), (_Float16)(g4[2] - (float)hi[2]),
                         (_Float16)(g4[3] - (float)hi[3])};
-          *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + sc4 * 4) = hi;
-          *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + 128 + sc4 * 4) = mid;
+          if (!(DT_ABL & 2048) || g4[0] == 1.2345e30f) *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + sc4 * 4) = hi;
+          if (!(DT_ABL & 2048) || g4[0] == 1.2345e30f) *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + 128 + sc4 * 4) = mid;
         }
       }
     }
