@@ -547,11 +547,14 @@ def main(argv=None):
             dt = time.perf_counter() - t0
             cap["plan"].verify_hints()
             # kernel durations for the roofline: EAGER steps after the timed region (events cannot sit inside a graph)
+            ops.reset_counters()
             ops.MP_TIMER = ops.KernelTimer()
             for i in range(10):
                 step(i)
             fence()
             timer, ops.MP_TIMER = ops.MP_TIMER, None
+            # the captured step launches what these eager steps launch: their counters are the step's
+            step_counters = {k: round(v / 10, 3) for k, v in ops.counters().items()}
         else:
             for i in range(args.warmup):
                 step(i)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 12
+#define ISG_ABI_VERSION 13
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -528,6 +528,27 @@ int isg_split_f16x2_frag(const float *w, int64_t rows, int32_t K, uint16_t *plan
 int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias, float *d,
                      int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, int32_t out_cols,
                      int64_t out_stride, void *stream);
+
+/* The K >= 256 engine (csrc/isg_gemm_h3p.hip): the Linears of the question encoder / decoder
+ * (ISubGVQA/models/question_encoder.py:20-38, question_decoder.py:25-71: nn.TransformerEncoder/DecoderLayer's in_proj,
+ * out_proj, linear1, linear2 -- cuBLAS GEMMs in the reference) and the C = 300 projections of MGAT
+ * (models/mgat_v2_conv.py:177-181,259; models/mgat.py:156), same fp16 three-product arithmetic as isg_linear_f16x3, with
+ * BOTH operands handed over pre-split as "planes32": row r, k-tile kt (32 columns) = one 128-byte line [hi 32 | mid 32]
+ * fp16 of the row scaled by its own power of two, rows ceil(K / 32) lines long, zero padded; inv_scale[r] = 1 / scale.
+ * The scale may come from any BOUND of the row's largest magnitude (the split stays exact to 2^-24 of the bound).
+ * isg_planes32_elems: uint16 elements of a planes32 image of `rows` rows of K columns. */
+int64_t isg_planes32_elems(int64_t rows, int32_t K);
+/* fp32 rows [M, K] (stride lda) -> planes32 + inv_scale[M] (exact row maxima).  K % 4 == 0, lda % 4 == 0, 16-byte aligned. */
+int isg_split_planes32(const float *a, int64_t M, int32_t K, int32_t lda, uint16_t *planes, float *inv_scale, void *stream);
+/* d = act(a . w^T + bias), act 0 none / 1 exact GELU / 2 ReLU.  Output, exactly one of:
+ *   d        fp32 [M, ldd]                                            (d_planes = d_inv = d_bound = NULL)
+ *   d_planes planes32 of the result (N % 32 == 0) + d_inv[M], scaled by the power of two of the bound
+ *            |d[m, :]| < a_inv[m] * d_bound[0] + d_bound[1],  d_bound = {2^14 * max_n ||w_n||_1, max |bias|} on the device
+ *            -- the next Linear's `a_planes` / `a_inv` with no pass in between (linear1 -> linear2).
+ * ISG_EUNSUPPORTED: N % 4 != 0, ldd % 4 != 0, a misaligned pointer, an operand of 2 GB or more. */
+int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, const uint16_t *w_planes, const float *w_inv,
+                   const float *bias, float *d, uint16_t *d_planes, float *d_inv, const float *d_bound, int64_t M,
+                   int32_t N, int32_t K, int32_t ldd, int32_t act, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scene-graph encoder (ISubGVQA/models/scene_graph_encoder.py:108-143) without its concatenations

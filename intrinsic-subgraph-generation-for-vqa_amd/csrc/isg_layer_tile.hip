@@ -682,9 +682,11 @@ struct TcArgs {
 __device__ __forceinline__ void edge_planes_row(const float *__restrict__ edge_attr, int lda, const int *__restrict__ eid, int E, int K,
                                                 _Float16 *__restrict__ planes, float *__restrict__ inv_out, int slot, int c4) {
   if (slot >= E) return;
-  const int e = eid ? eid[slot] : slot;
+  // the plan fills eid[0 .. rowptr[N]) only (edges with an endpoint outside [0, N) are dropped): a slot beyond that holds
+  // whatever the allocation held, so the id is checked before it becomes an address; such a slot gets zero planes
+  const unsigned e = eid ? (unsigned)eid[slot] : (unsigned)slot;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c4 * 4 < K) v = *reinterpret_cast<const float4 *>(edge_attr + (int64_t)e * lda + c4 * 4);
+  if (c4 * 4 < K && e < (unsigned)E) v = *reinterpret_cast<const float4 *>(edge_attr + (int64_t)e * lda + c4 * 4);
   const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   float s, inv;
   h3_scale(mx, s, inv);

@@ -1559,6 +1559,97 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# The K >= 256 engine (csrc/isg_gemm_h3p.hip): both operands pre-split ("planes32"), LDS-DMA operand path
+# ------------------------------------------------------------------------------------------------
+class Planes32(NamedTuple):
+    """An activation as the fp16 three-product GEMM reads it: planes [rows * ceil(cols / 32) * 64] int16 (row r, k-tile kt =
+    one 128-byte line [hi 32 | mid 32] of the row scaled by its own power of two), inv [rows] = 1 / scale."""
+    planes: Tensor
+    inv: Tensor
+    rows: int
+    cols: int
+
+
+def split_planes32(x: Tensor) -> Planes32:
+    """fp32 rows [M, K] -> planes32 (exact row maxima).  The planes stay attached to `x` (tied to its version counter, like
+    the row maxima): a second Linear over the same rows (the decoder layers' cross-attention over the encoder memory) does
+    not repeat the pass."""
+    hit = getattr(x, "_isg_planes32", None)
+    if hit is not None and hit[0] == (_ver(x), x.data_ptr(), tuple(x.shape)):
+        return hit[1]
+    lib = _lib.load()
+    M, K = x.shape
+    planes = torch.empty(int(lib.isg_planes32_elems(M, K)), dtype=torch.int16, device=x.device)
+    inv = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.check(lib.isg_split_planes32(_chk_rows(x, "x"), M, K, x.stride(0), planes.data_ptr(), inv.data_ptr(), _stream()),
+               "isg_split_planes32")
+    out = Planes32(planes, inv, M, K)
+    x._isg_planes32 = ((_ver(x), x.data_ptr(), tuple(x.shape)), out)
+    return out
+
+
+def _h3p_weight(weight: Tensor, bias: Optional[Tensor], cache: bool = True):
+    """planes32 of a weight [N, K], its inverse row scales and the output bound {2^14 * max_n ||w_n||_1, max |b|} (device)."""
+    def build():
+        w = weight.detach()
+        p = split_planes32(w.contiguous().clone())       # a private copy: nothing stays attached to the parameter
+        l1 = w.abs().sum(dim=1).max() * 16384.0
+        bm = bias.detach().abs().max() if bias is not None else torch.zeros((), device=w.device)
+        return p.planes, p.inv, torch.stack([l1, bm]).to(torch.float32).contiguous()
+    if not cache:
+        with torch.no_grad():
+            return build()
+    return derived_weight("h3p", (weight,) if bias is None else (weight, bias), build)
+
+
+H3P = True            # Linears with K >= H3P_MIN_K over at least H3P_MIN_M rows on isg_linear_h3p (A/B switch)
+H3P_MIN_K = 256
+H3P_MIN_M = 8192
+
+
+def h3p_supported(M: int, N: int, K: int) -> bool:
+    return (H3P and GEMM_BACKEND == "bf16x6" and GEMM_KERNEL == "auto" and GEMM_F16X3 and K >= H3P_MIN_K and (K & 3) == 0 and
+            (N & 3) == 0 and M >= H3P_MIN_M and M * ((K + 31) // 32) * 128 < (1 << 31) and N * ((K + 31) // 32) * 128 < (1 << 31))
+
+
+def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False, relu: bool = False,
+               planes_out: bool = False, cache_planes: bool = True):
+    """act(x @ weight^T + bias) on the planes32 engine.  x: Planes32 or fp32 rows (split here, once per tensor version).
+    planes_out: the result as Planes32 (N % 32 == 0), scaled by the bound known before the product -- the input of the next
+    Linear with no pass over it; otherwise fp32 [M, N]."""
+    lib = _lib.load()
+    xp = x if isinstance(x, Planes32) else split_planes32(x)
+    M, K = xp.rows, xp.cols
+    N = weight.size(0)
+    if weight.size(1) != K:
+        raise ValueError(f"linear_h3p: x has {K} columns, weight {tuple(weight.shape)}")
+    wp, winv, bound = _h3p_weight(weight, bias, cache_planes)
+    bptr = _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True)
+    act = 2 if relu else (1 if gelu else 0)
+    dev = xp.planes.device
+    if planes_out:
+        if N % 32:
+            raise ValueError("linear_h3p: planes_out needs N % 32 == 0")
+        dp = torch.empty(int(lib.isg_planes32_elems(M, N)), dtype=torch.int16, device=dev)
+        dinv = torch.empty(M, dtype=torch.float32, device=dev)
+        _lib.check(lib.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), bptr, 0,
+                                      dp.data_ptr(), dinv.data_ptr(), bound.data_ptr(), M, N, K, 0, act, _stream()),
+                   "isg_linear_h3p")
+        return Planes32(dp, dinv, M, N)
+    out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    _lib.check(lib.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), bptr,
+                                  out.data_ptr(), 0, 0, 0, M, N, K, N, act, _stream()), "isg_linear_h3p")
+    return out
+
+
+def planes32_to_rows(p: Planes32) -> Tensor:
+    """fp32 rows of a Planes32 (hi + mid) * inv: tests and diagnostics only."""
+    KT = (p.cols + 31) // 32
+    v = p.planes.view(torch.float16).view(p.rows, KT, 2, 32).float()
+    return ((v[:, :, 0] + v[:, :, 1]).reshape(p.rows, KT * 32)[:, :p.cols] * p.inv[:, None]).contiguous()
+
+
 LINEAR_MULTI = True     # A/B switch (tools/ab_step.py)
 
 
