@@ -27,6 +27,14 @@
 
 #include <stdlib.h>
 
+// -DISG_P3_STAMP (tools/stamp_h3p.py builds its own library): per-wave s_memtime totals of the persistent kernel's segments
+#ifdef ISG_P3_STAMP
+static __device__ long long *g_p3_stamps = nullptr;
+#define Q3_ST(i) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define Q3_ST(i)
+#endif
+
 namespace isg {
 
 typedef __attribute__((address_space(3))) void p3_lds_t;
@@ -76,7 +84,7 @@ struct P3Args {
   _Float16 *Dp;                   // planes32 [M][N / 32][64]
   float *d_inv;                   // [M]
   const float *d_bound;           // {2^14 * max_n ||W_n||_1, max |b|}: |D[m, :]| < inv_a[m] * d_bound[0] + d_bound[1]
-  int M, N, KT, ldd, tiles_n, nt_store;
+  int M, N, KT, ldd, tiles_n, nt_store, abl;
 };
 
 template <int ACT, bool PLANES_OUT>
@@ -92,8 +100,8 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
     n0 = (slot % a.tiles_n) * P3_T;
     if (m0 >= a.M) return;
   }
-  const int nk = a.KT;
-  const unsigned row_b = (unsigned)nk * 128u;          // bytes per operand row
+  const int nk = (a.abl & 2) ? 2 : a.KT;
+  const unsigned row_b = (unsigned)a.KT * 128u;          // bytes per operand row
 
   // ---- DMA sources: quarter image q, request u -> this lane's 16 bytes --------------------------------------------
   unsigned soff[4][2];
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
       if (ACT == 2) {     // ReLU (a NaN stays a NaN, as in torch)
         v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
       }
-      if (rows[mi] < a.M && col < a.N) {
+      if (rows[mi] < a.M && col < a.N && !(a.abl & 1)) {
         if constexpr (PLANES_OUT) {
           const float s = so[mi];
           v.x *= s; v.y *= s; v.z *= s; v.w *= s;
@@ -279,9 +287,373 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
   }
 }
 
+
+// =====================================================================================================================
+// PERSISTENT form (the default).  The 256 x 256 kernel above spends 16 us of a 48 us tile (K = 512) draining its result -- every
+// CU bursts 256 KB at the same moment, the chip's HBM write rate is all they get -- and ~5 us filling its pipeline, with the
+// matrix pipe idle in both (profiles/r04_b_h3p_ablation.txt); its main loop alone runs at 1.6 PF/s of fp16 products.  Here:
+//   * one workgroup per CU walks tiles L = b, b + G, ...; tile 256 x 128 x 32, 8 waves as 4 x 2 (64 x 64 per wave), so a
+//     wave holds TWO accumulator sets: `acc` of the tile in flight and `res` of the tile before it, whose epilogue (scales,
+//     bias, activation, one 16-byte store per lane) is issued one accumulator tile per phase through the first eight k-tiles
+//     of the next tile: the result leaves the chip as a steady stream beside the MFMAs instead of a burst between them;
+//   * the DMA stream never stops at a tile boundary: a ring of three 48 KB k-tile buffers is filled two k-tiles ahead of the
+//     reads, across tiles (a k-tile = A-lo, A-hi (the first / second 32 rows of the four wave rows) and B: three 16 KB
+//     images, three requests per thread and phase); a tile's row / column scales and bias arrive the same way, one 4-byte
+//     request per wave, a tile ahead;
+//   * everything else (planes32 operands, source-side swizzle, ping-pong wave groups, counted vmcnt, transposed product)
+//     is the kernel above.  A k-tile is two phases of 24 MFMAs.
+// =====================================================================================================================
+constexpr int Q3_BM = 256, Q3_BN = 128;
+constexpr int Q3_BUF = 3 * P3_SLOT;            // A-lo, A-hi, B
+constexpr int Q3_RING = 3 * Q3_BUF;            // 147456
+constexpr int Q3_PAR = 2048;                   // per tile: a_inv[256] | w_inv[128] | bias[128]
+constexpr int Q3_SMEM = Q3_RING + 3 * Q3_PAR + 256;  // 153856 (the last 256 bytes: a scratch line)
+constexpr int Q3_HEAD = 8;                     // fewest k-tiles per tile: 16 accumulator tiles leave two per k-tile (K < 512), else one per k-tile over 16
+
+struct Q3Args {
+  P3Args p;
+  int tiles_m, total_l;                        // row tiles; tiles_n * roundup8(tiles_m)
+};
+
+template <int ACT, bool PLANES_OUT, int HEAD>
+__global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args qa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char p3_smem[];
+  const P3Args &a = qa.p;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;       // wn = the wave group (ping-pong half)
+  const int nk = a.KT, G = gridDim.x;
+  const unsigned row_b = (unsigned)a.KT * 128u;
+  const unsigned char *Ab = reinterpret_cast<const unsigned char *>(a.A);
+  const unsigned char *Wb = reinterpret_cast<const unsigned char *>(a.W);
+
+  // tile L of the XCD-aware order -> origin; false: a padding entry of the order (row tile beyond M)
+  auto origin = [&](int L, int &m0, int &n0) -> bool {
+    const int slot = L >> 3;
+    m0 = ((L & 7) + 8 * (slot / a.tiles_n)) * Q3_BM;
+    n0 = (slot % a.tiles_n) * Q3_BN;
+    return m0 < a.M;
+  };
+  auto next_tile = [&](int L, int &m0, int &n0) -> int {      // first valid tile of this workgroup after L, or -1
+    for (L += G; L < qa.total_l; L += G)
+      if (origin(L, m0, n0)) return L;
+    return -1;
+  };
+  int cL, cm0 = 0, cn0 = 0;                                    // the tile being accumulated (its origin)
+  cL = blockIdx.x;
+  if (cL >= qa.total_l) return;
+  if (!origin(cL, cm0, cn0)) {
+    cL = next_tile(cL, cm0, cn0);
+    if (cL < 0) return;
+  }
+
+  // ---- the stager: stream position (tile, k-tile) two k-tiles ahead of the reads ----------------------------------------
+  const int piece16 = ((lane & 7) ^ ((lane >> 4) | ((wave & 1) << 2))) * 16;
+  const int img_r0 = wave * 8 + (lane >> 3), img_r1 = img_r0 + 64;             // image rows of requests u = 0, 1
+  const int alo0 = (img_r0 >> 5) * 64 + (img_r0 & 31), alo1 = (img_r1 >> 5) * 64 + (img_r1 & 31);   // tile rows of A-lo
+  unsigned so_alo[2], so_ahi[2], so_b[2];
+  int sL = cL, sm0 = cm0, sn0 = cn0, skt = 0;
+  bool s_live = true;                                          // false: past this workgroup's last tile (requests repeat, unread)
+#define Q3_SOFF()                                                                                                  \
+  {                                                                                                                \
+    so_alo[0] = (unsigned)min(sm0 + alo0, a.M - 1) * row_b + piece16;                                              \
+    so_alo[1] = (unsigned)min(sm0 + alo1, a.M - 1) * row_b + piece16;                                              \
+    so_ahi[0] = (unsigned)min(sm0 + alo0 + 32, a.M - 1) * row_b + piece16;                                         \
+    so_ahi[1] = (unsigned)min(sm0 + alo1 + 32, a.M - 1) * row_b + piece16;                                         \
+    so_b[0] = (unsigned)min(sn0 + img_r0, a.N - 1) * row_b + piece16;                                              \
+    so_b[1] = (unsigned)min(sn0 + img_r1, a.N - 1) * row_b + piece16;                                              \
+  }
+  Q3_SOFF()
+  int sb = 0;                                                  // ring buffer (byte offset) the stager fills
+#define Q3_DMA(base, off, slice, u)                                                                                \
+  __builtin_amdgcn_global_load_lds((p3_glb_t *)((base) + (size_t)skt * 128u + (off)),                              \
+                                   (p3_lds_t *)(p3_smem + sb + (slice) * P3_SLOT + ((u) * 8 + wave) * 1024), 16, 0, 0);
+#define Q3_STAGE_P0() { Q3_DMA(Wb, so_b[0], 2, 0) Q3_DMA(Wb, so_b[1], 2, 1) Q3_DMA(Ab, so_alo[0], 0, 0) Q3_DMA(Ab, so_alo[1], 0, 1) }
+#define Q3_STAGE_P1()                                                                                              \
+  {                                                                                                                \
+    Q3_DMA(Ab, so_ahi[0], 1, 0) Q3_DMA(Ab, so_ahi[1], 1, 1)                                                        \
+    sb = sb == 2 * Q3_BUF ? 0 : sb + Q3_BUF;                                                                       \
+    if (s_live && ++skt == nk) {                                                                                   \
+      int m1, n1;                                                                                                  \
+      const int L1 = next_tile(sL, m1, n1);                                                                        \
+      if (L1 < 0) { s_live = false; skt = nk - 1; }                                                                \
+      else { sL = L1; sm0 = m1; sn0 = n1; skt = 0; Q3_SOFF() }                                                     \
+    }                                                                                                              \
+  }
+  // a tile's scales and bias: ONE 4-byte request per wave (waves 0-3: a_inv of 64 rows each, 4 / 5: w_inv, 6 / 7: bias)
+#define Q3_PARAMS(pm0, pn0, region)                                                                                \
+  {                                                                                                                \
+    const float *src = wave < 4 ? a.a_inv + min((pm0) + wave * 64 + lane, a.M - 1)                                 \
+                       : (wave < 6 || !a.bias) ? a.w_inv + min((pn0) + (wave & 1) * 64 + lane, a.N - 1)            \
+                                               : a.bias + min((pn0) + (wave & 1) * 64 + lane, a.N - 1);            \
+    const int dst = wave < 4 ? wave * 256 : wave < 6 ? 1024 + (wave & 1) * 256 : 1536 + (wave & 1) * 256;          \
+    __builtin_amdgcn_global_load_lds((p3_glb_t *)src, (p3_lds_t *)(p3_smem + Q3_RING + (region) * Q3_PAR + dst), 4, 0, 0); \
+  }
+
+  // ---- fragment addresses ----------------------------------------------------------------------------------------------
+  const int pz = ((lane >> 4) ^ ((lane >> 1) & 7)) * 16;
+  const int a_rd = (wm * 32 + (lane & 15)) * 128 + pz;         // A-lo / A-hi image: + i * 2048, mid plane ^ 64
+  const int b_rd = 2 * P3_SLOT + (wn * 64 + (lane & 15)) * 128 + pz;   // B image: + j * 2048
+  int cb = 0;                                                  // ring buffer (byte offset) being read
+  const unsigned lds0 = (unsigned)(uintptr_t)(p3_lds_t *)p3_smem;
+
+  // `res`: the previous tile's 16 accumulator tiles; p_ia / p_iw: that tile's row scales (4 row tiles) and column scales (4
+  // column tiles x 4) for this lane, read from the parameter region ONCE per tile (per piece it was 245 cycles of LDS latency
+  // in the load segment); a piece's bias is requested when the piece falls due and used after the phase's fragment reads and
+  // DMA requests (holding it too would take 16 more registers than there are).  All indices into them are static: the k-tiles
+  // that carry pieces are unrolled (a runtime index puts the array into scratch memory; a switch over 16 cases measured 380
+  // cycles of scalar branches per piece; two 32-float vectors under a uniform dynamic index spilled 14-20 registers).
+  hf32x4 acc[4][4], res[4][4];
+  float p_ia[4] = {0.f, 0.f, 0.f, 0.f};
+  hf32x4 p_iw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    p_iw[i] = hf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[i][j] = hf32x4{0.f, 0.f, 0.f, 0.f}; res[i][j] = hf32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  hf16x8 fa[2][2], fb[4][2];
+  bool has_res = false;
+  int rm0 = 0, rn0 = 0, rpar = 0;                              // origin and parameter region of the tile `res` belongs to
+  int cpar = 0;                                                // parameter region of the tile being accumulated
+
+#define Q3_READ_A(slice)                                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+    fa[i][0] = *reinterpret_cast<const hf16x8 *>(p3_smem + cb + (slice) * P3_SLOT + i * 2048 + a_rd);              \
+    fa[i][1] = *reinterpret_cast<const hf16x8 *>(p3_smem + cb + (slice) * P3_SLOT + i * 2048 + (a_rd ^ 64));       \
+  }
+#define Q3_READ_B()                                                                                                \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
+    fb[j][0] = *reinterpret_cast<const hf16x8 *>(p3_smem + cb + j * 2048 + b_rd);                                  \
+    fb[j][1] = *reinterpret_cast<const hf16x8 *>(p3_smem + cb + j * 2048 + (b_rd ^ 64));                           \
+  }
+#define Q3_MMA(ah)                                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                    \
+    hf32x4 c = acc[(ah) * 2 + i][j];                                                                               \
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][1], fa[i][0], c, 0, 0, 0);                                    \
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][1], c, 0, 0, 0);                                    \
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][0], c, 0, 0, 0);                                    \
+    acc[(ah) * 2 + i][j] = c;                                                                                      \
+  }
+#define Q3_NS (PLANES_OUT ? 2 : 1)
+  // epilogue of ONE accumulator tile of `res` (static i, j): row scale, column scales, bias, activation, one 16-byte store per lane
+#define Q3_EPI(i, j, b4)                                                                                           \
+  {                                                                                                                \
+    if (!(rm0 + wm * 64 + (i) * 16 < a.M && rn0 + wn * 64 + (j) * 16 < a.N)) {                                     \
+      /* this wave's accumulator tile lies outside D: no store -- but the counted waits assume Q3_NS operations   */ \
+      /* per piece, so the wave issues as many 4-byte requests into a scratch line instead                         */ \
+      _Pragma("unroll") for (int z = 0; z < Q3_NS; ++z)                                                            \
+        __builtin_amdgcn_global_load_lds((p3_glb_t *)(a.a_inv + min(lane, a.M - 1)),                               \
+                                         (p3_lds_t *)(p3_smem + Q3_RING + 3 * Q3_PAR), 4, 0, 0);                   \
+    } else {                                                                                                       \
+      const hf32x4 c = res[i][j];                                                                                  \
+      const float ia = p_ia[i];                                                                                    \
+      const hf32x4 iw = p_iw[j];                                                                                   \
+      const int rl = wm * 64 + (i) * 16 + (lane & 15), cl = wn * 64 + (j) * 16 + 4 * (lane >> 4);                  \
+      float4 v;                                                                                                    \
+      v.x = (c[0] * ia) * iw[0] + b4[0]; v.y = (c[1] * ia) * iw[1] + b4[1];                                        \
+      v.z = (c[2] * ia) * iw[2] + b4[2]; v.w = (c[3] * ia) * iw[3] + b4[3];                                        \
+      if (ACT == 1) {                                                                                              \
+        const isg_f32x2 g0 = gelu_exact2(isg_f32x2{v.x, v.y}), g1 = gelu_exact2(isg_f32x2{v.z, v.w});              \
+        v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;                                                            \
+      }                                                                                                            \
+      if (ACT == 2) {                                                                                              \
+        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; \
+      }                                                                                                            \
+      const int row = min(rm0 + rl, a.M - 1), col = min(rn0 + cl, a.N - 4);                                        \
+      const bool live = rm0 + rl < a.M && rn0 + cl < a.N && !(a.abl & 1);                                          \
+      if constexpr (PLANES_OUT) {                                                                                  \
+        float so, inv;                                                                                             \
+        h3_scale(ia * a.d_bound[0] + a.d_bound[1], so, inv);                                                       \
+        v.x *= so; v.y *= so; v.z *= so; v.w *= so;                                                                \
+        const hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                            \
+        const hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]),                        \
+                            (_Float16)(v.z - (float)hi[2]), (_Float16)(v.w - (float)hi[3])};                       \
+        if (live) {                                                                                                \
+          _Float16 *d = a.Dp + (int64_t)row * (a.N * 2) + (col >> 5) * 64 + (col & 31);                            \
+          *reinterpret_cast<hf16x4 *>(d) = hi;                                                                     \
+          *reinterpret_cast<hf16x4 *>(d + 32) = mid;                                                               \
+          if (rn0 + cl == 0) a.d_inv[row] = inv;                                                                   \
+        }                                                                                                          \
+      } else if (live) {                                                                                           \
+        typedef float p3_f32x4 __attribute__((ext_vector_type(4)));                                                \
+        p3_f32x4 w4 = {v.x, v.y, v.z, v.w};                                                                        \
+        p3_f32x4 *dst = reinterpret_cast<p3_f32x4 *>(a.D + (int64_t)row * a.ldd + col);                            \
+        if (a.nt_store) __builtin_nontemporal_store(w4, dst);                                                      \
+        else *dst = w4;                                                                                            \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+  // the tile's accumulators become `res`; its scales come out of the parameter region the DMA filled a tile ago.  Read by
+  // inline asm: hipcc (ROCm 7.2) orders a VISIBLE LDS load behind every outstanding 4-byte LDS-DMA it cannot tell apart
+  // from the load's address -- `s_waitcnt vmcnt(0)`, the whole ring drained.
+#define Q3_TILE_END()                                                                                              \
+  {                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                  \
+      res[i][j] = acc[i][j];                                                                                       \
+      acc[i][j] = hf32x4{0.f, 0.f, 0.f, 0.f};                                                                      \
+    }                                                                                                              \
+    const unsigned pa = lds0 + Q3_RING + cpar * Q3_PAR;                                                            \
+    const unsigned par = pa + (wm * 64 + (lane & 15)) * 4, pac = pa + 1024 + (wn * 64 + 4 * (lane >> 4)) * 4;      \
+    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\t"         \
+                 "ds_read_b32 %3, %8 offset:192\n\t"                                                               \
+                 "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:64\n\tds_read_b128 %6, %9 offset:128\n\t"      \
+                 "ds_read_b128 %7, %9 offset:192\n\t"                                                              \
+                 "s_waitcnt lgkmcnt(0)"                                                                            \
+                 : "=&v"(p_ia[0]), "=&v"(p_ia[1]), "=&v"(p_ia[2]), "=&v"(p_ia[3]), "=&v"(p_iw[0]), "=&v"(p_iw[1]), \
+                   "=&v"(p_iw[2]), "=&v"(p_iw[3])                                                                  \
+                 : "v"(par), "v"(pac) : "memory");                                                                 \
+  }
+  // a piece's bias: requested from the parameter region of the tile `res` belongs to (no wait here)
+#define Q3_BIAS_REQ(bq, j)                                                                                         \
+  asm volatile("ds_read_b128 %0, %1 offset:1536" : "=&v"(bq)                                                       \
+               : "v"(lds0 + Q3_RING + rpar * Q3_PAR + (wn * 64 + (j) * 16 + 4 * (lane >> 4)) * 4) : "memory");
+#define Q3_BAR                                                                                                     \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  __builtin_amdgcn_s_barrier();                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+#define Q3_WAIT(n)                                                                                                 \
+  __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14));
+#define Q3_M(ah)                                                                                                   \
+  __builtin_amdgcn_s_waitcnt(0xC07F);                                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  Q3_ST(3 + 7 * (ah))                                                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                                   \
+  Q3_MMA(ah)                                                                                                       \
+  __builtin_amdgcn_s_setprio(0);                                                                                   \
+  Q3_ST(4 + 7 * (ah))                                                                                              \
+  Q3_BAR                                                                                                           \
+  Q3_ST(5 + 7 * (ah))
+  // End of a load segment: every request is waited for FOUR phases after its issue (B and A-lo leave in the first phase of
+  // a k-tile and are read two k-tiles later in a first phase, A-hi likewise in second phases), so the operations of the THREE
+  // youngest phases may be in flight: 4 + 2 + 4 = 10 requests at the end of a first phase, 2 + 4 + 2 = 8 at the end of a
+  // second, + Q3_NS per accumulator tile stored + 1 per parameter request inside that window (both are issued in second
+  // phases only).  A k-tile of the head: NP pieces (tiles NP * kh ... of `res`) leave in its second phase, after the phase's
+  // fragment reads and requests; the first also requests the NEXT tile's parameters.  `sp` / `pp`: stores / parameter
+  // requests of the previous k-tile's second phase (a head k-tile after a head k-tile: NP pieces; the first: taken as none,
+  // which only waits earlier than needed when the tile before was all head).
+#define Q3_KT(kh, NP, is_head)                                                                                     \
+  {                                                                                                                \
+    constexpr int sp = ((is_head) && (kh) > 0) ? (NP) * Q3_NS : 0, pp = ((is_head) && (kh) == 1) ? 1 : 0;          \
+    constexpr int sc = (is_head) ? (NP) * Q3_NS : 0, pc = ((is_head) && (kh) == 0) ? 1 : 0;                        \
+    Q3_READ_A(0) Q3_READ_B()                                                                                       \
+    Q3_STAGE_P0()                                                                                                  \
+    Q3_ST(0)                                                                                                       \
+    if (has_res) { Q3_WAIT(10 + sp + pp) } else { Q3_WAIT(10 + pp) }                                               \
+    Q3_ST(1)                                                                                                       \
+    Q3_BAR                                                                                                         \
+    Q3_ST(2)                                                                                                       \
+    Q3_M(0)                                                                                                        \
+    hf32x4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};                                                 \
+    if ((is_head) && has_res && a.bias) {                                                                          \
+      Q3_BIAS_REQ(bq0, ((NP) * (kh)) & 3)                                                                          \
+      if ((NP) > 1) Q3_BIAS_REQ(bq1, ((NP) * (kh) + 1) & 3)                                                        \
+    }                                                                                                              \
+    Q3_READ_A(1)                                                                                                   \
+    if ((is_head) && (kh) == 0) Q3_PARAMS(nm0, nn0, npar)                                                          \
+    Q3_STAGE_P1()                                                                                                  \
+    Q3_ST(7)                                                                                                       \
+    if ((is_head) && has_res) {                                                                                    \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      Q3_EPI(((NP) * (kh)) >> 2, ((NP) * (kh)) & 3, bq0)                                                           \
+      if ((NP) > 1) Q3_EPI((((NP) * (kh) + 1) & 15) >> 2, ((NP) * (kh) + 1) & 3, bq1)                              \
+    }                                                                                                              \
+    Q3_ST(6)                                                                                                       \
+    if (has_res) { Q3_WAIT(8 + sp + pp + sc + pc) } else { Q3_WAIT(8 + pp + pc) }                                  \
+    Q3_ST(8)                                                                                                       \
+    Q3_BAR                                                                                                         \
+    Q3_ST(9)                                                                                                       \
+    Q3_M(1)                                                                                                        \
+    cb = cb == 2 * Q3_BUF ? 0 : cb + Q3_BUF;                                                                       \
+  }
+
+  // ---- prologue: the first tile's parameters, stream k-tiles 0 and 1 -----------------------------------------------------
+  Q3_PARAMS(cm0, cn0, 0)
+  Q3_STAGE_P0()
+  Q3_STAGE_P1()
+  Q3_STAGE_P0()
+  Q3_STAGE_P1()
+  Q3_WAIT(6)
+  Q3_BAR
+  if (wn == 1) { Q3_BAR }                // the second wave group runs one barrier behind the first
+
+#ifdef ISG_P3_STAMP
+  long long st_acc[16] = {};
+  const long long st_begin = (long long)__builtin_amdgcn_s_memtime();
+  long long st_last = st_begin;
+#endif
+  while (true) {
+    // the tile after this one (for its parameters; the stager finds it by itself)
+    int nm0 = cm0, nn0 = cn0;
+    const int nL = next_tile(cL, nm0, nn0);
+    if (nL < 0) { nm0 = cm0; nn0 = cn0; }
+    const int npar = cpar == 2 ? 0 : cpar + 1;
+    if constexpr (HEAD == 16) {
+      Q3_KT(0, 1, true) Q3_KT(1, 1, true) Q3_KT(2, 1, true) Q3_KT(3, 1, true) Q3_KT(4, 1, true) Q3_KT(5, 1, true)
+      Q3_KT(6, 1, true) Q3_KT(7, 1, true) Q3_KT(8, 1, true) Q3_KT(9, 1, true) Q3_KT(10, 1, true) Q3_KT(11, 1, true)
+      Q3_KT(12, 1, true) Q3_KT(13, 1, true) Q3_KT(14, 1, true) Q3_KT(15, 1, true)
+    } else {
+      Q3_KT(0, 2, true) Q3_KT(1, 2, true) Q3_KT(2, 2, true) Q3_KT(3, 2, true) Q3_KT(4, 2, true) Q3_KT(5, 2, true)
+      Q3_KT(6, 2, true) Q3_KT(7, 2, true)
+    }
+#pragma unroll 1
+    for (int kt = HEAD; kt < nk; ++kt) Q3_KT(0, 0, false)
+    Q3_TILE_END()
+    has_res = true;
+    rm0 = cm0; rn0 = cn0; rpar = cpar;
+    if (nL < 0) break;
+    cL = nL; cm0 = nm0; cn0 = nn0; cpar = npar;
+  }
+  if (wn == 0) { Q3_BAR }
+  __builtin_amdgcn_s_waitcnt(0x0F70);    // the requests past the last k-tile have landed: nothing in flight at the end
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hf32x4 bq = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+        Q3_BIAS_REQ(bq, j)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      Q3_EPI(i, j, bq)
+    }
+#ifdef ISG_P3_STAMP
+  if (g_p3_stamps && lane == 0) {
+    st_acc[15] = (long long)__builtin_amdgcn_s_memtime() - st_begin;
+    long long *dst = g_p3_stamps + ((long long)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[i] = st_acc[i];
+  }
+#endif
+#undef Q3_KT
+#undef Q3_TILE_END
+#undef Q3_BIAS_REQ
+#undef Q3_NS
+#undef Q3_M
+#undef Q3_WAIT
+#undef Q3_BAR
+#undef Q3_EPI
+#undef Q3_MMA
+#undef Q3_READ_B
+#undef Q3_READ_A
+#undef Q3_PARAMS
+#undef Q3_STAGE_P1
+#undef Q3_STAGE_P0
+#undef Q3_DMA
+#undef Q3_SOFF
+}
+
 }  // namespace isg
 
 using namespace isg;
+
+#ifdef ISG_P3_STAMP
+extern "C" int isg_p3_set_stamp_buffer(long long *buf) {      // diagnostic build only: [workgroups * 8 waves][16] int64
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_p3_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int64_t isg_planes32_elems(int64_t rows, int32_t K) {
   if (rows <= 0 || K <= 0) return 0;
@@ -327,11 +699,45 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   a.d_bound = d_bound; a.M = (int)M; a.N = N; a.KT = KT; a.ldd = ldd; a.tiles_n = (int)tn;
   static const long long nt_mb = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return e ? atoll(e) : 128ll; }();
   a.nt_store = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
+  { const char *e = getenv("ISG_P3_ABL"); a.abl = e ? atoi(e) : 0; }
   hipStream_t st = as_stream(stream);
   // more than 64 KB of dynamic LDS is an attribute of (function, device): set once per device of this process
-  static bool attr_set[6][64] = {};
+  static bool attr_set[18][64] = {};
+  static int cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ISG_ELAUNCH;
+  static const int version = [] { const char *e = getenv("ISG_H3P_V"); return e ? atoi(e) : 2; }();
+  if (version != 1 && KT >= Q3_HEAD) {       // persistent 256 x 128 form
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return ISG_ELAUNCH;
+    Q3Args q;
+    q.p = a;
+    q.tiles_m = (int)tm;
+    const long long tn2 = (N + Q3_BN - 1) / Q3_BN;
+    const long long total = tn2 * ((tm + 7) / 8 * 8);
+    if (total >= (1ll << 31)) return ISG_EUNSUPPORTED;
+    q.p.tiles_n = (int)tn2;
+    q.total_l = (int)total;
+    const unsigned grid = (unsigned)(total < cus[dev] ? total : cus[dev]);
+#define ISG_Q3H(ACT_, PO_, H_, slot)                                                                              \
+  do {                                                                                                            \
+    if (!attr_set[slot][dev]) {                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_h3q_kernel<ACT_, PO_, H_>),                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, Q3_SMEM) != hipSuccess)                 \
+        return ISG_ELAUNCH;                                                                                       \
+      attr_set[slot][dev] = true;                                                                                 \
+    }                                                                                                             \
+    linear_h3q_kernel<ACT_, PO_, H_><<<grid, P3_THREADS, Q3_SMEM, st>>>(q);                                       \
+  } while (0)
+#define ISG_Q3(ACT_, PO_, slot) do { if (KT >= 16) ISG_Q3H(ACT_, PO_, 16, slot); else ISG_Q3H(ACT_, PO_, 8, (slot) + 6); } while (0)
+    if (planes_out) {
+      if (act == 1) ISG_Q3(1, true, 6); else if (act == 2) ISG_Q3(2, true, 7); else ISG_Q3(0, true, 8);
+    } else {
+      if (act == 1) ISG_Q3(1, false, 9); else if (act == 2) ISG_Q3(2, false, 10); else ISG_Q3(0, false, 11);
+    }
+#undef ISG_Q3
+#undef ISG_Q3H
+    return check_launch();
+  }
 #define ISG_P3(ACT_, PO_, slot)                                                                                   \
   do {                                                                                                            \
     if (!attr_set[slot][dev]) {                                                                                   \

@@ -1416,3 +1416,95 @@ def test_readout_tile_matches_the_unfused_pooling_and_the_oracle(dev, masked):
         assert torch.allclose(out, ref_out, atol=1e-4 * scale, rtol=0) and torch.allclose(gate, ref_gate, atol=2e-5, rtol=0)
         empty = torch.tensor([n == 0 for n in sizes])
         assert torch.equal(out.cpu()[empty], torch.zeros(int(empty.sum()), 128))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The K >= 256 engine (csrc/isg_gemm_h3p.hip): planes32 operands, persistent 256 x 128 tiles
+# ---------------------------------------------------------------------------------------------------------------------
+def _h3p_ref(x, w, b, act):
+    ref = x.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if act == "relu":
+        ref = torch.relu(ref)
+    return ref
+
+
+@pytest.mark.parametrize("M,N,K,act,bias", [
+    (256, 128, 256, None, True),          # one tile, the shortest reduction the persistent form takes (8 k-tiles)
+    (777, 300, 300, None, True),          # ragged rows, columns (N % 128 != 0) and k-tiles (K % 32 != 0)
+    (5000, 1200, 600, "gelu", True),      # 19 k-tiles: head + odd body
+    (70001, 128, 512, "relu", False),     # more tiles than CUs: every workgroup walks several tiles; no bias
+    (3000, 1536, 512, None, True),        # 12 column tiles
+    (1031, 2048, 2048, "relu", True),     # long reduction
+    (300, 64, 128, None, True),           # K < 256: the 256 x 256 form behind the same entry point
+])
+def test_linear_h3p_matches_fp64_within_fp32_gemm_error(dev, M, N, K, act, bias):
+    """isg_linear_h3p on every output element (tails included) against an fp64 product: the error of a plain fp32 GEMM at
+    most (ratio printed; <= 1.5 asserted), on rows spanning seven binades."""
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=dev, generator=g) * torch.rand(M, 1, device=dev, generator=g).mul(5).exp()
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(N, device=dev, generator=g) if bias else None
+    ref = _h3p_ref(x, w, b, act)
+    base = torch.nn.functional.linear(x, w, b)
+    base = torch.nn.functional.gelu(base) if act == "gelu" else (torch.relu(base) if act == "relu" else base)
+    e32 = (base.double() - ref).abs().max().item()
+    got = ops.linear_h3p(x, w, b, gelu=act == "gelu", relu=act == "relu")
+    assert got.shape == (M, N) and torch.isfinite(got).all()
+    err = (got.double() - ref).abs().max().item()
+    print(f"h3p {M}x{N}x{K} {act}: err {err:.3e} fp32 gemm {e32:.3e} ratio {err / e32:.2f}")
+    assert err <= 1.5 * e32 + 1e-30
+    # relative to each row's own magnitude as well: a row of small values must not inherit a large row's absolute error
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert ((got.double() - ref).abs() / scale).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1000, 512, 512, "relu"), (4099, 2048, 512, "relu"), (515, 1184, 320, "gelu")])
+def test_linear_h3p_planes_out_feeds_the_next_linear(dev, M, N, K, act):
+    """The result emitted as planes32 (scaled by the bound 2^14 * inv_a * max ||w||_1 + max |b|, known before the product)
+    reproduces the fp32 result to the split's 2^-24 of the bound, and a second Linear over it (linear1 -> linear2 of
+    question_encoder.py:22-25) matches the fp64 chain like an fp32 chain does."""
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    x = torch.randn(M, K, device=dev, generator=g) * torch.rand(M, 1, device=dev, generator=g).mul(3).exp()
+    w1 = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b1 = torch.randn(N, device=dev, generator=g)
+    w2 = torch.randn(256, N, device=dev, generator=g) / N ** 0.5
+    b2 = torch.randn(256, device=dev, generator=g)
+    kw = dict(gelu=act == "gelu", relu=act == "relu")
+    h32 = ops.linear_h3p(x, w1, b1, **kw)
+    hp = ops.linear_h3p(x, w1, b1, planes_out=True, **kw)
+    assert hp.rows == M and hp.cols == N
+    rows = ops.planes32_to_rows(hp)
+    bound = hp.inv[:, None] * 16384.0                  # the row's scaled range: |h| < bound
+    assert (rows - h32).abs().max().item() <= (bound * 2.0 ** -23).max().item()
+    assert ((rows - h32).abs() <= bound * 2.0 ** -23 + 1e-30).all()
+    y = ops.linear_h3p(hp, w2, b2)
+    f = torch.nn.functional.gelu if act == "gelu" else torch.relu
+    ref = f(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    base = torch.nn.functional.linear(f(torch.nn.functional.linear(x, w1, b1)), w2, b2)
+    e32 = (base.double() - ref).abs().max().item()
+    err = (y.double() - ref).abs().max().item()
+    print(f"h3p chain {M}x{N}x{K}: err {err:.3e} fp32 chain {e32:.3e} ratio {err / e32:.2f}")
+    assert err <= 1.5 * e32
+
+
+def test_split_planes32_is_an_exact_two_plane_split(dev):
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(513, 300, device=dev, generator=g) * torch.rand(513, 1, device=dev, generator=g).mul(20).sub(10).exp()
+    x[7] = 0.0
+    p = ops.split_planes32(x)
+    back = ops.planes32_to_rows(p)
+    amax = x.abs().amax(dim=1, keepdim=True)
+    assert ((back - x).abs() <= amax * 2.0 ** -23).all()
+    assert torch.equal(back[7], x[7])
+    inv = p.inv
+    assert (torch.log2(inv) == torch.log2(inv).round()).all()          # powers of two
+    live = amax.squeeze(1) > 0
+    scaled = amax.squeeze(1)[live] / inv[live]
+    assert (scaled >= 8192).all() and (scaled < 16384).all()
