@@ -327,7 +327,7 @@ LINE_SCHEMA = {
     "fallbacks": ["torch_linear", "torch_layer_norm", "torch_attention", "row_absmax"],
     "dense_err_vs_fp32": ["max"],
     "cfg5": ["workload", "graphs", "ms_per_step", "questions_per_s", "mp_kernel", "mp_avg_launch_us", "mp_achieved_GBps",
-             "mp_frac_of_hbm_peak", "imbalance_world8_max_over_mean"],
+             "mp_frac_of_hbm_peak", "imbalance_world8_max_over_mean", "fp32_rows"],
     "full_model": ["workload", "graphs", "ms_per_step", "questions_per_s"],
 }
 
@@ -430,6 +430,30 @@ def cfg5_leg(dev, graphs: int = 2048, steps: int = 10):
         dt = (time.perf_counter() - t0) / steps
         timer, ops.MP_TIMER = ops.MP_TIMER, None
     assert torch.isfinite(out).all()
+    # the same batch with fp32 feature rows: mixed dispatch (graphs within a 64-node / 256-slot tile on the tile kernels, the
+    # tail of the size distribution on the per-graph kernels: ops.GraphPlan.tile_mode)
+    cfg32 = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": graphs})
+    model32 = synthetic.build_answer_model(cfg32).to(dev).eval()
+    with torch.no_grad():
+        for i in range(3):
+            model32(wl, seed=50 + i)
+        torch.cuda.synchronize()
+        keep = dict(ops.COUNTERS)
+        ops.reset_counters()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out32 = model32(wl, seed=60 + i)[0]
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t0) / steps
+        c32 = ops.counters()
+        ops.COUNTERS.update(keep)
+    assert torch.isfinite(out32).all()
+    visits = c32["tile_nodes"] + c32["oversize_nodes"]
+    fp32_rows = {"ms_per_step": round(dt32 * 1e3, 3), "questions_per_s": round(graphs / dt32, 1),
+                 "dispatch": "mixed: tile kernels + per-graph kernels on the graphs beyond a tile" if c32["oversize_nodes"] else
+                             ("tile kernels" if visits else "per-graph kernels (tiles do not pay for this batch)"),
+                 "tile_kernel_node_share": round(c32["tile_nodes"] / visits, 4) if visits else 0.0}
+    del model32
     durs = timer.durations_ms()
     byt = [ops.mp_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"], m.get("feat_bytes", 4)) for m in timer.meta]
     mp_ms = sum(durs) / max(len(durs), 1)
@@ -444,7 +468,7 @@ def cfg5_leg(dev, graphs: int = 2048, steps: int = 10):
                           "tables for hub graphs)") + " (isg_gatv2_mp_fwd_f16; e_proj streamed as half rows)",
             "mp_avg_launch_us": round(mp_ms * 1e3, 2), "mp_algorithmic_bytes_per_launch_s2": int(sum(byt) / max(len(byt), 1)),
             "mp_achieved_GBps": round(gbps, 1), "mp_frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
-            "imbalance_world8_max_over_mean": imb, "steps": steps}
+            "imbalance_world8_max_over_mean": imb, "steps": steps, "fp32_rows": fp32_rows}
 
 
 def main(argv=None):

@@ -115,7 +115,12 @@ __device__ __forceinline__ void tile_plan_body(const int *__restrict__ ptr, cons
         tile_ptr[idx] = c0 + i;
         if (tile_info) {       // {first node, nodes, first CSR slot, CSR slots}: one load gives a workgroup its tile
           const int l1 = nx0 < TP_CH ? nx0 : cn;
-          tile_info[idx] = make_int4(s_ptr[i], s_ptr[l1] - s_ptr[i], s_eptr[i], s_eptr[l1] - s_eptr[i]);
+          int nn = s_ptr[l1] - s_ptr[i], ee = s_eptr[l1] - s_eptr[i];
+          // A graph beyond the caps is a tile of its own (i + 1 is forced above).  It gets NO rows and NO slots here: the tile
+          // kernels pass over it, and the caller runs the per-graph kernels on the list of such graphs (mixed dispatch:
+          // ops.GraphPlan.oversize) -- one 130-node graph no longer switches a whole batch off the tile kernels.
+          if (nn > ncap || (eptr && ee > ecap)) { nn = 0; ee = 0; }
+          tile_info[idx] = make_int4(s_ptr[i], nn, s_eptr[i], ee);
         }
       }
     }

@@ -71,8 +71,14 @@ def _ln(norm: torch.nn.LayerNorm, x: Tensor, residual: Tensor = None) -> Tensor:
 
 def _ffn(layer, x: Tensor) -> Tensor:
     # ReLU is the layers' default activation; linear1's epilogue leaves one maximum per 32 columns for linear2's K-chunks
-    h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, relu=True, want_rowmax=True)
-    return ops.linear(h, layer.linear2.weight, layer.linear2.bias)
+    w1, w2 = layer.linear1.weight, layer.linear2.weight
+    if (ops.H3P_CHAIN and ops.h3p_supported(x.size(0), w1.size(0), w1.size(1)) and ops.h3p_supported(x.size(0), w2.size(0), w2.size(1))
+            and w1.size(0) % 32 == 0):
+        # the 2048-wide intermediate never exists as fp32 rows: linear1's epilogue writes it as the planes linear2 reads
+        h = ops.linear_h3p(x, w1, layer.linear1.bias, relu=True, planes_out=True)
+        return ops.linear_h3p(h, w2, layer.linear2.bias)
+    h = ops.linear(x, w1, layer.linear1.bias, relu=True, want_rowmax=True)
+    return ops.linear(h, w2, layer.linear2.bias)
 
 
 class CLIPTextEmbeddings(torch.nn.Module):

@@ -21,7 +21,8 @@ MAX_NODES_PER_GRAPH = 1024   # LDS strip / sampler row capacity of the kernels
 
 # Launches that leave this library's own dense kernels, and extra passes a missing hand-off costs; bench.py prints them
 # per step ("no GEMM of the inference path runs on hipBLASLt" is then a number, not a sentence).
-COUNTERS = {"torch_linear": 0, "torch_layer_norm": 0, "torch_attention": 0, "row_absmax": 0}
+COUNTERS = {"torch_linear": 0, "torch_layer_norm": 0, "torch_attention": 0, "row_absmax": 0,
+            "tile_nodes": 0, "oversize_nodes": 0}      # nodes the tile kernels took / nodes of graphs beyond a tile (mixed dispatch)
 
 
 def reset_counters() -> None:
@@ -157,6 +158,20 @@ PLAN_FUSED = True     # isg_graph_plan_build (6 launches) instead of isg_graph_p
 BOUNDS_TO_HOST = True    # isg_graph_plan_build writes the batch's true bounds into pinned host memory (hint check without a copy)
 
 
+MIXED_DISPATCH = True       # graphs beyond a tile go to the per-graph kernels, the rest of the batch stays on the tile kernels
+MIXED_MAX_FRACTION = 0.5    # ... while at most this share of the batch's nodes sits in such graphs
+
+
+class OversizeGraphs(NamedTuple):
+    """The graphs of a batch that do not fit a graph tile, as a batch of their own (GraphPlan.oversize)."""
+    gids: Tensor                 # int64 [G] graph ids
+    nodes: Tensor                # int64 [Ns] node ids
+    edges: Optional[Tensor]      # int64 [Es] original edge ids (None: the plan has no CSR)
+    batch: Tensor                # int64 [Ns] local graph index
+    edge_index: Optional[Tensor]  # int64 [2, Es] local node ids
+    plan: "GraphPlan"
+
+
 @dataclass
 class GraphPlan:
     """What every layer needs to know about one PyG Batch, computed once on the device.
@@ -184,6 +199,7 @@ class GraphPlan:
     _slots: Optional[Tensor] = None
     _tiles: Optional[dict] = None
     _edge_planes: Optional[tuple] = None
+    _oversize: Optional[dict] = None
 
     def edge_planes(self, edge_attr: Tensor) -> Tuple[Tensor, Tensor]:
         """(planes int16 [E, 2, 128], inv_scale fp32 [E]) of the batch's edge features in CSR slot order (isg_edge_planes): the
@@ -254,6 +270,74 @@ class GraphPlan:
             hit = (tp, nt, cap, info.view(cap, 4))
             self._tiles[key] = hit
         return hit
+
+    def tile_mode(self, node_cap: int = 64, edge_cap: int = 256) -> str:
+        """How the graph-tile kernels (isg_gatv2_layer_conv / _tile_conv, isg_mgat_dense_tail, isg_readout_tile) can take this
+        batch: "tiles" -- every graph fits a tile; "mixed" -- a few do not: the tile kernels pass over them (isg_tile_plan
+        gives such a graph an empty tile) and the per-graph kernels run on the list of them (`oversize`), both writing disjoint
+        rows of the same outputs; "none" -- tiles do not pay (most nodes sit in oversize graphs) or the list cannot be made
+        (inside a hipGraph capture: it takes a device-to-host sync)."""
+        ecap = edge_cap if self.rowptr is not None else 0
+        if self.B <= 0 or self.nmax <= 0:
+            return "none"
+        if self.nmax <= node_cap and (ecap == 0 or self.emax <= ecap):
+            return "tiles"
+        if not MIXED_DISPATCH or torch.cuda.is_current_stream_capturing():
+            return "none"
+        sub = self.oversize(node_cap, edge_cap)
+        if sub is None:
+            return "tiles"                  # the hints overstated the batch
+        return "mixed" if sub.nodes.numel() <= MIXED_MAX_FRACTION * self.N else "none"
+
+    def oversize(self, node_cap: int = 64, edge_cap: int = 256) -> Optional["OversizeGraphs"]:
+        """The graphs of this batch beyond a tile (more than node_cap nodes or edge_cap in-edges) as a batch of their own: graph
+        ids, node ids, original edge ids (all ascending: segment sums keep their order), local batch vector / edge_index and the
+        GraphPlan over them.  None when every graph fits.  Built once per (plan, caps); two device-to-host syncs, paid only by
+        batches that have such graphs.  The reference puts no cap on the objects of a scene graph (datasets/scene_graph.py:199-389)."""
+        ecap = int(edge_cap) if self.rowptr is not None else 0
+        key = (int(node_cap), ecap)
+        if self._oversize is None:
+            self._oversize = {}
+        if key in self._oversize:
+            return self._oversize[key]
+        res = None
+        if self.nmax > key[0] or (ecap > 0 and self.emax > ecap):
+            dev = self.ptr.device
+            ptr = self.ptr.long()
+            n = ptr[1:] - ptr[:-1]
+            big = n > key[0]
+            e = None
+            if ecap > 0:
+                eptr = self.eptr.long()
+                e = eptr[1:] - eptr[:-1]
+                big = big | (e > ecap)
+            gids = torch.nonzero(big).squeeze(1)                          # sync 1: how many such graphs
+            G = gids.numel()
+            if G > 0:
+                cnt = n[gids]
+                stats = [cnt.sum(), cnt.max()]
+                if e is not None:
+                    stats += [e[gids].sum(), e[gids].max()]
+                stats = [int(v) for v in torch.stack(stats).tolist()]     # sync 2: their sizes
+                Ns, nmax_s = stats[0], stats[1]
+                ar = torch.arange(G, device=dev)
+                seg = torch.repeat_interleave(ar, cnt, output_size=Ns)
+                nodes = ptr[gids][seg] + (torch.arange(Ns, device=dev) - (cnt.cumsum(0) - cnt)[seg])
+                edges = sub_ei = None
+                emax_s = None
+                if e is not None:
+                    Es, emax_s = stats[2], stats[3]
+                    ce = e[gids]
+                    seg_e = torch.repeat_interleave(ar, ce, output_size=Es)
+                    slots = eptr[gids][seg_e] + (torch.arange(Es, device=dev) - (ce.cumsum(0) - ce)[seg_e])
+                    edges = torch.sort(self.eid.long()[slots]).values
+                    newid = torch.full((self.N,), -1, dtype=torch.int64, device=dev)
+                    newid[nodes] = torch.arange(Ns, device=dev)
+                    sub_ei = newid[self.edge_index[:, edges]].contiguous()
+                sub_plan = GraphPlan.build(seg.contiguous(), sub_ei, num_graphs=G, max_nodes=nmax_s, max_edges=emax_s)
+                res = OversizeGraphs(gids, nodes, edges, seg, sub_ei, sub_plan)
+        self._oversize[key] = res
+        return res
 
     def source_csr(self) -> Tuple[Tensor, Tensor, Tensor]:
         """(rowptr_s[N+1], eid_s[E], dst_s[E]): out-edges of every node in edge-id order.  Only the backward of the
@@ -630,10 +714,10 @@ TILE_CONV_NODES, TILE_CONV_EDGES = 64, 256
 
 def tile_conv_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
     """Shape test of isg_gatv2_tile_conv (inference, fp32 rows): C = 128, edge features <= 128 wide, every graph within one
-    64-node / 256-slot tile."""
+    64-node / 256-slot tile -- or all but a few (GraphPlan.tile_mode: those go to the per-graph kernels)."""
     return (FUSE_TILE_CONV and FUSE_LOGITS and GEMM_BACKEND == "bf16x6" and GEMM_F16X3 and MP_KERNEL == "graph" and
             channels == 128 and 0 < edge_dim <= 128 and edge_dim % 4 == 0 and heads <= 64 and plan.B > 0 and
-            0 < plan.nmax <= TILE_CONV_NODES and plan.emax <= TILE_CONV_EDGES and plan.rowptr is not None and plan.E > 0)
+            plan.rowptr is not None and plan.E > 0 and plan.tile_mode(TILE_CONV_NODES, TILE_CONV_EDGES) != "none")
 
 
 FUSE_LAYER_CONV = True     # ... and lin_l | lin_r inside as well (csrc/isg_layer_conv.hip): x_l / x_r never exist in memory
@@ -674,6 +758,37 @@ def instr_gate_planes(x: Tensor, instr: Tensor, batch: Tensor, want_rows: bool =
                                          _chk(batch, "batch", torch.int64, (N,)), 0 if rows is None else rows.data_ptr(),
                                          planes.data_ptr(), inv.data_ptr(), N, C, _stream()), "isg_instr_gate_planes")
     return rows, NodePlanes(planes, inv)
+
+
+def _count_tile_nodes(plan: "GraphPlan", sub: Optional["OversizeGraphs"]) -> None:
+    COUNTERS["tile_nodes"] += plan.N - (0 if sub is None else sub.nodes.numel())
+    COUNTERS["oversize_nodes"] += 0 if sub is None else sub.nodes.numel()
+
+
+def _mixed_sub(plan: "GraphPlan") -> Optional["OversizeGraphs"]:
+    """The oversize graphs of a batch the tile kernels take in "mixed" mode (None in "tiles" mode)."""
+    sub = plan.oversize(TILE_CONV_NODES, TILE_CONV_EDGES) if plan.tile_mode(TILE_CONV_NODES, TILE_CONV_EDGES) == "mixed" else None
+    _count_tile_nodes(plan, sub)
+    return sub
+
+
+def _oversize_conv(sub: "OversizeGraphs", x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, heads: int,
+                   bias, node_mask, edge_mask, negative_slope: float, out: Tensor, alpha: Tensor, rowmax: Optional[Tensor]) -> None:
+    """Message passing of the graphs the tile kernels passed over (mgat_v2_conv.py:215-279 on the sub-batch): lin_edge +
+    the per-graph kernel (256-node / 1024-edge tables, or node chunks beyond), written into the rows / edges of `out` /
+    `alpha` / `rowmax` that belong to those graphs."""
+    e_proj = linear(edge_attr.index_select(0, sub.edges), w_edge)
+    nm = None if node_mask is None else node_mask.reshape(-1).index_select(0, sub.nodes)
+    em = None if edge_mask is None else edge_mask.reshape(-1).index_select(0, sub.edges)
+    o, a = gatv2_mp(x_l, x_r, e_proj, att, sub.plan, heads, bias=bias, node_mask=nm, edge_mask=em,
+                    negative_slope=negative_slope, want_rowmax=rowmax is not None)
+    out.index_copy_(0, sub.nodes, o)
+    alpha.index_copy_(0, sub.edges, a)
+    if rowmax is not None:
+        rm = row_maxima(o)
+        if rm is None:                                  # the node-chunk kernel leaves none: one pass over the few rows
+            rm = o.view(o.size(0), heads, -1).abs().amax(dim=2)
+        rowmax.index_copy_(0, sub.nodes, rm)
 
 
 def gatv2_layer_conv(x, lin_l, lin_r, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan", heads: int,
@@ -735,6 +850,14 @@ def gatv2_layer_conv(x, lin_l, lin_r, edge_attr: Tensor, w_edge: Tensor, att: Te
     _lib.check(rc, "isg_gatv2_layer_conv")
     if timer is not None:
         ev1.record()
+    sub = _mixed_sub(plan)
+    if sub is not None:
+        # the gated rows of those graphs out of the SAME planes the tile kernel read (hi + mid, exact), projected per node
+        pl = x.planes.view(torch.float16).index_select(0, sub.nodes).float()
+        xs = ((pl[:, 0] + pl[:, 1]) * x.inv.index_select(0, sub.nodes)[:, None]).contiguous()
+        y = linear(xs, cat_w, cat_b)
+        _oversize_conv(sub, y[:, :HC], y[:, HC:], edge_attr, w_edge, att, H, bias, node_mask, edge_mask, negative_slope,
+                       out, alpha, rowmax)
     if rowmax is not None:
         attach_row_maxima(out, rowmax)
     return out, alpha
@@ -784,6 +907,10 @@ def gatv2_tile_conv(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor,
     _lib.check(rc, "isg_gatv2_tile_conv")
     if timer is not None:
         ev1.record()
+    sub = _mixed_sub(plan)
+    if sub is not None:
+        _oversize_conv(sub, x_l.index_select(0, sub.nodes), x_r.index_select(0, sub.nodes), edge_attr, w_edge, att, H, bias,
+                       node_mask, edge_mask, negative_slope, out, alpha, rowmax)
     if rowmax is not None:
         attach_row_maxima(out, rowmax)
     return out, alpha
@@ -1158,7 +1285,8 @@ def dense_tail_supported(plan: GraphPlan, x_proj: torch.nn.Sequential, width_in:
     if not (isinstance(l0, torch.nn.Linear) and isinstance(l2, torch.nn.Linear)) or l0.bias is None or l2.bias is None:
         return False
     return (width_in == 512 and channels == 128 and tuple(l0.weight.shape) == (256, 512) and
-            tuple(l2.weight.shape) == (128, 256) and plan.B > 0 and 0 < plan.nmax <= DENSE_TAIL_ROWS and plan.batch is not None)
+            tuple(l2.weight.shape) == (128, 256) and plan.B > 0 and plan.batch is not None and
+            plan.tile_mode(DENSE_TAIL_ROWS, TILE_CONV_EDGES) != "none")
 
 
 def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, h: Tensor, plan: GraphPlan, weight: Tensor,
@@ -1182,8 +1310,8 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
     ybound = derived_weight("dense_tail_bound", (l0.weight, l0.bias), lambda: torch.stack(
         [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
     # one tile plan per batch: the convolution's (64 nodes / 256 slots) serves this kernel too when it exists
-    shared = plan._tiles is not None and (DENSE_TAIL_ROWS, TILE_CONV_EDGES) in plan._tiles
-    tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if shared else 0)
+    # one tile plan per batch, the convolution's (64 nodes / 256 slots): the same graphs are "oversize" for every tile kernel
+    tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if plan.rowptr is not None else 0)
     h_out = torch.empty_like(h)
     xg = torch.empty_like(h) if ins_next is not None and want_rows else None
     xp = None
@@ -1205,6 +1333,21 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
     if rc == ISG_EUNSUPPORTED:
         return None
     _lib.check(rc, "isg_mgat_dense_tail")
+    sub = _mixed_sub(plan)
+    if sub is not None:
+        # mgat.py:156-177 on the graphs the tile kernel passed over: x_proj, the per-graph layer tail, the next gate
+        cs = mlp(x_proj, conv_out.index_select(0, sub.nodes))
+        nm = None if node_mask is None else node_mask.reshape(-1).index_select(0, sub.nodes).view(-1, 1)
+        hs = mgat_layer_tail(ins.index_select(0, sub.gids), cs.contiguous(), h.index_select(0, sub.nodes), sub.plan, weight, bias,
+                             mean_scale, eps, node_mask=nm)
+        h_out.index_copy_(0, sub.nodes, hs)
+        if ins_next is not None and (xg is not None or xp is not None):
+            rows, pl = instr_gate_planes(hs, ins_next.index_select(0, sub.gids), sub.batch, want_rows=xg is not None)
+            if xg is not None:
+                xg.index_copy_(0, sub.nodes, rows)
+            if xp is not None:
+                xp.planes.index_copy_(0, sub.nodes, pl.planes[:sub.nodes.numel()])
+                xp.inv.index_copy_(0, sub.nodes, pl.inv[:sub.nodes.numel()])
     return h_out, xg, xp
 
 
@@ -1222,7 +1365,7 @@ def readout_tile_supported(plan: GraphPlan, node_nn: torch.nn.Sequential, width_
     if not (isinstance(l0, torch.nn.Linear) and isinstance(l2, torch.nn.Linear)) or l0.bias is None or l2.bias is None:
         return False
     return (width_in == 128 and tuple(l0.weight.shape) == (128, 128) and tuple(l2.weight.shape) == (128, 128) and plan.B > 0 and
-            0 < plan.nmax <= DENSE_TAIL_ROWS and plan.batch is not None)
+            plan.batch is not None and plan.tile_mode(DENSE_TAIL_ROWS, TILE_CONV_EDGES) != "none")
 
 
 def readout_tile(x: Tensor, node_nn: torch.nn.Sequential, q: Tensor, plan: GraphPlan, node_mask: Optional[Tensor] = None):
@@ -1235,8 +1378,7 @@ def readout_tile(x: Tensor, node_nn: torch.nn.Sequential, q: Tensor, plan: Graph
     p2, inv2 = _weight_planes(l2.weight, True, "f16x3")
     ybound = derived_weight("dense_tail_bound", (l0.weight, l0.bias), lambda: torch.stack(
         [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
-    shared = plan._tiles is not None and (DENSE_TAIL_ROWS, TILE_CONV_EDGES) in plan._tiles
-    tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if shared else 0)
+    tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if plan.rowptr is not None else 0)
     out = torch.empty(plan.B, C, dtype=torch.float32, device=x.device)
     gate = torch.empty(N, 1, dtype=torch.float32, device=x.device)
     rc = lib.isg_readout_tile(
@@ -1249,6 +1391,14 @@ def readout_tile(x: Tensor, node_nn: torch.nn.Sequential, q: Tensor, plan: Graph
     if rc == ISG_EUNSUPPORTED:
         return None
     _lib.check(rc, "isg_readout_tile")
+    sub = _mixed_sub(plan)
+    if sub is not None:
+        # att_pooling.py:62-73 on the graphs the tile kernel passed over (it zeroed their rows of `out`)
+        xn = mlp(node_nn, x.index_select(0, sub.nodes))
+        nm = None if node_mask is None else node_mask.reshape(-1).index_select(0, sub.nodes).view(-1, 1)
+        o, g = global_attn_pool(xn.contiguous(), q.index_select(0, sub.gids), sub.plan, nm)
+        out.index_copy_(0, sub.gids, o)
+        gate.index_copy_(0, sub.nodes, g)
     return out, gate
 
 
@@ -1474,6 +1624,9 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         if M == 0:
             return x.new_empty(0, N)
         return _linear_torch(x, weight, bias, gelu, False)
+    if not f16_io and h3p_supported(M, N, K) and x.stride(1) == 1 and (x.stride(0) & 3) == 0 and (x.data_ptr() & 15) == 0:
+        # K >= 256 over many rows: the planes32 engine (csrc/isg_gemm_h3p.hip); the split of x stays attached to x
+        return linear_h3p(x, weight, bias, gelu=gelu, relu=relu, cache_planes=cache_planes)
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
     a_rowmax = row_maxima(x)
@@ -1605,6 +1758,7 @@ def _h3p_weight(weight: Tensor, bias: Optional[Tensor], cache: bool = True):
 
 H3P = True            # Linears with K >= H3P_MIN_K over at least H3P_MIN_M rows on isg_linear_h3p (A/B switch)
 H3P_MIN_K = 256
+H3P_CHAIN = True      # linear1 -> linear2 of the Transformer layers through planes (no fp32 intermediate): A/B switch
 H3P_MIN_M = 8192
 
 

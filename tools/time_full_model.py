@@ -8,11 +8,16 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from isubgvqa_amd import synthetic
+from isubgvqa_amd import ops, synthetic
 from isubgvqa_amd.models import build_model
 
-graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+graphs = int(args[0]) if len(args) > 0 else 2048
+steps = int(args[1]) if len(args) > 1 else 20
+if '--no-h3p' in sys.argv:
+    ops.H3P = False        # A/B: the round-3 tile kernel for the K >= 256 Linears
+if '--no-chain' in sys.argv:
+    ops.H3P_CHAIN = False
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = build_model(synthetic.full_model_args(), None).to(dev).eval()
