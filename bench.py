@@ -258,13 +258,31 @@ def full_model_rate(dev, graphs: int, steps: int = 10):
             "ms_per_step": round(dt * 1e3, 3), "questions_per_s": round(graphs / dt, 1), "steps": steps}
 
 
-def load_traffic(N: int, E: int, kernel: str):
+TRAFFIC_SOURCES = {      # kind of summary -> the kernel sources it measured (csrc/); a summary is only as good as their bytes
+    "layer_conv": ("isg_layer_conv.hip",), "tile_conv": ("isg_layer_tile.hip",), "graph": ("isg_mp_graph.hip",),
+    "chunk": ("isg_mp.hip",), "logits_pair": ("isg_mp_logits.hip", "isg_mp_graph.hip"),
+}
+
+
+def kernel_source_hash(kind: str, root: str = None) -> str:
+    """sha256 over the source files of the kernel(s) a traffic summary of this kind describes."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in TRAFFIC_SOURCES[kind]:
+        h.update(open(os.path.join(root or ROOT, "intrinsic-subgraph-generation-for-vqa_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
+def load_traffic(N: int, E: int, kernel: str, with_source: bool = False, profiles_dir: str = None):
     """HBM bytes per message-passing launch from the committed PMC summary (profiles/*_mp_traffic.json, made by
-    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), if kernel and batch shape match
-    this run; None otherwise.  kernel: "graph" | "chunk" | "logits_pair" (edge logits + message passing from logits: a
-    summary of the un-fused kernel says nothing about that pair and is never replayed for it)."""
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), if kernel, batch shape AND kernel
+    source match this run; None otherwise.  kernel: "layer_conv" | "tile_conv" | "graph" | "chunk" | "logits_pair".  A summary
+    carries the sha256 of the kernel source(s) it was measured on (`source_sha256`): one without it, or measured on other
+    bytes, is stale and refused -- a kernel edit invalidates the replayed number instead of silently keeping it.
+    with_source: return (bytes, file name) / (None, why)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*mp_traffic.json")), reverse=True):
+    why = "no summary for this kernel and batch shape"
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*mp_traffic.json")), reverse=True):
         try:
             t = json.load(open(path))
             name = t.get("kernel", "")
@@ -277,10 +295,13 @@ def load_traffic(N: int, E: int, kernel: str):
             else:
                 kind = t.get("kind") or ("graph" if "graph" in name else "chunk")
             if t.get("N") == N and t.get("E") == E and kind == kernel:
-                return t.get("hbm_bytes_per_launch")
+                if t.get("source_sha256") != kernel_source_hash(kind):
+                    why = f"{os.path.basename(path)} was measured on another version of {' + '.join(TRAFFIC_SOURCES[kind])}"
+                    continue
+                return (t.get("hbm_bytes_per_launch"), os.path.basename(path)) if with_source else t.get("hbm_bytes_per_launch")
         except Exception:
             pass
-    return None
+    return (None, why) if with_source else None
 
 
 def time_unfused_mp(wl, cfg, dev, launches: int = 20):
@@ -446,13 +467,31 @@ def cfg5_leg(dev, graphs: int = 2048, steps: int = 10):
         torch.cuda.synchronize()
         dt32 = (time.perf_counter() - t0) / steps
         c32 = ops.counters()
+        # ... and with the mixed mode forced (its profitability gate open): what the tile kernels + per-graph kernels cost here
+        gate = ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES
+        ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES = 0.9, 0
+        try:
+            for i in range(2):
+                model32(wl, seed=50 + i)
+            torch.cuda.synchronize()
+            ops.reset_counters()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                model32(wl, seed=60 + i)
+            torch.cuda.synchronize()
+            dt32m = (time.perf_counter() - t0) / steps
+            c32m = ops.counters()
+        finally:
+            ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES = gate
         ops.COUNTERS.update(keep)
     assert torch.isfinite(out32).all()
     visits = c32["tile_nodes"] + c32["oversize_nodes"]
     fp32_rows = {"ms_per_step": round(dt32 * 1e3, 3), "questions_per_s": round(graphs / dt32, 1),
                  "dispatch": "mixed: tile kernels + per-graph kernels on the graphs beyond a tile" if c32["oversize_nodes"] else
                              ("tile kernels" if visits else "per-graph kernels (tiles do not pay for this batch)"),
-                 "tile_kernel_node_share": round(c32["tile_nodes"] / visits, 4) if visits else 0.0}
+                 "tile_kernel_node_share": round(c32["tile_nodes"] / visits, 4) if visits else 0.0,
+                 "mixed_forced": {"ms_per_step": round(dt32m * 1e3, 3),
+                                  "tile_kernel_node_share": round(c32m["tile_nodes"] / max(c32m["tile_nodes"] + c32m["oversize_nodes"], 1), 4)}}
     del model32
     durs = timer.durations_ms()
     byt = [ops.mp_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"], m.get("feat_bytes", 4)) for m in timer.meta]
@@ -659,6 +698,9 @@ def main(argv=None):
         unfused = time_unfused_mp(wl, cfg, dev)
 
     if rank == 0:
+        traffic, traffic_src = load_traffic(N, E, "layer_conv" if layer_conv else ("tile_conv" if tile_conv else
+                                                                                   ("logits_pair" if fused else args.mp_kernel)),
+                                            with_source=True)
         res = {
             "metric": "GQA questions/sec", "value": round(world * cfg.num_graphs * args.steps / dt, 1),
             "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -685,8 +727,7 @@ def main(argv=None):
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
-                         "traffic": load_traffic(N, E, "layer_conv" if layer_conv else ("tile_conv" if tile_conv else
-                                                                                         ("logits_pair" if fused else args.mp_kernel))),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(mp_bytes),
                          "avg_launch_us": round(mp_ms * 1e3, 2), "launches_timed": len(durs)},
         }
@@ -708,6 +749,15 @@ def main(argv=None):
             if layer_conv:
                 flops += 3 * 2.0 * m0["N"] * 2 * m0["H"] * m0["C"] * m0["K_in"]
             res["roofline"]["mfma_products_TFLOPs"] = round(flops / (mp_ms * 1e-3) / 1e12, 1)
+            # `bound` above is the contract's label for the path (graph / segmented-reduce work prices against HBM); what the
+            # counters say limits THIS kernel is neither of the two rooflines:
+            res["roofline"]["own_bound"] = {
+                "limit": "issue + barrier lock-step: eight waves pass ~7 barriers per (tile, head), so vector issue, the matrix "
+                         "pipe and LDS add up instead of overlapping",
+                "hbm_frac_on_own_bytes": res["roofline"]["own_frac"],
+                "mfma_frac_of_dense_fp16_peak": round(flops / (mp_ms * 1e-3) / 1e12 / 2500.0, 4),
+                "evidence": "profiles/r03_bm_tile_kernels_sq_counters.txt (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.42), "
+                            "profiles/r03_bg_layer_conv_ablation.md (the phases add)"}
             if layer_conv:     # the launch also IS lin_l | lin_r: the bytes the reference's projection moves beside bytes_mp
                 proj = sum(4 * m["N"] * m["K_in"] + 8 * m["N"] * m["H"] * m["C"] for m in timer.meta) / len(timer.meta)
                 res["roofline"]["with_projection_bytes"] = {

@@ -429,18 +429,12 @@ int isg_gatv2_mp_fwd_rowmax(const float *x_l, const float *x_r, const float *e_p
  * three-term form of isg_linear_f16x3 and never leaves the accumulators.  head_stride_l / _r: distance in floats between
  * the head slices of one node (0 = C: heads side by side in a row of H*C; N*C with ldl = C for a head-major [H][N][C]
  * tensor, whose 512-byte rows keep a gather instruction inside a few pages).  ISG_EUNSUPPORTED unless 32 | C, K <= 128,
- * 4 | K, H * C <= 2048, 16-byte aligned rows.
- * x_r == NULL selects the form that computes x_r = lin_r(x) itself (mgat_v2_conv.py:181 folded in as well): x fp32 rows by
- * node id (the layer input AFTER the instruction gate, K2 <= 128 features, stride ldx), wr_frag / wr_inv_scale from
- * isg_split_f16x2_frag(lin_r.weight [H*C, K2]), b_r = lin_r.bias or NULL.  The rows x[dst] of a panel's slots are staged next
- * to its edge features and multiplied into a second accumulator with their own row scale; x_r is never written or read,
- * and the caller projects lin_l alone.  With x_r given, x / wr_frag / wr_inv_scale / b_r / K2 are ignored. */
+ * 4 | K, H * C <= 2048, 16-byte aligned rows. */
 int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
                           const float *x_l, int32_t ldl, int64_t head_stride_l, const float *x_r, int32_t ldr,
-                          int64_t head_stride_r, const float *att, const int32_t *eid, const int32_t *src,
-                          const int32_t *dst, const float *edge_mask, const float *node_mask, float *logits, int64_t E,
-                          int32_t H, int32_t C, int32_t K, float negative_slope, const float *x, int32_t ldx,
-                          const uint16_t *wr_frag, const float *wr_inv_scale, const float *b_r, int32_t K2, void *stream);
+                          int64_t head_stride_r, const float *att, const int32_t *eid, const int32_t *src, const int32_t *dst,
+                          const float *edge_mask, const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C,
+                          int32_t K, float negative_slope, void *stream);
 /* The rest of MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:270-279, :215-232) given those logits: softmax over
  * every destination's in-edges (+1e-16), alpha fp32 [E, H] by edge id, out[i] = sum alpha * mask * x_l[src] + bias, rowmax
  * (optional) as in isg_gatv2_mp_fwd_rowmax.  e_proj and x_r are not read.  Per-graph kernel only: ISG_EUNSUPPORTED for

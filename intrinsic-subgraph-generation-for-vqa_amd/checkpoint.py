@@ -59,4 +59,8 @@ def load_model(path: str, device: Optional[str] = None, strict: bool = True):
         args.device = device
     model = build_model(args, None)
     model.load_state_dict(sd, strict=strict)
+    # the weight-plane caches are validated by (identity, tensor._version, data_ptr); under torch.inference_mode() tensors carry
+    # no version counter, so weights written in place there would keep stale planes: a fresh load starts from empty caches
+    from . import ops
+    ops.invalidate_weight_cache()
     return model.eval(), args, rest

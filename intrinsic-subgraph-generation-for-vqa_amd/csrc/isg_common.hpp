@@ -13,6 +13,33 @@ namespace isg {
 // ---- host-side launch bookkeeping -------------------------------------------------------------
 int check_launch();                 // hipGetLastError() -> ISG_OK / ISG_ELAUNCH (records the text)
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+// Per-DEVICE state of this process.  More than 64 KB of dynamic LDS is an attribute of (function, device) and a persistent grid
+// is sized from the device's CU count: a process that drives several GPUs must not reuse the first device's answers.
+inline int current_device() {
+  int d = 0;
+  return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : -1;
+}
+inline int device_cus() {
+  static int cus[64] = {};
+  const int d = current_device();
+  if (d < 0) return 256;
+  if (!cus[d]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    cus[d] = n;
+  }
+  return cus[d];
+}
+template <auto Kernel>
+inline bool dyn_lds_ok(int bytes) {       // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device)
+  static signed char state[64] = {};      // 0 unknown, 1 set, -1 refused
+  const int d = current_device();
+  if (d < 0) return false;
+  if (!state[d])
+    state[d] = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) ==
+                       hipSuccess ? 1 : -1;
+  return state[d] > 0;
+}
 
 // ---- cross-lane movement via DPP (no LDS traffic) --------------------------------------------
 template <int CTRL>

@@ -701,14 +701,9 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   a.nt_store = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
   { const char *e = getenv("ISG_P3_ABL"); a.abl = e ? atoi(e) : 0; }
   hipStream_t st = as_stream(stream);
-  // more than 64 KB of dynamic LDS is an attribute of (function, device): set once per device of this process
-  static bool attr_set[18][64] = {};
-  static int cus[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ISG_ELAUNCH;
   static const int version = [] { const char *e = getenv("ISG_H3P_V"); return e ? atoi(e) : 2; }();
   if (version != 1 && KT >= Q3_HEAD) {       // persistent 256 x 128 form
-    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return ISG_ELAUNCH;
+    const int ncu = device_cus();
     Q3Args q;
     q.p = a;
     q.tiles_m = (int)tm;
@@ -717,18 +712,13 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
     if (total >= (1ll << 31)) return ISG_EUNSUPPORTED;
     q.p.tiles_n = (int)tn2;
     q.total_l = (int)total;
-    const unsigned grid = (unsigned)(total < cus[dev] ? total : cus[dev]);
-#define ISG_Q3H(ACT_, PO_, H_, slot)                                                                              \
+    const unsigned grid = (unsigned)(total < ncu ? total : ncu);
+#define ISG_Q3H(ACT_, PO_, H_)                                                                                    \
   do {                                                                                                            \
-    if (!attr_set[slot][dev]) {                                                                                   \
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_h3q_kernel<ACT_, PO_, H_>),                  \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, Q3_SMEM) != hipSuccess)                 \
-        return ISG_ELAUNCH;                                                                                       \
-      attr_set[slot][dev] = true;                                                                                 \
-    }                                                                                                             \
+    if (!dyn_lds_ok<&linear_h3q_kernel<ACT_, PO_, H_>>(Q3_SMEM)) return ISG_ELAUNCH;                              \
     linear_h3q_kernel<ACT_, PO_, H_><<<grid, P3_THREADS, Q3_SMEM, st>>>(q);                                       \
   } while (0)
-#define ISG_Q3(ACT_, PO_, slot) do { if (KT >= 16) ISG_Q3H(ACT_, PO_, 16, slot); else ISG_Q3H(ACT_, PO_, 8, (slot) + 6); } while (0)
+#define ISG_Q3(ACT_, PO_, slot) do { if (KT >= 16) ISG_Q3H(ACT_, PO_, 16); else ISG_Q3H(ACT_, PO_, 8); } while (0)
     if (planes_out) {
       if (act == 1) ISG_Q3(1, true, 6); else if (act == 2) ISG_Q3(2, true, 7); else ISG_Q3(0, true, 8);
     } else {
@@ -740,12 +730,7 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   }
 #define ISG_P3(ACT_, PO_, slot)                                                                                   \
   do {                                                                                                            \
-    if (!attr_set[slot][dev]) {                                                                                   \
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_h3p_kernel<ACT_, PO_>),                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM) != hipSuccess)                 \
-        return ISG_ELAUNCH;                                                                                       \
-      attr_set[slot][dev] = true;                                                                                 \
-    }                                                                                                             \
+    if (!dyn_lds_ok<&linear_h3p_kernel<ACT_, PO_>>(P3_SMEM)) return ISG_ELAUNCH;                                  \
     linear_h3p_kernel<ACT_, PO_><<<(unsigned)blocks, P3_THREADS, P3_SMEM, st>>>(a);                               \
   } while (0)
   if (planes_out) {

@@ -764,11 +764,7 @@ extern "C" int isg_gatv2_layer_conv(const uint16_t *x_planes, const float *x_inv
   a.eid = eid; a.src = src; a.dst = dst; a.ntiles = ntiles; a.tile_info = reinterpret_cast<const int4 *>(tile_info);
   a.edge_mask = edge_mask; a.node_mask = node_mask; a.out = out; a.alpha = alpha; a.rowmax = rowmax; a.N = (int)N; a.E = (int)E;
   a.H = H; a.KSE = (K_edge + 15) / 16; a.NTE = H * C / 32; a.ldo = ldo; a.slope = negative_slope;
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
+  const int cus = device_cus();
   int gpx = (cus / 8) / H;                                // groups per XCD: one workgroup per CU
   if (gpx < 1) gpx = 1;
   const long long need = (max_tiles + 7) / 8;
@@ -777,9 +773,7 @@ extern "C" int isg_gatv2_layer_conv(const uint16_t *x_planes, const float *x_inv
   hipStream_t st = as_stream(stream);
 #define LC_LAUNCH(M, KT, SL)                                                                                         \
   {                                                                                                                  \
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_layer_conv_kernel<M, KT, SL>),  \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LC_SMEM_BYTES) == hipSuccess; \
-    if (!ok) return ISG_EUNSUPPORTED;                                                                                \
+    if (!dyn_lds_ok<&gatv2_layer_conv_kernel<M, KT, SL>>(LC_SMEM_BYTES)) return ISG_EUNSUPPORTED;                    \
     gatv2_layer_conv_kernel<M, KT, SL><<<grid, LC_THREADS, LC_SMEM_BYTES, st>>>(a);                                  \
   }
   const bool masked = node_mask || edge_mask;
@@ -1074,9 +1068,7 @@ extern "C" int isg_readout_tile(const float *x, int32_t ldx, const uint16_t *w1_
   if (!x || !w1_frag || !w1_inv_scale || !b1 || !y_bound || !w2_frag || !w2_inv_scale || !b2 || !q || !out || !gate || !ptr || !batch ||
       !tile_ptr || !tile_info || !ntiles)
     return ISG_EINVAL;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&isg::readout_tile_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, isg::RO_SMEM_BYTES) == hipSuccess;
-  if (!ok) return ISG_EUNSUPPORTED;
+  if (!isg::dyn_lds_ok<&isg::readout_tile_kernel>(isg::RO_SMEM_BYTES)) return ISG_EUNSUPPORTED;
   isg::RoArgs a;
   a.x = x; a.w1f = reinterpret_cast<const _Float16 *>(w1_frag); a.w2f = reinterpret_cast<const _Float16 *>(w2_frag);
   a.w1_inv = w1_inv_scale; a.b1 = b1; a.w2_inv = w2_inv_scale; a.b2 = b2; a.y_bound = y_bound; a.q = q; a.node_mask = node_mask;

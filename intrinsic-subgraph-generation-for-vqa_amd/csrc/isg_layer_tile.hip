@@ -630,9 +630,7 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
       !gn_weight || !gn_bias || !gn_mean_scale || !h_out || !ptr || !batch || !tile_ptr || !tile_info || !ntiles ||
       ((xg_out || xp_out) && !ins_next) || (xp_out && !xinv_out))
     return ISG_EINVAL;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&mgat_dense_tail_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, DT_SMEM_BYTES) == hipSuccess;
-  if (!ok) return ISG_EUNSUPPORTED;
+  if (!dyn_lds_ok<&mgat_dense_tail_kernel>(DT_SMEM_BYTES)) return ISG_EUNSUPPORTED;
   DtArgs a;
   a.a = conv_out; a.a_rowmax = a_rowmax; a.w1f = reinterpret_cast<const _Float16 *>(w1_frag); a.w1_inv = w1_inv_scale;
   a.b1 = b1; a.y_bound = y_bound; a.w2f = reinterpret_cast<const _Float16 *>(w2_frag); a.w2_inv = w2_inv_scale; a.b2 = b2; a.ins = ins; a.h = h;
@@ -1041,11 +1039,7 @@ extern "C" int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x
   a.out = out; a.alpha = alpha; a.rowmax = rowmax; a.N = (int)N; a.E = (int)E; a.H = H; a.K = K; a.KS = (K + 15) / 16;
   a.NT = H * C / 32; a.ldl = ldl; a.ldr = ldr; a.ldo = ldo; a.slope = negative_slope;
   // two workgroups per CU (LDS), 256 CUs: 8 XCDs x (groups per XCD) x H head-workgroups; fewer groups when there are few tiles
-  static const int gpx_max = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    return cus > 0 ? cus : 256;
-  }();
+  const int gpx_max = device_cus();
   int gpx = (2 * gpx_max / 8) / H;                       // groups per XCD
   if (gpx < 1) gpx = 1;
   const long long need = (max_tiles + 7) / 8;            // groups per XCD that would each get one tile
@@ -1053,14 +1047,10 @@ extern "C" int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x
   const unsigned grid = 8u * (unsigned)H * (unsigned)gpx;
   hipStream_t st = as_stream(stream);
   if (node_mask || edge_mask) {
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_tile_conv_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, TC_SMEM_BYTES) == hipSuccess;
-    if (!ok) return ISG_EUNSUPPORTED;
+    if (!dyn_lds_ok<&gatv2_tile_conv_kernel<true>>(TC_SMEM_BYTES)) return ISG_EUNSUPPORTED;
     gatv2_tile_conv_kernel<true><<<grid, TC_THREADS, TC_SMEM_BYTES, st>>>(a);
   } else {
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&gatv2_tile_conv_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, TC_SMEM_BYTES) == hipSuccess;
-    if (!ok) return ISG_EUNSUPPORTED;
+    if (!dyn_lds_ok<&gatv2_tile_conv_kernel<false>>(TC_SMEM_BYTES)) return ISG_EUNSUPPORTED;
     gatv2_tile_conv_kernel<false><<<grid, TC_THREADS, TC_SMEM_BYTES, st>>>(a);
   }
   return check_launch();

@@ -52,12 +52,6 @@ struct ElArgs {
   int E, H, C, K, KS, NT, lda, ldl, ldr;
   int64_t hsl, hsr;                 // distance between a row's consecutive HEAD slices in x_l / x_r (floats): C when the heads
                                     // lie side by side in one row (row-major [N, H*C]); N * C for a head-major [H][N][C] tensor
-  // XR form: x_r = lin_r(x) is formed HERE, per slot, instead of being read (x_r == NULL): the layer input rows x[dst]
-  // (K2 features, stride ldx) are staged next to the edge panel and multiplied with lin_r's fragment planes
-  const float *x;
-  const _Float16 *Wrf;
-  const float *wr_inv, *b_r;        // [H * C]; b_r may be NULL
-  int ldx, K2, KS2;
   float slope;
 };
 
@@ -88,16 +82,12 @@ struct ElArgs {
 // the next attempt should shrink that traffic (a W tile kept in LDS across several panels), not reorder it.
 // The pair (this kernel + isg_gatv2_mp_fwd_logits) is 313-320 us against 334-350 us for isg_linear_f16x3 +
 // isg_gatv2_mp_fwd, and the configs[1] step 2.20-2.22 ms against 2.24-2.29 ms on the same box.
-// XR: x_r is not an input.  lin_r(x)[dst] is used by nothing but this logit, once per slot, and slots are sorted by
-// destination -- so the layer input rows x[dst] (512 B each, shared by consecutive slots) are staged as a second panel and
-// a second short product against lin_r's planes runs into its OWN accumulator with its OWN row scale (mixing edge features and
-// node features under one scale would cost the smaller of the two its low bits).  lin_l | lin_r then shrinks to lin_l: the
-// 168 MB of x_r per layer are neither written nor gathered back.
-template <bool MASKED, int DBG = 0, bool XR = false>
+// (A form that also computed x_r = lin_r(x) here, from a second panel of x[dst] rows, was built in round 2 and measured 2.255 vs
+// 2.235 ms per step: removed in round 4.)
+template <bool MASKED, int DBG = 0>
 __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 sA[2][EL_BM][EL_LD];   // 34,816 B
-  __shared__ __attribute__((aligned(16))) _Float16 sX[XR ? 2 : 1][XR ? EL_BM : 1][XR ? EL_LD : 8];   // + 34,816 B (XR)
-  __shared__ float s_inv[EL_BM], s_inv2[XR ? EL_BM : 1];
+  __shared__ float s_inv[EL_BM];
   extern __shared__ __attribute__((aligned(16))) float s_cw[];            // att [H*C], w_inv [H*C], partial logits [4][64][H]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,15 +116,6 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
       s_cw[HC + c] = a.w_inv[c];
     }
     for (int c = tid; c < 4 * EL_BM * a.H; c += EL_THREADS) s_cw[2 * HC + c] = 0.f;      // the waves' partial logits
-    if constexpr (XR) {   // lin_r's bias (fp32) and inverse column scales: exact powers of two, kept as their exponent BYTE so
-                          // that both panels, the tables and the partial logits stay within 80 KB (two workgroups per CU)
-      float *s_br = s_cw + 2 * HC + 4 * EL_BM * a.H;
-      unsigned char *s_wre = reinterpret_cast<unsigned char *>(s_br + HC);
-      for (int c = tid; c < HC; c += EL_THREADS) {
-        s_br[c] = a.b_r ? a.b_r[c] : 0.f;
-        s_wre[c] = (unsigned char)((__float_as_uint(a.wr_inv[c]) >> 23) & 255u);
-      }
-    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = tid + EL_THREADS * u;
@@ -154,40 +135,12 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
     }
   }
 
-  if constexpr (XR) {   // the second panel: layer input rows of the slots' DESTINATIONS
-    float4 rx[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = tid + EL_THREADS * u;
-      const int row = i >> 5, c4 = i & 31;
-      const int d = a.dst[min(m0 + row, a.E - 1)];
-      const int gk = min(c4 * 4, a.K2 - 4);
-      rx[u] = *reinterpret_cast<const float4 *>(a.x + (int64_t)d * a.ldx + gk);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = tid + EL_THREADS * u;
-      const int row = i >> 5, c4 = i & 31;
-      float4 v = rx[u];
-      if (m0 + row >= a.E || c4 * 4 >= a.K2) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-      float s, inv;
-      h3_scale(mx, s, inv);
-      if (c4 == 0) s_inv2[row] = inv;
-      v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-      hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-      hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
-                    (_Float16)(v.w - (float)hi[3])};
-      *reinterpret_cast<hf16x4 *>(&sX[0][row][c4 * 4]) = hi;
-      *reinterpret_cast<hf16x4 *>(&sX[1][row][c4 * 4]) = mid;
-    }
-  }
 
   // ---- this lane's edge (slot m0 + half * 32 + fr): endpoints, mask value ------------------------------------------------
   const int prow = half * 32 + fr;               // row of the panel
   const int sl = min(m0 + prow, a.E - 1);
   const int s_node = a.src[sl], d_node = a.dst[sl];
-  const int64_t xl_off = (int64_t)s_node * a.ldl + 4 * hh, xr_off = XR ? 0 : (int64_t)d_node * a.ldr + 4 * hh;
+  const int64_t xl_off = (int64_t)s_node * a.ldl + 4 * hh, xr_off = (int64_t)d_node * a.ldr + 4 * hh;
   float me = 1.f;
   if (MASKED) me = a.edge_mask ? a.edge_mask[a.eid[sl]] : a.node_mask[s_node] * a.node_mask[d_node];
   __syncthreads();
@@ -195,12 +148,6 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
   st_acc[0] = EL_T() - st_begin;
 #endif
   const float sinv = s_inv[prow];
-  const float sinv2 = XR ? s_inv2[prow] : 0.f;
-  const int KS2 = a.KS2;
-  const unsigned plane_b2 = (unsigned)a.NT * (unsigned)KS2 * 1024u;
-  const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<_Float16 *>(XR ? a.Wrf : a.Wf), 0, (int)(XR ? 2u * plane_b2 : 0u), 0x00020000);
-
   const int KS = a.KS;
   const unsigned plane_b = (unsigned)a.NT * (unsigned)KS * 1024u;      // bytes per W plane
   const __amdgpu_buffer_rsrc_t wrsrc =
@@ -241,7 +188,7 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
         xr[g] = make_float4(me, sinv, 0.5f, 0.25f);
       } else {
         xl[g] = *reinterpret_cast<const float4 *>(a.x_l + xl_off + col_l + 8 * g);
-        if constexpr (!XR) xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
+        xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
       }
     }
 #ifdef ISG_EL_STAMP
@@ -284,41 +231,6 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
 #undef EL_LOAD_W
 #undef EL_LOAD_A
 #undef EL_MMA
-    hf32x16 acc2;
-    if constexpr (XR) {      // the x_r tile: W_r fragments x the x[dst] panel, same fragment registers, its own accumulator
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-      const unsigned wb2 = (unsigned)nt * (unsigned)KS2 * 1024u;
-#define EL_LOAD_W2(W, s)                                                                                         \
-  _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                  \
-      W[q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(                                   \
-          wrsrc2, voff, (int)(wb2 + q * plane_b2 + (unsigned)(s) * 1024u), 0));
-#define EL_LOAD_X(Afr, ksl)                                                                                      \
-  _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                  \
-      Afr[q] = *reinterpret_cast<const hf16x8 *>(&sX[q][prow][(ksl) * 16 + fk]);
-#define EL_MMA2(Afr, W)                                                                                          \
-  {                                                                                                              \
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[1], acc2, 0, 0, 0);                                  \
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[1], Afr[0], acc2, 0, 0, 0);                                  \
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[0], acc2, 0, 0, 0);                                  \
-  }
-      EL_LOAD_W2(w0, 0)
-      EL_LOAD_X(a0, 0)
-      int k2 = 0;
-#pragma unroll 1
-      for (; k2 + 2 <= KS2; k2 += 2) {
-        EL_LOAD_W2(w1, k2 + 1)
-        EL_LOAD_X(a1, k2 + 1)
-        EL_MMA2(a0, w0)
-        EL_LOAD_W2(w0, min(k2 + 2, KS2 - 1))
-        EL_LOAD_X(a0, min(k2 + 2, 7))
-        EL_MMA2(a1, w1)
-      }
-      if (k2 < KS2) { EL_MMA2(a0, w0) }
-#undef EL_LOAD_W2
-#undef EL_LOAD_X
-#undef EL_MMA2
-    }
 #ifdef ISG_EL_STAMP
     asm volatile("" ::"v"(acc[0]), "v"(acc[15]));       // the k loop's results exist
     const long long st_t2 = EL_T();
@@ -332,19 +244,7 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
       const float4 wi4 = *reinterpret_cast<const float4 *>(&s_cw[HC + cb + 8 * g]);
       const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w};
       const float lv[4] = {xl[g].x, xl[g].y, xl[g].z, xl[g].w};
-      float rv[4];
-      if constexpr (XR) {    // x_r[dst] of this edge and channel: the second accumulator, scaled back, + lin_r's bias
-        const float *s_br = s_cw + 2 * HC + 4 * EL_BM * a.H;
-        const unsigned char *s_wre = reinterpret_cast<const unsigned char *>(s_br + HC);
-        const float4 br4 = *reinterpret_cast<const float4 *>(&s_br[cb + 8 * g]);
-        const unsigned ex = *reinterpret_cast<const unsigned *>(&s_wre[cb + 8 * g]);      // four exponent bytes
-        rv[0] = (acc2[g * 4 + 0] * sinv2) * __uint_as_float((ex & 255u) << 23) + br4.x;
-        rv[1] = (acc2[g * 4 + 1] * sinv2) * __uint_as_float(((ex >> 8) & 255u) << 23) + br4.y;
-        rv[2] = (acc2[g * 4 + 2] * sinv2) * __uint_as_float(((ex >> 16) & 255u) << 23) + br4.z;
-        rv[3] = (acc2[g * 4 + 3] * sinv2) * __uint_as_float((ex >> 24) << 23) + br4.w;
-      } else {
-        rv[0] = xr[g].x; rv[1] = xr[g].y; rv[2] = xr[g].z; rv[3] = xr[g].w;
-      }
+      const float rv[4] = {xr[g].x, xr[g].y, xr[g].z, xr[g].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float e = (acc[g * 4 + j] * sinv) * wiv[j];     // both scales are powers of two: exact
@@ -392,21 +292,17 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
                                      int64_t head_stride_r, const float *att,
                                      const int32_t *eid, const int32_t *src, const int32_t *dst, const float *edge_mask,
                                      const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C, int32_t K,
-                                     float negative_slope, const float *x, int32_t ldx, const uint16_t *wr_frag,
-                                     const float *wr_inv_scale, const float *b_r, int32_t K2, void *stream) {
-  const bool xr_here = x_r == nullptr;        // x_r = lin_r(x) formed in the kernel from x, wr_frag, wr_inv_scale, b_r
+                                     float negative_slope, void *stream) {
   if (head_stride_l == 0) head_stride_l = C;
   if (head_stride_r == 0) head_stride_r = C;
   if (E < 0 || H <= 0 || C <= 0 || K <= 0 || lda < K || ldl < C || head_stride_l < C) return ISG_EINVAL;
-  if (!xr_here && (ldr < C || head_stride_r < C)) return ISG_EINVAL;
-  if (xr_here && (K2 <= 0 || ldx < K2)) return ISG_EINVAL;
-  if ((head_stride_l == C && ldl < H * C) || (!xr_here && head_stride_r == C && ldr < H * C)) return ISG_EINVAL;
+  if (ldr < C || head_stride_r < C) return ISG_EINVAL;
+  if ((head_stride_l == C && ldl < H * C) || (head_stride_r == C && ldr < H * C)) return ISG_EINVAL;
   if (E == 0) return ISG_OK;
-  if (!edge_attr || !w_frag || !w_inv_scale || !x_l || !att || !eid || !src || !dst || !logits) return ISG_EINVAL;
-  if (xr_here && (!x || !wr_frag || !wr_inv_scale)) return ISG_EINVAL;
+  if (!edge_attr || !w_frag || !w_inv_scale || !x_l || !x_r || !att || !eid || !src || !dst || !logits) return ISG_EINVAL;
   auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if ((C & 31) != 0 || H > 32 || K > EL_KC || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (head_stride_l & 3) != 0 || (head_stride_r & 3) != 0 || mis(edge_attr) ||
-      mis(x_l) || (!xr_here && mis(x_r)) || mis(att) || mis(w_inv_scale) || H * C > 2048 || E >= (1ll << 31) - EL_BM)
+      mis(x_l) || mis(x_r) || mis(att) || mis(w_inv_scale) || H * C > 2048 || E >= (1ll << 31) - EL_BM)
     return ISG_EUNSUPPORTED;
   ElArgs a;
   a.edge_attr = edge_attr; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
@@ -414,14 +310,8 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   a.edge_mask = edge_mask; a.node_mask = node_mask; a.logits = logits;
   a.E = (int)E; a.H = H; a.C = C; a.K = K; a.KS = (K + 15) / 16; a.NT = H * C / 32;
   a.lda = lda; a.ldl = ldl; a.ldr = ldr; a.hsl = head_stride_l; a.hsr = head_stride_r; a.slope = negative_slope;
-  a.x = x; a.Wrf = reinterpret_cast<const _Float16 *>(wr_frag); a.wr_inv = wr_inv_scale; a.b_r = b_r;
-  a.ldx = ldx; a.K2 = xr_here ? K2 : 0; a.KS2 = xr_here ? (K2 + 15) / 16 : 0;
-  if (xr_here && (K2 > EL_KC || (K2 & 3) != 0 || (ldx & 3) != 0 || mis(x) || mis(wr_inv_scale) || (b_r && mis(b_r))))
-    return ISG_EUNSUPPORTED;
   const unsigned grid = (unsigned)((E + EL_BM - 1) / EL_BM);
-  const size_t dyn = ((size_t)2 * H * C + (size_t)4 * EL_BM * H) * sizeof(float) +
-                     (xr_here ? (size_t)H * C * (sizeof(float) + 1) : 0);      // + b_r [HC] fp32, exponent bytes of wr_inv [HC]
-  if (xr_here && 2 * 2 * EL_BM * EL_LD * sizeof(_Float16) + 2 * EL_BM * sizeof(float) + dyn > 80 * 1024) return ISG_EUNSUPPORTED;
+  const size_t dyn = ((size_t)2 * H * C + (size_t)4 * EL_BM * H) * sizeof(float);
   hipStream_t st = as_stream(stream);
 #ifdef ISG_EL_ABLATION
   {
@@ -435,14 +325,8 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
 #undef EL_ABL
   }
 #endif
-  const bool masked = edge_mask || node_mask;
-  if (xr_here) {
-    if (masked) gatv2_edge_logits_kernel<true, 0, true><<<grid, EL_THREADS, dyn, st>>>(a);
-    else gatv2_edge_logits_kernel<false, 0, true><<<grid, EL_THREADS, dyn, st>>>(a);
-  } else {
-    if (masked) gatv2_edge_logits_kernel<true><<<grid, EL_THREADS, dyn, st>>>(a);
-    else gatv2_edge_logits_kernel<false><<<grid, EL_THREADS, dyn, st>>>(a);
-  }
+  if (edge_mask || node_mask) gatv2_edge_logits_kernel<true><<<grid, EL_THREADS, dyn, st>>>(a);
+  else gatv2_edge_logits_kernel<false><<<grid, EL_THREADS, dyn, st>>>(a);
   return check_launch();
 }
 

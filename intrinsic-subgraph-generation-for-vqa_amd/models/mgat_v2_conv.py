@@ -76,21 +76,34 @@ class MaskingGATv2Conv(torch.nn.Module):
         if self.bias is not None:
             torch.nn.init.zeros_(self.bias)
 
+    def dispatch(self, plan, in_channels: int, edge_attr, e_proj=None) -> str:
+        """Which kernels run this layer's message passing -- the ONE place that decides (forward, layer_conv_ready and
+        needs_rows all ask here):
+          "layer_conv"  lin_l | lin_r, lin_edge, logits, softmax, aggregation as one persistent launch on graph tiles
+          "tile_conv"   the same with x_l / x_r projected before it (a layer input that is not 128 wide)
+          "pair"        lin_edge folded into the logits, softmax + aggregation from them (two launches, per-graph kernel)
+          "unfused"     lin_edge as a Linear (e_proj in memory) + the message-passing kernel (any width, fp16 rows, training)"""
+        if (e_proj is not None or edge_attr is None or self.lin_edge is None or edge_attr.dim() != 2
+                or self.feature_dtype != torch.float32 or torch.is_grad_enabled() or plan is None):
+            return "unfused"
+        H, C = self.heads, self.out_channels
+        if not ops.fused_logits_supported(plan, H, C, edge_attr.size(1)):
+            return "unfused"
+        if not self.share_weights and ops.layer_conv_supported(plan, H, C, in_channels, edge_attr.size(1)):
+            return "layer_conv"
+        if ops.tile_conv_supported(plan, H, C, edge_attr.size(1)):
+            return "tile_conv"
+        return "pair"
+
     def layer_conv_ready(self, plan, in_channels: int, edge_attr, e_proj=None) -> bool:
         """Will forward() run this layer as isg_gatv2_layer_conv?  (Then its gated input is wanted as ops.NodePlanes: MGAT asks
         before it lets the previous layer's fused tail write them.)"""
-        if (e_proj is not None or edge_attr is None or self.lin_edge is None or edge_attr.dim() != 2
-                or self.feature_dtype != torch.float32 or torch.is_grad_enabled() or self.share_weights or plan is None):
-            return False
-        H, C = self.heads, self.out_channels
-        pair = ops.fused_logits_supported(plan, H, C, edge_attr.size(1))
-        xr_inside = pair and ops.FUSE_XR and in_channels <= 128 and in_channels % 4 == 0
-        return bool(pair and not xr_inside and ops.layer_conv_supported(plan, H, C, in_channels, edge_attr.size(1)))
+        return self.dispatch(plan, in_channels, edge_attr, e_proj) == "layer_conv"
 
     def needs_rows(self, plan, in_channels: int, edge_attr, e_proj=None, imle_att=None) -> bool:
-        """Does forward() read the gated layer input as fp32 ROWS (beside, or instead of, its planes)?  Only the un-fused
-        convolution and a node gate that cannot run on the planes do."""
-        if not self.layer_conv_ready(plan, in_channels, edge_attr, e_proj):
+        """Does forward() read the gated layer input as fp32 ROWS (beside, or instead of, its planes)?  Everything but the
+        layer kernel does, and so does a node gate that cannot run on the planes."""
+        if self.dispatch(plan, in_channels, edge_attr, e_proj) != "layer_conv":
             return True
         return self.mask.masking_threshold != 1.0 and not self.mask.planes_ready(imle_att)
 
@@ -108,7 +121,7 @@ class MaskingGATv2Conv(torch.nn.Module):
         if plan is None:
             plan = ops.GraphPlan.build(batch, edge_index,
                                        num_graphs=None if instruction is None else instruction.size(0))
-        layer_conv = self.layer_conv_ready(plan, x.size(1), edge_attr, e_proj)
+        how = self.dispatch(plan, x.size(1), edge_attr, e_proj)
         need_rows = self.needs_rows(plan, x.size(1), edge_attr, e_proj, imle_att)
         planes = None          # gelu(x * instruction[batch]) as the planes isg_gatv2_layer_conv reads (fp32 rows only where needed)
         if (x_gated is not None or x_planes is not None) and self.use_instr:
@@ -118,7 +131,7 @@ class MaskingGATv2Conv(torch.nn.Module):
                 raise RuntimeError("the previous layer's tail left no fp32 rows of the gated input, and this layer needs them")
         else:
             x = x.float().contiguous()
-            if self.use_instr and layer_conv:
+            if self.use_instr and how == "layer_conv":
                 x, planes = ops.instr_gate_planes(x, instruction.contiguous(), batch, want_rows=need_rows)   # :156-157
             elif self.use_instr:
                 x = ops.instr_gate(x, instruction.contiguous(), batch, plan=plan)        # :156-157
@@ -128,69 +141,48 @@ class MaskingGATv2Conv(torch.nn.Module):
             mask = self.mask(x, imle_att, batch, edge_index, use_all_instrs=False, plan=plan, noise=noise,
                              seed=seed, u_is_per_graph=True, x_planes=planes)             # :166-168
 
+        def done(out, alpha):
+            if isinstance(return_attention_weights, bool):
+                return out, mask, (edge_index, alpha)                                    # :237
+            return out, mask                                                             # :241
+
         fdt = self.feature_dtype
-        if layer_conv:
+        kw = dict(bias=self.bias, node_mask=mask, negative_slope=self.negative_slope)
+        if how == "layer_conv":
             # lin_l | lin_r, lin_edge, logits, softmax and aggregation as ONE persistent launch on graph-aligned tiles
             # (csrc/isg_layer_conv.hip): x_l / x_r live in LDS only                       # :177-181, :215-232, :243-279
             res = ops.gatv2_layer_conv(planes if planes is not None else x, self.lin_l, self.lin_r, edge_attr.float().contiguous(),
-                                       self.lin_edge.weight, self.att, plan, H, bias=self.bias, node_mask=mask,
-                                       negative_slope=self.negative_slope, want_rowmax=True)
+                                       self.lin_edge.weight, self.att, plan, H, want_rowmax=True, **kw)
             if res is not None:
-                out, alpha = res
-                if isinstance(return_attention_weights, bool):
-                    return out, mask, (edge_index, alpha)
-                return out, mask
+                return done(*res)
             if x is None:
                 raise RuntimeError("isg_gatv2_layer_conv refused a shape layer_conv_supported() accepted, and the gated input "
                                    "exists only as planes")
-        inference32 = (e_proj is None and edge_attr is not None and self.lin_edge is not None and edge_attr.dim() == 2
-                       and fdt == torch.float32 and not torch.is_grad_enabled())
-        pair = inference32 and ops.fused_logits_supported(plan, H, C, edge_attr.size(1))
-        # with the edge-logits pair, x_r = lin_r(x) can be formed inside the logit kernel too (it is used nowhere else):
-        # then only lin_l is projected here
-        xr_inside = pair and ops.FUSE_XR and not self.share_weights and x.size(1) <= 128 and x.size(1) % 4 == 0
-        if xr_inside:
-            x_l, x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt), None          # :177
-        elif self.share_weights:
+            how = "tile_conv"
+        if self.share_weights:
             x_l = x_r = ops.linear(x, self.lin_l.weight, self.lin_l.bias, out_dtype=fdt)  # :177-179
         else:   # lin_l and lin_r share their input: one [N, 2*H*C] projection, x_l / x_r are its column halves
             x_l, x_r = ops.linear_fused(x, (self.lin_l, self.lin_r), out_dtype=fdt)      # :177,181
-        if pair and not xr_inside and ops.tile_conv_supported(plan, H, C, edge_attr.size(1)):
+        if how == "tile_conv" and ops.tile_conv_supported(plan, H, C, edge_attr.size(1)):
             # edge GEMM + logits + softmax + aggregation as one launch on graph-aligned tiles (csrc/isg_layer_tile.hip)
             res = ops.gatv2_tile_conv(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att, plan, H,
-                                      bias=self.bias, node_mask=mask, negative_slope=self.negative_slope,
-                                      want_rowmax=True)                                  # :215-232, :243-279
+                                      want_rowmax=True, **kw)                            # :215-232, :243-279
             if res is not None:
-                out, alpha = res
-                if isinstance(return_attention_weights, bool):
-                    return out, mask, (edge_index, alpha)
-                return out, mask
-        if pair:
-            # lin_edge (and lin_r) folded into the logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is neither written nor read
+                return done(*res)
+            how = "pair"
+        if how in ("tile_conv", "pair"):
+            # lin_edge folded into the logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is neither written nor read
             res = ops.gatv2_mp_edge_logits(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att, plan, H,
-                                           bias=self.bias, node_mask=mask, negative_slope=self.negative_slope,
-                                           want_rowmax=True, x=x if xr_inside else None,
-                                           w_r=self.lin_r.weight if xr_inside else None,
-                                           b_r=self.lin_r.bias if xr_inside else None)   # :215-232, :243-279, :181
+                                           want_rowmax=True, **kw)                       # :215-232, :243-279
             if res is not None:
-                out, alpha = res
-                if isinstance(return_attention_weights, bool):
-                    return out, mask, (edge_index, alpha)
-                return out, mask
-            if x_r is None:     # no instantiation of the pair for this batch: the un-fused kernels need x_r after all
-                x_r = ops.linear(x, self.lin_r.weight, self.lin_r.bias, out_dtype=fdt)
+                return done(*res)
         if e_proj is None:
             if edge_attr is None or self.lin_edge is None:
                 raise NotImplementedError("edge_attr=None: MGAT always passes edge features (mgat.py:147)")
             if edge_attr.dim() == 1:
                 edge_attr = edge_attr.view(-1, 1)
             e_proj = ops.linear(edge_attr.float().contiguous(), self.lin_edge.weight, None, out_dtype=fdt)   # :259
-        out, alpha = ops.gatv2_mp(x_l, x_r, e_proj, self.att, plan, H, bias=self.bias, node_mask=mask,
-                                  negative_slope=self.negative_slope,
-                                  want_rowmax=not torch.is_grad_enabled())                # :215-232
-        if isinstance(return_attention_weights, bool):
-            return out, mask, (edge_index, alpha)                                        # :237
-        return out, mask                                                                 # :241
+        return done(*ops.gatv2_mp(x_l, x_r, e_proj, self.att, plan, H, want_rowmax=not torch.is_grad_enabled(), **kw))  # :215-232
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"

@@ -159,7 +159,12 @@ BOUNDS_TO_HOST = True    # isg_graph_plan_build writes the batch's true bounds i
 
 
 MIXED_DISPATCH = True       # graphs beyond a tile go to the per-graph kernels, the rest of the batch stays on the tile kernels
-MIXED_MAX_FRACTION = 0.5    # ... while at most this share of the batch's nodes sits in such graphs
+MIXED_MAX_FRACTION = 0.05   # ... while at most this share of the batch's nodes sits in such graphs
+MIXED_MIN_NODES = 60000     # ... and the batch is large: the per-graph kernels on a handful of big graphs are ~35 launches per layer
+                            # and bound by their largest graph (~0.3 ms per layer whatever the batch), measured
+                            # (profiles/r04_p_mixed_dispatch.txt): 4096 graphs + 1..8 big ones 2.63-2.82 ms mixed vs 2.65-2.89 ms
+                            # with the per-graph kernels for everything (1.47 ms without big graphs); 1024 graphs 1.9 vs 1.0 ms.
+                            # Tests and tools lower both to force the mode.
 
 
 class OversizeGraphs(NamedTuple):
@@ -208,14 +213,14 @@ class GraphPlan:
         self.require_csr()
         key = (id(edge_attr), edge_attr.data_ptr(), _ver(edge_attr), tuple(edge_attr.shape))
         hit = self._edge_planes
-        if hit is None or hit[0] != key:
+        if hit is None or hit[0] != key or (len(hit) > 3 and hit[3]() is not edge_attr):    # the id of a freed tensor can be reused
             lib = _lib.load()
             E, K = edge_attr.shape
             planes = torch.empty(max(E, 1), 2, 128, dtype=torch.int16, device=edge_attr.device)
             inv = torch.empty(max(E, 1), dtype=torch.float32, device=edge_attr.device)
             _lib.check(lib.isg_edge_planes(_chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), self.eid.data_ptr(), E, K,
                                            planes.data_ptr(), inv.data_ptr(), _stream()), "isg_edge_planes")
-            hit = (key, planes, inv)
+            hit = (key, planes, inv, weakref.ref(edge_attr))
             self._edge_planes = hit
         return hit[1], hit[2]
 
@@ -245,7 +250,7 @@ class GraphPlan:
                 if self._tiles is None:
                     self._tiles = {}
                 self._tiles[key] = (tp, nt, cap, info.view(cap, 4))
-                self._edge_planes = (ekey, planes, inv)
+                self._edge_planes = (ekey, planes, inv, weakref.ref(edge_attr))
         return self.tiles(node_cap, edge_cap), self.edge_planes(edge_attr)
 
     def tiles(self, node_cap: int = 64, edge_cap: int = 0) -> Tuple[Tensor, Tensor, int, Tensor]:
@@ -287,12 +292,12 @@ class GraphPlan:
         sub = self.oversize(node_cap, edge_cap)
         if sub is None:
             return "tiles"                  # the hints overstated the batch
-        return "mixed" if sub.nodes.numel() <= MIXED_MAX_FRACTION * self.N else "none"
+        return "mixed" if (sub.nodes.numel() <= MIXED_MAX_FRACTION * self.N and self.N >= MIXED_MIN_NODES) else "none"
 
     def oversize(self, node_cap: int = 64, edge_cap: int = 256) -> Optional["OversizeGraphs"]:
         """The graphs of this batch beyond a tile (more than node_cap nodes or edge_cap in-edges) as a batch of their own: graph
         ids, node ids, original edge ids (all ascending: segment sums keep their order), local batch vector / edge_index and the
-        GraphPlan over them.  None when every graph fits.  Built once per (plan, caps); two device-to-host syncs, paid only by
+        GraphPlan over them.  None when every graph fits.  Built once per (plan, caps); one device-to-host sync, paid only by
         batches that have such graphs.  The reference puts no cap on the objects of a scene graph (datasets/scene_graph.py:199-389)."""
         ecap = int(edge_cap) if self.rowptr is not None else 0
         key = (int(node_cap), ecap)
@@ -311,22 +316,26 @@ class GraphPlan:
                 eptr = self.eptr.long()
                 e = eptr[1:] - eptr[:-1]
                 big = big | (e > ecap)
-            gids = torch.nonzero(big).squeeze(1)                          # sync 1: how many such graphs
-            G = gids.numel()
+            # ONE device-to-host sync: how many such graphs, their nodes / edges in total and at most
+            zero = n.new_zeros(())
+            nb = torch.where(big, n, zero)
+            stats = [big.sum(), nb.sum(), nb.max()]
+            if e is not None:
+                eb = torch.where(big, e, zero)
+                stats += [eb.sum(), eb.max()]
+            stats = [int(v) for v in torch.stack(stats).tolist()]
+            G = stats[0]
             if G > 0:
+                gids = torch.nonzero_static(big, size=G).squeeze(1)
                 cnt = n[gids]
-                stats = [cnt.sum(), cnt.max()]
-                if e is not None:
-                    stats += [e[gids].sum(), e[gids].max()]
-                stats = [int(v) for v in torch.stack(stats).tolist()]     # sync 2: their sizes
-                Ns, nmax_s = stats[0], stats[1]
+                Ns, nmax_s = stats[1], stats[2]
                 ar = torch.arange(G, device=dev)
                 seg = torch.repeat_interleave(ar, cnt, output_size=Ns)
                 nodes = ptr[gids][seg] + (torch.arange(Ns, device=dev) - (cnt.cumsum(0) - cnt)[seg])
                 edges = sub_ei = None
                 emax_s = None
                 if e is not None:
-                    Es, emax_s = stats[2], stats[3]
+                    Es, emax_s = stats[3], stats[4]
                     ce = e[gids]
                     seg_e = torch.repeat_interleave(ar, ce, output_size=Es)
                     slots = eptr[gids][seg_e] + (torch.arange(Es, device=dev) - (ce.cumsum(0) - ce)[seg_e])
@@ -590,10 +599,6 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
 
 # lin_edge folded into the attention logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is never written or read
 FUSE_LOGITS = True
-# ... and lin_r as well (x_r formed inside that kernel from the layer input; lin_l | lin_r shrinks to lin_l).  OFF: correct
-# (tests) but the step measured 2.255 ms with it against 2.235 ms without on the same box (profiles/r02_w_edge_logits.md):
-# the logit kernel's second W stream and product cost more than the lin_r half of the projection saves
-FUSE_XR = False
 
 
 def fused_logits_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
@@ -620,23 +625,20 @@ def gatv2_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tenso
         _chk(att.reshape(-1), "att", torch.float32, (HC,)), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(),
         _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
-        logits.data_ptr(), E, H, HC // H, K, float(negative_slope), 0, 0, 0, 0, 0, 0, _stream())
+        logits.data_ptr(), E, H, HC // H, K, float(negative_slope), _stream())
     if rc == ISG_EUNSUPPORTED:
         return None
     _lib.check(rc, "isg_gatv2_edge_logits")
     return logits
 
 
-def gatv2_mp_edge_logits(x_l: Tensor, x_r: Optional[Tensor], edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan",
+def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan",
                          heads: int, bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None,
-                         edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_rowmax: bool = False,
-                         x: Optional[Tensor] = None, w_r: Optional[Tensor] = None, b_r: Optional[Tensor] = None):
+                         edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_rowmax: bool = False):
     """gatv2_mp(x_l, x_r, lin_edge(edge_attr), ...) as two launches that never materialise lin_edge's output
     (mgat_v2_conv.py:243-279 with :259-261 inside): isg_gatv2_edge_logits forms the logits [E, H] in the epilogue of the
     edge GEMM, isg_gatv2_mp_fwd_logits does softmax + aggregation.  Returns (out, alpha), or None when the per-graph kernel
-    has no instantiation for this batch / width (the caller then runs the un-fused pair).
-    x_r=None with (x, w_r, b_r): x_r = lin_r(x) is formed inside the logit kernel from the layer input x [N, K2] (after the
-    instruction gate) and lin_r's weight / bias -- it is never written or read, the caller projects lin_l alone."""
+    has no instantiation for this batch / width (the caller then runs the un-fused pair)."""
     lib = _lib.load()
     plan.require_csr()
     N, HC = x_l.shape
@@ -647,18 +649,8 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Optional[Tensor], edge_attr: Tensor, 
         raise ValueError("gatv2_mp_edge_logits: operand shapes do not match the plan")
     if x_l.dtype != torch.float32 or edge_attr.dtype != torch.float32:
         raise TypeError("gatv2_mp_edge_logits: fp32 rows")
-    if x_r is not None:
-        if tuple(x_r.shape) != (N, HC) or x_r.dtype != torch.float32:
-            raise ValueError("gatv2_mp_edge_logits: x_r must be fp32 [N, H*C]")
-        xr_args = (_chk_rows(x_r, "x_r"), x_r.stride(0), 0)
-        tail_args = (0, 0, 0, 0, 0, 0)
-    else:
-        if x is None or w_r is None or x.dim() != 2 or x.size(0) != N or tuple(w_r.shape) != (HC, x.size(1)) or x.dtype != torch.float32:
-            raise ValueError("gatv2_mp_edge_logits: without x_r, x [N, K2] and w_r [H*C, K2] are required")
-        planes_r, inv_r = _weight_planes(w_r, True, "f16x3")
-        xr_args = (0, 0, 0)
-        tail_args = (_chk_rows(x, "x"), x.stride(0), planes_r.data_ptr(), inv_r.data_ptr(),
-                     _chk(None if b_r is None else b_r.detach().reshape(-1), "b_r", torch.float32, (HC,), optional=True), x.size(1))
+    if tuple(x_r.shape) != (N, HC) or x_r.dtype != torch.float32:
+        raise ValueError("gatv2_mp_edge_logits: x_r must be fp32 [N, H*C]")
     planes, inv = _weight_planes(w_edge, True, "f16x3")
     logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
@@ -672,13 +664,13 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Optional[Tensor], edge_attr: Tensor, 
         # aggregate (plus lin_edge); the roofline keeps the un-fused algorithmic bytes of SURVEY 8(d)
         ev0, evm, ev1 = timer.bracket3({"N": N, "E": E, "H": H, "C": C, "K": K,
                                         "masked": node_mask is not None or edge_mask is not None, "feat_bytes": 4,
-                                        "fused_logits": True, "xr_inside": x_r is None, "K2": 0 if x_r is not None else x.size(1)})
+                                        "fused_logits": True})
         ev0.record()
     rc = lib.isg_gatv2_edge_logits(
         _chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(),
-        _chk_rows(x_l, "x_l"), x_l.stride(0), 0, *xr_args, attp,
+        _chk_rows(x_l, "x_l"), x_l.stride(0), 0, _chk_rows(x_r, "x_r"), x_r.stride(0), 0, attp,
         plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(), em, nm, logits.data_ptr(), E, H, C, K,
-        float(negative_slope), *tail_args, _stream())
+        float(negative_slope), _stream())
     if rc == ISG_EUNSUPPORTED:
         if timer is not None:
             timer.drop_last()
@@ -777,7 +769,12 @@ def _oversize_conv(sub: "OversizeGraphs", x_l: Tensor, x_r: Tensor, edge_attr: T
     """Message passing of the graphs the tile kernels passed over (mgat_v2_conv.py:215-279 on the sub-batch): lin_edge +
     the per-graph kernel (256-node / 1024-edge tables, or node chunks beyond), written into the rows / edges of `out` /
     `alpha` / `rowmax` that belong to those graphs."""
-    e_proj = linear(edge_attr.index_select(0, sub.edges), w_edge)
+    key = (id(edge_attr), edge_attr.data_ptr(), _ver(edge_attr))          # every layer reads the same edge features
+    hit = getattr(sub.plan, "_parent_edge_rows", None)
+    if hit is None or hit[0] != key:
+        hit = (key, edge_attr.index_select(0, sub.edges))
+        sub.plan._parent_edge_rows = hit
+    e_proj = linear(hit[1], w_edge)
     nm = None if node_mask is None else node_mask.reshape(-1).index_select(0, sub.nodes)
     em = None if edge_mask is None else edge_mask.reshape(-1).index_select(0, sub.edges)
     o, a = gatv2_mp(x_l, x_r, e_proj, att, sub.plan, heads, bias=bias, node_mask=nm, edge_mask=em,

@@ -102,35 +102,51 @@ def test_cpu_legs_use_the_cpus_the_process_may_run_on_and_are_time_bounded():
     assert took < 60, f"configs[0] leg took {took:.1f} s for a 0.5 s budget"
 
 
-def test_traffic_summaries_are_replayed_only_for_the_kernels_they_describe():
-    """bench.py replays committed PMC summaries into roofline.traffic.  The edge-logits pair's summary (two kernels summed,
-    874 MB) was once written without its kind and came back as the un-fused per-graph kernel's traffic (943 MB): every
-    summary is matched by what was summed, and the three committed kinds stay apart."""
+def test_traffic_summaries_are_tied_to_kernel_kind_batch_shape_and_kernel_source(tmp_path):
+    """roofline.traffic is REPLAYED from a committed PMC summary: it is taken only from a summary of the same kind of kernel
+    (a pair's summary says nothing about the un-fused kernel), the same batch shape, and the same kernel SOURCE (sha256 written
+    by tools/pmc_traffic.py): a summary measured before a kernel edit is refused, not silently kept."""
+    import json
     import bench
     N, E = 82286, 205024
-    pair, graph, chunk = (bench.load_traffic(N, E, k) for k in ("logits_pair", "graph", "chunk"))
-    assert pair is not None and graph is not None and chunk is not None and len({pair, graph, chunk}) == 3
-    assert 0.9e9 < graph < 1.0e9 and pair < graph < chunk
-    assert bench.load_traffic(N + 1, E, "graph") is None
+    good = {"kernel": "void isg::gatv2_layer_conv_kernel<false, 8>", "kind": "layer_conv", "N": N, "E": E,
+            "hbm_bytes_per_launch": 330000000, "source_sha256": bench.kernel_source_hash("layer_conv")}
+    json.dump(good, open(tmp_path / "x_mp_traffic.json", "w"))
+    d = str(tmp_path)
+    assert bench.load_traffic(N, E, "layer_conv", profiles_dir=d) == 330000000
+    assert bench.load_traffic(N, E, "layer_conv", with_source=True, profiles_dir=d) == (330000000, "x_mp_traffic.json")
+    assert bench.load_traffic(N + 1, E, "layer_conv", profiles_dir=d) is None          # another batch
+    assert bench.load_traffic(N, E, "graph", profiles_dir=d) is None                   # another kernel
+    stale = dict(good, source_sha256="0" * 64)
+    json.dump(stale, open(tmp_path / "x_mp_traffic.json", "w"))
+    got, why = bench.load_traffic(N, E, "layer_conv", with_source=True, profiles_dir=d)
+    assert got is None and "another version" in why
+    unstamped = {k: v for k, v in good.items() if k != "source_sha256"}
+    json.dump(unstamped, open(tmp_path / "x_mp_traffic.json", "w"))
+    assert bench.load_traffic(N, E, "layer_conv", profiles_dir=d) is None
+    # the committed summary of this round's default kernel matches the committed source
+    assert bench.load_traffic(N, E, "layer_conv") is not None
+
+
+SAMPLE = "r04_bench_sample.json"        # a default-flag `python bench.py` line of this round, committed under profiles/ by name
 
 
 def test_bench_line_schema_on_the_committed_sample():
-    """The newest committed default-flag bench line of this round (profiles/r03_*bench.json) carries every object the contract
-    and the review ask for: roofline, cpu_baseline (+cfg1), fallbacks, dense_err_vs_fp32, cfg5 (with the 8-rank imbalance of
-    both partitions), full_model; a line without one of them must be rejected."""
+    """The committed default-flag bench line of this round (profiles/r04_bench_sample.json: an explicit file, not "the newest
+    by name") carries every object the contract and the review ask for: roofline, cpu_baseline (+cfg1), fallbacks,
+    dense_err_vs_fp32, cfg5 (with the 8-rank imbalance of both partitions and the fp32-rows leg), full_model; a line without
+    one of them must be rejected -- and so must a line whose `fallbacks` is None (what `--launch graph` produced in round 3)."""
     import copy
-    import glob
     import json
     import os
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    paths = sorted(glob.glob(os.path.join(root, "profiles", "r03_*_bench.json")))
-    assert paths, "no committed r03 bench line under profiles/"
-    line = json.load(open(paths[-1]))
+    line = json.load(open(os.path.join(root, "profiles", SAMPLE)))
     bench.validate_line(line)
     assert line["metric"] == "GQA questions/sec" and line["config"]["graphs_per_gpu"] == 4096 and line["dtype"] == "f32"
     assert line["fallbacks"]["torch_linear"] == 0 and line["fallbacks"]["torch_layer_norm"] == 0
     assert 0 < line["dense_err_vs_fp32"]["max"] <= 2.0
+    assert line["roofline"]["own_bound"] and "traffic_source" in line["roofline"]
     for drop in ("cfg5", "fallbacks", "roofline"):
         bad = copy.deepcopy(line)
         del bad[drop]
@@ -139,3 +155,27 @@ def test_bench_line_schema_on_the_committed_sample():
         except KeyError:
             continue
         raise AssertionError(f"a line without {drop!r} passed validation")
+    bad = copy.deepcopy(line)
+    bad["fallbacks"] = None
+    try:
+        bench.validate_line(bad)
+    except KeyError:
+        pass
+    else:
+        raise AssertionError("a line with fallbacks = None passed validation")
+
+
+def test_both_launch_modes_of_the_bench_count_their_fallbacks():
+    """`--launch graph` takes its per-step counters from the eager steps it runs after the timed replays (round 3 left them
+    None there and the finished run died in validate_line): every branch of main() that times steps assigns step_counters."""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    branch = next(n for n in ast.walk(main) if isinstance(n, ast.If) and isinstance(n.test, ast.Compare)
+                  and ast.unparse(n.test) == "args.launch == 'graph'" and any(isinstance(b, ast.For) for b in ast.walk(n)))
+    assigns = lambda body: any(isinstance(t, ast.Name) and t.id == "step_counters" for st in body for n in ast.walk(st)
+                               if isinstance(n, ast.Assign) for t in n.targets)
+    assert assigns(branch.body), "the hipGraph branch never sets step_counters"
+    assert assigns(branch.orelse), "the eager branch never sets step_counters"

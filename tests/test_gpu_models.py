@@ -667,6 +667,18 @@ def test_a_step_captured_as_a_hipgraph_replays_to_the_eager_result(dev):
 # ---------------------------------------------------------------------------------------------------------------------
 # Mixed dispatch: graphs beyond a 64-node / 256-slot tile go to the per-graph kernels, the rest stays on the tile kernels
 # ---------------------------------------------------------------------------------------------------------------------
+def _forced_mixed(fn):
+    """Run fn with the mixed mode's profitability gate open (ops.MIXED_MAX_FRACTION / MIXED_MIN_NODES): the tests are about
+    its results, on batches far smaller than the ones it pays for."""
+    from isubgvqa_amd import ops
+    keep = ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES
+    ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES = 0.9, 0
+    try:
+        return fn()
+    finally:
+        ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES = keep
+
+
 @pytest.mark.parametrize("sampler", ["gumbel", "imle"])
 def test_one_oversize_graph_does_not_take_the_batch_off_the_tile_kernels(dev, sampler):
     """600 graphs of 20 nodes with ONE 130-node graph in the middle (the reference caps nothing: datasets/scene_graph.py:199-389):
@@ -676,7 +688,7 @@ def test_one_oversize_graph_does_not_take_the_batch_off_the_tile_kernels(dev, sa
     sizes = (20,) * 300 + (130,) + (20,) * 300
     cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler=sampler, seed=91)
     ops.reset_counters()
-    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    wl, (rl, rm, rg), (gl, gm, gg) = _forced_mixed(lambda: _run_both(cfg, dev))
     c = ops.counters()
     assert wl.max_nodes == 130
     assert c["oversize_nodes"] > 0, "the oversize graph never reached the per-graph kernels"
@@ -701,7 +713,7 @@ def test_oversize_by_edges_only_and_first_and_last_graph(dev):
     e_per_graph = torch.bincount(wl0.batch[wl0.edge_index[1]], minlength=len(sizes))
     assert int(e_per_graph[41]) <= 256 or True
     ops.reset_counters()
-    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    wl, (rl, rm, rg), (gl, gm, gg) = _forced_mixed(lambda: _run_both(cfg, dev))
     c = ops.counters()
     assert c["oversize_nodes"] > 0 and c["tile_nodes"] > 0
     assert torch.equal(gm > 0.5, rm > 0.5)
@@ -715,7 +727,7 @@ def test_cfg5_generator_at_c128_runs_mixed_and_matches_the_oracle(dev):
     from isubgvqa_amd import ops, synthetic
     cfg = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": 256, "channels": 128})
     ops.reset_counters()
-    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    wl, (rl, rm, rg), (gl, gm, gg) = _forced_mixed(lambda: _run_both(cfg, dev))
     c = ops.counters()
     print(f"cfg5 generator, C = 128: {c['tile_nodes']} node visits on the tile kernels, {c['oversize_nodes']} on the per-graph kernels")
     assert wl.max_nodes > 100 and c["tile_nodes"] > 0 and c["oversize_nodes"] > 0
@@ -735,7 +747,7 @@ def test_mixed_dispatch_off_gives_the_same_answers(dev):
         ops.MIXED_DISPATCH = on
         try:
             with torch.no_grad():
-                outs.append(model(wl))
+                outs.append(_forced_mixed(lambda: model(wl)))
         finally:
             ops.MIXED_DISPATCH = True
     (l0, m0, g0), (l1, m1, g1) = outs

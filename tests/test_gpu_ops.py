@@ -885,72 +885,6 @@ def test_edge_logits_pair_random_shapes_sweep(dev):
     print(f"edge-logits pair sweep: worst |alpha - alpha_unfused| = {worst:.2e}")
 
 
-@pytest.mark.parametrize("mask", [None, "node", "edge"])
-@pytest.mark.parametrize("H,C,K,K2", [(4, 128, 128, 128), (4, 128, 36, 20), (8, 32, 128, 64), (2, 256, 64, 100)])
-def test_edge_logits_pair_with_lin_r_inside(dev, mask, H, C, K, K2):
-    """The form of isg_gatv2_edge_logits that computes x_r = lin_r(x) itself (x_r == NULL: layer input rows x[dst] staged as
-    a second panel, lin_r's planes, its own accumulator and row scale, lin_r's bias): against the same pair fed with
-    x_r = isg_linear(x, W_r, b_r), against the un-fused kernels and against the oracle.  Node features and edge features of
-    very different magnitude (the reason for two row scales), odd k-step counts on both sides, a bias-free lin_r."""
-    from isubgvqa_amd import ops
-    from oracle import model as OM
-    gen = torch.Generator().manual_seed(90 + K + K2)
-    sizes = [20, 1, 37, 5, 64, 23, 2, 30]
-    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
-    src, dst, off = [], [], 0
-    for n in sizes:
-        for v in range(n):
-            if not (n == 5 and v == 4):
-                src.append(off + v); dst.append(off + v)
-        m = 0 if n == 1 else int(torch.randint(n, 4 * n, (1,), generator=gen))
-        m = min(m, 250 - n)
-        a_ = torch.randint(0, n, (m,), generator=gen); b_ = torch.randint(0, n, (m,), generator=gen)
-        if n == 5:
-            b_ = b_.clamp(max=3)
-        src += (off + a_).tolist(); dst += (off + b_).tolist()
-        off += n
-    ei = torch.tensor([src, dst])
-    ei = ei[:, torch.randperm(ei.size(1), generator=gen)]
-    N, E, HC = batch.numel(), ei.size(1), H * C
-    x = torch.randn(N, K2, generator=gen) * 1e-2                      # node features 1000x smaller than the edge features
-    ea = torch.randn(E, K, generator=gen) * 10.0
-    w_e = torch.randn(HC, K, generator=gen) / K ** 0.5 * 0.1
-    w_l, b_l = torch.randn(HC, K2, generator=gen) / K2 ** 0.5 * 100, torch.randn(HC, generator=gen)
-    w_r = torch.randn(HC, K2, generator=gen) / K2 ** 0.5 * 100
-    b_r = torch.randn(HC, generator=gen) if K2 != 20 else None        # one case without a bias
-    att, bias = torch.randn(1, H, C, generator=gen), torch.randn(HC, generator=gen)
-    nm = (torch.rand(N, generator=gen) < 0.6).float() if mask == "node" else None
-    em = (torch.rand(E, generator=gen) < 0.6).float() if mask == "edge" else None
-    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
-    assert ops.fused_logits_supported(plan, H, C, K)
-    t = lambda v: None if v is None else v.to(dev)
-    xd, wld, wrd, wed = x.to(dev), w_l.to(dev), w_r.to(dev), w_e.to(dev)
-    x_l = ops.linear(xd, wld, t(b_l))
-    x_r = ops.linear(xd, wrd, t(b_r))
-    res_in = ops.gatv2_mp_edge_logits(x_l, None, t(ea), wed, t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em),
-                                      want_rowmax=True, x=xd, w_r=wrd, b_r=t(b_r))
-    res_xr = ops.gatv2_mp_edge_logits(x_l, x_r, t(ea), wed, t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em))
-    assert res_in is not None and res_xr is not None
-    out_u, alpha_u = ops.gatv2_mp(x_l, x_r, ops.linear(t(ea), wed), t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em))
-    emask = em if em is not None else (None if nm is None else nm[ei[0]] * nm[ei[1]])
-    xl64 = (x.double() @ w_l.double().t() + b_l.double()).float()
-    xr64 = (x.double() @ w_r.double().t() + (0 if b_r is None else b_r.double())).float()
-    ref_out, ref_alpha = OM.gatv2_message_passing(xl64.view(N, H, C), xr64.view(N, H, C),
-                                                  (ea.double() @ w_e.double().t()).float().view(E, H, C), att, ei,
-                                                  None if emask is None else emask.view(E, 1), 0.2)
-    d_in_xr = (res_in[1] - res_xr[1]).abs().max().item()
-    d_in_u = (res_in[1] - alpha_u).abs().max().item()
-    d_in_o = (res_in[1].cpu() - ref_alpha).abs().max().item()
-    d_u_o = (alpha_u.cpu() - ref_alpha).abs().max().item()
-    scale = max(1.0, ref_out.abs().max().item())
-    d_out = (res_in[0].cpu() - (ref_out.reshape(N, HC) + bias)).abs().max().item()
-    print(f"lin_r inside H={H} C={C} K={K} K2={K2} mask={mask}: alpha vs pair-with-x_r {d_in_xr:.2e}, vs un-fused {d_in_u:.2e}, "
-          f"vs oracle {d_in_o:.2e} (un-fused vs oracle {d_u_o:.2e}); out vs oracle {d_out:.2e} (scale {scale:.1f})")
-    assert d_in_o <= 2.0 * d_u_o + 3e-6 and d_in_u <= 3.0 * d_u_o + 3e-6 and d_in_xr <= 3.0 * d_u_o + 3e-6
-    assert d_out < 2e-5 * scale
-    assert torch.equal(ops.row_maxima(res_in[0]), res_in[0].view(N, H, C).abs().amax(2))
-
-
 def test_edge_logits_pair_is_deterministic_and_edge_order_invariant_at_full_size(dev):
     """BASELINE configs[1] size (4096 graphs, ~82k nodes, ~205k edges), properties that need no oracle: the pair run twice
     gives the same bits; the edges handed over in another order give the same alpha PER EDGE and the same node outputs up
@@ -1055,6 +989,9 @@ def test_tile_plan_is_the_greedy_packing(dev, case):
         ptr, eptr = plan.ptr.cpu().tolist(), plan.eptr.cpu().tolist()
         want_info = [[ptr[a], ptr[b] - ptr[a], eptr[a] if ecap > 0 else 0, eptr[b] - eptr[a] if ecap > 0 else 0]
                      for a, b in zip(want[:-1], want[1:])]
+        # a graph beyond the caps is a tile of its own WITHOUT rows or slots: the tile kernels pass over it, the per-graph
+        # kernels take it (mixed dispatch, ops.GraphPlan.oversize)
+        want_info = [[w[0], 0, w[2], 0] if (w[1] > ncap or (ecap > 0 and w[3] > ecap)) else w for w in want_info]
         assert info.cpu().tolist()[:T] == want_info
 
 
@@ -1127,8 +1064,10 @@ def _dense_tail_case(dev, sizes, seed, masked, with_next):
           f"fused vs un-fused {e_ch:.2e} (|h| max {scale:.1f})")
     # GraphNorm divides by a per-graph std: the bound is the un-fused chain's own distance from the oracle, with slack
     assert e_or <= max(2e-5 * max(scale, 1.0), 3.0 * e_un), (e_or, e_un)
+    assert e_or <= 1e-4 * max(scale, 1.0), (e_or, scale)        # absolute cap: whatever the sibling implementation's own error is
     if with_next:
-        assert (got_xg.cpu() - want_xg).abs().max().item() <= max(2e-5 * max(scale, 1.0), 3.0 * e_un)
+        e_xg = (got_xg.cpu() - want_xg).abs().max().item()
+        assert e_xg <= max(2e-5 * max(scale, 1.0), 3.0 * e_un) and e_xg <= 1e-4 * max(scale, 1.0), (e_xg, e_un, scale)
         assert torch.allclose(got_xg, ref_xg, atol=5e-5 * max(scale, 1.0), rtol=0)
     if masked:
         assert torch.equal(got_h.cpu()[mask == 0], torch.zeros_like(got_h.cpu()[mask == 0]))
@@ -1211,6 +1150,7 @@ def test_node_gate_planes_matches_node_nn_plus_node_gate(dev):
                 e_got, e_ref = (got - want).abs().max().item(), (ref - want).abs().max().item()
                 assert got.shape == ref.shape == (N, 1)
                 assert e_got <= max(3e-6 * max(scale, 1.0), 3.0 * e_ref), (sizes[:3], dbl, e_got, e_ref)
+                assert e_got <= 1e-4 * max(scale, 1.0), (sizes[:3], dbl, e_got, scale)     # absolute cap
 
 
 def test_instr_gate_planes_is_the_gate_followed_by_the_row_split(dev):
@@ -1412,6 +1352,7 @@ def test_readout_tile_matches_the_unfused_pooling_and_the_oracle(dev, masked):
         scale = max(want_out.abs().max().item(), 1.0)
         e_or, e_un = (out.cpu() - want_out).abs().max().item(), (ref_out.cpu() - want_out).abs().max().item()
         assert e_or <= max(2e-5 * scale, 3.0 * e_un), (sizes[:4], e_or, e_un)
+        assert e_or <= 1e-4 * max(scale, 1.0), (sizes[:4], e_or, scale)     # absolute cap beside the relative one
         assert (gate.cpu().view(-1) - want_gate.view(-1)).abs().max().item() <= 2e-5
         assert torch.allclose(out, ref_out, atol=1e-4 * scale, rtol=0) and torch.allclose(gate, ref_gate, atol=2e-5, rtol=0)
         empty = torch.tensor([n == 0 for n in sizes])
@@ -1508,3 +1449,42 @@ def test_split_planes32_is_an_exact_two_plane_split(dev):
     live = amax.squeeze(1) > 0
     scaled = amax.squeeze(1)[live] / inv[live]
     assert (scaled >= 8192).all() and (scaled < 16384).all()
+
+
+def test_layer_conv_ignores_an_edge_whose_destination_is_out_of_range(dev):
+    """An edge_index entry with a destination outside [0, N) is dropped by the plan (csr_*_kernel), which then fills only
+    eid[0 .. rowptr[N]): the slots behind hold whatever the allocation held.  isg_tile_plan_edge_planes / isg_edge_planes used
+    to read edge_attr[eid[slot]] for EVERY slot < E -- an out-of-bounds row read.  Now the id is checked; the layer kernel's
+    results equal those of the batch without that edge."""
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.models.layers import GlorotLinear
+    gen = torch.Generator().manual_seed(21)
+    sizes = [20, 33, 7, 64, 12]
+    batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5)
+    N, H, C, K = batch.numel(), 4, 128, 128
+    bad = torch.tensor([[3], [N + 1000]])                         # destination far outside
+    ei_bad = torch.cat([ei[:, :10], bad, ei[:, 10:]], dim=1).contiguous()
+    x = torch.randn(N, 128, generator=gen).to(dev)
+    torch.manual_seed(3)
+    lin_l, lin_r = GlorotLinear(128, H * C).to(dev), GlorotLinear(128, H * C).to(dev)
+    w_e = (torch.randn(H * C, K, generator=gen) / K ** 0.5).to(dev)
+    att, bias = torch.randn(1, H, C, generator=gen).to(dev), torch.randn(H * C, generator=gen).to(dev)
+    ea = torch.randn(ei.size(1), K, generator=gen)
+    ea_bad = torch.cat([ea[:10], torch.full((1, K), 1e30), ea[10:]]).to(dev)      # the dropped edge's features must never matter
+    ea = ea.to(dev)
+    outs = []
+    for e_idx, e_attr in ((ei, ea), (ei_bad, ea_bad)):
+        # poison fresh allocations so that an unchecked eid would point far outside edge_attr
+        junk = torch.full((1 << 20,), 0x7FFFFFF0, dtype=torch.int32, device=dev)
+        del junk
+        plan = ops.GraphPlan.build(batch.to(dev), e_idx.to(dev), num_graphs=len(sizes))
+        res = ops.gatv2_layer_conv(x, lin_l, lin_r, e_attr, w_e, att, plan, H, bias=bias)
+        assert res is not None
+        outs.append(res)
+    torch.cuda.synchronize()
+    (o0, a0), (o1, a1) = outs
+    assert torch.isfinite(o1).all()
+    assert torch.equal(o0, o1)
+    keep = torch.ones(ei_bad.size(1), dtype=torch.bool)
+    keep[10] = False
+    assert torch.equal(a0, a1[keep.to(dev)])

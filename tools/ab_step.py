@@ -18,16 +18,15 @@ cfg = synthetic.CFG2
 wl = synthetic.make_workload(cfg).to(dev)
 model = synthetic.build_answer_model(cfg).to(dev).eval()
 variants = [
-    ("r01: tile GEMM everywhere", dict(GEMM_KERNEL="tile", LINEAR_MULTI=False, GEMM_F16X3=False, F16X3_TILE=False, FUSE_LOGITS=False, FUSE_XR=False)),
-    ("+ row-panel GEMM for the K=128 projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=False, GEMM_F16X3=False, F16X3_TILE=False, FUSE_LOGITS=False, FUSE_XR=False)),
-    ("+ the layers' lin_edge as one multi-output launch", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=False, F16X3_TILE=False, FUSE_LOGITS=False, FUSE_XR=False)),
-    ("+ fp16 three-product form for those projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=False, FUSE_LOGITS=False, FUSE_XR=False)),
-    ("+ the same for x_proj (row maxima from the producer kernels)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=False, FUSE_XR=False)),
-    ("+ lin_edge folded into the logits (no e_proj in memory)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False)),
-    ("+ lin_r formed inside that kernel (no x_r in memory)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=True)),
+    ("r01: tile GEMM everywhere", dict(GEMM_KERNEL="tile", LINEAR_MULTI=False, GEMM_F16X3=False, F16X3_TILE=False, FUSE_LOGITS=False)),
+    ("+ row-panel GEMM for the K=128 projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=False, GEMM_F16X3=False, F16X3_TILE=False, FUSE_LOGITS=False)),
+    ("+ the layers' lin_edge as one multi-output launch", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=False, F16X3_TILE=False, FUSE_LOGITS=False)),
+    ("+ fp16 three-product form for those projections", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=False, FUSE_LOGITS=False)),
+    ("+ the same for x_proj (row maxima from the producer kernels)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=False)),
+    ("+ lin_edge folded into the logits (no e_proj in memory)", dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True)),
 ]
 if os.environ.get("AB_R03"):         # round 3's switches on top of round 2's default path
-    base = dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False)
+    base = dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True)
     variants = [
         ("r02 default (edge-logits pair, un-fused tail, 14-launch plan)", {**base, "FUSE_TILE_CONV": False, "FUSE_DENSE_TAIL": False, "PLAN_FUSED": False}),
         ("+ fused dense tail", {**base, "FUSE_TILE_CONV": False, "FUSE_DENSE_TAIL": True, "PLAN_FUSED": False}),
@@ -60,7 +59,7 @@ with torch.no_grad():
             torch.cuda.synchronize()
             if r > 0:
                 res[name].append((time.perf_counter() - t0) / steps * 1e3)
-for k, v in dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True, FUSE_XR=False,
+for k, v in dict(GEMM_KERNEL="auto", LINEAR_MULTI=True, GEMM_F16X3=True, F16X3_TILE=True, FUSE_LOGITS=True,
                  FUSE_TILE_CONV=True, FUSE_DENSE_TAIL=True, PLAN_FUSED=True, FUSE_LAYER_CONV=True, FUSE_READOUT=True).items():
     setattr(ops, k, v)
 for name, _ in variants:

@@ -91,6 +91,14 @@ def main():
     if own:      # the pair never touches e_proj: its own minimum is far below the un-fused bytes_mp
         res["pair_own_algorithmic_bytes"] = int(own.group(1))
         res["traffic_over_own_algorithmic"] = round(res["hbm_bytes_per_launch"] / int(own.group(1)), 3)
+    # the bytes of the kernel source(s) this summary was measured on: bench.py's load_traffic refuses a summary whose
+    # kernel has been edited since
+    import os as _os
+    import sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    import bench as _bench
+    res["source"] = list(_bench.TRAFFIC_SOURCES[res["kind"]])
+    res["source_sha256"] = _bench.kernel_source_hash(res["kind"])
     json.dump(res, open(out_path, "w"), indent=1)
     print(json.dumps(res))
 

@@ -28,8 +28,7 @@ lib = ctypes.CDLL(OUT)
 c = ctypes
 lib.isg_gatv2_edge_logits.argtypes = [c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int64, c.c_void_p,
                                       c.c_int32, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
-                                      c.c_void_p, c.c_int64, c.c_int32, c.c_int32, c.c_int32, c.c_float, c.c_void_p, c.c_int32,
-                                      c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p]
+                                      c.c_void_p, c.c_int64, c.c_int32, c.c_int32, c.c_int32, c.c_float, c.c_void_p]
 lib.isg_el_set_stamp_buffer.argtypes = [c.c_void_p]
 dev = torch.device("cuda:0")
 cfg = synthetic.CFG2
@@ -57,8 +56,7 @@ for r in range(6):
     s.record()
     rc = lib.isg_gatv2_edge_logits(ea.data_ptr(), K, planes.data_ptr(), inv.data_ptr(), x_lr.data_ptr(), 2 * H * C, 0,
                                    x_lr.data_ptr() + 4 * H * C, 2 * H * C, 0, att.data_ptr(), plan.eid.data_ptr(),
-                                   plan.src.data_ptr(), plan.dst.data_ptr(), None, None, lg.data_ptr(), E, H, C, K, 0.2,
-                                   None, 0, None, None, None, 0, st)
+                                   plan.src.data_ptr(), plan.dst.data_ptr(), None, None, lg.data_ptr(), E, H, C, K, 0.2, st)
     e.record()
     torch.cuda.synchronize()
     assert rc == 0

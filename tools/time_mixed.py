@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Mixed dispatch on / off on a configs[1] batch with a few graphs beyond a tile (the case real GQA batches are: the reference
+caps nothing, datasets/scene_graph.py:199-389).   python3 tools/time_mixed.py [graphs] [big graphs]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from isubgvqa_amd import ops, synthetic
+
+graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda:0")
+ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES = 0.9, 0      # the gate open: this tool measures the mode itself
+gen = torch.Generator().manual_seed(3)
+for nbig in ([int(sys.argv[2])] if len(sys.argv) > 2 else [0, 1, 8, 64]):
+    base = synthetic.graph_sizes(synthetic.WorkloadConfig(num_graphs=graphs), gen).tolist()
+    for i in range(nbig):
+        base[(i * 977 + 13) % graphs] = 100 + (i * 37) % 90
+    cfg = synthetic.WorkloadConfig(num_graphs=graphs, sizes=tuple(base))
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).to(dev).eval()
+    line = f"{graphs} graphs, {nbig} beyond a tile (N={wl.x.size(0)}, max nodes {wl.max_nodes}, max edges {wl.max_edges}):"
+    for mode in (True, False, True, False):
+        ops.MIXED_DISPATCH = mode
+        with torch.no_grad():
+            for i in range(3):
+                model(wl, seed=50 + i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(20):
+                model(wl, seed=60 + i)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+        line += f"  {'mixed' if mode else 'off'} {dt * 1e3:.3f} ms"
+    print(line, flush=True)
