@@ -82,8 +82,7 @@ SIGNATURES = {
                                         c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_gatv2_edge_logits": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                      c_int32, c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
-                                      c_int32, c_void_p]),
+                                      c_int32, c_int32, c_int32, c_float, c_void_p]),
     "isg_gatv2_mp_fwd_logits": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "isg_split_f16x2_rows": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
