@@ -536,7 +536,8 @@ int64_t isg_planes32_elems(int64_t rows, int32_t K);
 int isg_split_planes32(const float *a, int64_t M, int32_t K, int32_t lda, uint16_t *planes, float *inv_scale, void *stream);
 /* d = act(a . w^T + bias), act 0 none / 1 exact GELU / 2 ReLU.  Output, exactly one of:
  *   d        fp32 [M, ldd]                                            (d_planes = d_inv = d_bound = NULL)
- *   d_planes planes32 of the result (N % 32 == 0) + d_inv[M], scaled by the power of two of the bound
+ *   d_planes planes32 of the result (columns [N, roundup32(N)) written as zeros: the next Linear's k padding) + d_inv[M],
+ *            scaled by the power of two of the bound
  *            |d[m, :]| < a_inv[m] * d_bound[0] + d_bound[1],  d_bound = {2^14 * max_n ||w_n||_1, max |bias|} on the device
  *            -- the next Linear's `a_planes` / `a_inv` with no pass in between (linear1 -> linear2).
  * ISG_EUNSUPPORTED: N % 4 != 0, ldd % 4 != 0, a misaligned pointer, an operand of 2 GB or more. */
@@ -576,10 +577,12 @@ int isg_mha_small(const float *q, int32_t ldq, const float *k, int32_t ldk, cons
 /* out = LayerNorm(x + r) over the last dimension, r optional (NULL): the post-norm step of nn.TransformerEncoderLayer /
  * nn.TransformerDecoderLayer (question_encoder.py:20-38, question_decoder.py:25-71) with the residual add folded in;
  * torch.nn.LayerNorm's arithmetic ((v - mean) * rstd * gamma + beta, biased variance, fp32; beta may be NULL).  rowmax
- * fp32 [M] or NULL: max |out| per row, the a_rowmax (P = 1) of the Linear that reads `out`.  4 | D, D <= 2048, 16-byte
- * aligned rows (ISG_EUNSUPPORTED otherwise). */
+ * fp32 [M] or NULL: max |out| per row, the a_rowmax (P = 1) of the Linear that reads `out`.  planes / planes_inv (both or
+ * neither): `out` also as the planes32 operand of isg_linear_h3p (uint16 [M * D * 2], fp32 [M]; 32 | D), so that the
+ * Linears which read it need no isg_split_planes32 pass.  4 | D, D <= 2048, 16-byte aligned rows (ISG_EUNSUPPORTED otherwise). */
 int isg_add_layernorm(const float *x, int32_t ldx, const float *r, int32_t ldr, const float *gamma, const float *beta,
-                      float eps, float *out, int32_t ldo, float *rowmax, int64_t M, int32_t D, void *stream);
+                      float eps, float *out, int32_t ldo, float *rowmax, int64_t M, int32_t D, uint16_t *planes,
+                      float *planes_inv, void *stream);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,7 @@ SIGNATURES = {
     "isg_mha_small": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                               c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_add_layernorm": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_int32,
-                                  c_void_p, c_int64, c_int32, c_void_p]),
+                                  c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_linear_panel_multi": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "isg_split_f16x2_frag_elems": (c_int64, [c_int64, c_int32]),

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float eps,
                                                             float *__restrict__ out, float *__restrict__ rowmax, int M,
-                                                            int D, int ldx, int ldr, int ldo) {
+                                                            int D, int ldx, int ldr, int ldo,
+                                                            _Float16 *__restrict__ planes, float *__restrict__ pinv) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const int nv = D >> 2;
@@ -134,11 +135,35 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
       o.w = (v[i].w - mean) * rstd * g.w + bb.w;
       reinterpret_cast<float4 *>(out + (int64_t)row * ldo)[c] = o;
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+      v[i] = o;
     }
   }
-  if (rowmax) {
-    mx = wave_max(mx);
-    if (lane == 0) rowmax[row] = mx;
+  if (rowmax || planes) mx = wave_max(mx);
+  if (rowmax && lane == 0) rowmax[row] = mx;
+  if (planes) {
+    // the row as the planes32 operand of isg_linear_h3p (csrc/isg_gemm_h3p.hip): the wave holds the whole row and knows its
+    // exact maximum, so the Linears that read the result (in_proj, the cross-attention projections, linear1) need no split
+    // pass: k-tile kt of a row = [hi 32 | mid 32] fp16, D % 32 == 0
+    typedef __attribute__((ext_vector_type(4))) _Float16 ln_h4;
+    const int e = (int)((__float_as_uint(mx) >> 23) & 255u);
+    float sc = 1.f, inv = 1.f;
+    if (e >= 14 && e != 255) { sc = __uint_as_float((unsigned)(127 + 13 + 127 - e) << 23); inv = __uint_as_float((unsigned)(e - 13) << 23); }
+    if (lane == 0) pinv[row] = inv;
+    _Float16 *p = planes + (int64_t)row * (D * 2);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) {
+        const float4 o = v[i];
+        const float a0 = o.x * sc, a1 = o.y * sc, a2 = o.z * sc, a3 = o.w * sc;
+        const ln_h4 hi = {(_Float16)a0, (_Float16)a1, (_Float16)a2, (_Float16)a3};
+        const ln_h4 mid = {(_Float16)(a0 - (float)hi[0]), (_Float16)(a1 - (float)hi[1]), (_Float16)(a2 - (float)hi[2]),
+                           (_Float16)(a3 - (float)hi[3])};
+        _Float16 *d = p + (c >> 3) * 64 + (c & 7) * 4;
+        *reinterpret_cast<ln_h4 *>(d) = hi;
+        *reinterpret_cast<ln_h4 *>(d + 32) = mid;
+      }
+    }
   }
 }
 
@@ -148,7 +173,7 @@ using namespace isg;
 
 extern "C" int isg_add_layernorm(const float *x, int32_t ldx, const float *r, int32_t ldr, const float *gamma,
                                  const float *beta, float eps, float *out, int32_t ldo, float *rowmax, int64_t M,
-                                 int32_t D, void *stream) {
+                                 int32_t D, uint16_t *planes, float *planes_inv, void *stream) {
   if (M < 0 || D <= 0 || ldx < D || ldo < D || (r && ldr < D)) return ISG_EINVAL;
   if (M == 0) return ISG_OK;
   if (!x || !gamma || !out) return ISG_EINVAL;
@@ -156,9 +181,12 @@ extern "C" int isg_add_layernorm(const float *x, int32_t ldx, const float *r, in
   if ((D & 3) || D > 2048 || (ldx & 3) || (ldo & 3) || (r && (ldr & 3)) || mis(x) || mis(out) || (r && mis(r)) ||
       mis(gamma) || (beta && mis(beta)) || (M + 3) / 4 >= (1ll << 31))
     return ISG_EUNSUPPORTED;
+  if ((planes != nullptr) != (planes_inv != nullptr)) return ISG_EINVAL;
+  if (planes && ((D & 31) || mis(planes))) return ISG_EUNSUPPORTED;
+  _Float16 *pl = reinterpret_cast<_Float16 *>(planes);
   const unsigned grid = (unsigned)((M + 3) / 4);
   hipStream_t st = as_stream(stream);
-#define ISG_LN(NV_) add_layernorm_kernel<NV_><<<grid, 256, 0, st>>>(x, r, gamma, beta, eps, out, rowmax, (int)M, D, ldx, ldr, ldo)
+#define ISG_LN(NV_) add_layernorm_kernel<NV_><<<grid, 256, 0, st>>>(x, r, gamma, beta, eps, out, rowmax, (int)M, D, ldx, ldr, ldo, pl, planes_inv)
   if (D <= 256) ISG_LN(1);
   else if (D <= 512) ISG_LN(2);
   else if (D <= 1024) ISG_LN(4);

@@ -365,9 +365,16 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   }
   Q3_SOFF()
   int sb = 0;                                                  // ring buffer (byte offset) the stager fills
+#ifndef ISG_Q3_AUX_A
+#define ISG_Q3_AUX_A 0        // cache policy bits of the A-operand requests (2 = nt): A/B in tools/time_h3p.py builds
+#endif
+#ifndef ISG_Q3_AUX_B
+#define ISG_Q3_AUX_B 0
+#endif
 #define Q3_DMA(base, off, slice, u)                                                                                \
   __builtin_amdgcn_global_load_lds((p3_glb_t *)((base) + (size_t)skt * 128u + (off)),                              \
-                                   (p3_lds_t *)(p3_smem + sb + (slice) * P3_SLOT + ((u) * 8 + wave) * 1024), 16, 0, 0);
+                                   (p3_lds_t *)(p3_smem + sb + (slice) * P3_SLOT + ((u) * 8 + wave) * 1024), 16, 0,  \
+                                   (slice) == 2 ? ISG_Q3_AUX_B : ISG_Q3_AUX_A);
 #define Q3_STAGE_P0() { Q3_DMA(Wb, so_b[0], 2, 0) Q3_DMA(Wb, so_b[1], 2, 1) Q3_DMA(Ab, so_alo[0], 0, 0) Q3_DMA(Ab, so_alo[1], 0, 1) }
 #define Q3_STAGE_P1()                                                                                              \
   {                                                                                                                \
@@ -435,52 +442,93 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][0], c, 0, 0, 0);                                    \
     acc[(ah) * 2 + i][j] = c;                                                                                      \
   }
-#define Q3_NS (PLANES_OUT ? 2 : 1)
-  // epilogue of ONE accumulator tile of `res` (static i, j): row scale, column scales, bias, activation, one 16-byte store per lane
+  // one activation of this lane's four values of accumulator tile (i, j) of `res`
+#define Q3_VAL(v, i, j, b4)                                                                                        \
+  {                                                                                                                \
+    const hf32x4 c = res[i][j];                                                                                    \
+    const float ia = p_ia[i];                                                                                      \
+    const hf32x4 iw = p_iw[j];                                                                                     \
+    v.x = (c[0] * ia) * iw[0] + b4[0]; v.y = (c[1] * ia) * iw[1] + b4[1];                                          \
+    v.z = (c[2] * ia) * iw[2] + b4[2]; v.w = (c[3] * ia) * iw[3] + b4[3];                                          \
+    if (ACT == 1) {                                                                                                \
+      const isg_f32x2 g0 = gelu_exact2(isg_f32x2{v.x, v.y}), g1 = gelu_exact2(isg_f32x2{v.z, v.w});                \
+      v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;                                                              \
+    }                                                                                                              \
+    if (ACT == 2) {                                                                                                \
+      v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; \
+    }                                                                                                              \
+  }
+  // a wave whose accumulator tile lies outside D issues no store -- but the counted waits assume `n` operations, so it issues
+  // as many 4-byte requests into a scratch line instead
+#define Q3_DUMMY(n)                                                                                                \
+  _Pragma("unroll") for (int z = 0; z < (n); ++z)                                                                  \
+    __builtin_amdgcn_global_load_lds((p3_glb_t *)(a.a_inv + min(lane, a.M - 1)),                                   \
+                                     (p3_lds_t *)(p3_smem + Q3_RING + 3 * Q3_PAR), 4, 0, 0);
+  // fp32 result: ONE accumulator tile (static i, j): scales, bias, activation, one 16-byte store per lane
 #define Q3_EPI(i, j, b4)                                                                                           \
   {                                                                                                                \
     if (!(rm0 + wm * 64 + (i) * 16 < a.M && rn0 + wn * 64 + (j) * 16 < a.N)) {                                     \
-      /* this wave's accumulator tile lies outside D: no store -- but the counted waits assume Q3_NS operations   */ \
-      /* per piece, so the wave issues as many 4-byte requests into a scratch line instead                         */ \
-      _Pragma("unroll") for (int z = 0; z < Q3_NS; ++z)                                                            \
-        __builtin_amdgcn_global_load_lds((p3_glb_t *)(a.a_inv + min(lane, a.M - 1)),                               \
-                                         (p3_lds_t *)(p3_smem + Q3_RING + 3 * Q3_PAR), 4, 0, 0);                   \
+      Q3_DUMMY(1)                                                                                                  \
     } else {                                                                                                       \
-      const hf32x4 c = res[i][j];                                                                                  \
-      const float ia = p_ia[i];                                                                                    \
-      const hf32x4 iw = p_iw[j];                                                                                   \
       const int rl = wm * 64 + (i) * 16 + (lane & 15), cl = wn * 64 + (j) * 16 + 4 * (lane >> 4);                  \
       float4 v;                                                                                                    \
-      v.x = (c[0] * ia) * iw[0] + b4[0]; v.y = (c[1] * ia) * iw[1] + b4[1];                                        \
-      v.z = (c[2] * ia) * iw[2] + b4[2]; v.w = (c[3] * ia) * iw[3] + b4[3];                                        \
-      if (ACT == 1) {                                                                                              \
-        const isg_f32x2 g0 = gelu_exact2(isg_f32x2{v.x, v.y}), g1 = gelu_exact2(isg_f32x2{v.z, v.w});              \
-        v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;                                                            \
-      }                                                                                                            \
-      if (ACT == 2) {                                                                                              \
-        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; \
-      }                                                                                                            \
+      Q3_VAL(v, i, j, b4)                                                                                          \
       const int row = min(rm0 + rl, a.M - 1), col = min(rn0 + cl, a.N - 4);                                        \
-      const bool live = rm0 + rl < a.M && rn0 + cl < a.N && !(a.abl & 1);                                          \
-      if constexpr (PLANES_OUT) {                                                                                  \
-        float so, inv;                                                                                             \
-        h3_scale(ia * a.d_bound[0] + a.d_bound[1], so, inv);                                                       \
-        v.x *= so; v.y *= so; v.z *= so; v.w *= so;                                                                \
-        const hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                            \
-        const hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]),                        \
-                            (_Float16)(v.z - (float)hi[2]), (_Float16)(v.w - (float)hi[3])};                       \
-        if (live) {                                                                                                \
-          _Float16 *d = a.Dp + (int64_t)row * (a.N * 2) + (col >> 5) * 64 + (col & 31);                            \
-          *reinterpret_cast<hf16x4 *>(d) = hi;                                                                     \
-          *reinterpret_cast<hf16x4 *>(d + 32) = mid;                                                               \
-          if (rn0 + cl == 0) a.d_inv[row] = inv;                                                                   \
-        }                                                                                                          \
-      } else if (live) {                                                                                           \
+      if (rm0 + rl < a.M && rn0 + cl < a.N && !(a.abl & 1)) {                                                      \
         typedef float p3_f32x4 __attribute__((ext_vector_type(4)));                                                \
         p3_f32x4 w4 = {v.x, v.y, v.z, v.w};                                                                        \
         p3_f32x4 *dst = reinterpret_cast<p3_f32x4 *>(a.D + (int64_t)row * a.ldd + col);                            \
         if (a.nt_store) __builtin_nontemporal_store(w4, dst);                                                      \
         else *dst = w4;                                                                                            \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+  // planes32 result: the PAIR of accumulator tiles (i, j0), (i, j0 + 1) = one 32-column group of 16 rows.  A lane holds
+  // columns 4q .. 4q + 3 of each tile (q = lane >> 4): after the split it swaps ONE 8-byte fragment with lane ^ 16, so that it
+  // owns 8 consecutive columns of the group -- 16 bytes of the hi plane and 16 of the mid plane, four lanes = the row's 64
+  // contiguous bytes per plane: two stores per lane and pair, the store count and width of the fp32 path (the first form
+  // stored two 8-byte pieces per tile: 380 us where the fp32 result took 246).  Columns in [N, roundup32(N)) are the NEXT
+  // Linear's k padding: written as zeros.
+#define Q3_EPI_PAIR(i, j0, b4a, b4b)                                                                               \
+  {                                                                                                                \
+    const int npad = (a.N + 31) & ~31;                                                                             \
+    if (!(rm0 + wm * 64 + (i) * 16 < a.M && rn0 + wn * 64 + (j0) * 16 < npad)) {                                   \
+      Q3_DUMMY(2)                                                                                                  \
+    } else {                                                                                                       \
+      const int q = lane >> 4, rl = wm * 64 + (i) * 16 + (lane & 15), cl = wn * 64 + (j0) * 16 + 4 * q;            \
+      float4 va, vb;                                                                                               \
+      Q3_VAL(va, i, j0, b4a)                                                                                       \
+      Q3_VAL(vb, i, (j0) + 1, b4b)                                                                                 \
+      if (rn0 + cl >= a.N) va = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+      if (rn0 + cl + 16 >= a.N) vb = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
+      float so, inv;                                                                                               \
+      h3_scale(p_ia[i] * a.d_bound[0] + a.d_bound[1], so, inv);                                                    \
+      va.x *= so; va.y *= so; va.z *= so; va.w *= so; vb.x *= so; vb.y *= so; vb.z *= so; vb.w *= so;              \
+      const hf16x4 ha = {(_Float16)va.x, (_Float16)va.y, (_Float16)va.z, (_Float16)va.w};                          \
+      const hf16x4 hb = {(_Float16)vb.x, (_Float16)vb.y, (_Float16)vb.z, (_Float16)vb.w};                          \
+      const hf16x4 ma = {(_Float16)(va.x - (float)ha[0]), (_Float16)(va.y - (float)ha[1]),                         \
+                         (_Float16)(va.z - (float)ha[2]), (_Float16)(va.w - (float)ha[3])};                        \
+      const hf16x4 mb = {(_Float16)(vb.x - (float)hb[0]), (_Float16)(vb.y - (float)hb[1]),                         \
+                         (_Float16)(vb.z - (float)hb[2]), (_Float16)(vb.w - (float)hb[3])};                        \
+      typedef int p3_i32x2 __attribute__((ext_vector_type(2)));                                                    \
+      typedef int p3_i32x4 __attribute__((ext_vector_type(4)));                                                    \
+      const bool even = (q & 1) == 0;       /* even q keeps its tile-a fragment and sends tile b's; odd q the reverse */ \
+      const p3_i32x2 hka = __builtin_bit_cast(p3_i32x2, ha), hkb = __builtin_bit_cast(p3_i32x2, hb);               \
+      const p3_i32x2 mka = __builtin_bit_cast(p3_i32x2, ma), mkb = __builtin_bit_cast(p3_i32x2, mb);               \
+      const p3_i32x2 hs = even ? hkb : hka, ms = even ? mkb : mka;                                                 \
+      const p3_i32x2 hr = {__shfl_xor(hs[0], 16, 64), __shfl_xor(hs[1], 16, 64)};                                  \
+      const p3_i32x2 mr = {__shfl_xor(ms[0], 16, 64), __shfl_xor(ms[1], 16, 64)};                                  \
+      const p3_i32x4 h16 = even ? p3_i32x4{hka[0], hka[1], hr[0], hr[1]} : p3_i32x4{hr[0], hr[1], hkb[0], hkb[1]}; \
+      const p3_i32x4 m16 = even ? p3_i32x4{mka[0], mka[1], mr[0], mr[1]} : p3_i32x4{mr[0], mr[1], mkb[0], mkb[1]}; \
+      /* chunk of 8 columns this lane owns: q = 0, 1, 2, 3 -> columns 0-7, 16-23, 8-15, 24-31 of the group */         \
+      const int chunk = ((q & 1) << 1) | (q >> 1);                                                                 \
+      const int gcol = rn0 + wn * 64 + (j0) * 16;                      /* first column of the 32-column group */    \
+      const int row = min(rm0 + rl, a.M - 1);                                                                      \
+      if (rm0 + rl < a.M && gcol + chunk * 8 < npad && !(a.abl & 1)) {                                             \
+        _Float16 *d = a.Dp + (int64_t)row * (npad * 2) + (gcol >> 5) * 64 + chunk * 8;                             \
+        *reinterpret_cast<p3_i32x4 *>(d) = h16;                                                                    \
+        *reinterpret_cast<p3_i32x4 *>(d + 32) = m16;                                                               \
+        if (gcol == 0 && q == 0) a.d_inv[row] = inv;                                                               \
       }                                                                                                            \
     }                                                                                                              \
   }
@@ -527,15 +575,19 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   // End of a load segment: every request is waited for FOUR phases after its issue (B and A-lo leave in the first phase of
   // a k-tile and are read two k-tiles later in a first phase, A-hi likewise in second phases), so the operations of the THREE
   // youngest phases may be in flight: 4 + 2 + 4 = 10 requests at the end of a first phase, 2 + 4 + 2 = 8 at the end of a
-  // second, + Q3_NS per accumulator tile stored + 1 per parameter request inside that window (both are issued in second
+  // second, + 1 per 16-byte store of `res` + 1 per parameter request inside that window (both are issued in second
   // phases only).  A k-tile of the head: NP pieces (tiles NP * kh ... of `res`) leave in its second phase, after the phase's
   // fragment reads and requests; the first also requests the NEXT tile's parameters.  `sp` / `pp`: stores / parameter
   // requests of the previous k-tile's second phase (a head k-tile after a head k-tile: NP pieces; the first: taken as none,
   // which only waits earlier than needed when the tile before was all head).
+#define Q3_STORES(kh, NP) (PLANES_OUT ? ((NP) == 2 ? 2 : (((kh) & 1) ? 2 : 0)) : (NP))      /* counted stores of head k-tile kh */
 #define Q3_KT(kh, NP, is_head)                                                                                     \
   {                                                                                                                \
-    constexpr int sp = ((is_head) && (kh) > 0) ? (NP) * Q3_NS : 0, pp = ((is_head) && (kh) == 1) ? 1 : 0;          \
-    constexpr int sc = (is_head) ? (NP) * Q3_NS : 0, pc = ((is_head) && (kh) == 0) ? 1 : 0;                        \
+    constexpr int sp = ((is_head) && (kh) > 0) ? Q3_STORES((kh) - 1, NP) : 0, pp = ((is_head) && (kh) == 1) ? 1 : 0; \
+    constexpr int sc = (is_head) ? Q3_STORES(kh, NP) : 0, pc = ((is_head) && (kh) == 0) ? 1 : 0;                   \
+    /* the accumulator tiles that leave in this k-tile: fp32 NP single tiles from NP * kh; planes one pair (2 m, 2 m + 1) */ \
+    constexpr int t0 = PLANES_OUT ? ((NP) == 2 ? 2 * (kh) : ((kh) & ~1)) : (NP) * (kh);                            \
+    constexpr int nt = PLANES_OUT ? (sc ? 2 : 0) : (NP);                                                           \
     Q3_READ_A(0) Q3_READ_B()                                                                                       \
     Q3_STAGE_P0()                                                                                                  \
     Q3_ST(0)                                                                                                       \
@@ -545,19 +597,23 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     Q3_ST(2)                                                                                                       \
     Q3_M(0)                                                                                                        \
     hf32x4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};                                                 \
-    if ((is_head) && has_res && a.bias) {                                                                          \
-      Q3_BIAS_REQ(bq0, ((NP) * (kh)) & 3)                                                                          \
-      if ((NP) > 1) Q3_BIAS_REQ(bq1, ((NP) * (kh) + 1) & 3)                                                        \
+    if ((is_head) && has_res && a.bias && nt > 0) {                                                                \
+      Q3_BIAS_REQ(bq0, t0 & 3)                                                                                     \
+      if (nt > 1) Q3_BIAS_REQ(bq1, (t0 + 1) & 3)                                                                   \
     }                                                                                                              \
     Q3_READ_A(1)                                                                                                   \
     if ((is_head) && (kh) == 0) Q3_PARAMS(nm0, nn0, npar)                                                          \
     Q3_STAGE_P1()                                                                                                  \
     Q3_ST(7)                                                                                                       \
-    if ((is_head) && has_res) {                                                                                    \
+    if ((is_head) && has_res && nt > 0) {                                                                          \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
-      Q3_EPI(((NP) * (kh)) >> 2, ((NP) * (kh)) & 3, bq0)                                                           \
-      if ((NP) > 1) Q3_EPI((((NP) * (kh) + 1) & 15) >> 2, ((NP) * (kh) + 1) & 3, bq1)                              \
+      if constexpr (PLANES_OUT) {                                                                                  \
+        Q3_EPI_PAIR((t0 & 15) >> 2, t0 & 2, bq0, bq1)                                                              \
+      } else {                                                                                                     \
+        Q3_EPI((t0 & 15) >> 2, t0 & 3, bq0)                                                                        \
+        if (nt > 1) Q3_EPI(((t0 + 1) & 15) >> 2, (t0 + 1) & 3, bq1)                                                \
+      }                                                                                                            \
     }                                                                                                              \
     Q3_ST(6)                                                                                                       \
     if (has_res) { Q3_WAIT(8 + sp + pp + sc + pc) } else { Q3_WAIT(8 + pp + pc) }                                  \
@@ -610,14 +666,20 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      hf32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; j += 2) {
+      hf32x4 bqa = {0.f, 0.f, 0.f, 0.f}, bqb = {0.f, 0.f, 0.f, 0.f};
       if (a.bias) {
-        Q3_BIAS_REQ(bq, j)
+        Q3_BIAS_REQ(bqa, j)
+        Q3_BIAS_REQ(bqb, j + 1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
-      Q3_EPI(i, j, bq)
+      if constexpr (PLANES_OUT) {
+        Q3_EPI_PAIR(i, j, bqa, bqb)
+      } else {
+        Q3_EPI(i, j, bqa)
+        Q3_EPI(i, j + 1, bqb)
+      }
     }
 #ifdef ISG_P3_STAMP
   if (g_p3_stamps && lane == 0) {
@@ -630,7 +692,10 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 #undef Q3_KT
 #undef Q3_TILE_END
 #undef Q3_BIAS_REQ
-#undef Q3_NS
+#undef Q3_STORES
+#undef Q3_EPI_PAIR
+#undef Q3_DUMMY
+#undef Q3_VAL
 #undef Q3_M
 #undef Q3_WAIT
 #undef Q3_BAR
@@ -687,7 +752,7 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int KT = (K + 31) / 32;
   if ((N & 3) || mis(a_planes) || mis(w_planes) || mis(w_inv) || (bias && mis(bias)) ||
-      (planes_out ? ((N & 31) || mis(d_planes)) : ((ldd & 3) || mis(d))) ||
+      (planes_out ? mis(d_planes) : ((ldd & 3) || mis(d))) ||
       M * (int64_t)KT * 128 >= (1ll << 31) || (int64_t)N * KT * 128 >= (1ll << 31))
     return ISG_EUNSUPPORTED;
   const long long tm = (M + P3_T - 1) / P3_T, tn = (N + P3_T - 1) / P3_T;
@@ -702,6 +767,7 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   { const char *e = getenv("ISG_P3_ABL"); a.abl = e ? atoi(e) : 0; }
   hipStream_t st = as_stream(stream);
   static const int version = [] { const char *e = getenv("ISG_H3P_V"); return e ? atoi(e) : 2; }();
+  if (planes_out && (N & 31) && (version == 1 || KT < Q3_HEAD)) return ISG_EUNSUPPORTED;   // the 256 x 256 form pads no columns
   if (version != 1 && KT >= Q3_HEAD) {       // persistent 256 x 128 form
     const int ncu = device_cus();
     Q3Args q;

@@ -1561,10 +1561,15 @@ def row_maxima(x: Tensor) -> Optional[Tensor]:
 
 
 def carry_row_maxima(dst: Tensor, src: Tensor) -> Tensor:
-    """`dst` is a row-order-preserving view / reshape of `src` (same rows, same values): it keeps src's maxima."""
+    """`dst` is a row-order-preserving view / reshape of `src` (same rows, same values): it keeps src's maxima, and src's
+    planes32 (what a Linear on the engine would otherwise split again)."""
     rm = row_maxima(src)
     if rm is not None and dst.dim() >= 1:
         attach_row_maxima(dst, rm)
+    hit = getattr(src, "_isg_planes32", None)
+    if hit is not None and hit[0] == (_ver(src), src.data_ptr(), tuple(src.shape)) and dst.data_ptr() == src.data_ptr() \
+            and dst.numel() == src.numel():
+        dst._isg_planes32 = ((_ver(dst), dst.data_ptr(), tuple(dst.shape)), hit[1])
     return dst
 
 
@@ -1579,11 +1584,17 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], norm: torch.nn.LayerNor
         raise ValueError("add_layernorm: an affine LayerNorm over the last dimension")
     out = torch.empty(M, D, dtype=torch.float32, device=x.device)
     rm = torch.empty(M, 1, dtype=torch.float32, device=x.device) if want_rowmax else None
+    # the consumers of a LayerNorm result are Linears: where they run on the planes32 engine the kernel writes the planes too
+    pl = None
+    if LN_PLANES and H3P and D % 32 == 0 and D >= H3P_MIN_K and M >= H3P_MIN_M:
+        pl = Planes32(torch.empty(M * D * 2, dtype=torch.int16, device=x.device),
+                      torch.empty(M, dtype=torch.float32, device=x.device), M, D)
     rc = lib.isg_add_layernorm(_chk_rows(x, "x"), x.stride(0), 0 if residual is None else _chk_rows(residual, "residual"),
                                0 if residual is None else residual.stride(0),
                                _chk(norm.weight.detach(), "weight", torch.float32, (D,)),
                                _chk(None if norm.bias is None else norm.bias.detach(), "bias", torch.float32, (D,), optional=True),
-                               float(norm.eps), out.data_ptr(), D, 0 if rm is None else rm.data_ptr(), M, D, _stream())
+                               float(norm.eps), out.data_ptr(), D, 0 if rm is None else rm.data_ptr(), M, D,
+                               0 if pl is None else pl.planes.data_ptr(), 0 if pl is None else pl.inv.data_ptr(), _stream())
     if rc == ISG_EUNSUPPORTED:
         COUNTERS["torch_layer_norm"] += 1
         y = x if residual is None else x + residual
@@ -1591,6 +1602,8 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], norm: torch.nn.LayerNor
     _lib.check(rc, "isg_add_layernorm")
     if rm is not None:
         attach_row_maxima(out, rm)
+    if pl is not None:
+        out._isg_planes32 = ((_ver(out), out.data_ptr(), tuple(out.shape)), pl)       # what split_planes32(out) would make
     return out
 
 
@@ -1605,6 +1618,8 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     """act(x @ weight^T + bias), x [M,K] fp32, weight [N,K] (torch Linear layout).  Uses the bf16x6 matrix-core kernel
     when the shape allows it, hipBLASLt through torch otherwise (K not a multiple of 4).  ``cache_planes=False``: the
     weight is being trained (or is a temporary), so its bf16 planes are split per call instead of cached."""
+    if isinstance(x, Planes32):                    # the producer handed the rows over pre-split (a Linear's planes output)
+        return linear_h3p(x, weight, bias, gelu=gelu, relu=relu, cache_planes=cache_planes)
     M, K = x.shape
     f16_io = x.dtype == torch.float16 or out_dtype == torch.float16
     if f16_io and (GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or _rec(x, weight, bias)):
@@ -1755,6 +1770,7 @@ def _h3p_weight(weight: Tensor, bias: Optional[Tensor], cache: bool = True):
 
 H3P = True            # Linears with K >= H3P_MIN_K over at least H3P_MIN_M rows on isg_linear_h3p (A/B switch)
 H3P_MIN_K = 256
+LN_PLANES = True      # isg_add_layernorm writes its result as planes32 too where Linears on the engine read it (A/B switch)
 H3P_CHAIN = True      # linear1 -> linear2 of the Transformer layers through planes (no fp32 intermediate): A/B switch
 H3P_MIN_M = 8192
 
@@ -1767,8 +1783,8 @@ def h3p_supported(M: int, N: int, K: int) -> bool:
 def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False, relu: bool = False,
                planes_out: bool = False, cache_planes: bool = True):
     """act(x @ weight^T + bias) on the planes32 engine.  x: Planes32 or fp32 rows (split here, once per tensor version).
-    planes_out: the result as Planes32 (N % 32 == 0), scaled by the bound known before the product -- the input of the next
-    Linear with no pass over it; otherwise fp32 [M, N]."""
+    planes_out: the result as Planes32 (its columns padded with zeros to a multiple of 32), scaled by the bound known before the
+    product -- the input of the next Linear with no pass over it; otherwise fp32 [M, N]."""
     lib = _lib.load()
     xp = x if isinstance(x, Planes32) else split_planes32(x)
     M, K = xp.rows, xp.cols
@@ -1780,8 +1796,6 @@ def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = Fa
     act = 2 if relu else (1 if gelu else 0)
     dev = xp.planes.device
     if planes_out:
-        if N % 32:
-            raise ValueError("linear_h3p: planes_out needs N % 32 == 0")
         dp = torch.empty(int(lib.isg_planes32_elems(M, N)), dtype=torch.int16, device=dev)
         dinv = torch.empty(M, dtype=torch.float32, device=dev)
         _lib.check(lib.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), bptr, 0,
@@ -1901,13 +1915,22 @@ def mlp(seq: torch.nn.Sequential, x: Tensor, want_rowmax: bool = False) -> Tenso
             fuse = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.GELU) and mods[i + 1].approximate == "none"
             nxt = i + (2 if fuse else 1)
             more = nxt < len(mods) and hasattr(mods[nxt], "weight") and getattr(mods[nxt].weight, "dim", lambda: 0)() == 2
-            rm = row_maxima(x)
-            x = x.contiguous()
-            if rm is not None:
-                attach_row_maxima(x, rm)
+            if not isinstance(x, Planes32):
+                rm = row_maxima(x)
+                x = x.contiguous()
+                if rm is not None:
+                    attach_row_maxima(x, rm)
             tail = want_rowmax and not any(hasattr(t, "weight") and getattr(t.weight, "dim", lambda: 0)() == 2 for t in mods[nxt:]) \
                 and all(isinstance(t, torch.nn.Dropout) and not t.training for t in mods[nxt:])   # only identities follow
-            x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more or tail)      # the epilogue's maxima cost next to nothing
+            rows_in = x.rows if isinstance(x, Planes32) else x.size(0)
+            chain = (more and H3P_CHAIN and not _rec(m.weight, mods[nxt].weight) and not torch.is_grad_enabled() and
+                     (isinstance(x, Planes32) or x.dtype == torch.float32) and
+                     h3p_supported(rows_in, m.weight.size(0), m.weight.size(1)) and
+                     h3p_supported(rows_in, mods[nxt].weight.size(0), mods[nxt].weight.size(1)))
+            if chain:      # this Linear's result as the planes the next Linear reads: no fp32 intermediate, no split pass
+                x = linear_h3p(x, m.weight, m.bias, gelu=fuse, planes_out=True)
+            else:
+                x = linear(x, m.weight, m.bias, gelu=fuse, want_rowmax=more or tail)      # the epilogue's maxima cost next to nothing
             i = nxt
         else:
             x = m(x)
