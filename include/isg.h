@@ -534,6 +534,11 @@ int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const float *w_inv_
 int64_t isg_planes32_elems(int64_t rows, int32_t K);
 /* fp32 rows [M, K] (stride lda) -> planes32 + inv_scale[M] (exact row maxima).  K % 4 == 0, lda % 4 == 0, 16-byte aligned. */
 int isg_split_planes32(const float *a, int64_t M, int32_t K, int32_t lda, uint16_t *planes, float *inv_scale, void *stream);
+/* gelu(x * instr[batch]) (ISubGVQA/models/mgat_v2_conv.py:156-157) as planes32 + inv_scale[N] -- the operand of the lin_l | lin_r
+ * projection on isg_linear_h3p -- and as fp32 rows [N, C] where `rows` is not NULL (a masked layer's node gate reads them).
+ * x fp32 [N, C] contiguous, instr fp32 [B, C], batch int64 [N].  4 | C, 16-byte aligned rows. */
+int isg_instr_gate_planes32(const float *x, const float *instr, const int64_t *batch, float *rows, uint16_t *planes,
+                            float *inv_scale, int64_t N, int32_t C, void *stream);
 /* d = act(a . w^T + bias), act 0 none / 1 exact GELU / 2 ReLU.  Output, exactly one of:
  *   d        fp32 [M, ldd]                                            (d_planes = d_inv = d_bound = NULL)
  *   d_planes planes32 of the result (columns [N, roundup32(N)) written as zeros: the next Linear's k padding) + d_inv[M],

@@ -22,47 +22,67 @@ struct MhaArgs {
   float scale;
 };
 
+// PARTS lanes share one key's dot product (the head dimension in PARTS interleaved slices, combined by a DPP butterfly): with
+// lane = key, a 12-token question kept 12 of 64 lanes busy for 64 dependent FMAs per query row -- the kernel was bound by that
+// chain and by one global load of the query row per round (152 us for 49 152 x 8 rows: 2.6 TB/s of a 400 MB pass).  Q, K and
+// V of the head now arrive together (16-byte loads), a query row costs 64 / PARTS FMAs per lane.
+template <int PARTS>
 __global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
   extern __shared__ float smem[];
-  const int hd = a.hd, Tk = a.Tk, kp = hd + 1;
-  float *Ks = smem;                       // [Tk][hd + 1]
+  const int hd = a.hd, Tk = a.Tk, kp = hd + 4;       // K rows padded by one float4: conflict-free 16-byte reads down a column
+  float *Ks = smem;                       // [Tk][hd + 4]
   float *Vs = Ks + (size_t)Tk * kp;       // [Tk][hd]
-  float *qs = Vs + (size_t)Tk * hd;       // [4][64]
-  float *ps = qs + 4 * 64;                // [4][128]
+  float *Qs = Vs + (size_t)Tk * hd;       // [Tq][hd]
+  float *ps = Qs + (size_t)a.Tq * hd;     // [4][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-  const int col0 = h * hd;
-  for (int idx = tid; idx < Tk * hd; idx += 256) {
-    const int s = idx / hd, c = idx - s * hd;
+  const int col0 = h * hd, h4 = hd >> 2;
+  for (int idx = tid; idx < Tk * h4; idx += 256) {
+    const int s = idx / h4, c = idx - s * h4;
     const size_t row = (size_t)s * a.B + b;
-    Ks[s * kp + c] = a.k[row * a.ldk + col0 + c];
-    Vs[s * hd + c] = a.v[row * a.ldv + col0 + c];
+    *reinterpret_cast<float4 *>(Ks + s * kp + 4 * c) = *reinterpret_cast<const float4 *>(a.k + row * a.ldk + col0 + 4 * c);
+    *reinterpret_cast<float4 *>(Vs + s * hd + 4 * c) = *reinterpret_cast<const float4 *>(a.v + row * a.ldv + col0 + 4 * c);
+  }
+  for (int idx = tid; idx < a.Tq * h4; idx += 256) {
+    const int t = idx / h4, c = idx - t * h4;
+    *reinterpret_cast<float4 *>(Qs + t * hd + 4 * c) =
+        *reinterpret_cast<const float4 *>(a.q + ((size_t)t * a.B + b) * a.ldq + col0 + 4 * c);
   }
   __syncthreads();
-  float *qw = qs + wave * 64, *pw = ps + wave * 128;
+  float *pw = ps + wave * 128;
+  constexpr int KPL = 64 / PARTS;          // keys per wave pass
+  const int part = lane % PARTS, kslot = lane / PARTS;
   for (int tq = wave; tq < a.Tq; tq += 4) {
     const size_t qrow = (size_t)tq * a.B + b;
-    if (lane < hd) qw[lane] = a.q[qrow * a.ldq + col0 + lane];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float sc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int s = j * 64 + lane;
-      sc[j] = -INFINITY;
+    const float *qw = Qs + tq * hd;
+    float mx = -INFINITY;
+    for (int s0 = 0; s0 < Tk; s0 += KPL) {       // scores of KPL keys at a time
+      const int s = s0 + kslot;
+      float dot = 0.f;
       if (s < Tk) {
-        float dot = 0.f;
         const float *kr = Ks + s * kp;
-        for (int c = 0; c < hd; ++c) dot = fmaf(qw[c], kr[c], dot);
+        for (int c = part * 4; c < hd; c += 4 * PARTS) {          // this lane's interleaved float4 slices of the head
+          const float4 qv = *reinterpret_cast<const float4 *>(qw + c), kv = *reinterpret_cast<const float4 *>(kr + c);
+          dot = fmaf(qv.x, kv.x, dot); dot = fmaf(qv.y, kv.y, dot); dot = fmaf(qv.z, kv.z, dot); dot = fmaf(qv.w, kv.w, dot);
+        }
+      }
+      if (PARTS >= 2) dot += dpp_mov<ISG_DPP_XOR1>(dot);
+      if (PARTS >= 4) dot += dpp_mov<ISG_DPP_XOR2>(dot);
+      if (s < Tk && part == 0) {
         dot *= a.scale;
         if (a.key_bias) dot += a.key_bias[(size_t)b * Tk + s];
-        sc[j] = dot;
+        pw[s] = dot;
+        mx = fmaxf(mx, dot);
       }
     }
-    const float mx = wave_max(fmaxf(sc[0], sc[1]));
-    const float e0 = sc[0] == -INFINITY ? 0.f : expf(sc[0] - mx);
-    const float e1 = sc[1] == -INFINITY ? 0.f : expf(sc[1] - mx);
+    mx = wave_max(mx);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float e0 = 0.f, e1 = 0.f;
+    if (lane < Tk) e0 = expf(pw[lane] - mx);
+    if (64 + lane < Tk) e1 = expf(pw[64 + lane] - mx);
     const float den = wave_sum(e0 + e1);
+    __builtin_amdgcn_wave_barrier();
     if (lane < Tk) pw[lane] = e0 / den;
     if (64 + lane < Tk) pw[64 + lane] = e1 / den;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -204,8 +224,14 @@ extern "C" int isg_mha_small(const float *q, int32_t ldq, const float *k, int32_
   if (hd > 64 || Tk > 128 || B * H >= (1ll << 31)) return ISG_EUNSUPPORTED;
   if (ldq < H * hd || ldk < H * hd || ldv < H * hd || ldo < H * hd) return ISG_EINVAL;
   MhaArgs a{q, k, v, key_bias, out, rowmax, (int)B, H, hd, Tq, Tk, ldq, ldk, ldv, ldo, (float)(1.0 / sqrt((double)hd))};
-  const size_t lds = ((size_t)Tk * (2 * hd + 1) + 4 * 64 + 4 * 128) * sizeof(float);
+  auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if ((hd & 3) || (ldq & 3) || (ldk & 3) || (ldv & 3) || mis(q) || mis(k) || mis(v)) return ISG_EUNSUPPORTED;
+  const size_t lds = ((size_t)Tk * (2 * hd + 4) + (size_t)Tq * hd + 4 * 128) * sizeof(float);
   if (lds > 64 * 1024) return ISG_EUNSUPPORTED;
-  mha_small_kernel<<<(unsigned)(B * H), 256, lds, as_stream(stream)>>>(a);
+  const unsigned grid = (unsigned)(B * H);
+  hipStream_t st = as_stream(stream);
+  if (Tk <= 16 && (hd & 15) == 0) mha_small_kernel<4><<<grid, 256, lds, st>>>(a);
+  else if (Tk <= 32 && (hd & 7) == 0) mha_small_kernel<2><<<grid, 256, lds, st>>>(a);
+  else mha_small_kernel<1><<<grid, 256, lds, st>>>(a);
   return check_launch();
 }

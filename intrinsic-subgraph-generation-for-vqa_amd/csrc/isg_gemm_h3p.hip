@@ -76,6 +76,50 @@ __global__ __launch_bounds__(256) void split_planes32_kernel(const float *__rest
   }
 }
 
+// gelu(x * instr[batch]) (ISubGVQA/models/mgat_v2_conv.py:156-157) written as the planes32 operand of the lin_l | lin_r
+// projection, and as fp32 rows where a masked layer's node gate reads them: the instruction gate and the split as ONE pass over
+// the layer input (wave per row; the GELU is evaluated twice -- once for the row's maximum, once for the split -- instead of
+// holding the row in registers: C = 300 is 75 float4, and the kernel is bound by its 2 x 1.2 KB of traffic per row).
+__global__ __launch_bounds__(256) void instr_gate_planes32_kernel(const float *__restrict__ x, const float *__restrict__ instr,
+                                                                  const long long *__restrict__ batch, int N, int C,
+                                                                  float *__restrict__ rows, _Float16 *__restrict__ planes,
+                                                                  float *__restrict__ inv_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= N) return;
+  const int KT = (C + 31) >> 5, nc = C >> 2;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x + (int64_t)row * C);
+  const float4 *i4 = reinterpret_cast<const float4 *>(instr + batch[row] * (int64_t)C);
+  auto gate = [&](int c) {
+    const float4 a = x4[c], b = i4[c];
+    const isg_f32x2 g0 = gelu_exact2(isg_f32x2{a.x * b.x, a.y * b.y}), g1 = gelu_exact2(isg_f32x2{a.z * b.z, a.w * b.w});
+    return make_float4(g0.x, g0.y, g1.x, g1.y);
+  };
+  float mx = 0.f;
+  for (int c = lane; c < nc; c += 64) {
+    const float4 v = gate(c);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  mx = wave_max(mx);
+  float s, inv;
+  h3_scale(mx, s, inv);
+  if (lane == 0) inv_out[row] = inv;
+  _Float16 *p = planes + (int64_t)row * KT * 64;
+  for (int c = lane; c < KT * 8; c += 64) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nc) {
+      v = gate(c);
+      if (rows) reinterpret_cast<float4 *>(rows + (int64_t)row * C)[c] = v;
+    }
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    const hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    const hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
+                        (_Float16)(v.w - (float)hi[3])};
+    _Float16 *d = p + (c >> 3) * 64 + (c & 7) * 4;
+    *reinterpret_cast<hf16x4 *>(d) = hi;
+    *reinterpret_cast<hf16x4 *>(d + 32) = mid;
+  }
+}
+
 struct P3Args {
   const _Float16 *A, *W;          // planes32 [M][KT][64], [N][KT][64]
   const float *a_inv, *w_inv;     // [M], [N]
@@ -736,6 +780,19 @@ extern "C" int isg_split_planes32(const float *a, int64_t M, int32_t K, int32_t 
     return ISG_EUNSUPPORTED;
   split_planes32_kernel<<<(unsigned)((M + 3) / 4), 256, 0, as_stream(stream)>>>(a, (int)M, K, lda,
                                                                                reinterpret_cast<_Float16 *>(planes), inv_scale);
+  return check_launch();
+}
+
+// rows fp32 [N, C] or NULL; planes: uint16[isg_planes32_elems(N, C)]; inv_scale: float[N].  C % 4 == 0, 16-byte aligned rows.
+extern "C" int isg_instr_gate_planes32(const float *x, const float *instr, const int64_t *batch, float *rows, uint16_t *planes,
+                                       float *inv_scale, int64_t N, int32_t C, void *stream) {
+  if (N < 0 || C <= 0) return ISG_EINVAL;
+  if (N == 0) return ISG_OK;
+  if (!x || !instr || !batch || !planes || !inv_scale) return ISG_EINVAL;
+  auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if ((C & 3) || mis(x) || mis(instr) || mis(planes) || (rows && mis(rows)) || (N + 3) / 4 >= (1ll << 31)) return ISG_EUNSUPPORTED;
+  instr_gate_planes32_kernel<<<(unsigned)((N + 3) / 4), 256, 0, as_stream(stream)>>>(
+      x, instr, reinterpret_cast<const long long *>(batch), (int)N, C, rows, reinterpret_cast<_Float16 *>(planes), inv_scale);
   return check_launch();
 }
 

@@ -133,6 +133,12 @@ class MaskingGATv2Conv(torch.nn.Module):
             x = x.float().contiguous()
             if self.use_instr and how == "layer_conv":
                 x, planes = ops.instr_gate_planes(x, instruction.contiguous(), batch, want_rows=need_rows)   # :156-157
+            elif self.use_instr and not torch.is_grad_enabled() and self.feature_dtype == torch.float32 and \
+                    ops.h3p_supported(x.size(0), (1 if self.share_weights else 2) * H * C, x.size(1)):
+                # the projection runs on the planes32 engine: the gate writes its operand (and fp32 rows only for a node gate)
+                masked = self.mask.masking_threshold != 1.0
+                rows, xp = ops.instr_gate_planes32(x, instruction.contiguous(), batch, want_rows=masked)   # :156-157
+                x = rows if masked else xp
             elif self.use_instr:
                 x = ops.instr_gate(x, instruction.contiguous(), batch, plan=plan)        # :156-157
 

@@ -1754,6 +1754,24 @@ def split_planes32(x: Tensor) -> Planes32:
     return out
 
 
+def instr_gate_planes32(x: Tensor, instr: Tensor, batch: Tensor, want_rows: bool = False):
+    """gelu(x * instr[batch]) (mgat_v2_conv.py:156-157) as Planes32 for the lin_l | lin_r projection on the engine, plus the fp32
+    rows when a masked layer's node gate needs them (they then carry the planes: a Linear over them splits nothing).
+    Returns (rows or None, Planes32).  Inference only."""
+    lib = _lib.load()
+    N, C = x.shape
+    rows = torch.empty_like(x) if want_rows else None
+    planes = torch.empty(max(int(lib.isg_planes32_elems(N, C)), 1), dtype=torch.int16, device=x.device)
+    inv = torch.empty(max(N, 1), dtype=torch.float32, device=x.device)
+    _lib.check(lib.isg_instr_gate_planes32(_chk(x, "x", torch.float32), _chk(instr, "instr", torch.float32, (instr.size(0), C)),
+                                           _chk(batch, "batch", torch.int64, (N,)), 0 if rows is None else rows.data_ptr(),
+                                           planes.data_ptr(), inv.data_ptr(), N, C, _stream()), "isg_instr_gate_planes32")
+    pl = Planes32(planes, inv, N, C)
+    if rows is not None:
+        rows._isg_planes32 = ((_ver(rows), rows.data_ptr(), tuple(rows.shape)), pl)
+    return rows, pl
+
+
 def _h3p_weight(weight: Tensor, bias: Optional[Tensor], cache: bool = True):
     """planes32 of a weight [N, K], its inverse row scales and the output bound {2^14 * max_n ||w_n||_1, max |b|} (device)."""
     def build():
@@ -1845,9 +1863,10 @@ def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
 
 
 def mha_small_supported(t_kv: int, head_dim: int) -> bool:
-    """isg_mha_small's launch limits (csrc/isg_attn.hip): head_dim <= 64, <= 128 keys, and a head's K / V rows + score
-    strips within 64 KB of LDS -- at head_dim 64 that is 121 keys.  Callers ask BEFORE choosing the kernel path."""
-    return head_dim <= 64 and t_kv <= 128 and (t_kv * (2 * head_dim + 1) + 4 * 64 + 4 * 128) * 4 <= 64 * 1024
+    """isg_mha_small's launch limits (csrc/isg_attn.hip): head_dim <= 64 and a multiple of 4, <= 128 keys, and a head's Q / K /
+    V rows (as many queries as keys at most: the callers pass the longer of the two) + score strips within 64 KB of LDS -- at
+    head_dim 64 that is 83 keys (CLIP questions: 77).  Callers ask BEFORE choosing the kernel path."""
+    return head_dim <= 64 and head_dim % 4 == 0 and t_kv <= 128 and (t_kv * (3 * head_dim + 4) + 4 * 128) * 4 <= 64 * 1024
 
 
 def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_bias: Optional[Tensor] = None,
@@ -1944,7 +1963,7 @@ _CAT = {}   # (ids of the weights) -> (versions, concatenated weight, concatenat
 def linear_fused(x: Tensor, layers, out_dtype=torch.float32) -> Tuple[Tensor, ...]:
     """Several Linear layers that share their input as ONE projection (weights concatenated along the output dim, cached);
     returns one column-slice view of the fused output per layer (row stride = total width)."""
-    if _rec(x, *[m.weight for m in layers]):      # training: differentiable concatenation, nothing cached
+    if _rec(*([] if isinstance(x, Planes32) else [x]), *[m.weight for m in layers]):      # training: differentiable concatenation, nothing cached
         w = torch.cat([m.weight for m in layers], dim=0)
         b = torch.cat([m.bias if m.bias is not None else torch.zeros(m.weight.size(0), device=w.device)
                        for m in layers]) if any(m.bias is not None for m in layers) else None
