@@ -72,6 +72,10 @@ def parse(argv=None):
     ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
                     help="graph: the step (plan build included) captured once as a hipGraph and replayed; Gumbel noise from "
                          "torch's generator inside the graph (fresh on every replay); single GPU")
+    ap.add_argument("--gather", choices=["logits", "answers"], default="logits",
+                    help="N > 1: what every rank receives per step -- the fp32 logits [B_local,1842] of every peer (30 MB per "
+                         "rank per step at 4096 graphs), or their arg-max answers [B_local] i64 (32 KB: what the reference's "
+                         "evaluation loop needs, utils/misc.py:40-48 reduces counts only); DESIGN §7 has the budget")
     ap.add_argument("--no-fuse-logits", action="store_true",
                     help="A/B: lin_edge as its own GEMM + the message-passing kernel streaming e_proj (the round-1 boundary)")
     ap.add_argument("--features", choices=["fp32", "fp16"], default="fp32",
@@ -550,8 +554,9 @@ def main(argv=None):
     model = synthetic.build_answer_model(cfg).to(dev).eval()
     N, E = wl.x.size(0), wl.edge_index.size(1)
     # two gather buffers: the all-gather of step i runs on the communicator's stream while step i+1 computes
-    gathered = [torch.empty(world * cfg.num_graphs, 1842, dtype=torch.float32, device=dev) for _ in range(2)] \
-        if world > 1 else None
+    gshape = (world * cfg.num_graphs, 1842) if args.gather == "logits" else (world * cfg.num_graphs,)
+    gathered = [torch.empty(gshape, dtype=torch.float32 if args.gather == "logits" else torch.int64, device=dev)
+                for _ in range(2)] if world > 1 else None
     pending = []          # (work, logits kept alive) of the all-gather in flight
 
     def drain():
@@ -563,6 +568,8 @@ def main(argv=None):
         logits, mask, gate = model(wl, seed=1000 + i, use_hints=not args.no_hints)   # in-kernel Philox noise
         if world > 1:
             drain()       # at most one collective in flight: its buffer is free again, its input may be released
+            if args.gather == "answers":
+                logits = logits.argmax(dim=1)
             out, work = all_gather_logits(logits, gathered[i % 2], async_op=True)
             pending.append((work, logits))
             return out
@@ -658,7 +665,8 @@ def main(argv=None):
         all_devs = [torch.empty_like(devs) for _ in range(world)]
         dist.all_gather(all_devs, devs)
         rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(),
-                "devices": [int(d.item()) for d in all_devs], "collective": "all_gather_into_tensor(logits[B_local,1842] f32)"}
+                "devices": [int(d.item()) for d in all_devs], "collective": "all_gather_into_tensor(logits[B_local,1842] f32)" if args.gather == "logits"
+                else "all_gather_into_tensor(answers[B_local] i64)"}
     else:
         rccl = {"backend": None, "world": 1, "devices": [int(devs.item())], "collective": None}
     rccl["gpu"] = torch.cuda.get_device_name(dev)

@@ -50,8 +50,12 @@ def _worker(rank, world, port, balance, q):
     shard = shard_workload(wl, rank, world, balance=balance)
     local = _oracle_logits(cfg, shard, sd)
     full = all_gather_logits_ragged(local) if balance else all_gather_logits(local)
+    # the light collective (bench.py --gather answers): every rank's arg-max answers, async like the logits
+    ans, work = (None, None) if balance else all_gather_logits(local.argmax(dim=1), async_op=True)
+    if work is not None:
+        work.wait()
     if rank == 0:
-        q.put((full, shard.num_graphs))
+        q.put((full, shard.num_graphs, ans))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,7 +68,7 @@ def test_shard_compute_allgather_world2(balance):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, balance, q)) for r in range(2)]
     for p in procs:
         p.start()
-    full, n0 = q.get(timeout=120)
+    full, n0, ans = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -75,6 +79,8 @@ def test_shard_compute_allgather_world2(balance):
     ref = _oracle_logits(cfg, wl, sd)              # unsharded: equal because no layer samples (no Q1/Q3 coupling)
     assert full.shape == ref.shape
     assert torch.allclose(full, ref, atol=1e-5)
+    if not balance:
+        assert ans.dtype == torch.int64 and torch.equal(ans, full.argmax(dim=1))
 
 
 def test_graph_ranges_balance_by_nodes_plus_edges():
