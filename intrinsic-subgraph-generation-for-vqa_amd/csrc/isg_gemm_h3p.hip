@@ -39,6 +39,8 @@ namespace isg {
 
 typedef __attribute__((address_space(3))) void p3_lds_t;
 typedef __attribute__((address_space(1))) void p3_glb_t;
+typedef unsigned int p3_u32x4 __attribute__((ext_vector_type(4)));
+typedef int p3_i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int P3_T = 256, P3_THREADS = 512;
 constexpr int P3_SLOT = 128 * 128;          // one quarter image: 128 rows x (hi 32 | mid 32) fp16
@@ -465,6 +467,12 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   }
   hf16x8 fa[2][2], fb[4][2];
   bool has_res = false;
+  // the result as a buffer: a lane outside it (or a piece before the first tile is done) stores at an offset the hardware drops
+  const __amdgpu_buffer_rsrc_t drs = PLANES_OUT
+      ? __builtin_amdgcn_make_buffer_rsrc(a.Dp, 0, (int)((unsigned)a.M * (unsigned)(((a.N + 31) & ~31) * 4)), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(a.D, 0, (int)((unsigned)a.M * (unsigned)a.ldd * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(PLANES_OUT ? a.d_inv : nullptr, 0, PLANES_OUT ? a.M * 4 : 0, 0x00020000);
+  const float d_bound0 = PLANES_OUT ? a.d_bound[0] : 0.f, d_bound1 = PLANES_OUT ? a.d_bound[1] : 0.f;
   int rm0 = 0, rn0 = 0, rpar = 0;                              // origin and parameter region of the tile `res` belongs to
   int cpar = 0;                                                // parameter region of the tile being accumulated
 
@@ -502,30 +510,32 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
       v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; \
     }                                                                                                              \
   }
-  // a wave whose accumulator tile lies outside D issues no store -- but the counted waits assume `n` operations, so it issues
-  // as many 4-byte requests into a scratch line instead
-#define Q3_DUMMY(n)                                                                                                \
-  _Pragma("unroll") for (int z = 0; z < (n); ++z)                                                                  \
-    __builtin_amdgcn_global_load_lds((p3_glb_t *)(a.a_inv + min(lane, a.M - 1)),                                   \
-                                     (p3_lds_t *)(p3_smem + Q3_RING + 3 * Q3_PAR), 4, 0, 0);
-  // fp32 result: ONE accumulator tile (static i, j): scales, bias, activation, one 16-byte store per lane
-#define Q3_EPI(i, j, b4)                                                                                           \
+  // A piece = one accumulator tile of `res` (planes32 result: a pair of them).  Its ARITHMETIC (scales, bias, activation, the
+  // split) is straight-line vector code that sits inside an MFMA segment -- the matrix core runs 16 cycles per MFMA and
+  // takes 4 to issue, the vector instructions fill the gaps; in the load segment (where it sat first) its 390 cycles made
+  // that segment twice as long as the MFMA segment of the other wave group, which then waited at the barrier
+  // (profiles/r04_h_h3p_stamps.txt).  Its STORE is a buffer store issued after the segment's last MFMA: lanes outside D
+  // get an offset beyond the descriptor's range and the hardware drops them -- no branch, and EVERY wave issues every
+  // store, so the counted waits need no stand-in requests.
+  // fp32 result: the finished values of accumulator tile (i, j); the byte offset of this lane's 16 bytes (0xFFFFFFF0: dropped)
+#define Q3_EPI_VAL(v, i, j, b4) { float4 t_; Q3_VAL(t_, i, j, b4) v = hf32x4{t_.x, t_.y, t_.z, t_.w}; }
+#define Q3_EPI_OFF(off, i, j, live)                                                                                \
   {                                                                                                                \
-    if (!(rm0 + wm * 64 + (i) * 16 < a.M && rn0 + wn * 64 + (j) * 16 < a.N)) {                                     \
-      Q3_DUMMY(1)                                                                                                  \
-    } else {                                                                                                       \
-      const int rl = wm * 64 + (i) * 16 + (lane & 15), cl = wn * 64 + (j) * 16 + 4 * (lane >> 4);                  \
-      float4 v;                                                                                                    \
-      Q3_VAL(v, i, j, b4)                                                                                          \
-      const int row = min(rm0 + rl, a.M - 1), col = min(rn0 + cl, a.N - 4);                                        \
-      if (rm0 + rl < a.M && rn0 + cl < a.N && !(a.abl & 1)) {                                                      \
-        typedef float p3_f32x4 __attribute__((ext_vector_type(4)));                                                \
-        p3_f32x4 w4 = {v.x, v.y, v.z, v.w};                                                                        \
-        p3_f32x4 *dst = reinterpret_cast<p3_f32x4 *>(a.D + (int64_t)row * a.ldd + col);                            \
-        if (a.nt_store) __builtin_nontemporal_store(w4, dst);                                                      \
-        else *dst = w4;                                                                                            \
-      }                                                                                                            \
-    }                                                                                                              \
+    const int rl = wm * 64 + (i) * 16 + (lane & 15), cl = wn * 64 + (j) * 16 + 4 * (lane >> 4);                    \
+    const bool ok = (int)(live) & (int)(rm0 + rl < a.M) & (int)(rn0 + cl < a.N) & (int)!(a.abl & 1);   /* no branches */ \
+    off = ok ? ((unsigned)(rm0 + rl) * (unsigned)a.ldd + (unsigned)(rn0 + cl)) * 4u : 0xFFFFFFF0u;                 \
+  }
+#ifndef ISG_Q3_ST_AUX
+#define ISG_Q3_ST_AUX 2      // cache policy of a large (>= 128 MB) fp32 result's stores at K >= 512: nt.  A/B builds: at the
+#define ISG_Q3_NT_ALL 0      // K = 300 shapes nt loses 8-24 %; sc0 sc1 nt (19) ran 32 % faster in one process and 21 % slower in the next
+#endif
+#ifndef ISG_Q3_PST_AUX
+#define ISG_Q3_PST_AUX 0      // the same for a planes32 result
+#endif
+#define Q3_EPI_ST(v, off)                                                                                          \
+  {                                                                                                                \
+    if ((HEAD == 16 || ISG_Q3_NT_ALL) && a.nt_store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, v), drs, (int)(off), 0, ISG_Q3_ST_AUX); \
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, v), drs, (int)(off), 0, 0);           \
   }
   // planes32 result: the PAIR of accumulator tiles (i, j0), (i, j0 + 1) = one 32-column group of 16 rows.  A lane holds
   // columns 4q .. 4q + 3 of each tile (q = lane >> 4): after the split it swaps ONE 8-byte fragment with lane ^ 16, so that it
@@ -533,48 +543,60 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   // contiguous bytes per plane: two stores per lane and pair, the store count and width of the fp32 path (the first form
   // stored two 8-byte pieces per tile: 380 us where the fp32 result took 246).  Columns in [N, roundup32(N)) are the NEXT
   // Linear's k padding: written as zeros.
-#define Q3_EPI_PAIR(i, j0, b4a, b4b)                                                                               \
+#define Q3_PAIR_VAL(h16, m16, i, j0, b4a, b4b)                                                      \
+  {                                                                                                                \
+    const int q = lane >> 4, cl = wn * 64 + (j0) * 16 + 4 * q;                                                     \
+    float4 va, vb;                                                                                                 \
+    Q3_VAL(va, i, j0, b4a)                                                                                         \
+    Q3_VAL(vb, i, (j0) + 1, b4b)                                                                                   \
+    if (rn0 + cl >= a.N) va = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+    if (rn0 + cl + 16 >= a.N) vb = make_float4(0.f, 0.f, 0.f, 0.f);                                                \
+    float so, inv;                                                                                                 \
+    h3_scale(p_ia[i] * d_bound0 + d_bound1, so, inv);                                                              \
+    va.x *= so; va.y *= so; va.z *= so; va.w *= so; vb.x *= so; vb.y *= so; vb.z *= so; vb.w *= so;                \
+    const hf16x4 ha = {(_Float16)va.x, (_Float16)va.y, (_Float16)va.z, (_Float16)va.w};                            \
+    const hf16x4 hb = {(_Float16)vb.x, (_Float16)vb.y, (_Float16)vb.z, (_Float16)vb.w};                            \
+    const hf16x4 ma = {(_Float16)(va.x - (float)ha[0]), (_Float16)(va.y - (float)ha[1]),                           \
+                       (_Float16)(va.z - (float)ha[2]), (_Float16)(va.w - (float)ha[3])};                          \
+    const hf16x4 mb = {(_Float16)(vb.x - (float)hb[0]), (_Float16)(vb.y - (float)hb[1]),                           \
+                       (_Float16)(vb.z - (float)hb[2]), (_Float16)(vb.w - (float)hb[3])};                          \
+    typedef int p3_i32x2 __attribute__((ext_vector_type(2)));                                                      \
+    const bool even = (q & 1) == 0;       /* even q keeps its tile-a fragment and sends tile b's; odd q the reverse */ \
+    const p3_i32x2 hka = __builtin_bit_cast(p3_i32x2, ha), hkb = __builtin_bit_cast(p3_i32x2, hb);                 \
+    const p3_i32x2 mka = __builtin_bit_cast(p3_i32x2, ma), mkb = __builtin_bit_cast(p3_i32x2, mb);                 \
+    const p3_i32x2 hs = even ? hkb : hka, ms = even ? mkb : mka;                                                   \
+    const p3_i32x2 hr = {__shfl_xor(hs[0], 16, 64), __shfl_xor(hs[1], 16, 64)};                                    \
+    const p3_i32x2 mr = {__shfl_xor(ms[0], 16, 64), __shfl_xor(ms[1], 16, 64)};                                    \
+    h16 = even ? p3_i32x4{hka[0], hka[1], hr[0], hr[1]} : p3_i32x4{hr[0], hr[1], hkb[0], hkb[1]};                  \
+    m16 = even ? p3_i32x4{mka[0], mka[1], mr[0], mr[1]} : p3_i32x4{mr[0], mr[1], mkb[0], mkb[1]};                  \
+  }
+#define Q3_PAIR_OFF(off, ioff, inv, i, j0, live)                                                                   \
   {                                                                                                                \
     const int npad = (a.N + 31) & ~31;                                                                             \
-    if (!(rm0 + wm * 64 + (i) * 16 < a.M && rn0 + wn * 64 + (j0) * 16 < npad)) {                                   \
-      Q3_DUMMY(2)                                                                                                  \
+    const int q = lane >> 4, rl = wm * 64 + (i) * 16 + (lane & 15);                                                \
+    /* chunk of 8 columns this lane owns: q = 0, 1, 2, 3 -> columns 0-7, 16-23, 8-15, 24-31 of the group */          \
+    const int chunk = ((q & 1) << 1) | (q >> 1);                                                                   \
+    const int gcol = rn0 + wn * 64 + (j0) * 16;                      /* first column of the 32-column group */     \
+    const bool ok = (int)(live) & (int)(rm0 + rl < a.M) & (int)(gcol + chunk * 8 < npad) & (int)!(a.abl & 1);      \
+    off = ok ? ((unsigned)(rm0 + rl) * (unsigned)(npad * 2) + (unsigned)((gcol >> 5) * 64 + chunk * 8)) * 2u : 0xFFFFFFF0u; \
+    ioff = ((int)ok & (int)(gcol == 0) & (int)(q == 0)) ? (unsigned)(rm0 + rl) * 4u : 0xFFFFFFF0u;                 \
+    float so_;                                                                                                     \
+    h3_scale(p_ia[i] * d_bound0 + d_bound1, so_, inv);                                                             \
+  }
+  // (the row's inverse scale leaves with the row's first column group -- ioff is valid in that pair's lanes only: one more
+  // store in the waves of the first column tile; the counted waits then allow one operation fewer in flight than there are,
+  // i.e. they wait a little early, never late)
+#define Q3_PAIR_ST(h16, m16, off, ioff, inv)                                                                       \
+  {                                                                                                                \
+    const unsigned off2_ = (off) == 0xFFFFFFF0u ? 0xFFFFFFF0u : (off) + 64u;                                       \
+    if (ISG_Q3_PST_AUX && a.nt_store) {                                                                            \
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, h16), drs, (int)(off), 0, ISG_Q3_PST_AUX); \
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, m16), drs, (int)off2_, 0, ISG_Q3_PST_AUX); \
     } else {                                                                                                       \
-      const int q = lane >> 4, rl = wm * 64 + (i) * 16 + (lane & 15), cl = wn * 64 + (j0) * 16 + 4 * q;            \
-      float4 va, vb;                                                                                               \
-      Q3_VAL(va, i, j0, b4a)                                                                                       \
-      Q3_VAL(vb, i, (j0) + 1, b4b)                                                                                 \
-      if (rn0 + cl >= a.N) va = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
-      if (rn0 + cl + 16 >= a.N) vb = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
-      float so, inv;                                                                                               \
-      h3_scale(p_ia[i] * a.d_bound[0] + a.d_bound[1], so, inv);                                                    \
-      va.x *= so; va.y *= so; va.z *= so; va.w *= so; vb.x *= so; vb.y *= so; vb.z *= so; vb.w *= so;              \
-      const hf16x4 ha = {(_Float16)va.x, (_Float16)va.y, (_Float16)va.z, (_Float16)va.w};                          \
-      const hf16x4 hb = {(_Float16)vb.x, (_Float16)vb.y, (_Float16)vb.z, (_Float16)vb.w};                          \
-      const hf16x4 ma = {(_Float16)(va.x - (float)ha[0]), (_Float16)(va.y - (float)ha[1]),                         \
-                         (_Float16)(va.z - (float)ha[2]), (_Float16)(va.w - (float)ha[3])};                        \
-      const hf16x4 mb = {(_Float16)(vb.x - (float)hb[0]), (_Float16)(vb.y - (float)hb[1]),                         \
-                         (_Float16)(vb.z - (float)hb[2]), (_Float16)(vb.w - (float)hb[3])};                        \
-      typedef int p3_i32x2 __attribute__((ext_vector_type(2)));                                                    \
-      typedef int p3_i32x4 __attribute__((ext_vector_type(4)));                                                    \
-      const bool even = (q & 1) == 0;       /* even q keeps its tile-a fragment and sends tile b's; odd q the reverse */ \
-      const p3_i32x2 hka = __builtin_bit_cast(p3_i32x2, ha), hkb = __builtin_bit_cast(p3_i32x2, hb);               \
-      const p3_i32x2 mka = __builtin_bit_cast(p3_i32x2, ma), mkb = __builtin_bit_cast(p3_i32x2, mb);               \
-      const p3_i32x2 hs = even ? hkb : hka, ms = even ? mkb : mka;                                                 \
-      const p3_i32x2 hr = {__shfl_xor(hs[0], 16, 64), __shfl_xor(hs[1], 16, 64)};                                  \
-      const p3_i32x2 mr = {__shfl_xor(ms[0], 16, 64), __shfl_xor(ms[1], 16, 64)};                                  \
-      const p3_i32x4 h16 = even ? p3_i32x4{hka[0], hka[1], hr[0], hr[1]} : p3_i32x4{hr[0], hr[1], hkb[0], hkb[1]}; \
-      const p3_i32x4 m16 = even ? p3_i32x4{mka[0], mka[1], mr[0], mr[1]} : p3_i32x4{mr[0], mr[1], mkb[0], mkb[1]}; \
-      /* chunk of 8 columns this lane owns: q = 0, 1, 2, 3 -> columns 0-7, 16-23, 8-15, 24-31 of the group */         \
-      const int chunk = ((q & 1) << 1) | (q >> 1);                                                                 \
-      const int gcol = rn0 + wn * 64 + (j0) * 16;                      /* first column of the 32-column group */    \
-      const int row = min(rm0 + rl, a.M - 1);                                                                      \
-      if (rm0 + rl < a.M && gcol + chunk * 8 < npad && !(a.abl & 1)) {                                             \
-        _Float16 *d = a.Dp + (int64_t)row * (npad * 2) + (gcol >> 5) * 64 + chunk * 8;                             \
-        *reinterpret_cast<p3_i32x4 *>(d) = h16;                                                                    \
-        *reinterpret_cast<p3_i32x4 *>(d + 32) = m16;                                                               \
-        if (gcol == 0 && q == 0) a.d_inv[row] = inv;                                                               \
-      }                                                                                                            \
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, h16), drs, (int)(off), 0, 0);            \
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, m16), drs, (int)off2_, 0, 0);            \
     }                                                                                                              \
+    if (rn0 == 0 && wn == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(inv), irs, (int)(ioff), 0, 0); \
   }
   // the tile's accumulators become `res`; its scales come out of the parameter region the DMA filled a tile ago.  Read by
   // inline asm: hipcc (ROCm 7.2) orders a VISIBLE LDS load behind every outstanding 4-byte LDS-DMA it cannot tell apart
@@ -616,55 +638,100 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   Q3_ST(4 + 7 * (ah))                                                                                              \
   Q3_BAR                                                                                                           \
   Q3_ST(5 + 7 * (ah))
-  // End of a load segment: every request is waited for FOUR phases after its issue (B and A-lo leave in the first phase of
-  // a k-tile and are read two k-tiles later in a first phase, A-hi likewise in second phases), so the operations of the THREE
-  // youngest phases may be in flight: 4 + 2 + 4 = 10 requests at the end of a first phase, 2 + 4 + 2 = 8 at the end of a
-  // second, + 1 per 16-byte store of `res` + 1 per parameter request inside that window (both are issued in second
-  // phases only).  A k-tile of the head: NP pieces (tiles NP * kh ... of `res`) leave in its second phase, after the phase's
-  // fragment reads and requests; the first also requests the NEXT tile's parameters.  `sp` / `pp`: stores / parameter
-  // requests of the previous k-tile's second phase (a head k-tile after a head k-tile: NP pieces; the first: taken as none,
-  // which only waits earlier than needed when the tile before was all head).
-#define Q3_STORES(kh, NP) (PLANES_OUT ? ((NP) == 2 ? 2 : (((kh) & 1) ? 2 : 0)) : (NP))      /* counted stores of head k-tile kh */
+  // The same with a piece of `res` inside: its vector arithmetic is part of the MFMA segment's scheduling region (the matrix
+  // core takes a new MFMA every 16 cycles and an issue costs 4: the vector instructions fit the gaps), its store(s) follow the
+  // last MFMA.  TI / TJ: the accumulator tile (fp32) or the pair's first tile (planes32); BQ0 / BQ1: its bias, requested in
+  // the load segment before.  (Also built and measured, same-box A/B in DESIGN 15.1: the finished piece held in its registers
+  // and stored behind the NEXT load segment's requests -- every segment then issues a store, dropped when nothing is pending,
+  // and the K = 2048 shape lost 7 % to those.)
+#define Q3_M_PIECE(ah, TI, TJ, BQ0, BQ1)                                                                           \
+  __builtin_amdgcn_s_waitcnt(0xC07F);                                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  Q3_ST(3 + 7 * (ah))                                                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                                   \
+  if constexpr (PLANES_OUT) {                                                                                      \
+    p3_i32x4 h16_, m16_;                                                                                           \
+    unsigned off_, ioff_;                                                                                          \
+    float inv_;                                                                                                    \
+    Q3_PAIR_VAL(h16_, m16_, TI, TJ, BQ0, BQ1)                                                                      \
+    Q3_PAIR_OFF(off_, ioff_, inv_, TI, TJ, has_res)                                                                \
+    Q3_MMA(ah)                                                                                                     \
+    Q3_INTERLEAVE()                                                                                                \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    Q3_PAIR_ST(h16_, m16_, off_, ioff_, inv_)                                                                      \
+  } else {                                                                                                         \
+    hf32x4 v_;                                                                                                     \
+    unsigned off_;                                                                                                 \
+    Q3_EPI_VAL(v_, TI, TJ, BQ0)                                                                                    \
+    Q3_EPI_OFF(off_, TI, TJ, has_res)                                                                              \
+    Q3_MMA(ah)                                                                                                     \
+    Q3_INTERLEAVE()                                                                                                \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    Q3_EPI_ST(v_, off_)                                                                                            \
+  }                                                                                                                \
+  Q3_ST(4 + 7 * (ah))                                                                                              \
+  Q3_BAR                                                                                                           \
+  Q3_ST(5 + 7 * (ah))
+  // one MFMA, then up to three of the piece's vector instructions, 24 times (fp32 result).  The planes32 pair's arithmetic
+  // (two tiles, the split, the lane exchange) interleaved this way needs more registers than there are (1-2 spilled -- and a
+  // spill is a scratch access, i.e. a vector-memory operation the counted waits know nothing of): it stays in one block
+#ifndef ISG_Q3_VALU_PER_MFMA
+#define ISG_Q3_VALU_PER_MFMA 3
+#endif
+#define Q3_INTERLEAVE()                                                                                            \
+  _Pragma("unroll") for (int z = 0; z < 24; ++z) {                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x002, PLANES_OUT ? 0 : ISG_Q3_VALU_PER_MFMA, 0);                         \
+  }
+  // End of a load segment: every request is waited for FOUR segments after its issue (B and A-lo leave in the first load
+  // segment of a k-tile and are read two k-tiles later in a first segment, A-hi likewise in second segments).  A wave's
+  // operations in issue order, k-tile c:  P0(c): 4 requests | S0(c): stores of the piece in MFMA segment 0 | P1(c): pc(c)
+  // parameter request + 2 requests | S1(c): stores of the piece in MFMA segment 1.  The wait at the end of P0(c) needs P1(c - 2)
+  // landed, so everything younger may be in flight: S1(c-2) + 4 + S0(c-1) + 2 + pc(c-1) + S1(c-1) + 4; the wait at the end of
+  // P1(c) needs P0(c - 1): S0(c-1) + 2 + pc(c-1) + S1(c-1) + 4 + S0(c) + 2 + pc(c).  A term whose k-tile lies before the head
+  // (the tile before) is taken as 0, which only waits earlier than needed.
+  //   fp32 result: HEAD 16 -> one tile per k-tile, in segment 1; HEAD 8 -> tiles 2 kh (segment 0) and 2 kh + 1 (segment 1)
+  //   planes32:    one PAIR (two stores) in segment 1 -- of every k-tile at HEAD 8, of the odd ones at HEAD 16
+  // (a workgroup's first tile has no `res` yet: its pieces run on zeros and their stores are dropped like any lane outside D)
+#define Q3_S0(kh, NP, hd) (((hd) && (kh) >= 0 && !PLANES_OUT && (NP) == 2) ? 1 : 0)
+#define Q3_S1(kh, NP, hd) (((hd) && (kh) >= 0) ? (PLANES_OUT ? (((NP) == 2 || ((kh) & 1)) ? 2 : 0) : 1) : 0)
+#define Q3_PC(kh, hd) (((hd) && (kh) == 0) ? 1 : 0)
 #define Q3_KT(kh, NP, is_head)                                                                                     \
   {                                                                                                                \
-    constexpr int sp = ((is_head) && (kh) > 0) ? Q3_STORES((kh) - 1, NP) : 0, pp = ((is_head) && (kh) == 1) ? 1 : 0; \
-    constexpr int sc = (is_head) ? Q3_STORES(kh, NP) : 0, pc = ((is_head) && (kh) == 0) ? 1 : 0;                   \
-    /* the accumulator tiles that leave in this k-tile: fp32 NP single tiles from NP * kh; planes one pair (2 m, 2 m + 1) */ \
-    constexpr int t0 = PLANES_OUT ? ((NP) == 2 ? 2 * (kh) : ((kh) & ~1)) : (NP) * (kh);                            \
-    constexpr int nt = PLANES_OUT ? (sc ? 2 : 0) : (NP);                                                           \
+    constexpr int w0s = Q3_S1((kh) - 2, NP, is_head) + Q3_S0((kh) - 1, NP, is_head) + Q3_S1((kh) - 1, NP, is_head); \
+    constexpr int w0p = Q3_PC((kh) - 1, is_head);                                                                  \
+    constexpr int w1s = Q3_S0((kh) - 1, NP, is_head) + Q3_S1((kh) - 1, NP, is_head) + Q3_S0(kh, NP, is_head);      \
+    constexpr int w1p = Q3_PC((kh) - 1, is_head) + Q3_PC(kh, is_head);                                             \
+    constexpr bool pc0 = Q3_S0(kh, NP, is_head) > 0, pc1 = Q3_S1(kh, NP, is_head) > 0;                             \
+    /* the accumulator tile(s) that leave in this k-tile */                                                        \
+    constexpr int ta = PLANES_OUT ? 0 : (NP) * (kh);                             /* segment 0 (fp32, HEAD 8) */     \
+    constexpr int tb = PLANES_OUT ? ((NP) == 2 ? 2 * (kh) : ((kh) & ~1)) : ((NP) * (kh) + (NP) - 1);   /* segment 1 */ \
+    hf32x4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};                                                 \
     Q3_READ_A(0) Q3_READ_B()                                                                                       \
+    if (pc0 && a.bias) Q3_BIAS_REQ(bq0, ta & 3)                                                                    \
     Q3_STAGE_P0()                                                                                                  \
     Q3_ST(0)                                                                                                       \
-    if (has_res) { Q3_WAIT(10 + sp + pp) } else { Q3_WAIT(10 + pp) }                                               \
+    Q3_WAIT(10 + w0s + w0p)                                                                                        \
     Q3_ST(1)                                                                                                       \
     Q3_BAR                                                                                                         \
     Q3_ST(2)                                                                                                       \
-    Q3_M(0)                                                                                                        \
-    hf32x4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};                                                 \
-    if ((is_head) && has_res && a.bias && nt > 0) {                                                                \
-      Q3_BIAS_REQ(bq0, t0 & 3)                                                                                     \
-      if (nt > 1) Q3_BIAS_REQ(bq1, (t0 + 1) & 3)                                                                   \
-    }                                                                                                              \
+    if constexpr (pc0) { Q3_M_PIECE(0, (ta & 15) >> 2, ta & 3, bq0, bq0) } else { Q3_M(0) }                        \
     Q3_READ_A(1)                                                                                                   \
+    if (pc1 && a.bias) {                                                                                           \
+      Q3_BIAS_REQ(bq0, tb & 3)                                                                                     \
+      if (PLANES_OUT) Q3_BIAS_REQ(bq1, (tb + 1) & 3)                                                               \
+    }                                                                                                              \
     if ((is_head) && (kh) == 0) Q3_PARAMS(nm0, nn0, npar)                                                          \
     Q3_STAGE_P1()                                                                                                  \
     Q3_ST(7)                                                                                                       \
-    if ((is_head) && has_res && nt > 0) {                                                                          \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                                           \
-      if constexpr (PLANES_OUT) {                                                                                  \
-        Q3_EPI_PAIR((t0 & 15) >> 2, t0 & 2, bq0, bq1)                                                              \
-      } else {                                                                                                     \
-        Q3_EPI((t0 & 15) >> 2, t0 & 3, bq0)                                                                        \
-        if (nt > 1) Q3_EPI(((t0 + 1) & 15) >> 2, (t0 + 1) & 3, bq1)                                                \
-      }                                                                                                            \
-    }                                                                                                              \
     Q3_ST(6)                                                                                                       \
-    if (has_res) { Q3_WAIT(8 + sp + pp + sc + pc) } else { Q3_WAIT(8 + pp + pc) }                                  \
+    Q3_WAIT(8 + w1s + w1p)                                                                                         \
     Q3_ST(8)                                                                                                       \
     Q3_BAR                                                                                                         \
     Q3_ST(9)                                                                                                       \
-    Q3_M(1)                                                                                                        \
+    if constexpr (pc1) { Q3_M_PIECE(1, (tb & 15) >> 2, tb & 3, bq0, bq1) } else { Q3_M(1) }                        \
     cb = cb == 2 * Q3_BUF ? 0 : cb + Q3_BUF;                                                                       \
   }
 
@@ -719,10 +786,21 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (PLANES_OUT) {
-        Q3_EPI_PAIR(i, j, bqa, bqb)
+        p3_i32x4 h16_, m16_;
+        unsigned off_, ioff_;
+        float inv_;
+        Q3_PAIR_VAL(h16_, m16_, i, j, bqa, bqb)
+        Q3_PAIR_OFF(off_, ioff_, inv_, i, j, true)
+        Q3_PAIR_ST(h16_, m16_, off_, ioff_, inv_)
       } else {
-        Q3_EPI(i, j, bqa)
-        Q3_EPI(i, j + 1, bqb)
+        hf32x4 va_, vb_;
+        unsigned oa_, ob_;
+        Q3_EPI_VAL(va_, i, j, bqa)
+        Q3_EPI_VAL(vb_, i, j + 1, bqb)
+        Q3_EPI_OFF(oa_, i, j, true)
+        Q3_EPI_OFF(ob_, i, j + 1, true)
+        Q3_EPI_ST(va_, oa_)
+        Q3_EPI_ST(vb_, ob_)
       }
     }
 #ifdef ISG_P3_STAMP
@@ -737,13 +815,21 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 #undef Q3_TILE_END
 #undef Q3_BIAS_REQ
 #undef Q3_STORES
-#undef Q3_EPI_PAIR
-#undef Q3_DUMMY
+#undef Q3_PAIR_ST
+#undef Q3_PAIR_VAL
+#undef Q3_PAIR_OFF
+#undef Q3_EPI_OFF
+#undef Q3_M_PIECE
+#undef Q3_INTERLEAVE
+#undef Q3_S0
+#undef Q3_S1
+#undef Q3_PC
 #undef Q3_VAL
 #undef Q3_M
 #undef Q3_WAIT
 #undef Q3_BAR
-#undef Q3_EPI
+#undef Q3_EPI_ST
+#undef Q3_EPI_VAL
 #undef Q3_MMA
 #undef Q3_READ_B
 #undef Q3_READ_A
@@ -826,6 +912,8 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   static const int version = [] { const char *e = getenv("ISG_H3P_V"); return e ? atoi(e) : 2; }();
   if (planes_out && (N & 31) && (version == 1 || KT < Q3_HEAD)) return ISG_EUNSUPPORTED;   // the 256 x 256 form pads no columns
   if (version != 1 && KT >= Q3_HEAD) {       // persistent 256 x 128 form
+    // the result is addressed through a buffer descriptor with 32-bit byte offsets
+    if ((planes_out ? M * (int64_t)(((N + 31) & ~31) * 4) : M * (int64_t)ldd * 4) >= (1ll << 32) - 16) return ISG_EUNSUPPORTED;
     const int ncu = device_cus();
     Q3Args q;
     q.p = a;

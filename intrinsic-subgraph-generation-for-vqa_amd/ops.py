@@ -1795,7 +1795,8 @@ H3P_MIN_M = 8192
 
 def h3p_supported(M: int, N: int, K: int) -> bool:
     return (H3P and GEMM_BACKEND == "bf16x6" and GEMM_KERNEL == "auto" and GEMM_F16X3 and K >= H3P_MIN_K and (K & 3) == 0 and
-            (N & 3) == 0 and M >= H3P_MIN_M and M * ((K + 31) // 32) * 128 < (1 << 31) and N * ((K + 31) // 32) * 128 < (1 << 31))
+            (N & 3) == 0 and M >= H3P_MIN_M and M * ((K + 31) // 32) * 128 < (1 << 31) and N * ((K + 31) // 32) * 128 < (1 << 31)
+            and M * ((N + 31) // 32 * 32) * 4 < (1 << 32) - 16)       # the result through a buffer descriptor: 32-bit byte offsets
 
 
 def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False, relu: bool = False,
@@ -1865,7 +1866,7 @@ def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
 def mha_small_supported(t_kv: int, head_dim: int) -> bool:
     """isg_mha_small's launch limits (csrc/isg_attn.hip): head_dim <= 64 and a multiple of 4, <= 128 keys, and a head's Q / K /
     V rows (as many queries as keys at most: the callers pass the longer of the two) + score strips within 64 KB of LDS -- at
-    head_dim 64 that is 83 keys (CLIP questions: 77).  Callers ask BEFORE choosing the kernel path."""
+    head_dim 64 that is 80 keys (CLIP questions: 77).  Callers ask BEFORE choosing the kernel path."""
     return head_dim <= 64 and head_dim % 4 == 0 and t_kv <= 128 and (t_kv * (3 * head_dim + 4) + 4 * 128) * 4 <= 64 * 1024
 
 

@@ -13,7 +13,8 @@ from isubgvqa_amd import _lib, ops
 
 dev = torch.device("cuda:0")
 libs = {"shipped": _lib.load()}
-for n in sys.argv[1:]:
+PLANES = "--planes" in sys.argv          # time the planes32 result (d_planes / d_inv / d_bound) instead of fp32 rows
+for n in [a for a in sys.argv[1:] if not a.startswith("-")]:
     l = ctypes.CDLL(os.path.join(ROOT, "tools", "_build", f"libisg_h3p_{n}.so"))
     l.isg_linear_h3p.restype, l.isg_linear_h3p.argtypes = _lib.SIGNATURES["isg_linear_h3p"]
     libs[n] = l
@@ -25,13 +26,20 @@ for M, N, K in [(49152, 1536, 512), (49152, 512, 2048), (82189, 2400, 300), (205
     xp = ops.split_planes32(x)
     wp, winv, bound = ops._h3p_weight(w, b, False)
     out = torch.empty(M, N, device=dev)
+    npad = (N + 31) // 32 * 32
+    dpl = torch.empty(M * npad * 2, dtype=torch.int16, device=dev)
+    dinv = torch.empty(M, device=dev)
     res = {n: [] for n in libs}
     for r in range(9):
         for n, l in libs.items():
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            rc = l.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                  0, 0, 0, M, N, K, N, 0, torch.cuda.current_stream().cuda_stream)
+            if PLANES:
+                rc = l.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), b.data_ptr(), 0,
+                                      dpl.data_ptr(), dinv.data_ptr(), bound.data_ptr(), M, N, K, N, 1, torch.cuda.current_stream().cuda_stream)
+            else:
+                rc = l.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                      0, 0, 0, M, N, K, N, 0, torch.cuda.current_stream().cuda_stream)
             e.record()
             torch.cuda.synchronize()
             assert rc == 0

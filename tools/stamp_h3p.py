@@ -29,10 +29,16 @@ stamp.isg_linear_h3p.restype, stamp.isg_linear_h3p.argtypes = _lib.SIGNATURES["i
 stamp.isg_p3_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
-NAMES = ["L0: 12 reads + 2 requests (issue + LDS latency)", "L0: vmcnt wait", "L0: barrier", "M0: lgkmcnt wait", "M0: 24 MFMAs (issue)",
-         "M0: barrier", "L1: piece: arithmetic + store issue", "L1: 4 reads + 4 requests + stager", "L1: vmcnt wait", "L1: barrier", "M1: lgkmcnt wait",
-         "M1: 24 MFMAs (issue)", "M1: barrier", "L1: piece: register select (switch)", "L1: piece: parameter reads from LDS", "(total)"]
-for M, N, K in [(49152, 1536, 512), (65536, 1024, 2048)]:
+NAMES = ["L0: 12 reads + 2 requests (issue + LDS latency)", "L0: vmcnt wait", "L0: barrier", "M0: lgkmcnt wait", "M0: 24 MFMAs (+ piece) issue",
+         "M0: barrier", "L1: (piece, when it sat here)", "L1: 4 reads + 4 requests + stager", "L1: vmcnt wait", "L1: barrier", "M1: lgkmcnt wait",
+         "M1: 24 MFMAs (+ piece) issue", "M1: barrier", "L1: piece: register select (switch)", "L1: piece: parameter reads from LDS", "(total)"]
+SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:] if "x" in a and not a.startswith("-")] or [(49152, 1536, 512), (65536, 1024, 2048)]
+if "--lib" in sys.argv:           # another stamped build (e.g. of an older source), for a same-box comparison
+    OUT = sys.argv[sys.argv.index("--lib") + 1]
+    stamp = ctypes.CDLL(OUT)
+    stamp.isg_linear_h3p.restype, stamp.isg_linear_h3p.argtypes = _lib.SIGNATURES["isg_linear_h3p"]
+    stamp.isg_p3_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+for M, N, K in SHAPES:
     x = torch.randn(M, K, device=dev, generator=g)
     w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
     b = torch.randn(N, device=dev, generator=g)
