@@ -25,15 +25,13 @@
 //     consecutive columns, i.e. 16-byte stores straight from the accumulators.
 #include "isg_f16x3.hpp"
 
+#include "isg_diag.hpp"
+
 #include <stdlib.h>
 
-// -DISG_P3_STAMP (tools/stamp_h3p.py builds its own library): per-wave s_memtime totals of the persistent kernel's segments
-#ifdef ISG_P3_STAMP
-static __device__ long long *g_p3_stamps = nullptr;
-#define Q3_ST(i) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; }
-#else
-#define Q3_ST(i)
-#endif
+// -DISG_DIAG (tools/stamp_h3p.py builds its own library): per-wave s_memtime totals of the persistent kernel's segments
+ISG_DIAG_BUFFER(g_p3_stamps)            // [workgroups * 8 waves][16] int64
+#define Q3_ST(i) ISG_DIAG_ADD(i)
 
 namespace isg {
 
@@ -130,7 +128,7 @@ struct P3Args {
   _Float16 *Dp;                   // planes32 [M][N / 32][64]
   float *d_inv;                   // [M]
   const float *d_bound;           // {2^14 * max_n ||W_n||_1, max |b|}: |D[m, :]| < inv_a[m] * d_bound[0] + d_bound[1]
-  int M, N, KT, ldd, tiles_n, nt_store, abl;
+  int M, N, KT, ldd, tiles_n, nt_store;
 };
 
 template <int ACT, bool PLANES_OUT>
@@ -146,7 +144,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
     n0 = (slot % a.tiles_n) * P3_T;
     if (m0 >= a.M) return;
   }
-  const int nk = (a.abl & 2) ? 2 : a.KT;
+  const int nk = a.KT;
   const unsigned row_b = (unsigned)a.KT * 128u;          // bytes per operand row
 
   // ---- DMA sources: quarter image q, request u -> this lane's 16 bytes --------------------------------------------
@@ -311,7 +309,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
       if (ACT == 2) {     // ReLU (a NaN stays a NaN, as in torch)
         v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
       }
-      if (rows[mi] < a.M && col < a.N && !(a.abl & 1)) {
+      if (rows[mi] < a.M && col < a.N) {
         if constexpr (PLANES_OUT) {
           const float s = so[mi];
           v.x *= s; v.y *= s; v.z *= s; v.w *= s;
@@ -522,7 +520,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 #define Q3_EPI_OFF(off, i, j, live)                                                                                \
   {                                                                                                                \
     const int rl = wm * 64 + (i) * 16 + (lane & 15), cl = wn * 64 + (j) * 16 + 4 * (lane >> 4);                    \
-    const bool ok = (int)(live) & (int)(rm0 + rl < a.M) & (int)(rn0 + cl < a.N) & (int)!(a.abl & 1);   /* no branches */ \
+    const bool ok = (int)(live) & (int)(rm0 + rl < a.M) & (int)(rn0 + cl < a.N);   /* no branches */                    \
     off = ok ? ((unsigned)(rm0 + rl) * (unsigned)a.ldd + (unsigned)(rn0 + cl)) * 4u : 0xFFFFFFF0u;                 \
   }
 #ifndef ISG_Q3_ST_AUX
@@ -577,7 +575,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     /* chunk of 8 columns this lane owns: q = 0, 1, 2, 3 -> columns 0-7, 16-23, 8-15, 24-31 of the group */          \
     const int chunk = ((q & 1) << 1) | (q >> 1);                                                                   \
     const int gcol = rn0 + wn * 64 + (j0) * 16;                      /* first column of the 32-column group */     \
-    const bool ok = (int)(live) & (int)(rm0 + rl < a.M) & (int)(gcol + chunk * 8 < npad) & (int)!(a.abl & 1);      \
+    const bool ok = (int)(live) & (int)(rm0 + rl < a.M) & (int)(gcol + chunk * 8 < npad);                          \
     off = ok ? ((unsigned)(rm0 + rl) * (unsigned)(npad * 2) + (unsigned)((gcol >> 5) * 64 + chunk * 8)) * 2u : 0xFFFFFFF0u; \
     ioff = ((int)ok & (int)(gcol == 0) & (int)(q == 0)) ? (unsigned)(rm0 + rl) * 4u : 0xFFFFFFF0u;                 \
     float so_;                                                                                                     \
@@ -745,11 +743,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   Q3_BAR
   if (wn == 1) { Q3_BAR }                // the second wave group runs one barrier behind the first
 
-#ifdef ISG_P3_STAMP
-  long long st_acc[16] = {};
-  const long long st_begin = (long long)__builtin_amdgcn_s_memtime();
-  long long st_last = st_begin;
-#endif
+  ISG_DIAG_BEGIN()
   while (true) {
     // the tile after this one (for its parameters; the stager finds it by itself)
     int nm0 = cm0, nn0 = cn0;
@@ -803,14 +797,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
         Q3_EPI_ST(vb_, ob_)
       }
     }
-#ifdef ISG_P3_STAMP
-  if (g_p3_stamps && lane == 0) {
-    st_acc[15] = (long long)__builtin_amdgcn_s_memtime() - st_begin;
-    long long *dst = g_p3_stamps + ((long long)blockIdx.x * 8 + wave) * 16;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dst[i] = st_acc[i];
-  }
-#endif
+  ISG_DIAG_DUMP(g_p3_stamps, blockIdx.x * 8 + wave, 15, )
 #undef Q3_KT
 #undef Q3_TILE_END
 #undef Q3_BIAS_REQ
@@ -844,11 +831,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 
 using namespace isg;
 
-#ifdef ISG_P3_STAMP
-extern "C" int isg_p3_set_stamp_buffer(long long *buf) {      // diagnostic build only: [workgroups * 8 waves][16] int64
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_p3_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
-}
-#endif
+ISG_DIAG_SETTER(isg_p3_set_stamp_buffer, g_p3_stamps)
 
 extern "C" int64_t isg_planes32_elems(int64_t rows, int32_t K) {
   if (rows <= 0 || K <= 0) return 0;
@@ -907,7 +890,6 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   a.d_bound = d_bound; a.M = (int)M; a.N = N; a.KT = KT; a.ldd = ldd; a.tiles_n = (int)tn;
   static const long long nt_mb = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return e ? atoll(e) : 128ll; }();
   a.nt_store = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
-  { const char *e = getenv("ISG_P3_ABL"); a.abl = e ? atoi(e) : 0; }
   hipStream_t st = as_stream(stream);
   static const int version = [] { const char *e = getenv("ISG_H3P_V"); return e ? atoi(e) : 2; }();
   if (planes_out && (N & 31) && (version == 1 || KT < Q3_HEAD)) return ISG_EUNSUPPORTED;   // the 256 x 256 form pads no columns

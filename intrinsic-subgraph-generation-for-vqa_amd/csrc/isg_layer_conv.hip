@@ -23,18 +23,10 @@
 // phases) and what was tried: DESIGN.md 9.1, profiles/r03_bg_layer_conv_ablation.md.
 #include "isg_f16x3.hpp"
 
-#ifdef ISG_DT_STAMP
-static __device__ long long *g_lc_stamps = nullptr;
-#define LC_T() ((long long)__builtin_amdgcn_s_memtime())
-#define LC_STAMP(i) { const long long now_ = LC_T(); st_acc[i] += now_ - st_last; st_last = now_; }
-#else
-#define LC_STAMP(i)
-#endif
+#include "isg_diag.hpp"
 
-#ifndef LC_ABL
-#define LC_ABL 0   // ablation builds only (profiles/r03_bg_*): 1 no logit epilogue, 2 no edge MFMAs, 4 no node MFMAs, 8 no aggregation, 16 no node
-                   // GEMM, 32 no chunk data path, 64 no next-tile requests, 1024 no alpha stores
-#endif
+ISG_DIAG_BUFFER(g_lc_stamps)            // -DISG_DIAG builds only (tools/stamp_layer_conv.py): [workgroups * 8 waves][16] int64
+#define LC_STAMP(i) ISG_DIAG_ADD(i)
 
 namespace isg {
 
@@ -233,11 +225,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave >> 2, tw = wave & 3;      // edge GEMM: 32-slot half, 32-channel tile
-#ifdef ISG_DT_STAMP
-  long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const long long st_begin = LC_T();
-  long long st_last = st_begin;
-#endif
+  ISG_DIAG_BEGIN()
   const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
   const int hoff = hd * LC_C;
   const int srow = tid >> 5, scol = tid & 31, sc4 = scol;    // staging map: 32 lanes per 512-byte row, rows srow + 16 u
@@ -370,7 +358,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     // fragment = A operand, node panel = B operand): a lane then holds ONE node and 16 channels of it in four runs of four, which
     // go to the row-major LDS slices as 16-byte stores (with the panel as the A operand a lane holds one channel of 16 nodes:
     // 32 four-byte stores and 32 scale reads per lane, 2.9 k cycles per tile: profiles/r03_ah_*)
-    if (!(LC_ABL & 16)) {
+    {
       hf32x16 accn[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -387,19 +375,13 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           hf32x16 c = accn[i];
-          if (!(LC_ABL & 4)) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][1], an[i][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][0], c, 0, 0, 0);
-          } else {
-            c[0] += (float)an[i][0][0] + (float)an[i][1][0];
-          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][1], an[i][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_n[ks][0], an[i][0], c, 0, 0, 0);
           accn[i] = c;
         }
       }
-#ifdef ISG_DT_STAMP
-      asm volatile("" ::"v"(accn[0][0]), "v"(accn[1][15]));
-#endif
+      ISG_DIAG_KEEP2(accn[0][0], accn[1][15])
       LC_STAMP(8)            // node GEMM: k loop
       float(*dstx)[LC_LDX] = ct < 4 ? sXl : sXr;
       int frl = fr, hhl = hh;          // laundered: the addresses below, hoisted out of the tile loop, were spilled and came back
@@ -449,7 +431,6 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     const int slot = min(64 * (ch) + prow, ne - 1);                                                                  \
     const float sinv = s_einv[slot];                                                                                 \
     int4 rec = s_tab[slot];                                                                                          \
-    if (LC_ABL & 2048) { rec.x = 0; rec.z = 0; }     /* ablation: no scattered row gathers */                        \
     const float me = __int_as_float(rec.w);                                                                          \
     float part[4];                                                                                                   \
     int cb = tw * 32 + 4 * hh;       /* laundered: hoisted out of the chunk loop, the 16 addresses below cost 16 registers */ \
@@ -480,29 +461,21 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #define LC_EPILOGUE(ch) LC_EPILOGUE_(ch, SL01)
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
-      if (!(LC_ABL & 32)) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
-      }
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
       LC_STAMP(10)           // panel staging: the wait for the planes, LDS writes
       __syncthreads();
       LC_STAMP(2)            // staging barrier
-      if (c == creq && !(LC_ABL & 64)) LC_REQUEST_TILE(desc_n)
-      if (c + 1 < nchunk && !(LC_ABL & 32)) {      // the next chunk's planes: in flight under this chunk's product and epilogue
+      if (c == creq) LC_REQUEST_TILE(desc_n)
+      if (c + 1 < nchunk) {      // the next chunk's planes: in flight under this chunk's product and epilogue
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           ra[u] = *reinterpret_cast<const hf32x4 *>(a.ep + (int64_t)(e0 + min(64 * (c + 1) + srow + 16 * u, ne - 1)) * 256 + sc4 * 8);
       }
-#ifdef LC_LAT_PROBE          // diagnostic: how long does the request just made take when nothing hides it?
-      LC_STAMP(13)
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      LC_STAMP(14)
-#endif
       // a chunk's upper 32 slots are often past the tile's end (its last chunk holds ne mod 64 slots): the four waves of that half
       // then skip product and epilogue, and the other four have their SIMDs to themselves
       const bool live = half == 0 || 64 * c + 32 < ne;
-      if (!(LC_ABL & 32) && live) {
+      if (live) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         hf16x8 af[2][2];          // [stage][plane]
@@ -517,24 +490,16 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
                 af[(ks + 1) & 1][q] = *reinterpret_cast<const hf16x8 *>(&sA[q][prow][(ks + 1) * 16 + fk]);
             }
             // transposed product: W fragment = A operand (rows = channels), edge panel = B operand (columns = edges)
-            if (!(LC_ABL & 2)) {
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][1], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][1], af[ks & 1][0], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][0], acc, 0, 0, 0);
-            } else {
-              acc[0] += (float)af[ks & 1][0][0] + (float)af[ks & 1][1][0];
-            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][1], af[ks & 1][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq_e[ks][0], af[ks & 1][0], acc, 0, 0, 0);
           }
         }
       }
-#ifdef ISG_DT_STAMP
-      asm volatile("" ::"v"(acc[0]), "v"(acc[15]));
-#endif
+      ISG_DIAG_KEEP2(acc[0], acc[15])
       LC_STAMP(3)            // k loop
       if (MASKED && c + 1 == nchunk) LC_REQUEST_MASKS(desc_n)      // the ids they hang on were requested a k loop ago
-      if (live) {
-        if (!(LC_ABL & 1)) LC_EPILOGUE(c) else if (hh == 0) s_part[tw * 64 + prow] = acc[0];
-      }
+      if (live) LC_EPILOGUE(c)
       __syncthreads();
       LC_STAMP(4)            // epilogue + barrier
       if (tid < 64 && 64 * c + tid < ne)     // the tile-waves' partials in a fixed order
@@ -549,14 +514,12 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     // weights (the logits are broadcast reads), so no weight table and no barrier between the softmax and the aggregation; the
     // first four in-edges (most segments) are read once and stay in registers for all three uses.
     LC_STAMP(11)             // last logit sums + barrier
-    if (nchunk == 0 && !(LC_ABL & 64)) {          // a tile without edges: nothing hid the requests
+    if (nchunk == 0) {          // a tile without edges: nothing hid the requests
       LC_REQUEST_TILE(desc_n)
       LC_REQUEST_MASKS(desc_n)
     }
-    if (!(LC_ABL & 64)) {
-      LC_STORE_TILE(desc_n, cur ^ 1)      // panel image and scales are free since the last chunk's barrier; tables: the other set
-      LC_REQUEST_PLANES(desc_n)
-    }
+    LC_STORE_TILE(desc_n, cur ^ 1)      // panel image and scales are free since the last chunk's barrier; tables: the other set
+    LC_REQUEST_PLANES(desc_n)
     LC_STAMP(5)              // the next tile's planes and tables
     // 8 lanes per node (four 16-byte pieces each, 128 contiguous bytes per instruction): a wave aggregates EIGHT nodes at a time,
     // ONE pass covers the tile.  The phase is issue-bound on its per-node bookkeeping (bounds, records, softmax, stores), which a
@@ -564,7 +527,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     {
       const int q8 = lane >> 3, j8 = lane & 7;
       const int k = 8 * wave + q8;
-      if (k < nrows && !(LC_ABL & 8)) {
+      if (k < nrows) {
         const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
         float lg4[4], e4[4];
         int4 rc4[4];
@@ -613,7 +576,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
           {     // alpha: ONE store instruction per round, lane u of a node's eight writes in-edge u
             const float wsel = (j8 & 2) ? ((j8 & 1) ? e4[3] : e4[2]) : ((j8 & 1) ? e4[1] : e4[0]);
             const int esel = (j8 & 2) ? ((j8 & 1) ? rc4[3].y : rc4[2].y) : ((j8 & 1) ? rc4[1].y : rc4[0].y);
-            if (j8 < 4 && s + j8 < re && !(LC_ABL & 1024)) a.alpha[(int64_t)esel * a.H + hd] = wsel * rden;
+            if (j8 < 4 && s + j8 < re) a.alpha[(int64_t)esel * a.H + hd] = wsel * rden;
           }
 #pragma unroll
           for (int hp = 0; hp < 2; ++hp) {
@@ -681,25 +644,14 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #undef LC_REQUEST_PLANES
 #undef LC_REQUEST_MASKS
 #undef LC_STORE_TILE
-#ifdef ISG_DT_STAMP
-  if (g_lc_stamps && lane == 0) {
-    st_acc[12] = LC_T() - st_begin;
-    long long *dst = g_lc_stamps + ((long long)bid * 8 + wave) * 16;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dst[i] = st_acc[i];
-  }
-#endif
+  ISG_DIAG_DUMP(g_lc_stamps, bid * 8 + wave, 12, )
 }
 
 }  // namespace isg
 
 using namespace isg;
 
-#ifdef ISG_DT_STAMP
-extern "C" int isg_lc_set_stamp_buffer(long long *buf) {      // diagnostic build only: [workgroups * 8 waves][16] int64
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_lc_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
-}
-#endif
+ISG_DIAG_SETTER(isg_lc_set_stamp_buffer, g_lc_stamps)
 
 // gelu(x * instr[batch]) (mgat_v2_conv.py:156-157, isg_instr_gate) written as the (hi, mid) planes + inverse row scales that
 // isg_gatv2_layer_conv reads, and as fp32 rows too when `out` is given (the masked layer's node gate reads those): the same row

@@ -22,25 +22,11 @@
 // HBM traffic per layer at configs[1]: conv_out 168 MB + h 42 MB in, h' and x' 84 MB out (un-fused chain: ~590 MB).
 #include "isg_f16x3.hpp"
 
-#ifdef ISG_DT_STAMP
-// Diagnostic build (tools/stamp_dense_tail.py): every wave records the core clock (s_memtime) at phase boundaries and writes
-// the differences to a buffer of its own, [tile * 4 + wave][16]; no output value depends on a stamp.
-static __device__ long long *g_dt_stamps = nullptr;
-#define DT_T() ((long long)__builtin_amdgcn_s_memtime())
-#define DT_STAMP(i) { const long long now_ = DT_T(); st_acc[i] = now_ - st_last; st_last = now_; }
-#else
-#define DT_STAMP(i)
-#endif
+#include "isg_diag.hpp"
 
-#ifndef DT_ABL
-#define DT_ABL 0   // ablation builds only: 1 no GEMM1 MFMAs, 2 no GELU in epilogue 1, 4 no GEMM2 MFMAs, 8 no GELU in epilogue 2, 16 no phases A / B,
-                   // 32 no GraphNorm statistics, 64 no gate GELU, 128 no plane split of the gated rows, 256 multiply by 1/std instead of dividing,
-                   // 512 conv_out always from row 0 (no HBM stream), 1024 W0 fragments always the same 1 KB (no L2 stream), 2048 no stores
-#endif
-
-#define DT_GELU1(...) ((DT_ABL & 2) ? (__VA_ARGS__) : gelu_exact2(__VA_ARGS__))
-#define DT_GELU2(...) ((DT_ABL & 8) ? (__VA_ARGS__) : gelu_exact2(__VA_ARGS__))
-#define DT_GELU3(...) ((DT_ABL & 64) ? (__VA_ARGS__) : gelu_exact2(__VA_ARGS__))
+ISG_DIAG_BUFFER(g_dt_stamps)            // -DISG_DIAG builds only (tools/stamp_dense_tail.py, stamp_tile_conv.py): [tile * 4 + wave][16] int64
+#define DT_STAMP(i) ISG_DIAG_SET(i)     // the dense tail: one pass per launch
+#define TC_STAMP(i) ISG_DIAG_ADD(i)     // the tile convolution: persistent, accumulated over its tiles
 
 namespace isg {
 
@@ -193,11 +179,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   if (t >= *a.ntiles) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef ISG_DT_STAMP
-  long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const long long st_begin = DT_T();
-  long long st_last = st_begin;
-#endif
+  ISG_DIAG_BEGIN()
   const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
   const int r0 = tinfo.x;
   const int nrows = min(tinfo.y, DT_ROWS);
@@ -209,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #define DT_LOAD_CHUNK(c)                                                                                         \
   _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                \
     const int row = srow + 8 * u;                                                                                \
-    const int gr = (DT_ABL & 512) ? 0 : min(r0 + min(row, nrows - 1), a.N - 1);                                   \
+    const int gr = min(r0 + min(row, nrows - 1), a.N - 1);                                                       \
     { const hf32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const hf32x4 *>(a.a + (int64_t)gr * a.lda + (c) * DT_KC + sc4 * 4)); ra[u] = make_float4(t_[0], t_[1], t_[2], t_[3]); } \
   }
   float4 ra[8];
@@ -286,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #define DT_LOADW1(st, s)                                                                                         \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
       wq[st][j][q] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(                           \
-          wr1, voff, (DT_ABL & 1024) ? 0 : (int)(((unsigned)(2 * wave + j) * DT_KS1 + (unsigned)(s)) * 1024u + q * plane1), 0));
+          wr1, voff, (int)(((unsigned)(2 * wave + j) * DT_KS1 + (unsigned)(s)) * 1024u + q * plane1), 0));
 #define DT_LOADA1(b, ksl)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
       af[i][q] = *reinterpret_cast<const hf16x8 *>(&bufA[b][q][i * 32 + fr][(ksl) * 16 + fk]);
@@ -312,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     if (s + 3 < DT_KS1) { DT_LOADW1((s + 3) & 3, s + 3) }
     DT_LOADA1(c & 1, ksl)
     __builtin_amdgcn_sched_barrier(0);      // the prefetches stay AHEAD of this step's MFMAs (hipcc sinks them to their use otherwise)
-    if (!(DT_ABL & 1)) { DT_MMA1(af, wq[s & 3]) } else { acc[0][0][0] += (float)af[0][0][0] + (float)wq[s & 3][0][0][0]; acc[1][1][1] += (float)af[1][1][0] + (float)wq[s & 3][1][1][0]; }
+    DT_MMA1(af, wq[s & 3])
     __builtin_amdgcn_sched_barrier(0);
     if (ksl == 7 && c < 3) {
       DT_WRITE_CHUNK((c + 1) & 1)                  // last read two chunks ago: every wave is past that barrier
@@ -321,9 +303,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
       DT_STAMP(2 + c)          // chunk c computed, chunk c + 1 staged
     }
   }
-#ifdef ISG_DT_STAMP
-  asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][1][15]));
-#endif
+  ISG_DIAG_KEEP2(acc[0][0][0], acc[1][1][15])
   DT_STAMP(5)                  // last chunk computed
 #undef DT_LOADW1
 #undef DT_LOADA1
@@ -353,9 +333,9 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           // both scales are powers of two: exact
-          const isg_f32x2 va = DT_GELU1(isg_f32x2{(acc[i][j][4 * g] * si) * wi4[j][g][0] + bv4[j][g][0],
+          const isg_f32x2 va = gelu_exact2(isg_f32x2{(acc[i][j][4 * g] * si) * wi4[j][g][0] + bv4[j][g][0],
                                                      (acc[i][j][4 * g + 1] * si) * wi4[j][g][1] + bv4[j][g][1]}) * s2;
-          const isg_f32x2 vb = DT_GELU1(isg_f32x2{(acc[i][j][4 * g + 2] * si) * wi4[j][g][2] + bv4[j][g][2],
+          const isg_f32x2 vb = gelu_exact2(isg_f32x2{(acc[i][j][4 * g + 2] * si) * wi4[j][g][2] + bv4[j][g][2],
                                                      (acc[i][j][4 * g + 3] * si) * wi4[j][g][3] + bv4[j][g][3]}) * s2;
           const hf16x4 hi = {(_Float16)va.x, (_Float16)va.y, (_Float16)vb.x, (_Float16)vb.y};
           const hf16x4 mid = {(_Float16)(va.x - (float)hi[0]), (_Float16)(va.y - (float)hi[1]), (_Float16)(vb.x - (float)hi[2]),
@@ -405,7 +385,6 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
       if (s + 3 < DT_KS2) { DT_LOADW2((s + 3) & 3, s + 3) }
       if (s + 1 < DT_KS2) { DT_LOADA2((s + 1) & 1, s + 1) }
       __builtin_amdgcn_sched_barrier(0);
-      if (DT_ABL & 4) { acc2[kh][0][0] += (float)w2[s & 3][1][0] + (float)a2[s & 1][0][0][0] + (float)a2[s & 1][1][1][0]; continue; }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         acc2[kh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s & 3][1], a2[s & 1][i][0], acc2[kh][i], 0, 0, 0);       // transposed,
@@ -425,9 +404,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     wi2[g] = *reinterpret_cast<const hf32x4 *>(a.w2_inv + wave * 32 + 8 * g + 4 * hh);
     bv2[g] = *reinterpret_cast<const hf32x4 *>(a.b2 + wave * 32 + 8 * g + 4 * hh);
   }
-#ifdef ISG_DT_STAMP
-  asm volatile("" ::"v"(acc2[0][0][0]), "v"(acc2[1][1][15]));
-#endif
+  ISG_DIAG_KEEP2(acc2[0][0][0], acc2[1][1][15])
   DT_STAMP(7)                  // GEMM2
   __syncthreads();          // every wave is done with the planes of the intermediate: c may overwrite them
 #pragma unroll
@@ -436,9 +413,9 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     const float si2 = s_inv2[row];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const isg_f32x2 va = DT_GELU2(isg_f32x2{((acc2[0][i][4 * g] + acc2[1][i][4 * g]) * si2) * wi2[g][0] + bv2[g][0],
+      const isg_f32x2 va = gelu_exact2(isg_f32x2{((acc2[0][i][4 * g] + acc2[1][i][4 * g]) * si2) * wi2[g][0] + bv2[g][0],
                                                  ((acc2[0][i][4 * g + 1] + acc2[1][i][4 * g + 1]) * si2) * wi2[g][1] + bv2[g][1]});
-      const isg_f32x2 vb = DT_GELU2(isg_f32x2{((acc2[0][i][4 * g + 2] + acc2[1][i][4 * g + 2]) * si2) * wi2[g][2] + bv2[g][2],
+      const isg_f32x2 vb = gelu_exact2(isg_f32x2{((acc2[0][i][4 * g + 2] + acc2[1][i][4 * g + 2]) * si2) * wi2[g][2] + bv2[g][2],
                                                  ((acc2[0][i][4 * g + 3] + acc2[1][i][4 * g + 3]) * si2) * wi2[g][3] + bv2[g][3]});
       *reinterpret_cast<hf32x4 *>(&sC[row][wave * 32 + 8 * g + 4 * hh]) = hf32x4{va.x, va.y, vb.x, vb.y};
     }
@@ -449,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   // ---- the layer tail on the tile's graphs (isg_norm_pool.hip::graph_tail_kernel<2>, same arithmetic, rows from LDS) --------
   // phase A: a_n = <ins_g, c_n> / sqrt(C).  A half-wave per node, one float4 per lane, the 32-lane butterfly -- the same bits as
   // graph_tail_kernel's 64-lane wave_sum, whose upper half adds zeros; eight nodes per wave and iteration (independent chains)
-  for (int kb = 8 * wave; kb < ((DT_ABL & 16) ? 0 : nrows); kb += 32) {
+  for (int kb = 8 * wave; kb < nrows; kb += 32) {
     float part[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -471,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   __syncthreads();
   DT_STAMP(9)                  // phase A
   // phase B: softmax over a graph's nodes (the sum runs in node order), a wave per graph
-  for (int gi = wave; gi < ((DT_ABL & 16) ? 0 : ng); gi += 4) {
+  for (int gi = wave; gi < ng; gi += 4) {
     const int nb = gi < DT_GPC ? s_gp[gi] : a.ptr[g0 + gi] - r0;
     const int n = min(gi < DT_GPC ? s_gp[gi + 1] : a.ptr[g0 + gi + 1] - r0, nrows) - nb;
     if (n <= 0) continue;
@@ -498,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     {
       const int ch = tid & (DT_C - 1);
       const float ms = a.gn_ms[ch];
-      for (int gi = gb + (tid >> 7); gi < ((DT_ABL & 32) ? 0 : ge); gi += 2) {
+      for (int gi = gb + (tid >> 7); gi < ge; gi += 2) {
         const int nb = gi < DT_GPC ? s_gp[gi] : a.ptr[g0 + gi] - r0;
         const int n = min(gi < DT_GPC ? s_gp[gi + 1] : a.ptr[g0 + gi + 1] - r0, nrows) - nb;
         if (n <= 0) continue;
@@ -540,20 +517,20 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float o = __fsub_rn(__fmul_rn(an, cv[j]), mv[j]);
-          float y = (DT_ABL & 256) ? __fadd_rn(__fmul_rn(wv[j], o) * __builtin_amdgcn_rcpf(dv[j]), bv[j]) : __fadd_rn(__fmul_rn(wv[j], o) / dv[j], bv[j]);
+          float y = __fadd_rn(__fmul_rn(wv[j], o) / dv[j], bv[j]);
           y = __fadd_rn(y, rh[u][j]);
           if (a.node_mask) y = __fmul_rn(mk, y);
           y4[j] = y;
         }
         if (a.xg_out || a.xp_out) {
-          const isg_f32x2 ga = DT_GELU3(isg_f32x2{y4[0] * xv[0], y4[1] * xv[1]});
-          const isg_f32x2 gb2 = DT_GELU3(isg_f32x2{y4[2] * xv[2], y4[3] * xv[3]});
+          const isg_f32x2 ga = gelu_exact2(isg_f32x2{y4[0] * xv[0], y4[1] * xv[1]});
+          const isg_f32x2 gb2 = gelu_exact2(isg_f32x2{y4[2] * xv[2], y4[3] * xv[3]});
           g4 = hf32x4{ga.x, ga.y, gb2.x, gb2.y};
         }
         const int64_t at = (int64_t)(r0 + row) * DT_C + sc4 * 4;
-        if (!(DT_ABL & 2048) || y4[0] == 1.2345e30f) *reinterpret_cast<hf32x4 *>(a.h_out + at) = y4;
+        *reinterpret_cast<hf32x4 *>(a.h_out + at) = y4;
         if (a.xg_out) *reinterpret_cast<hf32x4 *>(a.xg_out + at) = g4;
-        if (a.xp_out && !(DT_ABL & 128)) {          // row scale + (hi, mid) split once per row here, not once per (tile, head) in the layer kernel
+        if (a.xp_out) {          // row scale + (hi, mid) split once per row here, not once per (tile, head) in the layer kernel
           const float mx = group_max<32>(fmaxf(fmaxf(fabsf(g4[0]), fabsf(g4[1])), fmaxf(fabsf(g4[2]), fabsf(g4[3]))));
           float sc, inv;
           h3_scale(mx, sc, inv);
@@ -562,35 +539,22 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
           hf16x4 hi = {(_Float16)g4[0], (_Float16)g4[1], (_Float16)g4[2], (_Float16)g4[3]};
           hf16x4 mid = {(_Float16)(g4[0] - (float)hi[0]), (_Float16)(g4[1] - (float)hi[1]), (_Float16)(g4[2] - (float)hi[2]),
                         (_Float16)(g4[3] - (float)hi[3])};
-          if (!(DT_ABL & 2048) || g4[0] == 1.2345e30f) *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + sc4 * 4) = hi;
-          if (!(DT_ABL & 2048) || g4[0] == 1.2345e30f) *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + 128 + sc4 * 4) = mid;
+          *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + sc4 * 4) = hi;
+          *reinterpret_cast<hf16x4 *>(a.xp_out + (int64_t)(r0 + row) * 256 + 128 + sc4 * 4) = mid;
         }
       }
     }
     if (gb + 32 < ng) __syncthreads();
   }
-#ifdef ISG_DT_STAMP
   DT_STAMP(11)                 // phase C
-  if (g_dt_stamps && lane == 0) {
-    st_acc[12] = DT_T() - st_begin;
-    st_acc[13] = nrows;
-    st_acc[14] = ng;
-    long long *dst = g_dt_stamps + ((long long)t * 4 + wave) * 16;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dst[i] = st_acc[i];
-  }
-#endif
+  ISG_DIAG_DUMP(g_dt_stamps, t * 4 + wave, 12, st_acc[13] = nrows; st_acc[14] = ng;)
 }
 
 }  // namespace isg
 
 using namespace isg;
 
-#ifdef ISG_DT_STAMP
-extern "C" int isg_dt_set_stamp_buffer(long long *buf) {      // diagnostic build only: [tiles * 4 waves][16] int64
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_dt_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
-}
-#endif
+ISG_DIAG_SETTER(isg_dt_set_stamp_buffer, g_dt_stamps)
 
 extern "C" int64_t isg_tile_plan_capacity(int64_t N, int64_t E, int64_t B, int32_t node_cap, int32_t edge_cap) {
   if (N < 0 || E < 0 || B < 0 || node_cap <= 0) return 0;
@@ -752,14 +716,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
   if (t >= T) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = one of the head's four 32-channel tiles, all 64 slots
-#ifdef ISG_DT_STAMP
-  long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const long long st_begin = DT_T();
-  long long st_last = st_begin;
-#define TC_STAMP(i) { const long long now_ = DT_T(); st_acc[i] += now_ - st_last; st_last = now_; }
-#else
-#define TC_STAMP(i)
-#endif
+  ISG_DIAG_BEGIN()
   const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
   const int hoff = hd * TC_C;
   const int srow = tid >> 5, sc4 = tid & 31;          // staging map: 32 lanes per 512-byte row, rows srow + 8 u
@@ -900,9 +857,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
           }
         }
       }
-#ifdef ISG_DT_STAMP
-      asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][15]));
-#endif
+      ISG_DIAG_KEEP2(acc[0][0], acc[1][15])
       TC_STAMP(3)            // k loop
       // epilogue: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask, z * att in 4 chains
 #pragma unroll
@@ -998,14 +953,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
 #undef TC_REQUEST_TILE
 #undef TC_REQUEST_ROWS0
 #undef TC_STORE_TILE
-#ifdef ISG_DT_STAMP
-  if (g_dt_stamps && lane == 0) {
-    st_acc[12] = DT_T() - st_begin;
-    long long *dst = g_dt_stamps + ((long long)bid * 4 + tw) * 16;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dst[i] = st_acc[i];
-  }
-#endif
+  ISG_DIAG_DUMP(g_dt_stamps, bid * 4 + tw, 12, )
 }
 
 }  // namespace isg

@@ -27,14 +27,6 @@
 
 #include <stdlib.h>
 
-#ifdef ISG_EL_STAMP
-// Diagnostic build (tools/stamp_edge_logits.py): every wave adds up core-clock cycles (s_memtime) per phase and writes
-// them to a buffer of its own; no output value depends on a stamp.  [workgroup * 8 + wave][8]:
-//   0 staging (kernel start -> after the panel barrier)   1 issuing a tile's gathers   2 k loop   3 wait for the gathers
-//   (s_waitcnt vmcnt(0) right after the k loop)   4 epilogue arithmetic   5 flush + final reduction   6 whole kernel   7 tiles
-static __device__ long long *g_el_stamps = nullptr;
-#define EL_T() ((long long)__builtin_amdgcn_s_memtime())
-#endif
 
 namespace isg {
 
@@ -55,8 +47,6 @@ struct ElArgs {
   float slope;
 };
 
-// DBG (ablation builds only, -DISG_EL_ABLATION, tools/ablate_edge_logits.py): bit 0 no x_l / x_r row gathers, bit 1 no MFMAs
-//
 // What was measured on the way to this form, all at BASELINE configs[1] on one MI355X, same-box A/B (first version: 4 waves,
 // a wave = 64 slots x one head, 194 VGPRs, 2 waves per SIMD: 214 us; profiles/r02_w_edge_logits.md has the tables):
 //   * ablation of the first version: 112 us without the x_l / x_r gathers, 180 without the MFMAs, 171 without the W loads
@@ -71,7 +61,8 @@ struct ElArgs {
 //     rows, 8 per page): 228 / 228 / 229 us, identical logits
 //   * counters: HBM fetch 508 MB per launch = 1.15x the algorithmic 442 MB; L2 hit rate 67 %; 71 M L1 line accesses (the
 //     plain lin_edge GEMM: 23 M); TCP_UTCL1_STALL_INFLIGHT_MAX 24.6 M (10.0 M)
-//   * in-kernel stamps (-DISG_EL_STAMP, tools/stamp_edge_logits.py): a wave lives 68k cycles for its 4 tiles: staging 18 %,
+//   * in-kernel stamps (a diagnostic build of round 2, gone from the source with its ablation arms: the tables are
+//     profiles/r02_w_edge_logits.md): a wave lives 68k cycles for its 4 tiles: staging 18 %,
 //     issuing the gathers 10 % (1.8k cycles per tile: back-pressure), k loops 57 % (9.8k cycles per tile for 768 cycles of
 //     MFMA), residual gather wait after the k loop 0.1 %, epilogue 8 %: the gathers' latency under load (3-4 us per tile) is
 //     paid at the first W-fragment wait of every k loop -- vector-memory operations retire in order
@@ -84,7 +75,7 @@ struct ElArgs {
 // isg_gatv2_mp_fwd, and the configs[1] step 2.20-2.22 ms against 2.24-2.29 ms on the same box.
 // (A form that also computed x_r = lin_r(x) here, from a second panel of x[dst] rows, was built in round 2 and measured 2.255 vs
 // 2.235 ms per step: removed in round 4.)
-template <bool MASKED, int DBG = 0>
+template <bool MASKED>
 __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 sA[2][EL_BM][EL_LD];   // 34,816 B
   __shared__ float s_inv[EL_BM];
@@ -95,10 +86,6 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
   const int m0 = blockIdx.x * EL_BM;
   const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
   const int HC = a.H * a.C;
-#ifdef ISG_EL_STAMP
-  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const long long st_begin = EL_T();
-#endif
 
   // ---- stage the edge panel once: rows gathered by edge id -> row scale -> (hi, mid) planes -------------------------------
   {
@@ -144,9 +131,6 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
   float me = 1.f;
   if (MASKED) me = a.edge_mask ? a.edge_mask[a.eid[sl]] : a.node_mask[s_node] * a.node_mask[d_node];
   __syncthreads();
-#ifdef ISG_EL_STAMP
-  st_acc[0] = EL_T() - st_begin;
-#endif
   const float sinv = s_inv[prow];
   const int KS = a.KS;
   const unsigned plane_b = (unsigned)a.NT * (unsigned)KS * 1024u;      // bytes per W plane
@@ -177,23 +161,12 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
     }
     const int cb = nt * 32 + 4 * hh;         // this lane's channels of the tile: cb + 8 * g + j, g = r >> 2, j = r & 3
     const int64_t col_l = (int64_t)hd * a.hsl + (nt - hd * tph) * 32, col_r = (int64_t)hd * a.hsr + (nt - hd * tph) * 32;
-#ifdef ISG_EL_STAMP
-    const long long st_t0 = EL_T();
-#endif
     float4 xl[4], xr[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if (DBG & 1) {
-        xl[g] = make_float4(1.f, 2.f, 3.f, 4.f);
-        xr[g] = make_float4(me, sinv, 0.5f, 0.25f);
-      } else {
-        xl[g] = *reinterpret_cast<const float4 *>(a.x_l + xl_off + col_l + 8 * g);
-        xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
-      }
+      xl[g] = *reinterpret_cast<const float4 *>(a.x_l + xl_off + col_l + 8 * g);
+      xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
     }
-#ifdef ISG_EL_STAMP
-    const long long st_t1 = EL_T();
-#endif
     hf32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -208,13 +181,9 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
       Afr[q] = *reinterpret_cast<const hf16x8 *>(&sA[q][prow][(ksl) * 16 + fk]);
     // transposed product: W fragment = A operand (rows = channels), edge panel = B operand (columns = edges)
 #define EL_MMA(Afr, W)                                                                                           \
-  if (DBG & 2) {                                                                                                 \
-    acc[0] += (float)W[0][0] + (float)W[1][1] + (float)Afr[0][0] + (float)Afr[1][2];                             \
-  } else {                                                                                                       \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[1], acc, 0, 0, 0);                                    \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[1], Afr[0], acc, 0, 0, 0);                                    \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[0], acc, 0, 0, 0);                                    \
-  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[1], acc, 0, 0, 0);                                      \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[1], Afr[0], acc, 0, 0, 0);                                      \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[0], acc, 0, 0, 0);
     EL_LOAD_W(w0, 0)
     EL_LOAD_A(a0, 0)
     int ks = 0;
@@ -231,12 +200,6 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
 #undef EL_LOAD_W
 #undef EL_LOAD_A
 #undef EL_MMA
-#ifdef ISG_EL_STAMP
-    asm volatile("" ::"v"(acc[0]), "v"(acc[15]));       // the k loop's results exist
-    const long long st_t2 = EL_T();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // whatever of the gathers is still in flight
-    const long long st_t3 = EL_T();
-#endif
     // ---- epilogue of the tile: the logit's partial sums over this lane's 16 channels ---------------------------------------
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -255,15 +218,7 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
         part[g] = fmaf(z, atv[j], part[g]);
       }
     }
-#ifdef ISG_EL_STAMP
-    asm volatile("" ::"v"(part[0]), "v"(part[1]), "v"(part[2]), "v"(part[3]));
-    const long long st_t4 = EL_T();
-    st_acc[1] += st_t1 - st_t0; st_acc[2] += st_t2 - st_t1; st_acc[3] += st_t3 - st_t2; st_acc[4] += st_t4 - st_t3; st_acc[7] += 1;
-#endif
   }
-#ifdef ISG_EL_STAMP
-  const long long st_t5 = EL_T();
-#endif
   if (cur_hd >= 0) flush(cur_hd);
   __syncthreads();
   for (int c = tid; c < EL_BM * a.H; c += EL_THREADS) {       // (slot, head): the tile-waves' partials in a fixed order
@@ -271,16 +226,6 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
     const int slot = m0 + c / a.H;
     if (slot < a.E) a.logits[(int64_t)slot * a.H + (c % a.H)] = v;
   }
-#ifdef ISG_EL_STAMP
-  if (g_el_stamps && lane == 0) {
-    const long long st_end = EL_T();
-    st_acc[5] = st_end - st_t5;
-    st_acc[6] = st_end - st_begin;
-    long long *dst = g_el_stamps + ((long long)blockIdx.x * 8 + wave) * 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
-  }
-#endif
 }
 
 }  // namespace isg
@@ -313,25 +258,8 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   const unsigned grid = (unsigned)((E + EL_BM - 1) / EL_BM);
   const size_t dyn = ((size_t)2 * H * C + (size_t)4 * EL_BM * H) * sizeof(float);
   hipStream_t st = as_stream(stream);
-#ifdef ISG_EL_ABLATION
-  {
-    const char *e = getenv("ISG_EL_DBG");
-    const int dbg = e ? atoi(e) : 0;
-#define EL_ABL(D_) case D_: gatv2_edge_logits_kernel<false, D_><<<grid, EL_THREADS, dyn, st>>>(a); return check_launch();
-    switch (dbg) {
-      EL_ABL(1) EL_ABL(2) EL_ABL(3)
-      default: break;
-    }
-#undef EL_ABL
-  }
-#endif
   if (edge_mask || node_mask) gatv2_edge_logits_kernel<true><<<grid, EL_THREADS, dyn, st>>>(a);
   else gatv2_edge_logits_kernel<false><<<grid, EL_THREADS, dyn, st>>>(a);
   return check_launch();
 }
 
-#ifdef ISG_EL_STAMP
-extern "C" int isg_el_set_stamp_buffer(long long *buf) {      // diagnostic build only: [workgroups * 8 waves][8] int64
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_el_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a wave of isg_mgat_dense_tail spend its cycles?  `--build` (in the build container) makes
-tools/_build/libisg_dt_stamp.so from isg_layer_tile.hip with -DISG_DT_STAMP; the run launches it once at the BASELINE configs[1]
+tools/_build/libisg_dt_stamp.so from isg_layer_tile.hip with -DISG_DIAG; the run launches it once at the BASELINE configs[1]
 shapes and prints the mean core-clock cycles per phase over all waves."""
 import ctypes
 import os
@@ -14,7 +14,7 @@ OUT = os.path.join(ROOT, "tools", "_build", "libisg_dt_stamp.so")
 
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DISG_DT_STAMP",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DISG_DIAG",
                            *[a for a in sys.argv[1:] if a.startswith("-D")],
                            os.path.join(CSRC, "isg_layer_tile.hip"), os.path.join(CSRC, "isg_layer_conv.hip"), os.path.join(CSRC, "isg_graph.hip"),
                            "-o", OUT])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a wave of the persistent planes32 GEMM (isg_linear_h3p, linear_h3q_kernel) spend its cycles?  `--build` (in the
-build container) makes tools/_build/libisg_p3_stamp.so with -DISG_P3_STAMP; the run launches it on a few shapes and prints the
+build container) makes tools/_build/libisg_p3_stamp.so with -DISG_DIAG; the run launches it on a few shapes and prints the
 mean core-clock cycles per segment and k-tile over all waves (s_memtime; a stamp waits for the LDS reads before it)."""
 import ctypes
 import os
@@ -14,7 +14,7 @@ OUT = os.path.join(ROOT, "tools", "_build", "libisg_p3_stamp.so")
 
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DISG_P3_STAMP",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DISG_DIAG",
                            *[a for a in sys.argv[1:] if a.startswith("-D")],
                            os.path.join(CSRC, "isg_gemm_h3p.hip"), os.path.join(CSRC, "isg_graph.hip"), "-o", OUT])
     print("built", OUT)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a wave of isg_gatv2_tile_conv spend its cycles?  Uses tools/_build/libisg_dt_stamp.so (tools/stamp_dense_tail.py
---build makes it: isg_layer_tile.hip with -DISG_DT_STAMP)."""
+--build makes it: isg_layer_tile.hip with -DISG_DIAG)."""
 import ctypes
 import os
 import sys
