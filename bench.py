@@ -238,7 +238,7 @@ def full_model_rate(dev, graphs: int, steps: int = 10):
     """BASELINE configs[2] stand-in, measured in the same run: the FULL model (question encoder/decoder, scene-graph
     encoder, 4 MGAT layers at C = 300, I-MLE k = 5, pooling, classifier) on GQA-shaped synthetic token batches."""
     import torch
-    from isubgvqa_amd import synthetic
+    from isubgvqa_amd import ops, synthetic
     from isubgvqa_amd.models import build_model
     torch.manual_seed(0)
     model = build_model(synthetic.full_model_args(), None).to(dev).eval()
@@ -259,7 +259,10 @@ def full_model_rate(dev, graphs: int, steps: int = 10):
     return {"workload": "BASELINE configs[2] stand-in: full ISubGVQA model, C=300, 4 MGAT layers, I-MLE k=5, 12-token "
                         "questions, GQA-shaped synthetic scene graphs (no GQA data in the container)",
             "graphs": graphs, "nodes": int(wl.x.size(0)), "edges": int(wl.edge_index.size(1)),
-            "ms_per_step": round(dt * 1e3, 3), "questions_per_s": round(graphs / dt, 1), "steps": steps}
+            "ms_per_step": round(dt * 1e3, 3), "questions_per_s": round(graphs / dt, 1), "steps": steps,
+            # isg_linear_h3p's large-result store policy as measured on this box in the warm-up (ops._h3p_tune): -1 = the
+            # library's choice, 2 = write-through streaming; `us`: the two medians it compared
+            "h3p_store_policy": ops.h3p_store_policy()}
 
 
 TRAFFIC_SOURCES = {      # kind of summary -> the kernel sources it measured (csrc/); a summary is only as good as their bytes
@@ -353,7 +356,7 @@ LINE_SCHEMA = {
     "dense_err_vs_fp32": ["max"],
     "cfg5": ["workload", "graphs", "ms_per_step", "questions_per_s", "mp_kernel", "mp_avg_launch_us", "mp_achieved_GBps",
              "mp_frac_of_hbm_peak", "imbalance_world8_max_over_mean", "fp32_rows"],
-    "full_model": ["workload", "graphs", "ms_per_step", "questions_per_s"],
+    "full_model": ["workload", "graphs", "ms_per_step", "questions_per_s", "h3p_store_policy"],
 }
 
 

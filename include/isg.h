@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 13
+#define ISG_ABI_VERSION 14
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -549,6 +549,11 @@ int isg_instr_gate_planes32(const float *x, const float *instr, const int64_t *b
 int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, const uint16_t *w_planes, const float *w_inv,
                    const float *bias, float *d, uint16_t *d_planes, float *d_inv, const float *d_bound, int64_t M,
                    int32_t N, int32_t K, int32_t ldd, int32_t act, void *stream);
+/* The cache policy of a LARGE (>= 128 MB) fp32 result's stores in isg_linear_h3p, for the rest of the process: 0 plain, 1 nt,
+ * 2 sc0 sc1 nt (write-through, streaming), -1 (the default) the built-in choice: nt at K >= 512, plain below.  Results do not
+ * depend on it; the kernel's own time does, by box (profiles/r04_ag_h3p_store_policy.txt), the full model's does not.
+ * ISG_EINVAL on any other value. */
+int isg_linear_h3p_store_policy(int32_t policy);
 
 /* ---------------------------------------------------------------------------------------------
  * Scene-graph encoder (ISubGVQA/models/scene_graph_encoder.py:108-143) without its concatenations

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -93,6 +93,7 @@ SIGNATURES = {
     "isg_split_planes32": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_instr_gate_planes32": (c_int, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
     "isg_linear_h3p": (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_linear_h3p_store_policy": (c_int, [c_int32]),
     "isg_tile_plan_capacity": (c_int64, [c_int64, c_int64, c_int64, c_int32, c_int32]),
     "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "isg_mgat_dense_tail": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32] + [c_void_p] * 12 + [c_double] +

@@ -523,16 +523,14 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     const bool ok = (int)(live) & (int)(rm0 + rl < a.M) & (int)(rn0 + cl < a.N);   /* no branches */                    \
     off = ok ? ((unsigned)(rm0 + rl) * (unsigned)a.ldd + (unsigned)(rn0 + cl)) * 4u : 0xFFFFFFF0u;                 \
   }
-#ifndef ISG_Q3_ST_AUX
-#define ISG_Q3_ST_AUX 2      // cache policy of a large (>= 128 MB) fp32 result's stores at K >= 512: nt.  A/B builds: at the
-#define ISG_Q3_NT_ALL 0      // K = 300 shapes nt loses 8-24 %; sc0 sc1 nt (19) ran 32 % faster in one process and 21 % slower in the next
-#endif
-#ifndef ISG_Q3_PST_AUX
-#define ISG_Q3_PST_AUX 0      // the same for a planes32 result
-#endif
+  // `a.nt_store`: the cache policy of a large result's stores, uniform: 0 plain, 1 nt, 2 sc0 sc1 nt (write-through, streaming).
+  // A 128-KB-per-tile result stream through a 4 MB L2 pushes the weights out of it.  Measured (profiles/r04_ag_h3p_store_policy.txt):
+  // alone, policy 2 runs the K = 300 shapes 15-32 % faster than 0 on some MI355X boxes and 20 % slower on others; inside the full
+  // model every policy gives the same step, so the default (isg_linear_h3p_store_policy(-1)) is 1 at K >= 512, 0 below.
 #define Q3_EPI_ST(v, off)                                                                                          \
   {                                                                                                                \
-    if ((HEAD == 16 || ISG_Q3_NT_ALL) && a.nt_store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, v), drs, (int)(off), 0, ISG_Q3_ST_AUX); \
+    if (a.nt_store == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, v), drs, (int)(off), 0, 19); \
+    else if (a.nt_store == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, v), drs, (int)(off), 0, 2); \
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, v), drs, (int)(off), 0, 0);           \
   }
   // planes32 result: the PAIR of accumulator tiles (i, j0), (i, j0 + 1) = one 32-column group of 16 rows.  A lane holds
@@ -587,13 +585,8 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 #define Q3_PAIR_ST(h16, m16, off, ioff, inv)                                                                       \
   {                                                                                                                \
     const unsigned off2_ = (off) == 0xFFFFFFF0u ? 0xFFFFFFF0u : (off) + 64u;                                       \
-    if (ISG_Q3_PST_AUX && a.nt_store) {                                                                            \
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, h16), drs, (int)(off), 0, ISG_Q3_PST_AUX); \
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, m16), drs, (int)off2_, 0, ISG_Q3_PST_AUX); \
-    } else {                                                                                                       \
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, h16), drs, (int)(off), 0, 0);            \
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, m16), drs, (int)off2_, 0, 0);            \
-    }                                                                                                              \
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, h16), drs, (int)(off), 0, 0);              \
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, m16), drs, (int)off2_, 0, 0);              \
     if (rn0 == 0 && wn == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(inv), irs, (int)(ioff), 0, 0); \
   }
   // the tile's accumulators become `res`; its scales come out of the parameter region the DMA filled a tile ago.  Read by
@@ -831,6 +824,17 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 
 using namespace isg;
 
+#include <atomic>
+static std::atomic<int> g_h3p_store_policy{-1};
+
+// The cache policy of a LARGE (>= 128 MB) fp32 result's stores for the rest of the process: 0 plain, 1 nt, 2 sc0 sc1 nt, -1 the
+// built-in choice (nt at K >= 512, plain below); ISG_EINVAL on anything else.  An experiment's switch (see Q3_EPI_ST).
+extern "C" int isg_linear_h3p_store_policy(int32_t policy) {
+  if (policy < -1 || policy > 2) return ISG_EINVAL;
+  g_h3p_store_policy.store(policy, std::memory_order_relaxed);
+  return ISG_OK;
+}
+
 ISG_DIAG_SETTER(isg_p3_set_stamp_buffer, g_p3_stamps)
 
 extern "C" int64_t isg_planes32_elems(int64_t rows, int32_t K) {
@@ -889,7 +893,9 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   a.a_inv = a_inv; a.w_inv = w_inv; a.bias = bias; a.D = d; a.Dp = reinterpret_cast<_Float16 *>(d_planes); a.d_inv = d_inv;
   a.d_bound = d_bound; a.M = (int)M; a.N = N; a.KT = KT; a.ldd = ldd; a.tiles_n = (int)tn;
   static const long long nt_mb = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return e ? atoll(e) : 128ll; }();
-  a.nt_store = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
+  const bool large = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
+  const int forced = g_h3p_store_policy.load(std::memory_order_relaxed);
+  a.nt_store = !large || planes_out ? 0 : forced >= 0 ? forced : (KT >= 16 ? 1 : 0);      // a planes32 result: plain (measured)
   hipStream_t st = as_stream(stream);
   static const int version = [] { const char *e = getenv("ISG_H3P_V"); return e ? atoi(e) : 2; }();
   if (planes_out && (N & 31) && (version == 1 || KT < Q3_HEAD)) return ISG_EUNSUPPORTED;   // the 256 x 256 form pads no columns

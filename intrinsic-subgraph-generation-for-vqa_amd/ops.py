@@ -1799,6 +1799,60 @@ def h3p_supported(M: int, N: int, K: int) -> bool:
             and M * ((N + 31) // 32 * 32) * 4 < (1 << 32) - 16)       # the result through a buffer descriptor: 32-bit byte offsets
 
 
+# The cache policy of a large (>= 128 MB) fp32 result's stores in isg_linear_h3p: -1 (the library's choice: nt at K >= 512, plain
+# below) / 0 plain / 1 nt / 2 sc0 sc1 nt, or "auto" = measured once per process on the box (_h3p_tune).  Results do not depend on
+# it.  In ISOLATION 2 runs the K = 300 projections 15-32 % faster than plain stores on some MI355X boxes and 21 % slower on others
+# (the same way in every process on a box); in the full model, on a box where it wins in isolation, every policy gives the same
+# step (20.09-20.29 ms: profiles/r04_ag_h3p_store_policy.txt) -- what the producer gains by not leaving its result in L2 / the
+# Infinity Cache its consumer loses.  So the default is the library's choice and "auto" stays an experiment.
+H3P_STORE_POLICY = -1
+_h3p_policy_state = {"chosen": None, "us": None}
+
+
+def h3p_store_policy():
+    """What _h3p_tune chose in this process (None before the first large Linear), with the times it measured."""
+    return dict(_h3p_policy_state)
+
+
+def _h3p_tune(dev) -> None:
+    """One-time choice of the store policy for large results: the K = 300 projection of 65 536 rows onto 1 200 columns (a 315 MB
+    result), the library's own choice against write-through streaming stores, median of three launches each.  ~3 ms, once per
+    process; skipped (library's choice) while a stream is being captured."""
+    lib = _lib.load()
+    if H3P_STORE_POLICY != "auto":
+        _lib.check(lib.isg_linear_h3p_store_policy(int(H3P_STORE_POLICY)), "isg_linear_h3p_store_policy")
+        _h3p_policy_state.update(chosen=int(H3P_STORE_POLICY), us=None)
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    M, N, K = 65536, 1200, 300
+    KT = (K + 31) // 32
+    ap = torch.zeros(M * KT * 64, dtype=torch.int16, device=dev)
+    ainv = torch.ones(M, dtype=torch.float32, device=dev)
+    wp = torch.zeros(N * KT * 64, dtype=torch.int16, device=dev)
+    winv = torch.ones(N, dtype=torch.float32, device=dev)
+    out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ap.random_(0, 15000)          # fp16 bit patterns of finite values in [0, 0.8): the kernel's speed does not depend on the
+    wp.random_(0, 15000)          # values, but the chip's clocks do on all-zero operands
+    us = {}
+    for pol in (-1, 2, -1, 2):
+        _lib.check(lib.isg_linear_h3p_store_policy(pol), "isg_linear_h3p_store_policy")
+        ts = []
+        for _ in range(4):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            _lib.check(lib.isg_linear_h3p(ap.data_ptr(), ainv.data_ptr(), wp.data_ptr(), winv.data_ptr(), 0, out.data_ptr(), 0, 0, 0,
+                                          M, N, K, N, 0, _stream()), "isg_linear_h3p")
+            e.record()
+            e.synchronize()
+            ts.append(s.elapsed_time(e) * 1e3)
+        us.setdefault(pol, []).extend(ts[1:])
+    med = {k: sorted(v)[len(v) // 2] for k, v in us.items()}
+    chosen = 2 if med[2] < 0.95 * med[-1] else -1
+    _lib.check(lib.isg_linear_h3p_store_policy(chosen), "isg_linear_h3p_store_policy")
+    _h3p_policy_state.update(chosen=chosen, us={str(k): round(v, 1) for k, v in med.items()})
+
+
 def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False, relu: bool = False,
                planes_out: bool = False, cache_planes: bool = True):
     """act(x @ weight^T + bias) on the planes32 engine.  x: Planes32 or fp32 rows (split here, once per tensor version).
@@ -1821,6 +1875,8 @@ def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = Fa
                                       dp.data_ptr(), dinv.data_ptr(), bound.data_ptr(), M, N, K, 0, act, _stream()),
                    "isg_linear_h3p")
         return Planes32(dp, dinv, M, N)
+    if _h3p_policy_state["chosen"] is None and M * N * 4 >= 128_000_000:
+        _h3p_tune(dev)
     out = torch.empty(M, N, dtype=torch.float32, device=dev)
     _lib.check(lib.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), bptr,
                                   out.data_ptr(), 0, 0, 0, M, N, K, N, act, _stream()), "isg_linear_h3p")

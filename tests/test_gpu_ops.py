@@ -1404,6 +1404,44 @@ def test_linear_h3p_matches_fp64_within_fp32_gemm_error(dev, M, N, K, act, bias)
     assert ((got.double() - ref).abs() / scale).max().item() < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(40961, 1000, 300), (33000, 1024, 512)])
+def test_linear_h3p_store_policy_changes_speed_only(dev, M, N, K):
+    """A large (>= 128 MB) fp32 result leaves isg_linear_h3p under one of three cache policies (isg_linear_h3p_store_policy: plain,
+    nt, write-through streaming; ops.H3P_STORE_POLICY): the bits of the result are the same under all of them, at both
+    k-tile regimes (two pieces per k-tile below K = 512, one from there), tails included; an unknown policy is refused."""
+    from isubgvqa_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(K)
+    x = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(N, device=dev, generator=g)
+    assert M * N * 4 >= 128_000_000
+    before = ops.H3P_STORE_POLICY
+    try:
+        outs = []
+        for pol in (0, 1, 2, -1):
+            ops.H3P_STORE_POLICY = pol
+            ops._h3p_policy_state.update(chosen=None)
+            got = ops.linear_h3p(x, w, b, gelu=True)
+            assert ops.h3p_store_policy()["chosen"] == pol
+            outs.append(got.clone())
+            got.fill_(float("nan"))
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        ref = torch.nn.functional.gelu(torch.nn.functional.linear(x.double(), w.double(), b.double()))
+        assert (outs[0].double() - ref).abs().max().item() < 1e-4
+        assert lib.isg_linear_h3p_store_policy(3) == -1 and lib.isg_linear_h3p_store_policy(-2) == -1
+        ops.H3P_STORE_POLICY = "auto"                 # the measurement itself: chooses one of the two it compares, reports both times
+        ops._h3p_policy_state.update(chosen=None)
+        ops.linear_h3p(x, w, b)
+        st = ops.h3p_store_policy()
+        print("store policy chosen on this box:", st)
+        assert st["chosen"] in (-1, 2) and set(st["us"]) == {"-1", "2"}
+    finally:
+        ops.H3P_STORE_POLICY = before
+        ops._h3p_policy_state.update(chosen=None, us=None)
+        lib.isg_linear_h3p_store_policy(-1)
+
+
 @pytest.mark.parametrize("M,N,K,act", [(1000, 512, 512, "relu"), (4099, 2048, 512, "relu"), (515, 1184, 320, "gelu"),
                                           (2049, 600, 1200, "gelu"), (300, 1200, 300, "gelu"), (777, 44, 512, None)])
 def test_linear_h3p_planes_out_feeds_the_next_linear(dev, M, N, K, act):

@@ -11,9 +11,12 @@ import torch
 from isubgvqa_amd import ops, synthetic
 from isubgvqa_amd.models import build_model
 
-args = [a for a in sys.argv[1:] if not a.startswith('--')]
+pol = sys.argv[sys.argv.index('--policy') + 1] if '--policy' in sys.argv else None
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith('--') and sys.argv[i - 1] != '--policy']
 graphs = int(args[0]) if len(args) > 0 else 2048
 steps = int(args[1]) if len(args) > 1 else 20
+if '--policy' in sys.argv:          # isg_linear_h3p's large-result store policy: -1 / 0 / 1 / 2 instead of the measured choice
+    ops.H3P_STORE_POLICY = int(pol)
 if '--no-h3p' in sys.argv:
     ops.H3P = False        # A/B: the round-3 tile kernel for the K >= 256 Linears
 if '--no-chain' in sys.argv:
@@ -40,4 +43,4 @@ with torch.no_grad():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
 print(f"full model, {graphs} graphs (N={wl.x.size(0)}, E={wl.edge_index.size(1)}, T={wl.questions.size(1)}): "
-      f"{dt * 1e3:.2f} ms/step = {graphs / dt:,.0f} questions/s")
+      f"{dt * 1e3:.2f} ms/step = {graphs / dt:,.0f} questions/s; h3p store policy {ops.h3p_store_policy()}")
