@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 14
+#define ISG_ABI_VERSION 15
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -564,10 +564,14 @@ int isg_linear_h3p_store_policy(int32_t policy);
  * (:139-140): the node parts are projected once per NODE (A, B: rows gathered by int64 index), the edge-token part is a
  * row of a projected [vocabulary, C] table (T, with the added_sym_edge sign, :80), D is a per-edge dense term.  B / T /
  * D / sign / bias may be NULL.  lda / ldb / ldt / ldd: row strides in floats (multiples of 4, so column slices of a wider
- * projection are valid operands); every pointer 16-byte aligned; act 0 = none, 1 = exact GELU. */
+ * projection are valid operands); every pointer 16-byte aligned; act 0 = none, 1 = exact GELU.
+ * planes / planes_inv (both or neither): the rows ALSO (or, with out = NULL, ONLY) as the planes32 operand of isg_linear_h3p
+ * (uint16 [isg_planes32_elems(E, C)], fp32 [E]) -- the Linear that reads them (edge_mlp.2, node_mlp_1.2) needs no
+ * isg_split_planes32 pass. */
 int isg_gather_add(const float *A, const int64_t *ia, int32_t lda, const float *B, const int64_t *ib, int32_t ldb,
                    const float *T, const int64_t *it, const float *sign, int32_t ldt, const float *D, int32_t ldd,
-                   const float *bias, float *out, int64_t E, int32_t C, int32_t act, void *stream);
+                   const float *bias, float *out, int64_t E, int32_t C, int32_t act, uint16_t *planes, float *planes_inv,
+                   void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Question encoder / program decoder attention (ISubGVQA/models/question_encoder.py:20-38, question_decoder.py:25-71)

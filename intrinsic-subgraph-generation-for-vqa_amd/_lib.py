@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -67,7 +67,7 @@ SIGNATURES = {
     "isg_linear_panel": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                  c_int32, c_int32, c_int32, c_void_p]),
     "isg_gather_add": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
-                               c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+                               c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_mha_small": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                               c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_add_layernorm": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_int32,

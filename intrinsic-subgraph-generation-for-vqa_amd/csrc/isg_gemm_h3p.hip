@@ -46,79 +46,94 @@ constexpr int P3_BUF = 4 * P3_SLOT;         // A-lo, A-hi, B-lo, B-hi of one k-t
 constexpr int P3_SMEM = 2 * P3_BUF;         // 128 KB
 constexpr int P3_ALO = 0, P3_AHI = 1, P3_BLO = 2, P3_BHI = 3;
 
-// planes32 of fp32 rows: wave per row; the row's largest magnitude decides its scale
-__global__ __launch_bounds__(256) void split_planes32_kernel(const float *__restrict__ a, int M, int K, int lda,
-                                                             _Float16 *__restrict__ planes, float *__restrict__ inv_out) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const int KT = (K + 31) >> 5, nc = K >> 2;
-  const float4 *r4 = reinterpret_cast<const float4 *>(a + (int64_t)row * lda);
+// One row -> its planes32 lines, by a group of LPR lanes (wave per row for wide rows; sixteen lanes per row up to 128 float4 --
+// K = 300 is 75 float4: five passes of 16 lanes keep 94 % of the lane slots busy, a whole wave 59 %).  `val(c)` = float4 c of the
+// row; with PMAX > 0 the row is held in registers between its largest magnitude and its split, else it is evaluated twice.
+template <int LPR, int PMAX, typename F, typename G>
+__device__ __forceinline__ void planes32_row(int l, int nc, int KT, _Float16 *__restrict__ p, float *__restrict__ inv_slot, F val, G keep) {
+  float4 v[PMAX > 0 ? PMAX : 1];
   float mx = 0.f;
-  for (int c = lane; c < nc; c += 64) {
-    const float4 v = r4[c];
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  if constexpr (PMAX > 0) {
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) {
+      const int c = l + LPR * q;
+      v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < nc) v[q] = val(c);
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w))));
+    }
+  } else {
+    for (int c = l; c < nc; c += LPR) {
+      const float4 t = val(c);
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
+    }
   }
-  mx = wave_max(mx);
+  mx = group_max<LPR>(mx);
   float s, inv;
   h3_scale(mx, s, inv);
-  if (lane == 0) inv_out[row] = inv;
-  _Float16 *p = planes + (int64_t)row * KT * 64;
-  for (int c = lane; c < KT * 8; c += 64) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < nc) v = r4[c];
-    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-    const hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-    const hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
-                        (_Float16)(v.w - (float)hi[3])};
+  if (l == 0) *inv_slot = inv;
+  auto put = [&](int c, float4 t) {
+    if (c < nc) keep(c, t);
+    t.x *= s; t.y *= s; t.z *= s; t.w *= s;
+    const hf16x4 hi = {(_Float16)t.x, (_Float16)t.y, (_Float16)t.z, (_Float16)t.w};
+    const hf16x4 mid = {(_Float16)(t.x - (float)hi[0]), (_Float16)(t.y - (float)hi[1]), (_Float16)(t.z - (float)hi[2]),
+                        (_Float16)(t.w - (float)hi[3])};
     _Float16 *d = p + (c >> 3) * 64 + (c & 7) * 4;
     *reinterpret_cast<hf16x4 *>(d) = hi;
     *reinterpret_cast<hf16x4 *>(d + 32) = mid;
+  };
+  if constexpr (PMAX > 0) {
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q)
+      if (l + LPR * q < KT * 8) put(l + LPR * q, v[q]);         // beyond nc: the zeros of the k padding
+  } else {
+    for (int c = l; c < KT * 8; c += LPR) put(c, c < nc ? val(c) : make_float4(0.f, 0.f, 0.f, 0.f));
   }
+}
+
+// planes32 of fp32 rows; the row's largest magnitude decides its scale
+template <int LPR, int PMAX>
+__global__ __launch_bounds__(256) void split_planes32_kernel(const float *__restrict__ a, int M, int K, int lda,
+                                                             _Float16 *__restrict__ planes, float *__restrict__ inv_out) {
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, l = threadIdx.x % LPR;
+  if (row >= M) return;
+  const int KT = (K + 31) >> 5, nc = K >> 2;
+  const float4 *r4 = reinterpret_cast<const float4 *>(a + (int64_t)row * lda);
+  planes32_row<LPR, PMAX>(l, nc, KT, planes + (int64_t)row * KT * 64, inv_out + row, [&](int c) { return r4[c]; },
+                          [](int, float4) {});
 }
 
 // gelu(x * instr[batch]) (ISubGVQA/models/mgat_v2_conv.py:156-157) written as the planes32 operand of the lin_l | lin_r
 // projection, and as fp32 rows where a masked layer's node gate reads them: the instruction gate and the split as ONE pass over
-// the layer input (wave per row; the GELU is evaluated twice -- once for the row's maximum, once for the split -- instead of
-// holding the row in registers: C = 300 is 75 float4, and the kernel is bound by its 2 x 1.2 KB of traffic per row).
+// the layer input.
+template <int LPR, int PMAX>
 __global__ __launch_bounds__(256) void instr_gate_planes32_kernel(const float *__restrict__ x, const float *__restrict__ instr,
                                                                   const long long *__restrict__ batch, int N, int C,
                                                                   float *__restrict__ rows, _Float16 *__restrict__ planes,
                                                                   float *__restrict__ inv_out) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, l = threadIdx.x % LPR;
   if (row >= N) return;
   const int KT = (C + 31) >> 5, nc = C >> 2;
   const float4 *x4 = reinterpret_cast<const float4 *>(x + (int64_t)row * C);
   const float4 *i4 = reinterpret_cast<const float4 *>(instr + batch[row] * (int64_t)C);
-  auto gate = [&](int c) {
-    const float4 a = x4[c], b = i4[c];
-    const isg_f32x2 g0 = gelu_exact2(isg_f32x2{a.x * b.x, a.y * b.y}), g1 = gelu_exact2(isg_f32x2{a.z * b.z, a.w * b.w});
-    return make_float4(g0.x, g0.y, g1.x, g1.y);
-  };
-  float mx = 0.f;
-  for (int c = lane; c < nc; c += 64) {
-    const float4 v = gate(c);
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-  }
-  mx = wave_max(mx);
-  float s, inv;
-  h3_scale(mx, s, inv);
-  if (lane == 0) inv_out[row] = inv;
-  _Float16 *p = planes + (int64_t)row * KT * 64;
-  for (int c = lane; c < KT * 8; c += 64) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < nc) {
-      v = gate(c);
-      if (rows) reinterpret_cast<float4 *>(rows + (int64_t)row * C)[c] = v;
-    }
-    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-    const hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-    const hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
-                        (_Float16)(v.w - (float)hi[3])};
-    _Float16 *d = p + (c >> 3) * 64 + (c & 7) * 4;
-    *reinterpret_cast<hf16x4 *>(d) = hi;
-    *reinterpret_cast<hf16x4 *>(d + 32) = mid;
-  }
+  float4 *o4 = rows ? reinterpret_cast<float4 *>(rows + (int64_t)row * C) : nullptr;
+  planes32_row<LPR, PMAX>(l, nc, KT, planes + (int64_t)row * KT * 64, inv_out + row,
+                          [&](int c) {
+                            const float4 a = x4[c], b = i4[c];
+                            const isg_f32x2 g0 = gelu_exact2(isg_f32x2{a.x * b.x, a.y * b.y}), g1 = gelu_exact2(isg_f32x2{a.z * b.z, a.w * b.w});
+                            return make_float4(g0.x, g0.y, g1.x, g1.y);
+                          },
+                          [&](int c, float4 t) { if (o4) o4[c] = t; });
 }
+
+// launch of a row -> planes32 kernel: sixteen lanes per row with the row in registers up to 128 float4, else a wave per row
+#define ISG_PLANES32_ROWS_LAUNCH(kern, rows_, nc_, st_, ...)                                                       \
+  do {                                                                                                             \
+    const int pad_ = ((nc_) + 7) / 8 * 8;                                                                          \
+    if (pad_ <= 80) kern<16, 5><<<(unsigned)(((rows_) + 15) / 16), 256, 0, st_>>>(__VA_ARGS__);                   \
+    else if (pad_ <= 128) kern<16, 8><<<(unsigned)(((rows_) + 15) / 16), 256, 0, st_>>>(__VA_ARGS__);             \
+    else if (pad_ <= 512) kern<64, 8><<<(unsigned)(((rows_) + 3) / 4), 256, 0, st_>>>(__VA_ARGS__);               \
+    else kern<64, 0><<<(unsigned)(((rows_) + 3) / 4), 256, 0, st_>>>(__VA_ARGS__);                                \
+  } while (0)
 
 struct P3Args {
   const _Float16 *A, *W;          // planes32 [M][KT][64], [N][KT][64]
@@ -851,8 +866,8 @@ extern "C" int isg_split_planes32(const float *a, int64_t M, int32_t K, int32_t 
   if ((K & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15) ||
       (M + 3) / 4 >= (1ll << 31))
     return ISG_EUNSUPPORTED;
-  split_planes32_kernel<<<(unsigned)((M + 3) / 4), 256, 0, as_stream(stream)>>>(a, (int)M, K, lda,
-                                                                               reinterpret_cast<_Float16 *>(planes), inv_scale);
+  ISG_PLANES32_ROWS_LAUNCH(split_planes32_kernel, M, K >> 2, as_stream(stream), a, (int)M, K, lda,
+                           reinterpret_cast<_Float16 *>(planes), inv_scale);
   return check_launch();
 }
 
@@ -864,8 +879,8 @@ extern "C" int isg_instr_gate_planes32(const float *x, const float *instr, const
   if (!x || !instr || !batch || !planes || !inv_scale) return ISG_EINVAL;
   auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if ((C & 3) || mis(x) || mis(instr) || mis(planes) || (rows && mis(rows)) || (N + 3) / 4 >= (1ll << 31)) return ISG_EUNSUPPORTED;
-  instr_gate_planes32_kernel<<<(unsigned)((N + 3) / 4), 256, 0, as_stream(stream)>>>(
-      x, instr, reinterpret_cast<const long long *>(batch), (int)N, C, rows, reinterpret_cast<_Float16 *>(planes), inv_scale);
+  ISG_PLANES32_ROWS_LAUNCH(instr_gate_planes32_kernel, N, C >> 2, as_stream(stream), x, instr,
+                           reinterpret_cast<const long long *>(batch), (int)N, C, rows, reinterpret_cast<_Float16 *>(planes), inv_scale);
   return check_launch();
 }
 

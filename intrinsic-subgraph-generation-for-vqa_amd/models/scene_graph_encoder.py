@@ -77,10 +77,14 @@ class _MetaLayer(torch.nn.Module):
         row, col = edge_index[0].contiguous(), edge_index[1].contiguous()
         P = ops.linear(x, w_nodes, None)                                   # [N, 3C]: W_a x | W_b x | W_x x
         table = ops.linear(embedding.weight, w_tok, None)                  # [V, C]: W_c emb
-        h = ops.gather_add(P[:, :C], row, P[:, C:2 * C], col, table, edge_tokens, edge_sign, bias=em[0].bias, gelu=True)
+        E = row.numel()
+        po = ops.GATHER_ADD_PLANES and ops.h3p_supported(E, em[2].weight.size(0), C)   # the Linear behind a gather-add runs on the planes32
+        h = ops.gather_add(P[:, :C], row, P[:, C:2 * C], col, table, edge_tokens, edge_sign, bias=em[0].bias, gelu=True,
+                           planes_out=po)                                  # engine: its operand leaves the gather-add as planes
         e_new = ops.linear(h, em[2].weight, em[2].bias)                    # :119-120 second layer
         g = ops.linear(e_new, w_e, None)                                   # W_e e'
-        h = ops.gather_add(P[:, 2 * C:], row, D=g, bias=nm[0].bias, gelu=True)
+        po = ops.GATHER_ADD_PLANES and ops.h3p_supported(E, nm[2].weight.size(0), nm[2].weight.size(1))
+        h = ops.gather_add(P[:, 2 * C:], row, D=g, bias=nm[0].bias, gelu=True, planes_out=po)
         m = ops.linear(h, nm[2].weight, nm[2].bias)                        # :139-140
         agg = ops.scatter_mean(m, plan)                                    # :141
         return ops.mlp(self.node_model.node_mlp_2, torch.cat([x, agg], dim=1)), e_new   # :142-143

@@ -1461,13 +1461,16 @@ def derived_weight(tag: str, sources, build):
 
 def gather_add(A: Tensor, ia: Tensor, B: Optional[Tensor] = None, ib: Optional[Tensor] = None, T: Optional[Tensor] = None,
                it: Optional[Tensor] = None, sign: Optional[Tensor] = None, D: Optional[Tensor] = None,
-               bias: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
+               bias: Optional[Tensor] = None, gelu: bool = False, planes_out: bool = False):
     """act(A[ia] + B[ib] + sign * T[it] + D + bias) -> [E, C]: the per-edge remainder of a Linear over
     cat([x[row], x[col], emb]) once its node parts are projected per node (scene_graph_encoder.py:119-120,139-140;
-    csrc/isg_sgenc.hip).  A / B / T / D may be column slices of wider tensors (row stride a multiple of 4)."""
+    csrc/isg_sgenc.hip).  A / B / T / D may be column slices of wider tensors (row stride a multiple of 4).
+    planes_out: the rows as Planes32 only (the operand of the Linear that follows, no split pass, no fp32 rows)."""
     lib = _lib.load()
     E, C = ia.numel(), A.size(1)
-    out = torch.empty(E, C, dtype=torch.float32, device=A.device)
+    out = None if planes_out else torch.empty(E, C, dtype=torch.float32, device=A.device)
+    pl = torch.empty(int(lib.isg_planes32_elems(E, C)), dtype=torch.int16, device=A.device) if planes_out else None
+    pinv = torch.empty(E, dtype=torch.float32, device=A.device) if planes_out else None
 
     def rows(t, name):
         if t is None:
@@ -1491,9 +1494,11 @@ def gather_add(A: Tensor, ia: Tensor, B: Optional[Tensor] = None, ib: Optional[T
         raise ValueError(f"D: expected {E} rows, got {D.size(0)}")
     _lib.check(lib.isg_gather_add(pa, idx(ia, "ia", E), la, pb, idx(ib, "ib", E), lb, pt, idx(it, "it", E),
                                   _chk(None if sign is None else sign.reshape(-1), "sign", torch.float32, (E,), optional=True),
-                                  lt, pd, ld, _chk(bias, "bias", torch.float32, (C,), optional=True), out.data_ptr(), E, C,
-                                  1 if gelu else 0, _stream()), "isg_gather_add")
-    return out
+                                  lt, pd, ld, _chk(bias, "bias", torch.float32, (C,), optional=True),
+                                  0 if out is None else out.data_ptr(), E, C, 1 if gelu else 0,
+                                  0 if pl is None else pl.data_ptr(), 0 if pinv is None else pinv.data_ptr(), _stream()),
+               "isg_gather_add")
+    return Planes32(pl, pinv, E, C) if planes_out else out
 
 
 def invalidate_weight_cache() -> None:
@@ -1806,6 +1811,7 @@ def h3p_supported(M: int, N: int, K: int) -> bool:
 # step (20.09-20.29 ms: profiles/r04_ag_h3p_store_policy.txt) -- what the producer gains by not leaving its result in L2 / the
 # Infinity Cache its consumer loses.  So the default is the library's choice and "auto" stays an experiment.
 H3P_STORE_POLICY = -1
+GATHER_ADD_PLANES = True       # isg_gather_add hands its rows to the Linear behind it as planes32 (A/B switch)
 _h3p_policy_state = {"chosen": None, "us": None}
 
 

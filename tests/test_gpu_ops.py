@@ -1404,6 +1404,36 @@ def test_linear_h3p_matches_fp64_within_fp32_gemm_error(dev, M, N, K, act, bias)
     assert ((got.double() - ref).abs() / scale).max().item() < 2e-6
 
 
+@pytest.mark.parametrize("E,C,full", [(1001, 300, True), (517, 128, False), (3, 44, True)])
+def test_gather_add_rows_and_planes(dev, E, C, full):
+    """isg_gather_add (scene_graph_encoder.py:119-120, 139-140 without the concatenations) against the torch expression, and its
+    planes32 output against isg_split_planes32 of its own fp32 rows: the same bits (same row maximum, scale and split), the
+    columns behind C up to the next multiple of 32 zero."""
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(E + C)
+    Nn, V = 97, 13
+    P = torch.randn(Nn, 3 * C, device=dev, generator=g)
+    A, B = P[:, :C], P[:, C:2 * C]                              # column slices of a wider projection
+    ia = torch.randint(0, Nn, (E,), device=dev, generator=g)
+    ib = torch.randint(0, Nn, (E,), device=dev, generator=g)
+    T = torch.randn(V, C, device=dev, generator=g) if full else None
+    it = torch.randint(0, V, (E,), device=dev, generator=g) if full else None
+    sign = (torch.randint(0, 2, (E,), device=dev, generator=g).float() * 2 - 1) if full else None
+    D = torch.randn(E, C, device=dev, generator=g) * 3 if full else None
+    bias = torch.randn(C, device=dev, generator=g)
+    want = A[ia] + B[ib] + bias
+    if full:
+        want = want + sign[:, None] * T[it] + D
+    want = torch.nn.functional.gelu(want.double()).float()
+    rows = ops.gather_add(A, ia, B, ib, T, it, sign, D, bias=bias, gelu=True)
+    assert (rows - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+    pl = ops.gather_add(A, ia, B, ib, T, it, sign, D, bias=bias, gelu=True, planes_out=True)
+    ref = ops.split_planes32(rows.clone())
+    assert pl.rows == E and pl.cols == C
+    assert torch.equal(pl.inv, ref.inv) and torch.equal(pl.planes, ref.planes)
+    assert torch.equal(ops.planes32_to_rows(pl), ops.planes32_to_rows(ref))
+
+
 @pytest.mark.parametrize("M,N,K", [(40961, 1000, 300), (33000, 1024, 512)])
 def test_linear_h3p_store_policy_changes_speed_only(dev, M, N, K):
     """A large (>= 128 MB) fp32 result leaves isg_linear_h3p under one of three cache policies (isg_linear_h3p_store_policy: plain,

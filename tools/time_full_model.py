@@ -17,6 +17,10 @@ graphs = int(args[0]) if len(args) > 0 else 2048
 steps = int(args[1]) if len(args) > 1 else 20
 if '--policy' in sys.argv:          # isg_linear_h3p's large-result store policy: -1 / 0 / 1 / 2 instead of the measured choice
     ops.H3P_STORE_POLICY = int(pol)
+for a_ in sys.argv[1:]:             # --set=NAME=VALUE: any switch of isubgvqa_amd.ops (A/B runs), e.g. --set=GATHER_ADD_PLANES=False
+    if a_.startswith('--set='):
+        k_, v_ = a_[6:].split('=')
+        setattr(ops, k_, eval(v_))
 if '--no-h3p' in sys.argv:
     ops.H3P = False        # A/B: the round-3 tile kernel for the K >= 256 Linears
 if '--no-chain' in sys.argv:
