@@ -583,10 +583,14 @@ int isg_gather_add(const float *A, const int64_t *ia, int32_t lda, const float *
  * projection (ldq / ldk / ldv: row strides in floats).  key_bias fp32 [B, Tk] or NULL is ADDED to the scores -- the
  * reference passes the HF attention mask as a FLOAT src_key_padding_mask (question_encoder.py:35-37: +1 on real tokens,
  * padding is attended).  out fp32 rows of H * hd columns, stride ldo.
- * rowmax fp32 [Tq * B, H] or NULL: the largest |out| of every (row, head) -- a_rowmax (P = H) of the out_proj Linear. */
+ * rowmax fp32 [Tq * B, H] or NULL: the largest |out| of every (row, head) -- a_rowmax (P = H) of the out_proj Linear.
+ * planes / planes_inv (both or neither; with them `out` may be NULL and rowmax must be): the result ALSO / ONLY as the planes32
+ * operand of isg_linear_h3p (uint16 [isg_planes32_elems(Tq * B, H * hd)], fp32 [Tq * B]) -- one workgroup per batch item then
+ * walks all heads and assembles the item's rows in LDS (Tq * H * hd more floats: ISG_EUNSUPPORTED beyond 64 KB in all), and
+ * out_proj needs no isg_split_planes32 pass. */
 int isg_mha_small(const float *q, int32_t ldq, const float *k, int32_t ldk, const float *v, int32_t ldv,
                   const float *key_bias, float *out, int32_t ldo, float *rowmax, int64_t B, int32_t H, int32_t hd,
-                  int32_t Tq, int32_t Tk, void *stream);
+                  int32_t Tq, int32_t Tk, uint16_t *planes, float *planes_inv, void *stream);
 
 /* out = LayerNorm(x + r) over the last dimension, r optional (NULL): the post-norm step of nn.TransformerEncoderLayer /
  * nn.TransformerDecoderLayer (question_encoder.py:20-38, question_decoder.py:25-71) with the residual add folded in;

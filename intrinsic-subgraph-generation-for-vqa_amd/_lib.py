@@ -69,7 +69,7 @@ SIGNATURES = {
     "isg_gather_add": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_mha_small": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
-                              c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+                              c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_add_layernorm": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_int32,
                                   c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_linear_panel_multi": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,

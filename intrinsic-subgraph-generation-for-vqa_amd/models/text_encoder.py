@@ -59,7 +59,11 @@ def _attention(mha: torch.nn.MultiheadAttention, x_q: Tensor, x_kv: Tensor, B: i
         q = ops.linear(x_q, wq, bq)
         kv = ops.linear(x_kv, wkv, bkv)                                          # [S*B, 2D]
         k, v = kv[:, :D], kv[:, D:]
-    att = ops.mha_small(q, k, v, B, mha.num_heads, key_bias, want_rowmax=True)   # + max |att| per (row, head)
+    Tq, Tk, H = q.size(0) // B, k.size(0) // B, mha.num_heads
+    if ops.mha_rows_supported(Tq, Tk, H, D // H) and ops.h3p_supported(q.size(0), mha.out_proj.weight.size(0), D):
+        att = ops.mha_small(q, k, v, B, H, key_bias, planes_out=True)            # out_proj's operand leaves the kernel as planes32
+    else:
+        att = ops.mha_small(q, k, v, B, H, key_bias, want_rowmax=True)           # + max |att| per (row, head)
     return ops.linear(att, mha.out_proj.weight, mha.out_proj.bias)
 
 

@@ -1932,23 +1932,42 @@ def mha_small_supported(t_kv: int, head_dim: int) -> bool:
     return head_dim <= 64 and head_dim % 4 == 0 and t_kv <= 128 and (t_kv * (3 * head_dim + 4) + 4 * 128) * 4 <= 64 * 1024
 
 
+MHA_ROWS_PLANES = True         # attention results as planes32 where the all-heads form fits (A/B switch)
+
+
+def mha_rows_supported(t_q: int, t_kv: int, heads: int, head_dim: int) -> bool:
+    """The all-heads form of isg_mha_small (one workgroup per batch item, the result rows assembled in LDS and written as
+    planes32): a head's Q / K / V, the score strips and t_q whole rows within 64 KB -- 12-token questions and the decoder's 4
+    queries at d = 512, not CLIP's 77 tokens."""
+    return (MHA_ROWS_PLANES and mha_small_supported(max(t_q, t_kv), head_dim) and
+            (t_kv * (2 * head_dim + 4) + t_q * head_dim + 4 * 128 + t_q * heads * head_dim) * 4 <= 64 * 1024)
+
+
 def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_bias: Optional[Tensor] = None,
-              want_rowmax: bool = False) -> Tensor:
+              want_rowmax: bool = False, planes_out: bool = False):
     """softmax(Q K^T / sqrt(hd) + key_bias) V per (batch item, head) for short sequences (csrc/isg_attn.hip).
     q [Tq*B, D], k / v [Tk*B, D] in torch's [T, B, D] row order (row t*B + b; column slices of a fused projection are
-    fine), key_bias fp32 [B, Tk] additive (question_encoder.py:35-37) -> [Tq*B, D]."""
+    fine), key_bias fp32 [B, Tk] additive (question_encoder.py:35-37) -> [Tq*B, D].
+    planes_out (callers ask mha_rows_supported first): the result as Planes32 only -- out_proj's operand, no split pass."""
     lib = _lib.load()
     B, H, D = int(batch_size), int(heads), q.size(1)
     hd = D // H
     Tq, Tk = q.size(0) // B, k.size(0) // B
     if H * hd != D or Tq * B != q.size(0) or Tk * B != k.size(0) or tuple(v.shape) != tuple(k.shape):
         raise ValueError(f"mha_small: q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)} vs B={B}, H={H}")
+    kb = _chk(key_bias, "key_bias", torch.float32, (B, Tk), optional=True)
+    if planes_out:
+        pl = torch.empty(int(lib.isg_planes32_elems(Tq * B, D)), dtype=torch.int16, device=q.device)
+        pinv = torch.empty(Tq * B, dtype=torch.float32, device=q.device)
+        _lib.check(lib.isg_mha_small(_chk_rows(q, "q"), q.stride(0), _chk_rows(k, "k"), k.stride(0), _chk_rows(v, "v"),
+                                     v.stride(0), kb, 0, D, 0, B, H, hd, Tq, Tk, pl.data_ptr(), pinv.data_ptr(), _stream()),
+                   "isg_mha_small")
+        return Planes32(pl, pinv, Tq * B, D)
     out = torch.empty(Tq * B, D, dtype=torch.float32, device=q.device)
     rm = torch.empty(Tq * B, H, dtype=torch.float32, device=q.device) if want_rowmax else None
     _lib.check(lib.isg_mha_small(_chk_rows(q, "q"), q.stride(0), _chk_rows(k, "k"), k.stride(0), _chk_rows(v, "v"),
-                                 v.stride(0), _chk(key_bias, "key_bias", torch.float32, (B, Tk), optional=True),
-                                 out.data_ptr(), D, 0 if rm is None else rm.data_ptr(), B, H, hd, Tq, Tk, _stream()),
-               "isg_mha_small")
+                                 v.stride(0), kb, out.data_ptr(), D, 0 if rm is None else rm.data_ptr(), B, H, hd, Tq, Tk, 0, 0,
+                                 _stream()), "isg_mha_small")
     if rm is not None:
         attach_row_maxima(out, rm)
     return out

@@ -562,6 +562,14 @@ def test_mha_small_matches_fp64_attention(dev, B, H, hd, Tq, Tk, bias):
                          want_rowmax=True)
     assert torch.equal(got2, got)
     assert torch.equal(ops.row_maxima(got2), got.view(Tq * B, H, hd).abs().amax(2))      # per (row, head), exact
+    # the all-heads form (one workgroup per batch item, rows assembled in LDS, planes32 out): the same bits as splitting `got`
+    if ops.mha_rows_supported(Tq, Tk, H, hd):
+        pl = ops.mha_small(qkv_d[:, :D], kv_d[:, D:2 * D], kv_d[:, 2 * D:], B, H, None if kb is None else kb.to(dev),
+                           planes_out=True)
+        ref_pl = ops.split_planes32(got.clone())
+        assert torch.equal(pl.inv, ref_pl.inv) and torch.equal(pl.planes, ref_pl.planes)
+    else:
+        assert Tq >= 77 or not ops.MHA_ROWS_PLANES       # only CLIP-length questions fall outside it in this matrix
 
 
 def test_linear_multi_equals_the_separate_projections(dev):
