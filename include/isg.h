@@ -435,6 +435,18 @@ int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w
                           int64_t head_stride_r, const float *att, const int32_t *eid, const int32_t *src, const int32_t *dst,
                           const float *edge_mask, const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C,
                           int32_t K, float negative_slope, void *stream);
+/* isg_gatv2_mp_fwd whose result leaves as the SEGMENTED planes32 operand of isg_linear_h3p instead of fp32 rows: H = 4 and a head
+ * dimension served by the flat per-graph kernel (the reference's C = 300); ISG_EUNSUPPORTED wherever that kernel does not run --
+ * the caller then takes isg_gatv2_mp_fwd and isg_split_planes32.  out_planes uint16 [N][2 * ceil(2 C / 32)][64]; out_inv fp32
+ * [2][N]: the row scales of columns [0, 2C) (a_inv_first of isg_linear_h3p, k_split = 32 * ceil(2 C / 32)) and [2C, 4C) (a_inv).
+ * x_proj.0 (ISubGVQA/models/mgat.py:156) reads it with no pass in between. */
+int isg_gatv2_mp_fwd_planes(const float *x_l, const float *x_r, const float *e_proj, const float *att, const float *bias,
+                            const int32_t *rowptr, const int32_t *eid, const int32_t *src, const float *node_mask,
+                            const float *edge_mask, uint16_t *out_planes, float *out_inv, float *alpha, int64_t N, int64_t E,
+                            int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr, const int32_t *graph_eptr,
+                            const int32_t *dst, int64_t B, int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r,
+                            int32_t ld_e, void *stream);
+
 /* The rest of MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:270-279, :215-232) given those logits: softmax over
  * every destination's in-edges (+1e-16), alpha fp32 [E, H] by edge id, out[i] = sum alpha * mask * x_l[src] + bias, rowmax
  * (optional) as in isg_gatv2_mp_fwd_rowmax.  e_proj and x_r are not read.  Per-graph kernel only: ISG_EUNSUPPORTED for
@@ -545,10 +557,13 @@ int isg_instr_gate_planes32(const float *x, const float *instr, const int64_t *b
  *            scaled by the power of two of the bound
  *            |d[m, :]| < a_inv[m] * d_bound[0] + d_bound[1],  d_bound = {2^14 * max_n ||w_n||_1, max |bias|} on the device
  *            -- the next Linear's `a_planes` / `a_inv` with no pass in between (linear1 -> linear2).
+ * SEGMENTED a (a_inv_first != NULL, k_split > 0 a multiple of 32): columns [0, k_split) of a row are scaled by a_inv_first[m],
+ *   columns [k_split, K) by a_inv[m] -- what isg_gatv2_mp_fwd_planes writes (half rows under their own scales, each padded to
+ *   whole 32-column lines; w laid out to match, zero columns under the padding).  act = 1 and K >= 512, k_split >= 512 only.
  * ISG_EUNSUPPORTED: N % 4 != 0, ldd % 4 != 0, a misaligned pointer, an operand of 2 GB or more. */
 int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, const uint16_t *w_planes, const float *w_inv,
                    const float *bias, float *d, uint16_t *d_planes, float *d_inv, const float *d_bound, int64_t M,
-                   int32_t N, int32_t K, int32_t ldd, int32_t act, void *stream);
+                   int32_t N, int32_t K, int32_t ldd, int32_t act, const float *a_inv_first, int32_t k_split, void *stream);
 /* The cache policy of a LARGE (>= 128 MB) fp32 result's stores in isg_linear_h3p, for the rest of the process: 0 plain, 1 nt,
  * 2 sc0 sc1 nt (write-through, streaming), -1 (the default) the built-in choice: nt at K >= 512, plain below.  Results do not
  * depend on it; the kernel's own time does, by box (profiles/r04_ag_h3p_store_policy.txt), the full model's does not.

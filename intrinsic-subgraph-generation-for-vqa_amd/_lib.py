@@ -92,7 +92,9 @@ SIGNATURES = {
     "isg_planes32_elems": (c_int64, [c_int64, c_int32]),
     "isg_split_planes32": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_instr_gate_planes32": (c_int, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
-    "isg_linear_h3p": (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_linear_h3p": (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "isg_gatv2_mp_fwd_planes": (c_int, [c_void_p] * 13 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                                        c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_linear_h3p_store_policy": (c_int, [c_int32]),
     "isg_tile_plan_capacity": (c_int64, [c_int64, c_int64, c_int64, c_int32, c_int32]),
     "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

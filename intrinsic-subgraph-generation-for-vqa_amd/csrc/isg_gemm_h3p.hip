@@ -100,6 +100,8 @@ struct P3Args {
   float *d_inv;                   // [M]
   const float *d_bound;           // {2^14 * max_n ||W_n||_1, max |b|}: |D[m, :]| < inv_a[m] * d_bound[0] + d_bound[1]
   int M, N, KT, ldd, tiles_n, nt_store;
+  const float *a_inv0;            // SEGMENTED A (persistent form): the row scales of k-tiles [0, kseg); a_inv then holds those of
+  int kseg;                       // [kseg, KT).  NULL / 0: one scale per row
 };
 
 template <int ACT, bool PLANES_OUT>
@@ -321,8 +323,8 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
 constexpr int Q3_BM = 256, Q3_BN = 128;
 constexpr int Q3_BUF = 3 * P3_SLOT;            // A-lo, A-hi, B
 constexpr int Q3_RING = 3 * Q3_BUF;            // 147456
-constexpr int Q3_PAR = 2048;                   // per tile: a_inv[256] | w_inv[128] | bias[128]
-constexpr int Q3_SMEM = Q3_RING + 3 * Q3_PAR + 256;  // 153856 (the last 256 bytes: a scratch line)
+constexpr int Q3_PAR = 4096;                   // per tile: a_inv[256] | w_inv[128] | bias[128] | segmented A only: a_inv0[256] | max(a_inv0, a_inv)[256]
+constexpr int Q3_SMEM = Q3_RING + 3 * Q3_PAR + 256;  // 160000 (the last 256 bytes: a scratch line)
 constexpr int Q3_HEAD = 8;                     // fewest k-tiles per tile: 16 accumulator tiles leave two per k-tile (K < 512), else one per k-tile over 16
 
 struct Q3Args {
@@ -330,7 +332,11 @@ struct Q3Args {
   int tiles_m, total_l;                        // row tiles; tiles_n * roundup8(tiles_m)
 };
 
-template <int ACT, bool PLANES_OUT, int HEAD>
+// SEG: the A operand's k-tiles [0, kseg) and [kseg, KT) carry different row scales (a_inv0 / a_inv: the flat message-passing
+// kernel writes half rows, each under its own scale).  The accumulators are in units of the first scale until k-tile kseg, where
+// they are multiplied by a_inv0 / a_inv -- a power of two, exact -- and from there in units of the second, which the epilogue
+// undoes as always.  kseg >= HEAD: the k-tiles that carry pieces are unrolled and know nothing of it.
+template <int ACT, bool PLANES_OUT, int HEAD, bool SEG = false>
 __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args qa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char p3_smem[];
   const P3Args &a = qa.p;
@@ -410,6 +416,11 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
                                                : a.bias + min((pn0) + (wave & 1) * 64 + lane, a.N - 1);            \
     const int dst = wave < 4 ? wave * 256 : wave < 6 ? 1024 + (wave & 1) * 256 : 1536 + (wave & 1) * 256;          \
     __builtin_amdgcn_global_load_lds((p3_glb_t *)src, (p3_lds_t *)(p3_smem + Q3_RING + (region) * Q3_PAR + dst), 4, 0, 0); \
+    if constexpr (SEG) {      /* every wave a second request (the counted waits are per wave and uniform): a_inv0 by waves 0-3, */ \
+      const float *src0 = a.a_inv0 + min((pm0) + (wave & 3) * 64 + lane, a.M - 1);      /* again, identically, by waves 4-7 */ \
+      __builtin_amdgcn_global_load_lds((p3_glb_t *)src0,                                                           \
+                                       (p3_lds_t *)(p3_smem + Q3_RING + (region) * Q3_PAR + 2048 + (wave & 3) * 256), 4, 0, 0); \
+    }                                                                                                              \
   }
 
   // ---- fragment addresses ----------------------------------------------------------------------------------------------
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   // contiguous bytes per plane: two stores per lane and pair, the store count and width of the fp32 path (the first form
   // stored two 8-byte pieces per tile: 380 us where the fp32 result took 246).  Columns in [N, roundup32(N)) are the NEXT
   // Linear's k padding: written as zeros.
-#define Q3_PAIR_VAL(h16, m16, i, j0, b4a, b4b)                                                      \
+#define Q3_PAIR_VAL(h16, m16, i, j0, b4a, b4b, ibnd)                                                      \
   {                                                                                                                \
     const int q = lane >> 4, cl = wn * 64 + (j0) * 16 + 4 * q;                                                     \
     float4 va, vb;                                                                                                 \
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     if (rn0 + cl >= a.N) va = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
     if (rn0 + cl + 16 >= a.N) vb = make_float4(0.f, 0.f, 0.f, 0.f);                                                \
     float so, inv;                                                                                                 \
-    h3_scale(p_ia[i] * d_bound0 + d_bound1, so, inv);                                                              \
+    h3_scale((ibnd) * d_bound0 + d_bound1, so, inv);                                                               \
     va.x *= so; va.y *= so; va.z *= so; va.w *= so; vb.x *= so; vb.y *= so; vb.z *= so; vb.w *= so;                \
     const hf16x4 ha = {(_Float16)va.x, (_Float16)va.y, (_Float16)va.z, (_Float16)va.w};                            \
     const hf16x4 hb = {(_Float16)vb.x, (_Float16)vb.y, (_Float16)vb.z, (_Float16)vb.w};                            \
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     h16 = even ? p3_i32x4{hka[0], hka[1], hr[0], hr[1]} : p3_i32x4{hr[0], hr[1], hkb[0], hkb[1]};                  \
     m16 = even ? p3_i32x4{mka[0], mka[1], mr[0], mr[1]} : p3_i32x4{mr[0], mr[1], mkb[0], mkb[1]};                  \
   }
-#define Q3_PAIR_OFF(off, ioff, inv, i, j0, live)                                                                   \
+#define Q3_PAIR_OFF(off, ioff, inv, i, j0, live, ibnd)                                                                   \
   {                                                                                                                \
     const int npad = (a.N + 31) & ~31;                                                                             \
     const int q = lane >> 4, rl = wm * 64 + (i) * 16 + (lane & 15);                                                \
@@ -548,7 +559,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     off = ok ? ((unsigned)(rm0 + rl) * (unsigned)(npad * 2) + (unsigned)((gcol >> 5) * 64 + chunk * 8)) * 2u : 0xFFFFFFF0u; \
     ioff = ((int)ok & (int)(gcol == 0) & (int)(q == 0)) ? (unsigned)(rm0 + rl) * 4u : 0xFFFFFFF0u;                 \
     float so_;                                                                                                     \
-    h3_scale(p_ia[i] * d_bound0 + d_bound1, so_, inv);                                                             \
+    h3_scale((ibnd) * d_bound0 + d_bound1, so_, inv);                                                              \
   }
   // (the row's inverse scale leaves with the row's first column group -- ioff is valid in that pair's lanes only: one more
   // store in the waves of the first column tile; the counted waits then allow one operation fewer in flight than there are,
@@ -584,6 +595,36 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 #define Q3_BIAS_REQ(bq, j)                                                                                         \
   asm volatile("ds_read_b128 %0, %1 offset:1536" : "=&v"(bq)                                                       \
                : "v"(lds0 + Q3_RING + rpar * Q3_PAR + (wn * 64 + (j) * 16 + 4 * (lane >> 4)) * 4) : "memory");
+  // segmented A, planes32 result: the row's LARGER inverse scale (what the result's bound needs), left in the a_inv0 slot of the
+  // tile's parameter region by Q3_RESCALE (its own slot: the two wave groups pass the boundary a segment apart and each
+  // needs a_inv0 intact)
+#define Q3_BND_REQ(ib, i)                                                                                          \
+  asm volatile("ds_read_b32 %0, %1 offset:3072" : "=&v"(ib)                                                        \
+               : "v"(lds0 + Q3_RING + rpar * Q3_PAR + (wm * 64 + (i) * 16 + (lane & 15)) * 4) : "memory");
+  // k-tile kseg of a segmented A operand: the accumulators pass from units of a_inv0 to units of a_inv (see SEG above)
+#define Q3_RESCALE()                                                                                               \
+  {                                                                                                                \
+    const unsigned pa_ = lds0 + Q3_RING + cpar * Q3_PAR + (wm * 64 + (lane & 15)) * 4;                             \
+    float i1_[4], i0_[4];                                                                                          \
+    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\t"          \
+                 "ds_read_b32 %3, %8 offset:192\n\t"                                                               \
+                 "ds_read_b32 %4, %8 offset:2048\n\tds_read_b32 %5, %8 offset:2112\n\tds_read_b32 %6, %8 offset:2176\n\t" \
+                 "ds_read_b32 %7, %8 offset:2240\n\t"                                                              \
+                 "s_waitcnt lgkmcnt(0)"                                                                            \
+                 : "=&v"(i1_[0]), "=&v"(i1_[1]), "=&v"(i1_[2]), "=&v"(i1_[3]), "=&v"(i0_[0]), "=&v"(i0_[1]),       \
+                   "=&v"(i0_[2]), "=&v"(i0_[3])                                                                    \
+                 : "v"(pa_) : "memory");                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+      /* both are powers of two: their quotient by exponent arithmetic, exact */                                   \
+      const float r_ = __uint_as_float(__float_as_uint(i0_[i]) - __float_as_uint(i1_[i]) + 0x3F800000u);           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] *= r_;                                               \
+      i0_[i] = fmaxf(i0_[i], i1_[i]);                                                                              \
+    }                                                                                                              \
+    asm volatile("ds_write_b32 %4, %0 offset:3072\n\tds_write_b32 %4, %1 offset:3136\n\tds_write_b32 %4, %2 offset:3200\n\t" \
+                 "ds_write_b32 %4, %3 offset:3264\n\t"                                                             \
+                 "s_waitcnt lgkmcnt(0)"                                                                            \
+                 :: "v"(i0_[0]), "v"(i0_[1]), "v"(i0_[2]), "v"(i0_[3]), "v"(pa_) : "memory");                      \
+  }
 #define Q3_BAR                                                                                                     \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   __builtin_amdgcn_s_barrier();                                                                                    \
@@ -606,7 +647,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   // the load segment before.  (Also built and measured, same-box A/B in DESIGN 15.1: the finished piece held in its registers
   // and stored behind the NEXT load segment's requests -- every segment then issues a store, dropped when nothing is pending,
   // and the K = 2048 shape lost 7 % to those.)
-#define Q3_M_PIECE(ah, TI, TJ, BQ0, BQ1)                                                                           \
+#define Q3_M_PIECE(ah, TI, TJ, BQ0, BQ1, IB)                                                                        \
   __builtin_amdgcn_s_waitcnt(0xC07F);                                                                              \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   Q3_ST(3 + 7 * (ah))                                                                                              \
@@ -615,8 +656,8 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     p3_i32x4 h16_, m16_;                                                                                           \
     unsigned off_, ioff_;                                                                                          \
     float inv_;                                                                                                    \
-    Q3_PAIR_VAL(h16_, m16_, TI, TJ, BQ0, BQ1)                                                                      \
-    Q3_PAIR_OFF(off_, ioff_, inv_, TI, TJ, has_res)                                                                \
+    Q3_PAIR_VAL(h16_, m16_, TI, TJ, BQ0, BQ1, IB)                                                                  \
+    Q3_PAIR_OFF(off_, ioff_, inv_, TI, TJ, has_res, IB)                                                            \
     Q3_MMA(ah)                                                                                                     \
     Q3_INTERLEAVE()                                                                                                \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
@@ -659,7 +700,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   // (a workgroup's first tile has no `res` yet: its pieces run on zeros and their stores are dropped like any lane outside D)
 #define Q3_S0(kh, NP, hd) (((hd) && (kh) >= 0 && !PLANES_OUT && (NP) == 2) ? 1 : 0)
 #define Q3_S1(kh, NP, hd) (((hd) && (kh) >= 0) ? (PLANES_OUT ? (((NP) == 2 || ((kh) & 1)) ? 2 : 0) : 1) : 0)
-#define Q3_PC(kh, hd) (((hd) && (kh) == 0) ? 1 : 0)
+#define Q3_PC(kh, hd) (((hd) && (kh) == 0) ? (SEG ? 2 : 1) : 0)
 #define Q3_KT(kh, NP, is_head)                                                                                     \
   {                                                                                                                \
     constexpr int w0s = Q3_S1((kh) - 2, NP, is_head) + Q3_S0((kh) - 1, NP, is_head) + Q3_S1((kh) - 1, NP, is_head); \
@@ -679,12 +720,14 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     Q3_ST(1)                                                                                                       \
     Q3_BAR                                                                                                         \
     Q3_ST(2)                                                                                                       \
-    if constexpr (pc0) { Q3_M_PIECE(0, (ta & 15) >> 2, ta & 3, bq0, bq0) } else { Q3_M(0) }                        \
+    if constexpr (pc0) { Q3_M_PIECE(0, (ta & 15) >> 2, ta & 3, bq0, bq0, p_ia[(ta & 15) >> 2]) } else { Q3_M(0) }  \
     Q3_READ_A(1)                                                                                                   \
     if (pc1 && a.bias) {                                                                                           \
       Q3_BIAS_REQ(bq0, tb & 3)                                                                                     \
       if (PLANES_OUT) Q3_BIAS_REQ(bq1, (tb + 1) & 3)                                                               \
     }                                                                                                              \
+    float ib_ = p_ia[(tb & 15) >> 2];                                                                              \
+    if constexpr (SEG && PLANES_OUT && pc1) Q3_BND_REQ(ib_, (tb & 15) >> 2)                                        \
     if ((is_head) && (kh) == 0) Q3_PARAMS(nm0, nn0, npar)                                                          \
     Q3_STAGE_P1()                                                                                                  \
     Q3_ST(7)                                                                                                       \
@@ -693,7 +736,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     Q3_ST(8)                                                                                                       \
     Q3_BAR                                                                                                         \
     Q3_ST(9)                                                                                                       \
-    if constexpr (pc1) { Q3_M_PIECE(1, (tb & 15) >> 2, tb & 3, bq0, bq1) } else { Q3_M(1) }                        \
+    if constexpr (pc1) { Q3_M_PIECE(1, (tb & 15) >> 2, tb & 3, bq0, bq1, ib_) } else { Q3_M(1) }                   \
     cb = cb == 2 * Q3_BUF ? 0 : cb + Q3_BUF;                                                                       \
   }
 
@@ -723,7 +766,10 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
       Q3_KT(6, 2, true) Q3_KT(7, 2, true)
     }
 #pragma unroll 1
-    for (int kt = HEAD; kt < nk; ++kt) Q3_KT(0, 0, false)
+    for (int kt = HEAD; kt < nk; ++kt) {
+      if constexpr (SEG) if (kt == a.kseg) Q3_RESCALE()
+      Q3_KT(0, 0, false)
+    }
     Q3_TILE_END()
     has_res = true;
     rm0 = cm0; rn0 = cn0; rpar = cpar;
@@ -746,9 +792,14 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
       if constexpr (PLANES_OUT) {
         p3_i32x4 h16_, m16_;
         unsigned off_, ioff_;
-        float inv_;
-        Q3_PAIR_VAL(h16_, m16_, i, j, bqa, bqb)
-        Q3_PAIR_OFF(off_, ioff_, inv_, i, j, true)
+        float inv_, ib_ = p_ia[i];
+        if constexpr (SEG) {
+          Q3_BND_REQ(ib_, i)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        Q3_PAIR_VAL(h16_, m16_, i, j, bqa, bqb, ib_)
+        Q3_PAIR_OFF(off_, ioff_, inv_, i, j, true, ib_)
         Q3_PAIR_ST(h16_, m16_, off_, ioff_, inv_)
       } else {
         hf32x4 va_, vb_;
@@ -765,6 +816,8 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
 #undef Q3_KT
 #undef Q3_TILE_END
 #undef Q3_BIAS_REQ
+#undef Q3_BND_REQ
+#undef Q3_RESCALE
 #undef Q3_STORES
 #undef Q3_PAIR_ST
 #undef Q3_PAIR_VAL
@@ -844,8 +897,11 @@ extern "C" int isg_instr_gate_planes32(const float *x, const float *instr, const
 // ISG_EUNSUPPORTED: N % 4, ldd % 4, misaligned pointers, an operand of 2 GB or more.
 extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, const uint16_t *w_planes, const float *w_inv,
                               const float *bias, float *d, uint16_t *d_planes, float *d_inv, const float *d_bound, int64_t M,
-                              int32_t N, int32_t K, int32_t ldd, int32_t act, void *stream) {
-  if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return ISG_EINVAL;
+                              int32_t N, int32_t K, int32_t ldd, int32_t act, const float *a_inv_first, int32_t k_split,
+                              void *stream) {
+  if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 2 || k_split < 0 || (k_split & 31) || k_split >= K ||
+      (a_inv_first != nullptr) != (k_split > 0))
+    return ISG_EINVAL;
   const bool planes_out = d == nullptr;
   if (planes_out ? (!d_planes || !d_inv || !d_bound) : (d_planes || d_inv || ldd < N)) return ISG_EINVAL;
   if (M == 0) return ISG_OK;
@@ -863,6 +919,7 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   a.A = reinterpret_cast<const _Float16 *>(a_planes); a.W = reinterpret_cast<const _Float16 *>(w_planes);
   a.a_inv = a_inv; a.w_inv = w_inv; a.bias = bias; a.D = d; a.Dp = reinterpret_cast<_Float16 *>(d_planes); a.d_inv = d_inv;
   a.d_bound = d_bound; a.M = (int)M; a.N = N; a.KT = KT; a.ldd = ldd; a.tiles_n = (int)tn;
+  a.a_inv0 = a_inv_first; a.kseg = k_split >> 5;
   static const long long nt_mb = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return e ? atoll(e) : 128ll; }();
   const bool large = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
   const int forced = g_h3p_store_policy.load(std::memory_order_relaxed);
@@ -870,6 +927,9 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   hipStream_t st = as_stream(stream);
   static const int version = [] { const char *e = getenv("ISG_H3P_V"); return e ? atoi(e) : 2; }();
   if (planes_out && (N & 31) && (version == 1 || KT < Q3_HEAD)) return ISG_EUNSUPPORTED;   // the 256 x 256 form pads no columns
+  // a segmented A operand: the persistent form's instantiations with an exact GELU (x_proj.0 of mgat.py:156), the boundary behind
+  // the k-tiles that carry result pieces
+  if (a.kseg && (version == 1 || KT < 16 || a.kseg < 16 || act != 1)) return ISG_EUNSUPPORTED;
   if (version != 1 && KT >= Q3_HEAD) {       // persistent 256 x 128 form
     // the result is addressed through a buffer descriptor with 32-bit byte offsets
     if ((planes_out ? M * (int64_t)(((N + 31) & ~31) * 4) : M * (int64_t)ldd * 4) >= (1ll << 32) - 16) return ISG_EUNSUPPORTED;
@@ -889,7 +949,15 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
     linear_h3q_kernel<ACT_, PO_, H_><<<grid, P3_THREADS, Q3_SMEM, st>>>(q);                                       \
   } while (0)
 #define ISG_Q3(ACT_, PO_, slot) do { if (KT >= 16) ISG_Q3H(ACT_, PO_, 16); else ISG_Q3H(ACT_, PO_, 8); } while (0)
-    if (planes_out) {
+    if (a.kseg) {
+      if (planes_out) {
+        if (!dyn_lds_ok<&linear_h3q_kernel<1, true, 16, true>>(Q3_SMEM)) return ISG_ELAUNCH;
+        linear_h3q_kernel<1, true, 16, true><<<grid, P3_THREADS, Q3_SMEM, st>>>(q);
+      } else {
+        if (!dyn_lds_ok<&linear_h3q_kernel<1, false, 16, true>>(Q3_SMEM)) return ISG_ELAUNCH;
+        linear_h3q_kernel<1, false, 16, true><<<grid, P3_THREADS, Q3_SMEM, st>>>(q);
+      }
+    } else if (planes_out) {
       if (act == 1) ISG_Q3(1, true, 6); else if (act == 2) ISG_Q3(2, true, 7); else ISG_Q3(0, true, 8);
     } else {
       if (act == 1) ISG_Q3(1, false, 9); else if (act == 2) ISG_Q3(2, false, 10); else ISG_Q3(0, false, 11);

@@ -275,10 +275,11 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
                   const float *edge_mask, void *out, float *alpha, int64_t N, int64_t E, int32_t H, int32_t C,
                   float negative_slope, const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst,
                   int64_t B, int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e,
-                  void *stream, int f16, float *rowmax = nullptr, const float *logits = nullptr) {
+                  void *stream, int f16, float *rowmax = nullptr, const float *logits = nullptr, uint16_t *planes = nullptr,
+                  float *planes_inv = nullptr) {
   if (N < 0 || E < 0 || H <= 0 || C <= 0) return ISG_EINVAL;
   if (N == 0) return ISG_OK;
-  if (!x_l || !att || !rowptr || !out || (E > 0 && (!eid || !src || !alpha))) return ISG_EINVAL;
+  if (!x_l || !att || !rowptr || (!out && !planes) || (E > 0 && (!eid || !src || !alpha))) return ISG_EINVAL;
   if (!logits && (!x_r || (E > 0 && !e_proj))) return ISG_EINVAL;      // with logits handed in, e_proj and x_r are not read
   if ((C & 3) != 0 || N >= (1ll << 31) || E >= (1ll << 31)) return ISG_EUNSUPPORTED;
   if (ld_l == 0) ld_l = H * C;
@@ -298,6 +299,8 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
   a.f16 = f16;
   a.rowmax = rowmax;
   a.logits = logits;
+  a.planes = planes; a.planes_inv = planes_inv;
+  a.planes_kt = 2 * ((2 * (C >> 2) + 7) >> 3);      // two half rows of 2 C columns, each padded to whole 32-column lines
   static const int mp_flags = [] { const char *f = getenv("ISG_MP_FLAGS"); return f ? atoi(f) : ISG_MP_DEFAULT_FLAGS; }();
   a.flags = mp_flags;          // experiment switch, read once; default = tuned setting
   a.nchunks = 0;
@@ -306,7 +309,7 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
     int rc = launch_mp_graph(a, nmax_host, emax_host, st);
     if (rc != ISG_EUNSUPPORTED) return rc;   // shapes without a per-graph instantiation use the node-chunk kernel
   }
-  if (rowmax || logits) return ISG_EUNSUPPORTED;   // row maxima out / logits in: the grouped per-graph kernel only
+  if (rowmax || logits || planes) return ISG_EUNSUPPORTED;   // row maxima out / logits in / planes out: per-graph kernels only
   if (f16) return ISG_EUNSUPPORTED;          // fp16 rows exist in the per-graph kernel only
   switch (H) {
     case 1: return launch_mp<1>(a, st);
@@ -395,6 +398,24 @@ extern "C" int isg_gatv2_mp_fwd_rowmax(const float *x_l, const float *x_r, const
   if (!rowmax) return ISG_EINVAL;
   return mp_fwd(x_l, x_r, e_proj, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
                 negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, ld_r, ld_e, stream, 0, rowmax);
+}
+
+// isg_gatv2_mp_fwd whose result leaves as the SEGMENTED planes32 operand of isg_linear_h3p instead of fp32 rows (H = 4, the flat
+// per-graph kernel of head dimensions like the reference's C = 300; ISG_EUNSUPPORTED wherever that kernel does not run -- the
+// caller then takes isg_gatv2_mp_fwd and isg_split_planes32): out_planes uint16 [N][2 * ceil(2 C / 32)][64], out_inv fp32 [2][N]
+// = the row scales of columns [0, 2C) and [2C, 4C).  x_proj.0 (mgat.py:156) reads it with no pass in between.
+extern "C" int isg_gatv2_mp_fwd_planes(const float *x_l, const float *x_r, const float *e_proj, const float *att,
+                                       const float *bias, const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                       const float *node_mask, const float *edge_mask, uint16_t *out_planes, float *out_inv,
+                                       float *alpha, int64_t N, int64_t E, int32_t H, int32_t C, float negative_slope,
+                                       const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst, int64_t B,
+                                       int32_t nmax_host, int32_t emax_host, int32_t ld_l, int32_t ld_r, int32_t ld_e,
+                                       void *stream) {
+  if (!out_planes || !out_inv) return ISG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(out_planes) & 15) != 0 || H != 4) return ISG_EUNSUPPORTED;
+  return mp_fwd(x_l, x_r, e_proj, att, bias, rowptr, eid, src, node_mask, edge_mask, nullptr, alpha, N, E, H, C,
+                negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, ld_r, ld_e, stream, 0, nullptr,
+                nullptr, out_planes, out_inv);
 }
 
 // isg_gatv2_mp_fwd with the attention logits handed in (fp32 [E, H] in CSR slot order, from isg_gatv2_edge_logits)

@@ -33,6 +33,10 @@ struct MpArgs {
                           // NULL.  When given, the logit phase (and with it e_proj and x_r) is skipped
   float *rowmax;          // per-graph kernel, fp32 rows: largest |out| per (node, head) [N, H], or NULL: the row scales of
                           // the fp16 three-product GEMM that consumes `out` (isg_linear_f16x3_tile) come from here
+  uint16_t *planes;       // flat per-graph kernel (H = 4, two heads per workgroup), instead of `out`: the result as the SEGMENTED
+  float *planes_inv;      // planes32 operand of isg_linear_h3p -- columns [0, 2C) and [2C, 4C) each padded to whole 32-column
+  int planes_kt;          // lines and each under its own row scale planes_inv[segment * N + node] (a workgroup owns two heads:
+                          // it knows that half row's largest magnitude, not the whole row's); planes_kt = lines per row
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -28,6 +28,7 @@
 // workgroup; rows of a larger graph are read from global memory under a wave-uniform branch.  A source id outside
 // its graph (never produced by PyG batching) is clamped into the graph instead of faulting.
 #include "isg_mp.hpp"
+#include "isg_f16x3.hpp"
 
 #include <stdlib.h>
 
@@ -448,6 +449,42 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_flat_kernel(MpArgs 
       }
     }
     const size_t orow = (size_t)(nb + k) * R + hoff;
+    if (a.planes) {
+      // the half row (this workgroup's two heads) as planes32 lines under its own scale: x_proj.0 reads the result from
+      // these, with no fp32 copy and no split pass in between (isg_linear_h3p's segmented A operand)
+      float mx = 0.f;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (ok[p]) {
+          if (a.bias) {
+            const float4 b = a.bias[hoff + off[p]];
+            acc[p].x += b.x; acc[p].y += b.y; acc[p].z += b.z; acc[p].w += b.w;
+          }
+          mx = fmaxf(mx, fmaxf(fmaxf(fabsf(acc[p].x), fabsf(acc[p].y)), fmaxf(fabsf(acc[p].z), fabsf(acc[p].w))));
+        }
+      }
+      mx = wave_max(mx);
+      float sc, inv;
+      h3_scale(mx, sc, inv);
+      if (lane == 0) a.planes_inv[(size_t)hg * a.N + nb + k] = inv;
+      const int seg_kt = (RQ + 7) >> 3;
+      _Float16 *pl = reinterpret_cast<_Float16 *>(a.planes) + ((size_t)(nb + k) * a.planes_kt + (size_t)hg * seg_kt) * 64;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = lane + 64 * p;
+        if (i < seg_kt * 8) {                    // beyond the half row: the zeros of its k padding
+          float4 t = ok[p] ? acc[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+          t.x *= sc; t.y *= sc; t.z *= sc; t.w *= sc;
+          const hf16x4 hi = {(_Float16)t.x, (_Float16)t.y, (_Float16)t.z, (_Float16)t.w};
+          const hf16x4 mid = {(_Float16)(t.x - (float)hi[0]), (_Float16)(t.y - (float)hi[1]), (_Float16)(t.z - (float)hi[2]),
+                              (_Float16)(t.w - (float)hi[3])};
+          _Float16 *d = pl + (i >> 3) * 64 + (i & 7) * 4;
+          *reinterpret_cast<hf16x4 *>(d) = hi;
+          *reinterpret_cast<hf16x4 *>(d + 32) = mid;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       if (ok[p]) {
@@ -495,6 +532,7 @@ static int launch_flat_sized(MpArgs a, int nmax_host, hipStream_t st) {
 // fp32 rows, scene-graph sized graphs (64 nodes / 256 edges): HS heads per workgroup, P = ceil(HS * C / 256) passes
 static int launch_mp_graph_flat(const MpArgs &a, int nmax_host, int emax_host, hipStream_t st) {
   if (a.f16 || nmax_host > GK_NCAP_S || emax_host > GK_ECAP_S || (a.H & 1)) return ISG_EUNSUPPORTED;
+  if (a.planes && a.H != 4) return ISG_EUNSUPPORTED;      // two segments = two workgroups of two heads each
   const int RQ = 2 * (a.C >> 2);
   const int P = (RQ + 63) / 64;
   if (P == 3) return launch_flat_sized<2, 3, GK_NCAP_S, GK_ECAP_S>(a, nmax_host, st);
@@ -564,6 +602,7 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
     }
     return ISG_EUNSUPPORTED;      // node-chunk kernel
   }
+  if (a.planes) return ISG_EUNSUPPORTED;      // the segmented planes32 result exists in the flat kernel only
 #define ISG_GK(hs, p) if (HS == hs && P == p) return launch_one<hs, p>(a, nmax_host, emax_host, st)
   ISG_GK(1, 1); ISG_GK(1, 2);
   ISG_GK(2, 1); ISG_GK(2, 2);

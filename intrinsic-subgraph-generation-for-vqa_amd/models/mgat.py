@@ -62,6 +62,16 @@ class MGAT(torch.nn.Module):
         for bn in self.bns:
             bn.reset_parameters()
 
+    def _x_proj_reads_planes(self, i: int, rows: int, explainer: bool) -> bool:
+        """x_proj[i] = Linear, GELU(exact), ... with its first Linear on the planes32 engine: the convolution may hand its result
+        over as segmented planes32 (ops.gatv2_mp want_planes) instead of fp32 rows."""
+        seq = self.x_proj[i]
+        if explainer or torch.is_grad_enabled() or not isinstance(seq, torch.nn.Sequential) or len(seq) < 2:
+            return False
+        lin, act = seq[0], seq[1]
+        return (isinstance(lin, torch.nn.Linear) and isinstance(act, torch.nn.GELU) and act.approximate == "none" and
+                ops.MP_PLANES and ops.h3p_supported(rows, lin.weight.size(0), lin.weight.size(1)))
+
     def forward(self, x, edge_index, instr_vectors, global_language_feats, edge_attr, batch, return_masks=False,
                 explainer=False, explainer_stage=False, expl_bypass_x=False, plan: Optional[ops.GraphPlan] = None,
                 noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
@@ -96,7 +106,8 @@ class MGAT(torch.nn.Module):
                 return_masks=return_masks, return_attention_weights=True, imle_att=glf, all_instrs=instr_vectors,
                 plan=plan, noise=None if noises is None else noises.get(i),
                 seed=None if seed is None else seed + i,
-                e_proj=None if e_projs is None else e_projs[i], x_gated=x_gated, x_planes=x_planes)      # :144-154
+                e_proj=None if e_projs is None else e_projs[i], x_gated=x_gated, x_planes=x_planes,
+                out_planes=self._x_proj_reads_planes(i, h.size(0), explainer))                           # :144-154
             x_gated = x_planes = None
             if return_attention:
                 edge_attns.append(edge_att)
@@ -107,7 +118,7 @@ class MGAT(torch.nn.Module):
             elif self.interpretable_mode and mask is not None:                           # :176-177
                 tail_mask = mask
             bn = self.bns[i]
-            if (conv_res.dtype == torch.float32 and not explainer
+            if (isinstance(conv_res, Tensor) and conv_res.dtype == torch.float32 and not explainer
                     and ops.dense_tail_supported(plan, self.x_proj[i], wide, self.convs[0].out_channels)):
                 # x_proj + instruction attention + GraphNorm + residual (+ mask) + the NEXT layer's instruction gate: one
                 # launch on graph-aligned row tiles (csrc/isg_layer_tile.hip); :156-177 and mgat_v2_conv.py:156-157

@@ -112,7 +112,9 @@ class MaskingGATv2Conv(torch.nn.Module):
                 return_attention_weights: bool = None, return_masks: bool = None, all_instrs=None,
                 plan: Optional[ops.GraphPlan] = None, noise: Optional[Tensor] = None, seed: Optional[int] = None,
                 e_proj: Optional[Tensor] = None, x_gated: Optional[Tensor] = None,
-                x_planes: Optional["ops.NodePlanes"] = None):
+                x_planes: Optional["ops.NodePlanes"] = None, out_planes: bool = False):
+        # out_planes (inference): the caller feeds the result to a Linear + GELU on the planes32 engine (MGAT's x_proj.0) and
+        # takes it as a segmented ops.Planes32 where the message-passing kernel can write that (H = 4, the flat kernel)
         H, C = self.heads, self.out_channels
         if x.dim() != 2:
             raise ValueError("x must be [N, C]")
@@ -188,7 +190,8 @@ class MaskingGATv2Conv(torch.nn.Module):
             if edge_attr.dim() == 1:
                 edge_attr = edge_attr.view(-1, 1)
             e_proj = ops.linear(edge_attr.float().contiguous(), self.lin_edge.weight, None, out_dtype=fdt)   # :259
-        return done(*ops.gatv2_mp(x_l, x_r, e_proj, self.att, plan, H, want_rowmax=not torch.is_grad_enabled(), **kw))  # :215-232
+        return done(*ops.gatv2_mp(x_l, x_r, e_proj, self.att, plan, H, want_rowmax=not torch.is_grad_enabled(),
+                                  want_planes=out_planes and not torch.is_grad_enabled(), **kw))          # :215-232
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"

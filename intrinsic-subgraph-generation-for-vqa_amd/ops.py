@@ -528,10 +528,14 @@ MP_KERNEL = "graph"    # "graph": per-graph LDS-resident kernel; "chunk": node-c
 
 def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphPlan, heads: int,
              bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None,
-             negative_slope: float = 0.2, kernel: Optional[str] = None, want_rowmax: bool = False) -> Tuple[Tensor, Tensor]:
+             negative_slope: float = 0.2, kernel: Optional[str] = None, want_rowmax: bool = False,
+             want_planes: bool = False) -> Tuple[Tensor, Tensor]:
     """MaskingGATv2Conv.message + aggregate (mgat_v2_conv.py:243-279).  Returns (out[N,H*C], alpha[E,H]).
     want_rowmax (inference, fp32 rows): the kernel also writes max |out| per (node, head) and `out` carries it as
-    ``out._isg_rowmax`` [N, H] -- the row scales of the fp16 three-product GEMM that reads `out` next (x_proj)."""
+    ``out._isg_rowmax`` [N, H] -- the row scales of the fp16 three-product GEMM that reads `out` next (x_proj).
+    want_planes (inference, fp32 rows, H = 4): where the flat per-graph kernel runs (the reference's C = 300), `out` comes back
+    as a SEGMENTED Planes32 -- the operand of x_proj.0 on isg_linear_h3p with no fp32 copy and no split pass; anywhere else the
+    fp32 rows as always."""
     if _rec(x_l, x_r, e_proj, att, bias, node_mask, edge_mask):
         from . import autograd
         return autograd.gatv2_mp(x_l, x_r, e_proj, att, plan, heads, bias, node_mask, edge_mask, negative_slope, kernel)
@@ -560,6 +564,25 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None,
                                   "feat_bytes": 2 if fdt == torch.float16 else 4})
         ev0.record()
+    if want_planes and MP_PLANES and use_graph and fdt == torch.float32 and E > 0 and H == 4 and C % 4 == 0:
+        seg = 2 * C
+        st = (seg + 31) // 32
+        pl = torch.empty(N * 2 * st * 64, dtype=torch.int16, device=x_l.device)
+        pinv = torch.empty(2, N, dtype=torch.float32, device=x_l.device)
+        rc = lib.isg_gatv2_mp_fwd_planes(
+            _chk_rows(x_l, "x_l", fdt), _chk_rows(x_r, "x_r", fdt), _chk_rows(e_proj, "e_proj", fdt),
+            _chk(att.reshape(-1), "att", torch.float32, (HC,)),
+            _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+            plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(),
+            _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),
+            _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
+            pl.data_ptr(), pinv.data_ptr(), alpha.data_ptr(), N, E, H, C, float(negative_slope), plan.ptr.data_ptr(),
+            plan.eptr.data_ptr(), plan.dst.data_ptr(), plan.B, plan.nmax, plan.emax, ld_l, ld_r, ld_e, _stream())
+        if rc != ISG_EUNSUPPORTED:
+            _lib.check(rc, "isg_gatv2_mp_fwd_planes")
+            if timer is not None:
+                ev1.record()
+            return Planes32(pl, pinv[1], N, HC, pinv[0], seg), alpha
     rowmax = None
     if want_rowmax and use_graph and fdt == torch.float32 and E > 0:
         rowmax = torch.empty(N, H, dtype=torch.float32, device=x_l.device)
@@ -1739,6 +1762,10 @@ class Planes32(NamedTuple):
     inv: Tensor
     rows: int
     cols: int
+    # SEGMENTED (isg_gatv2_mp_fwd_planes): columns [0, seg_cols) of a row under inv_first, the rest under inv; each segment padded
+    # to whole 32-column lines, so the planes hold 2 * ceil(seg_cols / 32) lines per row and the weight is laid out to match
+    inv_first: Optional[Tensor] = None
+    seg_cols: int = 0
 
 
 def split_planes32(x: Tensor) -> Planes32:
@@ -1777,18 +1804,27 @@ def instr_gate_planes32(x: Tensor, instr: Tensor, batch: Tensor, want_rows: bool
     return rows, pl
 
 
-def _h3p_weight(weight: Tensor, bias: Optional[Tensor], cache: bool = True):
-    """planes32 of a weight [N, K], its inverse row scales and the output bound {2^14 * max_n ||w_n||_1, max |b|} (device)."""
+def _h3p_weight(weight: Tensor, bias: Optional[Tensor], cache: bool = True, seg_cols: int = 0):
+    """planes32 of a weight [N, K], its inverse row scales and the output bound {2^14 * max_n ||w_n||_1, max |b|} (device).
+    seg_cols: the layout of a SEGMENTED activation -- columns [0, seg_cols) and [seg_cols, K) each padded with zero columns to a
+    multiple of 32."""
     def build():
         w = weight.detach()
-        p = split_planes32(w.contiguous().clone())       # a private copy: nothing stays attached to the parameter
+        if seg_cols:
+            sp = (seg_cols + 31) // 32 * 32
+            wl = torch.zeros(w.size(0), 2 * sp, dtype=w.dtype, device=w.device)
+            wl[:, :seg_cols] = w[:, :seg_cols]
+            wl[:, sp:sp + w.size(1) - seg_cols] = w[:, seg_cols:]
+            p = split_planes32(wl)
+        else:
+            p = split_planes32(w.contiguous().clone())       # a private copy: nothing stays attached to the parameter
         l1 = w.abs().sum(dim=1).max() * 16384.0
         bm = bias.detach().abs().max() if bias is not None else torch.zeros((), device=w.device)
         return p.planes, p.inv, torch.stack([l1, bm]).to(torch.float32).contiguous()
     if not cache:
         with torch.no_grad():
             return build()
-    return derived_weight("h3p", (weight,) if bias is None else (weight, bias), build)
+    return derived_weight(f"h3p{seg_cols or ''}", (weight,) if bias is None else (weight, bias), build)
 
 
 H3P = True            # Linears with K >= H3P_MIN_K over at least H3P_MIN_M rows on isg_linear_h3p (A/B switch)
@@ -1811,6 +1847,7 @@ def h3p_supported(M: int, N: int, K: int) -> bool:
 # step (20.09-20.29 ms: profiles/r04_ag_h3p_store_policy.txt) -- what the producer gains by not leaving its result in L2 / the
 # Infinity Cache its consumer loses.  So the default is the library's choice and "auto" stays an experiment.
 H3P_STORE_POLICY = -1
+MP_PLANES = True               # the flat message-passing kernel hands x_proj.0 its operand as segmented planes32 (A/B switch)
 GATHER_ADD_PLANES = True       # isg_gather_add hands its rows to the Linear behind it as planes32 (A/B switch)
 _h3p_policy_state = {"chosen": None, "us": None}
 
@@ -1848,7 +1885,7 @@ def _h3p_tune(dev) -> None:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             _lib.check(lib.isg_linear_h3p(ap.data_ptr(), ainv.data_ptr(), wp.data_ptr(), winv.data_ptr(), 0, out.data_ptr(), 0, 0, 0,
-                                          M, N, K, N, 0, _stream()), "isg_linear_h3p")
+                                          M, N, K, N, 0, 0, 0, _stream()), "isg_linear_h3p")
             e.record()
             e.synchronize()
             ts.append(s.elapsed_time(e) * 1e3)
@@ -1870,27 +1907,39 @@ def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = Fa
     N = weight.size(0)
     if weight.size(1) != K:
         raise ValueError(f"linear_h3p: x has {K} columns, weight {tuple(weight.shape)}")
-    wp, winv, bound = _h3p_weight(weight, bias, cache_planes)
+    seg = xp.seg_cols
+    if seg and (not gelu or relu or 2 * seg != K):
+        raise ValueError("linear_h3p: a segmented operand (isg_gatv2_mp_fwd_planes) feeds a Linear + GELU over two equal halves")
+    wp, winv, bound = _h3p_weight(weight, bias, cache_planes, seg)
     bptr = _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True)
     act = 2 if relu else (1 if gelu else 0)
     dev = xp.planes.device
+    ksplit = (seg + 31) // 32 * 32
+    Kc = 2 * ksplit if seg else K                    # the k extent the kernel walks: both segments with their padding
+    seg_args = (xp.inv_first.data_ptr(), ksplit) if seg else (0, 0)
     if planes_out:
         dp = torch.empty(int(lib.isg_planes32_elems(M, N)), dtype=torch.int16, device=dev)
         dinv = torch.empty(M, dtype=torch.float32, device=dev)
         _lib.check(lib.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), bptr, 0,
-                                      dp.data_ptr(), dinv.data_ptr(), bound.data_ptr(), M, N, K, 0, act, _stream()),
+                                      dp.data_ptr(), dinv.data_ptr(), bound.data_ptr(), M, N, Kc, 0, act, *seg_args, _stream()),
                    "isg_linear_h3p")
         return Planes32(dp, dinv, M, N)
     if _h3p_policy_state["chosen"] is None and M * N * 4 >= 128_000_000:
         _h3p_tune(dev)
     out = torch.empty(M, N, dtype=torch.float32, device=dev)
     _lib.check(lib.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), bptr,
-                                  out.data_ptr(), 0, 0, 0, M, N, K, N, act, _stream()), "isg_linear_h3p")
+                                  out.data_ptr(), 0, 0, 0, M, N, Kc, N, act, *seg_args, _stream()), "isg_linear_h3p")
     return out
 
 
 def planes32_to_rows(p: Planes32) -> Tensor:
     """fp32 rows of a Planes32 (hi + mid) * inv: tests and diagnostics only."""
+    if p.seg_cols:
+        st = (p.seg_cols + 31) // 32
+        v = p.planes.view(torch.float16).view(p.rows, 2 * st, 2, 32).float()
+        full = (v[:, :, 0] + v[:, :, 1]).reshape(p.rows, 2, st * 32)
+        return torch.cat([full[:, 0, :p.seg_cols] * p.inv_first[:, None], full[:, 1, :p.cols - p.seg_cols] * p.inv[:, None]],
+                         dim=1).contiguous()
     KT = (p.cols + 31) // 32
     v = p.planes.view(torch.float16).view(p.rows, KT, 2, 32).float()
     return ((v[:, :, 0] + v[:, :, 1]).reshape(p.rows, KT * 32)[:, :p.cols] * p.inv[:, None]).contiguous()

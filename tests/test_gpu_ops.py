@@ -124,6 +124,45 @@ def test_gatv2_message_passing_matches_oracle(dev, H, C, sizes, extra, hub, mask
         assert torch.allclose(s[has], torch.ones_like(s[has]), atol=1e-5)
 
 
+@pytest.mark.parametrize("C,sizes,mask", [(300, [12, 20, 7, 1, 33], None), (300, [12, 20, 7], "node"), (268, [9, 30, 2], "edge"),
+                                          (128, [20, 17, 33], None)])
+def test_message_passing_result_as_segmented_planes(dev, C, sizes, mask):
+    """isg_gatv2_mp_fwd_planes (the flat per-graph kernel, H = 4): the result as two half rows of planes32, each under its own
+    scale -- the same bits as isg_split_planes32 of the halves of the fp32 result, alpha untouched; where the flat kernel does
+    not run (C = 128: the grouped kernel) the call comes back with fp32 rows."""
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    H = 4
+    gen = torch.Generator().manual_seed(C + len(sizes))
+    batch, ei = _rand_graphs(gen, sizes, 1.5, None)
+    N, E = batch.numel(), ei.size(1)
+    x_l, x_r = torch.randn(N, H * C, generator=gen).to(dev), torch.randn(N, H * C, generator=gen).to(dev)
+    x_l[:, :2 * C] *= 37.0                                  # the halves' row scales differ
+    e_proj = torch.randn(E, H * C, generator=gen).to(dev)
+    att = torch.randn(1, H, C, generator=gen).to(dev)
+    bias = torch.randn(H * C, generator=gen).to(dev)
+    nm = em = None
+    if mask == "node":
+        nm = (torch.rand(N, 1, generator=gen) > 0.4).float().to(dev)
+    elif mask == "edge":
+        em = (torch.rand(E, 1, generator=gen) > 0.4).float().to(dev)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    out, alpha = ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias, node_mask=nm, edge_mask=em)
+    got, alpha2 = ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias, node_mask=nm, edge_mask=em, want_planes=True)
+    assert torch.equal(alpha, alpha2)
+    if C == 128:
+        assert isinstance(got, torch.Tensor) and torch.equal(got, out)
+        return
+    assert isinstance(got, ops.Planes32) and got.seg_cols == 2 * C and got.rows == N and got.cols == 4 * C
+    for half, inv in ((0, got.inv_first), (1, got.inv)):
+        ref = ops.split_planes32(out[:, half * 2 * C:(half + 1) * 2 * C].contiguous())
+        st = (2 * C + 31) // 32
+        mine = got.planes.view(N, 2 * st, 64)[:, half * st:(half + 1) * st].contiguous().view(-1)
+        assert torch.equal(inv, ref.inv) and torch.equal(mine, ref.planes)
+    assert torch.equal(ops.planes32_to_rows(got), torch.cat([ops.planes32_to_rows(ops.split_planes32(out[:, :2 * C].contiguous())),
+                                                              ops.planes32_to_rows(ops.split_planes32(out[:, 2 * C:].contiguous()))], 1))
+
+
 def test_message_passing_is_equivariant_to_edge_order(dev):
     """Permuting the edge list permutes alpha and leaves the node output unchanged (CSR keeps edge-id order, so
     the aggregation order changes: equality is to rounding, not bitwise)."""
@@ -1410,6 +1449,47 @@ def test_linear_h3p_matches_fp64_within_fp32_gemm_error(dev, M, N, K, act, bias)
     # relative to each row's own magnitude as well: a row of small values must not inherit a large row's absolute error
     scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
     assert ((got.double() - ref).abs() / scale).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,seg,planes_out", [(9001, 600, 600, True), (8200, 600, 600, False), (8193, 304, 512, True)])
+def test_linear_h3p_segmented_operand(dev, M, N, seg, planes_out):
+    """A SEGMENTED A operand (two half rows, each padded to whole 32-column lines and under its own power-of-two scale: what
+    isg_gatv2_mp_fwd_planes writes) through isg_linear_h3p + GELU: the accumulators change units at the segment boundary, exactly.
+    Halves of very different magnitude (one 2^9 x the other, either way round by row): against the fp64 product like an fp32 GEMM."""
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + seg)
+    K = 2 * seg
+    x = torch.randn(M, K, device=dev, generator=g)
+    big = torch.rand(M, 1, device=dev, generator=g) < 0.5
+    x[:, :seg] *= torch.where(big, 512.0, 1.0)
+    x[:, seg:] *= torch.where(big, 1.0, 512.0) * torch.rand(M, 1, device=dev, generator=g).mul(3).exp()
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(N, device=dev, generator=g)
+    sp = (seg + 31) // 32 * 32
+    halves = [ops.split_planes32(x[:, :seg].contiguous()), ops.split_planes32(x[:, seg:].contiguous())]
+    st = sp // 32
+    pl = torch.cat([h.planes.view(M, st, 64) for h in halves], dim=1).contiguous().view(-1)
+    xs = ops.Planes32(pl, halves[1].inv, M, K, halves[0].inv, seg)
+    assert torch.equal(ops.planes32_to_rows(xs)[:, :seg], ops.planes32_to_rows(halves[0]))
+    ref = torch.nn.functional.gelu(torch.nn.functional.linear(x.double(), w.double(), b.double()))
+    e32 = (torch.nn.functional.gelu(torch.nn.functional.linear(x, w, b)).double() - ref).abs().max().item()
+    got = ops.linear_h3p(xs, w, b, gelu=True, planes_out=planes_out)
+    if planes_out:
+        npad = (N + 31) // 32 * 32
+        rows = ops.planes32_to_rows(ops.Planes32(got.planes, got.inv, M, npad))
+        assert rows[:, N:].abs().max().item() == 0.0 if npad > N else True
+        rows = rows[:, :N]
+        lim = 2.0
+    else:
+        rows, lim = got, 1.5
+    err = (rows.double() - ref).abs().max().item()
+    print(f"segmented h3p {M}x{N}x{K}: err {err:.3e} fp32 gemm {e32:.3e} ratio {err / e32:.2f}")
+    assert err <= lim * e32
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    # relative to each row's own magnitude (K = 1024-1200 under a 2^9 spread between the halves: an fp32 GEMM sits at ~2e-6 too)
+    assert ((rows.double() - ref).abs() / scale).max().item() < (1e-4 if planes_out else 4e-6)
+    with pytest.raises(ValueError):
+        ops.linear_h3p(xs, w, b)                   # no GELU: not the Linear a segmented operand is for
 
 
 @pytest.mark.parametrize("E,C,full", [(1001, 300, True), (517, 128, False), (3, 44, True)])

@@ -36,10 +36,10 @@ for M, N, K in [(49152, 1536, 512), (49152, 512, 2048), (82189, 2400, 300), (205
             s.record()
             if PLANES:
                 rc = l.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), b.data_ptr(), 0,
-                                      dpl.data_ptr(), dinv.data_ptr(), bound.data_ptr(), M, N, K, N, 1, torch.cuda.current_stream().cuda_stream)
+                                      dpl.data_ptr(), dinv.data_ptr(), bound.data_ptr(), M, N, K, N, 1, 0, 0, torch.cuda.current_stream().cuda_stream)
             else:
                 rc = l.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                      0, 0, 0, M, N, K, N, 0, torch.cuda.current_stream().cuda_stream)
+                                      0, 0, 0, M, N, K, N, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
             e.record()
             torch.cuda.synchronize()
             assert rc == 0

@@ -35,7 +35,7 @@ for off in (0, 1024, 16 << 10, 256 << 10, 1 << 20, 3 << 20, 8 << 20, 33 << 20):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             rc = l.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                  0, 0, 0, M, N, K, N, 0, torch.cuda.current_stream().cuda_stream)
+                                  0, 0, 0, M, N, K, N, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
             e.record()
             torch.cuda.synchronize()
             assert rc == 0

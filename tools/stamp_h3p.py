@@ -50,7 +50,7 @@ for M, N, K in SHAPES:
     for rep in range(2):
         buf.zero_()
         rc = stamp.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                  0, 0, 0, M, N, K, N, 0, torch.cuda.current_stream().cuda_stream)
+                                  0, 0, 0, M, N, K, N, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
         assert rc == 0
         torch.cuda.synchronize()
     s = buf.double().cpu()
