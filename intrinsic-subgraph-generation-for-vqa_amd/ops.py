@@ -1847,6 +1847,7 @@ def h3p_supported(M: int, N: int, K: int) -> bool:
 # step (20.09-20.29 ms: profiles/r04_ag_h3p_store_policy.txt) -- what the producer gains by not leaving its result in L2 / the
 # Infinity Cache its consumer loses.  So the default is the library's choice and "auto" stays an experiment.
 H3P_STORE_POLICY = -1
+LINEAR_MULTI_H3P = True        # the layers' lin_edge over the shared edge features as one engine launch (A/B switch)
 MP_PLANES = True               # the flat message-passing kernel hands x_proj.0 its operand as segmented planes32 (A/B switch)
 GATHER_ADD_PLANES = True       # isg_gather_add hands its rows to the Linear behind it as planes32 (A/B switch)
 _h3p_policy_state = {"chosen": None, "us": None}
@@ -1956,7 +1957,16 @@ def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
         return None
     M, K = x.shape
     n = weights[0].size(0)
-    if any(tuple(w.shape) != (n, K) for w in weights) or (n & 31) or (K & 3) or not _use_panel(M, len(weights) * n, K):
+    if any(tuple(w.shape) != (n, K) for w in weights):
+        return None
+    if (LINEAR_MULTI_H3P and x.dtype == torch.float32 and out_dtype == torch.float32 and (n & 3) == 0 and
+            h3p_supported(M, len(weights) * n, K) and x.stride(1) == 1 and (x.stride(0) & 3) == 0 and (x.data_ptr() & 15) == 0):
+        # K >= 256 (the reference's default width): ONE launch of the planes32 engine over the concatenated weights -- the shared
+        # rows are read once instead of once per layer (262 MB per layer at 205 k edges); the layers' results are column slices
+        cat = derived_weight("linear_multi", tuple(weights), lambda: torch.cat([w.detach() for w in weights], 0).contiguous())
+        y = linear_h3p(x, cat, None)
+        return tuple(y[:, i * n:(i + 1) * n] for i in range(len(weights)))
+    if (n & 31) or (K & 3) or not _use_panel(M, len(weights) * n, K):
         return None
     lib = _lib.load()
     cat = derived_weight("linear_multi", tuple(weights), lambda: torch.cat([w.detach() for w in weights], 0).contiguous())
