@@ -110,7 +110,7 @@ class SceneGraphEncoder(torch.nn.Module):
         # train(): the BatchNorm layers use batch statistics like the reference's (torch modules); the two HIP operators
         # of this encoder (scatter_mean, fp64 GraphNorm) differentiate through autograd.py
         first = explainer and (explainer_stage == 0)
-        x_embed_sum = x if first else torch.sum(self.sg_vocab_embedding(x), dim=-2)      # :63-70
+        x_embed_sum = x if first else ops.embedding_sum(self.sg_vocab_embedding.weight, x)   # :63-70 (sum of the token rows)
         x_bbox = ops.mlp(self.bbox_encoding, gt_scene_graphs.x_bbox.to(dtype=x_embed_sum.dtype))   # :72
         x_embed_sum = ops.mlp(self.feat_reduc, torch.cat((x_embed_sum, x_bbox), dim=1))  # :73-74
         sym = gt_scene_graphs.added_sym_edge

@@ -1522,6 +1522,21 @@ def test_gather_add_rows_and_planes(dev, E, C, full):
     assert torch.equal(ops.planes32_to_rows(pl), ops.planes32_to_rows(ref))
 
 
+@pytest.mark.parametrize("T", [2, 3, 4, 6])
+def test_embedding_sum_is_the_sum_of_the_token_rows(dev, T):
+    """ops.embedding_sum (scene_graph_encoder.py:63-70 through isg_gather_add) against torch.sum(embedding(idx), dim=-2): equal to
+    rounding (the order of the additions may differ), rows of the padding index contribute zeros."""
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(T)
+    emb = torch.nn.Embedding(50, 300, padding_idx=1).to(dev)
+    idx = torch.randint(0, 50, (777, T), device=dev, generator=g)
+    idx[::5, -1] = 1
+    with torch.no_grad():
+        want = torch.sum(emb(idx), dim=-2)
+        got = ops.embedding_sum(emb.weight, idx)
+    assert got.shape == want.shape and (got - want).abs().max().item() <= 4e-6 * want.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(40961, 1000, 300), (33000, 1024, 512)])
 def test_linear_h3p_store_policy_changes_speed_only(dev, M, N, K):
     """A large (>= 128 MB) fp32 result leaves isg_linear_h3p under one of three cache policies (isg_linear_h3p_store_policy: plain,
