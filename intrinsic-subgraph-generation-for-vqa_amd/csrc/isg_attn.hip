@@ -32,15 +32,18 @@ struct MhaArgs {
 // largest magnitude over all heads is known where the row is written: the result leaves as planes32 (and as fp32 rows where `out`
 // is given) and out_proj needs no isg_split_planes32 pass over it -- ten such passes per full-model step (36 / 21 us each at 4096
 // questions).  Needs Tq * H * hd more floats of LDS: 12-token questions and the decoder's 4 queries, not CLIP's 77.
-template <int PARTS, bool ROWS>
-__global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
+// NW waves per workgroup, one query row per wave and round: a row is a chain of LDS round trips (scores -> strip -> softmax ->
+// strip -> P V), so a 12-token head on 4 waves was three such chains in a row per wave; the ROWS form runs 12 waves for it.
+template <int PARTS, bool ROWS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void mha_small_kernel(MhaArgs a) {
+  constexpr int NT = 64 * NW;
   extern __shared__ float smem[];
   const int hd = a.hd, Tk = a.Tk, kp = hd + 4;       // K rows padded by one float4: conflict-free 16-byte reads down a column
   float *Ks = smem;                       // [Tk][hd + 4]
   float *Vs = Ks + (size_t)Tk * kp;       // [Tk][hd]
   float *Qs = Vs + (size_t)Tk * hd;       // [Tq][hd]
-  float *ps = Qs + (size_t)a.Tq * hd;     // [4][128]
-  float *Cs = ps + 4 * 128;               // ROWS: [Tq][H * hd]
+  float *ps = Qs + (size_t)a.Tq * hd;     // [NW][128]
+  float *Cs = ps + NW * 128;              // ROWS: [Tq][H * hd]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = ROWS ? blockIdx.x : blockIdx.x / a.H;
   const int h4 = hd >> 2, D = a.H * hd;
@@ -50,15 +53,15 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
   // ROWS: the NEXT head's Q / K / V are requested into registers before this head's rows are computed (up to NPF float4 per
   // thread and operand: a 12-token head is 192 float4 per operand over 256 threads) and stored to LDS behind the barrier that
   // ends the head -- eight heads in a row would otherwise pay eight exposed round trips to memory per workgroup.
-  constexpr int NPF = 2;
-  const bool pf = ROWS && Tk * h4 <= NPF * 256 && a.Tq * h4 <= NPF * 256;
+  constexpr int NPF = NW >= 8 ? 1 : 2;
+  const bool pf = ROWS && Tk * h4 <= NPF * NT && a.Tq * h4 <= NPF * NT;
   float4 rk[NPF], rv[NPF], rq[NPF];
   // (macros, not lambdas: register arrays captured by reference end up in scratch memory)
 #define MHA_REQUEST(hh)                                                                                            \
   {                                                                                                                \
     const int c0_ = (hh) * hd;                                                                                     \
     _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                                              \
-      const int idx = tid + 256 * u;                                                                               \
+      const int idx = tid + NT * u;                                                                                \
       rk[u] = rv[u] = rq[u] = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
       if (idx < Tk * h4) {                                                                                         \
         const int s_ = idx / h4, c = idx - s_ * h4;                                                                \
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
   }
 #define MHA_LAND()                                                                                                 \
   _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                                                \
-    const int idx = tid + 256 * u;                                                                                 \
+    const int idx = tid + NT * u;                                                                                  \
     if (idx < Tk * h4) {                                                                                           \
       const int s_ = idx / h4, c = idx - s_ * h4;                                                                  \
       *reinterpret_cast<float4 *>(Ks + s_ * kp + 4 * c) = rk[u];                                                   \
@@ -92,20 +95,20 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
       MHA_LAND()
       if (h + 1 < hend) MHA_REQUEST(h + 1)
     } else {
-      for (int idx = tid; idx < Tk * h4; idx += 256) {
+      for (int idx = tid; idx < Tk * h4; idx += NT) {
         const int s = idx / h4, c = idx - s * h4;
         const size_t row = (size_t)s * a.B + b;
         *reinterpret_cast<float4 *>(Ks + s * kp + 4 * c) = *reinterpret_cast<const float4 *>(a.k + row * a.ldk + col0 + 4 * c);
         *reinterpret_cast<float4 *>(Vs + s * hd + 4 * c) = *reinterpret_cast<const float4 *>(a.v + row * a.ldv + col0 + 4 * c);
       }
-      for (int idx = tid; idx < a.Tq * h4; idx += 256) {
+      for (int idx = tid; idx < a.Tq * h4; idx += NT) {
         const int t = idx / h4, c = idx - t * h4;
         *reinterpret_cast<float4 *>(Qs + t * hd + 4 * c) =
             *reinterpret_cast<const float4 *>(a.q + ((size_t)t * a.B + b) * a.ldq + col0 + 4 * c);
       }
     }
     __syncthreads();
-    for (int tq = wave; tq < a.Tq; tq += 4) {
+    for (int tq = wave; tq < a.Tq; tq += NW) {
       const size_t qrow = (size_t)tq * a.B + b;
       const float *qw = Qs + tq * hd;
       float mx = -INFINITY;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaArgs a) {
   }
   if constexpr (ROWS) {
     const int KT = (D + 31) >> 5, nc = D >> 2;
-    for (int tq = wave; tq < a.Tq; tq += 4) {
+    for (int tq = wave; tq < a.Tq; tq += NW) {
       const size_t qrow = (size_t)tq * a.B + b;
       const float4 *c4 = reinterpret_cast<const float4 *>(Cs + (size_t)tq * D);
       float4 *o4 = a.out ? reinterpret_cast<float4 *>(a.out + qrow * a.ldo) : nullptr;
@@ -296,16 +299,22 @@ extern "C" int isg_mha_small(const float *q, int32_t ldq, const float *k, int32_
             reinterpret_cast<_Float16 *>(planes), planes_inv};
   auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if ((hd & 3) || (ldq & 3) || (ldk & 3) || (ldv & 3) || mis(q) || mis(k) || mis(v)) return ISG_EUNSUPPORTED;
-  size_t lds = ((size_t)Tk * (2 * hd + 4) + (size_t)Tq * hd + 4 * 128) * sizeof(float);
+  const int nw = !planes || Tq <= 4 ? 4 : Tq <= 8 ? 8 : 12;      // waves per workgroup: a query row each (ROWS form)
+  size_t lds = ((size_t)Tk * (2 * hd + 4) + (size_t)Tq * hd + nw * 128) * sizeof(float);
   if (planes) lds += (size_t)Tq * H * hd * sizeof(float);
   if (lds > 64 * 1024) return ISG_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
   if (planes) {                  // all heads of a batch item in one workgroup, the rows as planes32 (+ fp32 rows if `out`)
     if (mis(planes) || (out && ((ldo & 3) || mis(out))) || rowmax) return ISG_EUNSUPPORTED;
     const unsigned grid = (unsigned)B;
-    if (Tk <= 16 && (hd & 15) == 0) mha_small_kernel<4, true><<<grid, 256, lds, st>>>(a);
-    else if (Tk <= 32 && (hd & 7) == 0) mha_small_kernel<2, true><<<grid, 256, lds, st>>>(a);
-    else mha_small_kernel<1, true><<<grid, 256, lds, st>>>(a);
+#define ISG_MHA_ROWS(NW_)                                                                                          \
+  do {                                                                                                             \
+    if (Tk <= 16 && (hd & 15) == 0) mha_small_kernel<4, true, NW_><<<grid, 64 * NW_, lds, st>>>(a);                \
+    else if (Tk <= 32 && (hd & 7) == 0) mha_small_kernel<2, true, NW_><<<grid, 64 * NW_, lds, st>>>(a);            \
+    else mha_small_kernel<1, true, NW_><<<grid, 64 * NW_, lds, st>>>(a);                                           \
+  } while (0)
+    if (nw == 4) ISG_MHA_ROWS(4); else if (nw == 8) ISG_MHA_ROWS(8); else ISG_MHA_ROWS(12);
+#undef ISG_MHA_ROWS
     return check_launch();
   }
   const unsigned grid = (unsigned)(B * H);

@@ -2023,7 +2023,8 @@ def mha_rows_supported(t_q: int, t_kv: int, heads: int, head_dim: int) -> bool:
     planes32): a head's Q / K / V, the score strips and t_q whole rows within 64 KB -- 12-token questions and the decoder's 4
     queries at d = 512, not CLIP's 77 tokens."""
     return (MHA_ROWS_PLANES and mha_small_supported(max(t_q, t_kv), head_dim) and
-            (t_kv * (2 * head_dim + 4) + t_q * head_dim + 4 * 128 + t_q * heads * head_dim) * 4 <= 64 * 1024)
+            (t_kv * (2 * head_dim + 4) + t_q * head_dim + (4 if t_q <= 4 else 8 if t_q <= 8 else 12) * 128 +
+             t_q * heads * head_dim) * 4 <= 64 * 1024)
 
 
 def mha_small(q: Tensor, k: Tensor, v: Tensor, batch_size: int, heads: int, key_bias: Optional[Tensor] = None,
