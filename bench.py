@@ -72,10 +72,11 @@ def parse(argv=None):
     ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
                     help="graph: the step (plan build included) captured once as a hipGraph and replayed; Gumbel noise from "
                          "torch's generator inside the graph (fresh on every replay); single GPU")
-    ap.add_argument("--gather", choices=["logits", "answers"], default="logits",
-                    help="N > 1: what every rank receives per step -- the fp32 logits [B_local,1842] of every peer (30 MB per "
-                         "rank per step at 4096 graphs), or their arg-max answers [B_local] i64 (32 KB: what the reference's "
-                         "evaluation loop needs, utils/misc.py:40-48 reduces counts only); DESIGN §7 has the budget")
+    ap.add_argument("--gather", choices=["answers", "logits"], default="answers",
+                    help="N > 1: what every rank receives per step -- the arg-max answers [B_local] i64 of every peer (32 KB per "
+                         "rank; the path shards by graph with no data-path exchange, and the reference's evaluation loop moves "
+                         "counts only, utils/misc.py:40-48), or their fp32 logits [B_local,1842] (30 MB per rank per step at 4096 "
+                         "graphs: 211 MB received per step at N = 8, DESIGN §7 has the budget)")
     ap.add_argument("--no-fuse-logits", action="store_true",
                     help="A/B: lin_edge as its own GEMM + the message-passing kernel streaming e_proj (the round-1 boundary)")
     ap.add_argument("--features", choices=["fp32", "fp16"], default="fp32",
