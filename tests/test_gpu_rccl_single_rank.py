@@ -38,6 +38,13 @@ SCRIPT = textwrap.dedent("""
         pending.pop(0)[0].wait()
     torch.cuda.synchronize()
     assert torch.equal(bufs[1], sent[3]) and torch.equal(bufs[0], sent[2]), "gathered logits differ from what was sent"
+    # the default collective of bench.py (--gather answers): every rank's arg-max answers, i64, async like the logits
+    ans = sent[3].argmax(dim=1)
+    abuf = torch.empty_like(ans)
+    w = dist.all_gather_into_tensor(abuf, ans, async_op=True)
+    w.wait()
+    torch.cuda.synchronize()
+    assert abuf.dtype == torch.int64 and torch.equal(abuf, ans)
     t = torch.tensor([1.25], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert float(t.item()) == 1.25
