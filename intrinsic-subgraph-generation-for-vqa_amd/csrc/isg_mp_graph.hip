@@ -45,8 +45,9 @@ constexpr int GK_NCAP_L = 256, GK_ECAP_L = 1024;
 #endif
 constexpr int GK_U = ISG_GK_U;
 #ifndef ISG_GKF_U
-#define ISG_GKF_U 2
-#endif   // slots a wave has in flight in phase B (tuning builds: -DISG_GK_U=n)
+#define ISG_GKF_U 1      // the flat kernel: ONE slot in flight per wave (62 VGPRs) and a 40 KB window, i.e. more workgroups per CU,
+#endif                   // beat two slots (112 VGPRs) and a 78 KB window by 0.6 ms per full-model step (profiles/r04_ao_*)
+// slots a wave has in flight in phase B (tuning builds: -DISG_GK_U=n)
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v) {
@@ -505,9 +506,9 @@ static int launch_flat_sized(MpArgs a, int nmax_host, hipStream_t st) {
   if (items >= (1ll << 31)) return ISG_EUNSUPPORTED;
   const size_t row_bytes = (size_t)HS * a.C * 4;
   const size_t static_bytes = (size_t)EC * 16 + (size_t)EC * HS * 4 + (NC + 4) * 4;
-  // window: 2 workgroups per CU (16 waves); a graph's rows beyond it are read from global memory (L2).  ISG_MPF_LDS_KB: sweep
-  // switch (52 = three workgroups per CU with a 22-row window at H * C = 1200)
-  static const int flat_kb = [] { const char *e = getenv("ISG_MPF_LDS_KB"); const int v = e ? atoi(e) : 78; return v < 16 || v > 78 ? 78 : v; }();
+  // window: 40 KB = a 14-row window at H * C = 1200 and three to four workgroups per CU; a graph's rows beyond it are read from
+  // global memory (L2).  ISG_MPF_LDS_KB: sweep switch (78 = two workgroups per CU with a 30-row window: the round-2 setting)
+  static const int flat_kb = [] { const char *e = getenv("ISG_MPF_LDS_KB"); const int v = e ? atoi(e) : 40; return v < 16 || v > 78 ? 40 : v; }();
   const size_t budget = (size_t)flat_kb * 1024;
   if (budget < static_bytes + 8 * row_bytes) return ISG_EUNSUPPORTED;
   a.lrows = (int)((budget - static_bytes) / row_bytes);
