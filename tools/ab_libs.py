@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Same-process, interleaved A/B of TWO BUILDS of libisg_hip.so on the whole BASELINE configs[1] step (and, with --full, on the
-full C = 300 model): the shipped library against a variant built elsewhere (e.g. one .hip recompiled with a change and linked
+"""Same-process, interleaved A/B of TWO BUILDS of libisg_hip.so on the whole BASELINE configs[1] step (with --full on the
+full C = 300 model, with --cfg5 [--fp16] on configs[4]'s skewed batch): the shipped library against a variant built elsewhere (e.g. one .hip recompiled with a change and linked
 with the shipped objects).  Box-to-box and process-to-process scatter is +-5 %; inside one process the two builds alternate
 round by round.      python3 tools/ab_libs.py tools/_build/libisg_variant.so [--full] [--graphs 4096]"""
 import ctypes
@@ -31,6 +31,12 @@ if "--full" in sys.argv:
     wl = synthetic.make_full_workload(graphs).to(dev)
     sg = wl.scene_graphs()
     step = lambda i: model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg)[0]
+elif "--cfg5" in sys.argv:      # BASELINE configs[4]'s skewed generator (2048 graphs of 8-200 nodes, AIMLE): the per-graph kernels
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": 2048 if "--graphs" not in sys.argv else graphs,
+                                      "feature_dtype": "fp16" if "--fp16" in sys.argv else "fp32"})
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).to(dev).eval()
+    step = lambda i: model(wl, seed=1000 + i)[0]
 else:
     cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs})
     wl = synthetic.make_workload(cfg).to(dev)
