@@ -63,7 +63,7 @@ __device__ __forceinline__ void phase_softmax(int n, float eps_add, float *s_a) 
 #define ISG_TAIL_UNROLL 8
 #endif
 template <int MODE>
-__global__ __launch_bounds__(256) void graph_tail_kernel(const float *__restrict__ query, const float *__restrict__ key,
+__global__ __launch_bounds__(512) void graph_tail_kernel(const float *__restrict__ query, const float *__restrict__ key,
                                                          const float *h, const int *__restrict__ ptr,
                                                          const float *__restrict__ weight, const float *__restrict__ bias,
                                                          const float *__restrict__ mean_scale, float eps,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void graph_tail_kernel(const float *__restrict
 }
 
 // GraphNorm with every intermediate in double (scene_graph_encoder.py:99-102).
-__global__ __launch_bounds__(256) void graph_norm_f64_kernel(const float *__restrict__ x, const int *__restrict__ ptr,
+__global__ __launch_bounds__(512) void graph_norm_f64_kernel(const float *__restrict__ x, const int *__restrict__ ptr,
                                                              const float *__restrict__ weight, const float *__restrict__ bias,
                                                              const float *__restrict__ mean_scale, double eps,
                                                              float *__restrict__ out, int C) {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void graph_norm_f64_kernel(const float *__rest
   }
 }
 
-__global__ __launch_bounds__(256) void global_attn_pool_kernel(const float *__restrict__ xn, const float *__restrict__ q,
+__global__ __launch_bounds__(512) void global_attn_pool_kernel(const float *__restrict__ xn, const float *__restrict__ q,
                                                                const int *__restrict__ ptr, const float *__restrict__ node_mask,
                                                                float *__restrict__ out, float *__restrict__ gate, int C,
                                                                float denom) {
@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void global_attn_pool_kernel(const float *__re
   }
 }
 
-static int block_for(int C) { return C <= 64 ? 64 : (C <= 128 ? 128 : 256); }
+// threads per graph: one per channel in phase C (a channel count just above a block size -- the reference's C = 300 on 256 threads --
+// made a second, mostly idle round of three passes over the graph's column)
+static int block_for(int C) { return C <= 64 ? 64 : (C <= 128 ? 128 : (C <= 256 ? 256 : (C <= 320 ? 320 : (C <= 384 ? 384 : 512)))); }
 
 }  // namespace isg
 
