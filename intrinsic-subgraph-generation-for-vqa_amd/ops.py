@@ -2016,13 +2016,14 @@ def mha_small_supported(t_kv: int, head_dim: int) -> bool:
 
 
 MHA_ROWS_PLANES = True         # attention results as planes32 where the all-heads form fits (A/B switch)
+MHA_ROWS_MAX_TQ = 16           # ... up to this many query rows per batch item
 
 
 def mha_rows_supported(t_q: int, t_kv: int, heads: int, head_dim: int) -> bool:
     """The all-heads form of isg_mha_small (one workgroup per batch item, the result rows assembled in LDS and written as
     planes32): a head's Q / K / V, the score strips and t_q whole rows within 64 KB -- 12-token questions and the decoder's 4
     queries at d = 512, not CLIP's 77 tokens."""
-    return (MHA_ROWS_PLANES and mha_small_supported(max(t_q, t_kv), head_dim) and
+    return (MHA_ROWS_PLANES and t_q <= MHA_ROWS_MAX_TQ and mha_small_supported(max(t_q, t_kv), head_dim) and
             (t_kv * (2 * head_dim + 4) + t_q * head_dim + (4 if t_q <= 4 else 8 if t_q <= 8 else 12) * 128 +
              t_q * heads * head_dim) * 4 <= 64 * 1024)
 
