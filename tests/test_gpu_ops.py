@@ -1522,6 +1522,23 @@ def test_gather_add_rows_and_planes(dev, E, C, full):
     assert torch.equal(ops.planes32_to_rows(pl), ops.planes32_to_rows(ref))
 
 
+def test_linear_multi_on_the_engine_equals_the_separate_launches(dev):
+    """The layers' lin_edge projections of the shared edge features at the reference's default width (K = 300, n = 1200) as ONE
+    isg_linear_h3p launch over the concatenated weights: every layer's column slice equals its own launch bit for bit (the same
+    k order per output element), and the slices are views of one [M, L * n] tensor (row stride L * n)."""
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(12)
+    M, K, n, L = 9000, 300, 1200, 3
+    x = torch.randn(M, K, device=dev, generator=g) * torch.rand(M, 1, device=dev, generator=g).mul(3).exp()
+    ws = [torch.randn(n, K, device=dev, generator=g) / K ** 0.5 for _ in range(L)]
+    outs = ops.linear_multi(x, ws)
+    assert outs is not None and len(outs) == L and all(o.shape == (M, n) and o.stride(0) == L * n for o in outs)
+    for o, w in zip(outs, ws):
+        assert torch.equal(o, ops.linear(x, w, None))
+    ref = x.double() @ ws[1].double().t()
+    assert (outs[1].double() - ref).abs().max().item() <= 1.5 * (torch.nn.functional.linear(x, ws[1]).double() - ref).abs().max().item()
+
+
 @pytest.mark.parametrize("T", [2, 3, 4, 6])
 def test_embedding_sum_is_the_sum_of_the_token_rows(dev, T):
     """ops.embedding_sum (scene_graph_encoder.py:63-70 through isg_gather_add) against torch.sum(embedding(idx), dim=-2): equal to
