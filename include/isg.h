@@ -235,10 +235,14 @@ int isg_instr_attn_graphnorm_residual(const float *ins, const float *c, const fl
  * tile_ptr int32[capacity + 1] receives the first graph of every tile and B behind the last; ntiles int32[1] the count (it
  * stays on the device: kernels launch `capacity` workgroups, or walk the tiles persistently); tile_info (optional, 16-byte
  * aligned int32[capacity * 4]) receives {first node, nodes, first CSR slot, CSR slots} per tile, so that a workgroup learns its
- * tile in one load.  isg_tile_plan_capacity() bounds the count from the sizes alone.  No reference counterpart: the reference's kernels are per-op, not per-layer. */
+ * tile in one load.  isg_tile_plan_capacity() bounds the count from the sizes alone.  No reference counterpart: the reference's kernels are per-op, not per-layer.  * tile_info_heavy_first (NULL, or int32 [capacity, 4], 16-byte aligned, tile_info requested too): the same descriptors ordered
+ * by descending CSR-slot count (in 32-slot classes, ties in tile order).  isg_gatv2_layer_conv / isg_gatv2_tile_conv walk their
+ * tile list persistently, workgroup w taking entries w, w + G, ...: handed THIS list they get one tile of every weight class per
+ * round (the slowest workgroup's share 1.03x the mean instead of 1.06x at BASELINE configs[1]); any order gives the same results. */
 int64_t isg_tile_plan_capacity(int64_t N, int64_t E, int64_t B, int32_t node_cap, int32_t edge_cap);
 int isg_tile_plan(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
-                  int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity, void *stream);
+                  int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity, int32_t *tile_info_heavy_first,
+                  void *stream);
 
 /* The dense back half of one MGAT layer and the first line of the next as ONE launch on graph-aligned 64-row tiles
  * (isg_tile_plan with node_cap = 64):   ISubGVQA/models/mgat.py:156-177, mgat_v2_conv.py:156-157
@@ -323,9 +327,9 @@ int isg_edge_planes(const float *edge_attr, int32_t lda, const int32_t *eid, int
  * (22 us at 4096 graphs) that otherwise has the chip to itself; here it is workgroup 0 of the launch that splits the edge rows.
  * Operands and results exactly as the two entry points'. */
 int isg_tile_plan_edge_planes(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
-                              int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity, const float *edge_attr,
-                              int32_t lda, const int32_t *eid, int64_t E, int32_t K, uint16_t *planes, float *inv_scale,
-                              void *stream);
+                              int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity,
+                              int32_t *tile_info_heavy_first, const float *edge_attr, int32_t lda, const int32_t *eid, int64_t E,
+                              int32_t K, uint16_t *planes, float *inv_scale, void *stream);
 
 /* Question-conditioned softmax pooling: GlobalAttention.forward, ISubGVQA/models/att_pooling.py:63-73
  *   x = xn * node_mask;  gate = softmax_g(<x, q[g]>/sqrt(C)) (+1e-16 in the denominator);

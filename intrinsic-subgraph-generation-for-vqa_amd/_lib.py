@@ -97,12 +97,12 @@ SIGNATURES = {
                                         c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_linear_h3p_store_policy": (c_int, [c_int32]),
     "isg_tile_plan_capacity": (c_int64, [c_int64, c_int64, c_int64, c_int32, c_int32]),
-    "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "isg_tile_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "isg_mgat_dense_tail": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32] + [c_void_p] * 12 + [c_double] +
                             [c_void_p] * 11 + [c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "isg_instr_gate_planes": (c_int, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
     "isg_tile_plan_edge_planes": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64,
-                                          c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_cat_mul_rowmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_gate_planes": (c_int, [c_void_p] * 7 + [c_int32, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_gatv2_layer_conv": (c_int, [c_void_p, c_void_p] + [c_void_p] * 15 + [c_int64] + [c_void_p] * 3 +

@@ -40,7 +40,7 @@ constexpr int TP_CH = 1024;
 
 __device__ __forceinline__ void tile_plan_body(const int *__restrict__ ptr, const int *__restrict__ eptr, int B, int ncap, int ecap,
                                                int *__restrict__ tile_ptr, int *__restrict__ ntiles, int cap,
-                                               int4 *__restrict__ tile_info) {
+                                               int4 *__restrict__ tile_info, int4 *__restrict__ tile_heavy_first = nullptr) {
   __shared__ int s_jump[2][TP_CH];
   __shared__ int s_mark[TP_CH];
   __shared__ int s_ptr[TP_CH + 1], s_eptr[TP_CH + 1];
@@ -119,12 +119,45 @@ __device__ __forceinline__ void tile_plan_body(const int *__restrict__ ptr, cons
     tile_ptr[T] = B;
     *ntiles = T;
   }
+  // The same descriptors HEAVY TILES FIRST (by 32-slot half chunks, the unit of the layer kernel's edge loop; ties in tile order):
+  // a persistent kernel whose workgroup w walks entries w, w + G, w + 2G, ... of THIS list gets one tile of every weight class
+  // per round instead of whatever the batch order deals it -- at BASELINE configs[1] the slowest workgroup's share of the work
+  // drops from 1.062x to 1.029x the mean (tools/sim_tile_balance.py).  One wave, two passes of ballots over the list.
+  if (tile_info && tile_heavy_first && wave == 0) {          // (every tile_info entry is written and behind a barrier)
+    const int T = min(s_base, cap);
+    constexpr int NB = 9;                                     // classes: 8, 7, ..., 0 half chunks (8 = a full 256-slot tile)
+    int base[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) base[b] = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      const int cls = t < T ? NB - 1 - min((tile_info[t].w + 31) >> 5, NB - 1) : -1;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) base[b] += __popcll(__ballot(cls == b));
+    }
+    int run = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { const int c = base[b]; base[b] = run; run += c; }
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      int4 d = make_int4(0, 0, 0, 0);
+      if (t < T) d = tile_info[t];
+      const int cls = t < T ? NB - 1 - min((d.w + 31) >> 5, NB - 1) : -1;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const unsigned long long m = __ballot(cls == b);
+        if (cls == b) tile_heavy_first[base[b] + __popcll(m & ((1ull << lane) - 1ull))] = d;
+        base[b] += __popcll(m);
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(TP_CH) void tile_plan_kernel(const int *__restrict__ ptr, const int *__restrict__ eptr, int B,
                                                           int ncap, int ecap, int *__restrict__ tile_ptr,
-                                                          int *__restrict__ ntiles, int cap, int4 *__restrict__ tile_info) {
-  tile_plan_body(ptr, eptr, B, ncap, ecap, tile_ptr, ntiles, cap, tile_info);
+                                                          int *__restrict__ ntiles, int cap, int4 *__restrict__ tile_info,
+                                                          int4 *__restrict__ tile_heavy_first) {
+  tile_plan_body(ptr, eptr, B, ncap, ecap, tile_ptr, ntiles, cap, tile_info, tile_heavy_first);
 }
 
 // =====================================================================================================================
@@ -565,13 +598,17 @@ extern "C" int64_t isg_tile_plan_capacity(int64_t N, int64_t E, int64_t B, int32
 }
 
 extern "C" int isg_tile_plan(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
-                             int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity, void *stream) {
-  if (B < 0 || node_cap <= 0 || capacity < 0 || !tile_ptr || !ntiles || (B > 0 && !ptr)) return ISG_EINVAL;
+                             int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity,
+                             int32_t *tile_info_heavy_first, void *stream) {
+  if (B < 0 || node_cap <= 0 || capacity < 0 || !tile_ptr || !ntiles || (B > 0 && !ptr) || (tile_info_heavy_first && !tile_info))
+    return ISG_EINVAL;
+  if (tile_info_heavy_first && (reinterpret_cast<uintptr_t>(tile_info_heavy_first) & 15) != 0) return ISG_EINVAL;
   if (eptr && edge_cap <= 0) return ISG_EINVAL;
   if (B >= (1ll << 31) || capacity >= (1ll << 31)) return ISG_EUNSUPPORTED;
   if (tile_info && (reinterpret_cast<uintptr_t>(tile_info) & 15) != 0) return ISG_EINVAL;
   tile_plan_kernel<<<1, TP_CH, 0, as_stream(stream)>>>(ptr, eptr, (int)B, node_cap, edge_cap, tile_ptr, ntiles, (int)capacity,
-                                                       reinterpret_cast<int4 *>(tile_info));
+                                                       reinterpret_cast<int4 *>(tile_info),
+                                                       reinterpret_cast<int4 *>(tile_info_heavy_first));
   return check_launch();
 }
 
@@ -677,11 +714,12 @@ __global__ __launch_bounds__(256) void edge_planes_kernel(const float *__restric
 __global__ __launch_bounds__(TP_CH) void tile_plan_edge_planes_kernel(const int *__restrict__ ptr, const int *__restrict__ eptr, int B,
                                                                       int ncap, int ecap, int *__restrict__ tile_ptr,
                                                                       int *__restrict__ ntiles, int cap, int4 *__restrict__ tile_info,
+                                                                      int4 *__restrict__ tile_heavy_first,
                                                                       const float *__restrict__ edge_attr, int lda,
                                                                       const int *__restrict__ eid, int E, int K,
                                                                       _Float16 *__restrict__ planes, float *__restrict__ inv_out) {
   if (blockIdx.x == 0)
-    tile_plan_body(ptr, eptr, B, ncap, ecap, tile_ptr, ntiles, cap, tile_info);
+    tile_plan_body(ptr, eptr, B, ncap, ecap, tile_ptr, ntiles, cap, tile_info, tile_heavy_first);
   else
     edge_planes_row(edge_attr, lda, eid, E, K, planes, inv_out, (blockIdx.x - 1) * 32 + (threadIdx.x >> 5), threadIdx.x & 31);
 }
@@ -1023,9 +1061,11 @@ extern "C" int isg_edge_planes(const float *edge_attr, int32_t lda, const int32_
 // isg_tile_plan + isg_edge_planes as ONE launch (see tile_plan_edge_planes_kernel): same operands, same results.
 extern "C" int isg_tile_plan_edge_planes(const int32_t *ptr, const int32_t *eptr, int64_t B, int32_t node_cap, int32_t edge_cap,
                                          int32_t *tile_ptr, int32_t *ntiles, int32_t *tile_info, int64_t capacity,
-                                         const float *edge_attr, int32_t lda, const int32_t *eid, int64_t E, int32_t K,
-                                         uint16_t *planes, float *inv_scale, void *stream) {
-  if (B < 0 || node_cap <= 0 || capacity < 0 || !tile_ptr || !ntiles || (B > 0 && !ptr) || E < 0 || K <= 0 || lda < K) return ISG_EINVAL;
+                                         int32_t *tile_info_heavy_first, const float *edge_attr, int32_t lda, const int32_t *eid,
+                                         int64_t E, int32_t K, uint16_t *planes, float *inv_scale, void *stream) {
+  if (B < 0 || node_cap <= 0 || capacity < 0 || !tile_ptr || !ntiles || (B > 0 && !ptr) || E < 0 || K <= 0 || lda < K ||
+      (tile_info_heavy_first && (!tile_info || (reinterpret_cast<uintptr_t>(tile_info_heavy_first) & 15) != 0)))
+    return ISG_EINVAL;
   if (eptr && edge_cap <= 0) return ISG_EINVAL;
   if (B >= (1ll << 31) || capacity >= (1ll << 31) || K > 128 || (K & 3) != 0 || (lda & 3) != 0 ||
       (reinterpret_cast<uintptr_t>(edge_attr) & 15) != 0 || (reinterpret_cast<uintptr_t>(planes) & 15) != 0 || E >= (1ll << 31) - 1024)
@@ -1033,7 +1073,7 @@ extern "C" int isg_tile_plan_edge_planes(const int32_t *ptr, const int32_t *eptr
   if (tile_info && (reinterpret_cast<uintptr_t>(tile_info) & 15) != 0) return ISG_EINVAL;
   if (E > 0 && (!edge_attr || !planes || !inv_scale)) return ISG_EINVAL;
   tile_plan_edge_planes_kernel<<<(unsigned)(1 + (E + 31) / 32), TP_CH, 0, as_stream(stream)>>>(
-      ptr, eptr, (int)B, node_cap, edge_cap, tile_ptr, ntiles, (int)capacity, reinterpret_cast<int4 *>(tile_info), edge_attr, lda, eid,
-      (int)E, K, reinterpret_cast<_Float16 *>(planes), inv_scale);
+      ptr, eptr, (int)B, node_cap, edge_cap, tile_ptr, ntiles, (int)capacity, reinterpret_cast<int4 *>(tile_info),
+      reinterpret_cast<int4 *>(tile_info_heavy_first), edge_attr, lda, eid, (int)E, K, reinterpret_cast<_Float16 *>(planes), inv_scale);
   return check_launch();
 }

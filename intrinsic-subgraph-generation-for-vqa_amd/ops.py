@@ -237,21 +237,30 @@ class GraphPlan:
             self.require_csr()
             E, K = edge_attr.shape
             cap = int(lib.isg_tile_plan_capacity(self.N, self.E, self.B, key[0], key[1]))
-            buf = torch.empty(5 * cap + 8, dtype=torch.int32, device=self.ptr.device)     # info first: 16-byte aligned
-            info, tp, nt = buf[:4 * cap], buf[4 * cap + 4:5 * cap + 5], buf[5 * cap + 5:5 * cap + 6]
+            buf = torch.empty(9 * cap + 8, dtype=torch.int32, device=self.ptr.device)     # info first: 16-byte aligned
+            info, heavy, tp, nt = buf[:4 * cap], buf[4 * cap:8 * cap], buf[8 * cap + 4:9 * cap + 5], buf[9 * cap + 5:9 * cap + 6]
             planes = torch.empty(max(E, 1), 2, 128, dtype=torch.int16, device=edge_attr.device)
             inv = torch.empty(max(E, 1), dtype=torch.float32, device=edge_attr.device)
             rc = lib.isg_tile_plan_edge_planes(self.ptr.data_ptr(), self.eptr.data_ptr(), self.B, key[0], key[1], tp.data_ptr(),
-                                               nt.data_ptr(), info.data_ptr(), cap, _chk_rows(edge_attr, "edge_attr"),
+                                               nt.data_ptr(), info.data_ptr(), cap, heavy.data_ptr(), _chk_rows(edge_attr, "edge_attr"),
                                                edge_attr.stride(0), self.eid.data_ptr(), E, K, planes.data_ptr(), inv.data_ptr(),
                                                _stream())
             if rc != ISG_EUNSUPPORTED:
                 _lib.check(rc, "isg_tile_plan_edge_planes")
                 if self._tiles is None:
                     self._tiles = {}
-                self._tiles[key] = (tp, nt, cap, info.view(cap, 4))
+                self._tiles[key] = (tp, nt, cap, info.view(cap, 4), heavy.view(cap, 4))
                 self._edge_planes = (ekey, planes, inv, weakref.ref(edge_attr))
         return self.tiles(node_cap, edge_cap), self.edge_planes(edge_attr)
+
+    def tiles_heavy_first(self, node_cap: int = 64, edge_cap: int = 0) -> Tensor:
+        """tile_info of tiles(node_cap, edge_cap) ordered by descending CSR-slot count (32-slot classes, ties in tile order): the list
+        the PERSISTENT tile kernels (isg_gatv2_layer_conv / _tile_conv: workgroup w takes entries w, w + G, ...) are handed, so that
+        every workgroup gets one tile of each weight class per round -- the slowest workgroup's share of the work is 1.03x the mean
+        instead of 1.06x at BASELINE configs[1] (tools/sim_tile_balance.py).  Any order gives the same results."""
+        self.tiles(node_cap, edge_cap)
+        hit = self._tiles[(int(node_cap), int(edge_cap))]
+        return hit[4] if TILE_HEAVY_FIRST else hit[3]
 
     def tiles(self, node_cap: int = 64, edge_cap: int = 0) -> Tuple[Tensor, Tensor, int, Tensor]:
         """(tile_ptr int32[cap + 1], ntiles int32[1] on the device, cap, tile_info int32[cap, 4]): consecutive graphs packed greedily into tiles of
@@ -268,13 +277,14 @@ class GraphPlan:
             if edge_cap > 0:
                 self.require_csr()
             cap = int(lib.isg_tile_plan_capacity(self.N, self.E, self.B, key[0], key[1]))
-            buf = torch.empty(5 * cap + 8, dtype=torch.int32, device=self.ptr.device)     # info first: 16-byte aligned
-            info, tp, nt = buf[:4 * cap], buf[4 * cap + 4:5 * cap + 5], buf[5 * cap + 5:5 * cap + 6]
+            buf = torch.empty(9 * cap + 8, dtype=torch.int32, device=self.ptr.device)     # info first: 16-byte aligned
+            info, heavy, tp, nt = buf[:4 * cap], buf[4 * cap:8 * cap], buf[8 * cap + 4:9 * cap + 5], buf[9 * cap + 5:9 * cap + 6]
             _lib.check(lib.isg_tile_plan(self.ptr.data_ptr(), self.eptr.data_ptr() if edge_cap > 0 else 0, self.B, key[0],
-                                         key[1], tp.data_ptr(), nt.data_ptr(), info.data_ptr(), cap, _stream()), "isg_tile_plan")
-            hit = (tp, nt, cap, info.view(cap, 4))
+                                         key[1], tp.data_ptr(), nt.data_ptr(), info.data_ptr(), cap, heavy.data_ptr(), _stream()),
+                       "isg_tile_plan")
+            hit = (tp, nt, cap, info.view(cap, 4), heavy.view(cap, 4))
             self._tiles[key] = hit
-        return hit
+        return hit[:4]
 
     def tile_mode(self, node_cap: int = 64, edge_cap: int = 256) -> str:
         """How the graph-tile kernels (isg_gatv2_layer_conv / _tile_conv, isg_mgat_dense_tail, isg_readout_tile) can take this
@@ -844,7 +854,8 @@ def gatv2_layer_conv(x, lin_l, lin_r, edge_attr: Tensor, w_edge: Tensor, att: Te
     cat_b = derived_weight("layer_conv_b", srcs, lambda: torch.cat([zeros(lin_l), zeros(lin_r)]).float().contiguous())
     wn, wn_inv = _weight_planes(cat_w, True, "f16x3")
     we, we_inv = _weight_planes(w_edge, True, "f16x3")
-    (_, ntiles, cap, tile_info), (ep, ep_inv) = plan.tiles_and_edge_planes(edge_attr, TILE_CONV_NODES, TILE_CONV_EDGES)
+    (_, ntiles, cap, _), (ep, ep_inv) = plan.tiles_and_edge_planes(edge_attr, TILE_CONV_NODES, TILE_CONV_EDGES)
+    tile_info = plan.tiles_heavy_first(TILE_CONV_NODES, TILE_CONV_EDGES)        # a persistent kernel: balanced rounds
     out = torch.empty(N, HC, dtype=torch.float32, device=dev)
     alpha = torch.empty(E, H, dtype=torch.float32, device=dev)
     rowmax = torch.empty(N, H, dtype=torch.float32, device=dev) if want_rowmax else None
@@ -901,7 +912,8 @@ def gatv2_tile_conv(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor,
         raise TypeError("gatv2_tile_conv: fp32 rows")
     planes, inv = _weight_planes(w_edge, True, "f16x3")
     ep, ep_inv = plan.edge_planes(edge_attr)
-    _, ntiles, cap, tile_info = plan.tiles(TILE_CONV_NODES, TILE_CONV_EDGES)
+    _, ntiles, cap, _ = plan.tiles(TILE_CONV_NODES, TILE_CONV_EDGES)
+    tile_info = plan.tiles_heavy_first(TILE_CONV_NODES, TILE_CONV_EDGES)        # a persistent kernel: balanced rounds
     out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     rowmax = torch.empty(N, H, dtype=torch.float32, device=x_l.device) if want_rowmax else None
@@ -2015,6 +2027,7 @@ def mha_small_supported(t_kv: int, head_dim: int) -> bool:
     return head_dim <= 64 and head_dim % 4 == 0 and t_kv <= 128 and (t_kv * (3 * head_dim + 4) + 4 * 128) * 4 <= 64 * 1024
 
 
+TILE_HEAVY_FIRST = True        # persistent tile kernels walk the tile list heavy tiles first (A/B switch)
 MHA_ROWS_PLANES = True         # attention results as planes32 where the all-heads form fits (A/B switch)
 MHA_ROWS_MAX_TQ = 16           # ... up to this many query rows per batch item
 

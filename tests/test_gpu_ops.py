@@ -1040,6 +1040,11 @@ def test_tile_plan_is_the_greedy_packing(dev, case):
         # kernels take it (mixed dispatch, ops.GraphPlan.oversize)
         want_info = [[w[0], 0, w[2], 0] if (w[1] > ncap or (ecap > 0 and w[3] > ecap)) else w for w in want_info]
         assert info.cpu().tolist()[:T] == want_info
+        # the same descriptors heavy tiles first (32-slot classes, ties in tile order): what the persistent kernels walk
+        heavy = plan.tiles_heavy_first(ncap, ecap).cpu().tolist()[:T]
+        cls = lambda w: min((w[3] + 31) // 32, 8)
+        assert heavy == sorted(want_info, key=lambda w: -cls(w))          # Python's sort is stable: ties keep the tile order
+        assert sorted(heavy) == sorted(want_info)
 
 
 def _dense_tail_case(dev, sizes, seed, masked, with_next):
