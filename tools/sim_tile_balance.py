@@ -24,3 +24,13 @@ def spread(order):
 print("static order     : max/mean per workgroup", spread(torch.arange(T)))
 print("sorted by cost   : ", spread(torch.argsort(cost, descending=True)))
 print("bucket by chunks : ", spread(torch.argsort(chunks, descending=True, stable=True)))
+
+import heapq
+def lpt(order):          # dynamic fetch: the next tile of the list goes to the workgroup that is free first
+    h = [0.0] * G
+    heapq.heapify(h)
+    for t in order.tolist():
+        heapq.heappush(h, heapq.heappop(h) + cost[t].item())
+    return max(h) / (cost.sum().item() / G)
+print("dynamic fetch, batch order    :", lpt(torch.arange(T)))
+print("dynamic fetch, heavy first    :", lpt(torch.argsort(chunks, descending=True, stable=True)))
