@@ -95,6 +95,14 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
 
+// The same with four products and three sums each rounded, left to right: written out so that the bits do not depend on which
+// products the compiler happens to contract or vectorize in a given loop (one source line gave unfused packed products in one
+// kernel and v_pk_fma chains in its neighbour).  For the per-graph attention logits and gates, whose per-graph and tile kernels
+// must agree bit for bit (isg_norm_pool.hip / isg_layer_tile.hip / isg_layer_conv.hip / isg_sampler.hip).
+__device__ __forceinline__ float dot4_rn(const float4 &a, const float4 &b) {
+  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)), __fmul_rn(a.z, b.z)), __fmul_rn(a.w, b.w));
+}
+
 // exact (erf) GELU, the torch.nn.functional.gelu default used everywhere in the reference: 0.5 x (1 + erf(x / sqrt 2)).
 // GELU epilogues are VALU-bound (profiles/r03_c_dense_tail_stamps.txt: libm's erff is ~60 instructions with both of its
 // branches live in a wave), so the factor 1 + erf is formed without erf:  with t = |x| / sqrt 2 and e = erfc(t),

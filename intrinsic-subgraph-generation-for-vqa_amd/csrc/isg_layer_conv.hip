@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256, 3) void node_gate_planes_kernel(const _Float16
     float part = 0.f;
     if (n < nrows) {
       const float *qr = q + (int64_t)s_b[n] * NG_C;
-      part += dot4(*reinterpret_cast<const float4 *>(&sC[n][4 * l]), *reinterpret_cast<const float4 *>(qr + 4 * l));
-      part += dot4(*reinterpret_cast<const float4 *>(&sC[n][4 * (l + 16)]), *reinterpret_cast<const float4 *>(qr + 4 * (l + 16)));
+      part += dot4_rn(*reinterpret_cast<const float4 *>(&sC[n][4 * l]), *reinterpret_cast<const float4 *>(qr + 4 * l));
+      part += dot4_rn(*reinterpret_cast<const float4 *>(&sC[n][4 * (l + 16)]), *reinterpret_cast<const float4 *>(qr + 4 * (l + 16)));
     }
     const float dot = group_sum<16>(part);
     if (n < nrows && l == 0) gate[r0 + n] = gelu_libm(dot / denom);
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void readout_tile_kernel(RoArgs a) {
       const int k = min(kb + 2 * u + hh, nrows - 1);
       const float4 q4 = *reinterpret_cast<const float4 *>(a.q + (int64_t)s_gid[k] * RO_C + fr * 4);
       const float4 v = *reinterpret_cast<const float4 *>(&sC[k][fr * 4]);
-      part[u] = 0.f + dot4(v, q4);
+      part[u] = 0.f + dot4_rn(v, q4);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) part[u] = group_sum<32>(part[u]);

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
       const float4 q = gi < DT_GST ? *reinterpret_cast<const float4 *>(&s_ins[gi * DT_C + fr * 4])
                                    : *reinterpret_cast<const float4 *>(a.ins + (int64_t)(g0 + gi) * DT_C + fr * 4);
       const float4 v = *reinterpret_cast<const float4 *>(&sC[k][fr * 4]);
-      part[u] = 0.f + dot4(v, q);
+      part[u] = 0.f + dot4_rn(v, q);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) part[u] = group_sum<32>(part[u]);

@@ -8,29 +8,50 @@
 //   phase C  threads stride over channels; each walks the graph's nodes in order, so per-graph
 //            means / variances / pooled sums accumulate in node order with unfused mul+add --
 //            the order and roundings of the reference's CPU scatter kernels
-// Rows are re-read from L1/L2 in phase C (a 20-node x 128-channel graph is 10 KB).
+// Rows are re-read from L1/L2 in phase C (a 20-node x 128-channel graph is 10 KB).  A graph is ONE workgroup, so a large graph
+// bounds the launch (BASELINE configs[4]'s 200-node graphs: 155 us for 67 MB of traffic with two waves taking one node each per
+// round trip): phase A keeps four nodes per wave in flight on at least four waves, the elementwise last pass of the layer tail
+// runs on every thread.  (Keeping the graph's first 16 or 32 KB of rows in LDS on top of that bought nothing on configs[4] and
+// cost the C = 300 model 0.06-0.08 ms per step in occupancy: profiles/r04_au_per_graph_tail.txt.)
+#include <algorithm>
+
 #include "isg_common.hpp"
 
 namespace isg {
 
 constexpr int GN_NCAP = 1024;  // nodes per graph the LDS strip holds (host rejects larger graphs)
+constexpr int GN_CMAX = 512;    // channels whose per-graph statistics fit the LDS strips of the layer tail's last pass
 
-// phase A: s_a[k] = <q, key[nb+k] (* mask)> / denom
+// phase A: s_a[k] = <q, key[nb+k] (* mask)> / denom.  A wave takes FOUR nodes per round: their loads are in flight together (one
+// node per round was one exposed memory round trip per node and wave -- 100 of them in a row for a 200-node graph on two waves).
+// A lane's partial sum still runs over its float4 columns in ascending order and the 64-lane butterfly is the same: same bits.
 __device__ __forceinline__ void phase_logits(const float4 *__restrict__ q4, const float4 *__restrict__ key4,
                                              const float *__restrict__ node_mask, int nb, int n, int Q, float denom,
                                              float *s_a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int k = wave; k < n; k += nw) {
-    const float4 *row = key4 + (size_t)(nb + k) * Q;
-    const float m = node_mask ? node_mask[nb + k] : 1.f;
-    float part = 0.f;
+  for (int k0 = 4 * wave; k0 < n; k0 += 4 * nw) {
+    float part[4] = {0.f, 0.f, 0.f, 0.f}, m[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m[u] = node_mask ? node_mask[nb + min(k0 + u, n - 1)] : 1.f;
     for (int c = lane; c < Q; c += 64) {
-      float4 v = row[c];
-      if (node_mask) { v.x = __fmul_rn(v.x, m); v.y = __fmul_rn(v.y, m); v.z = __fmul_rn(v.z, m); v.w = __fmul_rn(v.w, m); }
-      part += dot4(v, q4[c]);
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = key4[(size_t)(nb + min(k0 + u, n - 1)) * Q + c];
+      const float4 qv = q4[c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (node_mask) {
+          v[u].x = __fmul_rn(v[u].x, m[u]); v[u].y = __fmul_rn(v[u].y, m[u]);
+          v[u].z = __fmul_rn(v[u].z, m[u]); v[u].w = __fmul_rn(v[u].w, m[u]);
+        }
+        part[u] += dot4_rn(v[u], qv);
+      }
     }
-    const float dot = wave_sum(part);
-    if (lane == 0) s_a[k] = dot / denom;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float dot = wave_sum(part[u]);
+      if (lane == 0 && k0 + u < n) s_a[k0 + u] = dot / denom;
+    }
   }
 }
 
@@ -70,6 +91,7 @@ __global__ __launch_bounds__(512) void graph_tail_kernel(const float *__restrict
                                                          const float *__restrict__ node_mask, float *out,
                                                          int C, float denom) {
   __shared__ float s_a[GN_NCAP];
+  __shared__ float s_mean[MODE == 0 ? 1 : GN_CMAX], s_std[MODE == 0 ? 1 : GN_CMAX];
   const int g = blockIdx.x;
   const int nb = ptr[g];
   const int n = MODE == 1 ? ptr[g + 1] - nb : min(ptr[g + 1] - nb, GN_NCAP);
@@ -80,37 +102,38 @@ __global__ __launch_bounds__(512) void graph_tail_kernel(const float *__restrict
     if (threadIdx.x < 64) phase_softmax(n, 0.f, s_a);
     __syncthreads();
   }
-  const float cnt = (float)n;
-  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-    const float *col = key + (size_t)nb * C + ch;
-    if (MODE == 0) {   // h carries `value` here
+  if (MODE == 0) {   // h carries `value` here
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
       const float *val = h + (size_t)nb * C + ch;
       for (int k = 0; k < n; ++k) out[(size_t)(nb + k) * C + ch] = __fmul_rn(s_a[k], val[(size_t)k * C]);
-      continue;
     }
+    return;
+  }
+  const float cnt = (float)n;
+  const bool strips = C <= GN_CMAX && (int)blockDim.x >= C;     // the statistics go through LDS, the last pass runs on every thread
+#define GT_VALUE(k, src) (MODE == 2 ? __fmul_rn(s_a[k], (src)) : (src))
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const float *col = key + (size_t)nb * C + ch;
     float sum = 0.f;
 #pragma unroll ISG_TAIL_UNROLL
-    for (int k = 0; k < n; ++k) {
-      float v = col[(size_t)k * C];
-      if (MODE == 2) v = __fmul_rn(s_a[k], v);
-      sum = __fadd_rn(sum, v);
-    }
+    for (int k = 0; k < n; ++k) sum = __fadd_rn(sum, GT_VALUE(k, col[(size_t)k * C]));
     const float mean_ms = __fmul_rn(sum / cnt, mean_scale[ch]);
     float sq = 0.f;
 #pragma unroll ISG_TAIL_UNROLL
     for (int k = 0; k < n; ++k) {
-      float v = col[(size_t)k * C];
-      if (MODE == 2) v = __fmul_rn(s_a[k], v);
-      const float o = __fsub_rn(v, mean_ms);
+      const float o = __fsub_rn(GT_VALUE(k, col[(size_t)k * C]), mean_ms);
       sq = __fadd_rn(sq, __fmul_rn(o, o));
     }
     const float stdv = sqrtf(__fadd_rn(sq / cnt, eps));
+    if (strips) {
+      s_mean[ch] = mean_ms;
+      s_std[ch] = stdv;
+      continue;
+    }
     const float w = weight[ch], b = bias[ch];
 #pragma unroll ISG_TAIL_UNROLL
     for (int k = 0; k < n; ++k) {
-      float v = col[(size_t)k * C];
-      if (MODE == 2) v = __fmul_rn(s_a[k], v);
-      const float o = __fsub_rn(v, mean_ms);
+      const float o = __fsub_rn(GT_VALUE(k, col[(size_t)k * C]), mean_ms);
       float y = __fadd_rn(__fmul_rn(w, o) / stdv, b);
       if (MODE == 2) {
         y = __fadd_rn(y, h[(size_t)(nb + k) * C + ch]);
@@ -119,6 +142,24 @@ __global__ __launch_bounds__(512) void graph_tail_kernel(const float *__restrict
       out[(size_t)(nb + k) * C + ch] = y;
     }
   }
+  if (!strips) return;
+  __syncthreads();
+  // the last pass has no order to keep: thread = (row lane, channel), the workgroup's spare threads take every other row
+  const int nrl = (int)blockDim.x / C, rl = (int)threadIdx.x / C, ch = (int)threadIdx.x - rl * C;
+  if (rl >= nrl) return;
+  const float *col = key + (size_t)nb * C + ch;
+  const float mean_ms = s_mean[ch], stdv = s_std[ch], w = weight[ch], b = bias[ch];
+#pragma unroll ISG_TAIL_UNROLL
+  for (int k = rl; k < n; k += nrl) {
+    const float o = __fsub_rn(GT_VALUE(k, col[(size_t)k * C]), mean_ms);
+    float y = __fadd_rn(__fmul_rn(w, o) / stdv, b);
+    if (MODE == 2) {
+      y = __fadd_rn(y, h[(size_t)(nb + k) * C + ch]);
+      if (node_mask) y = __fmul_rn(node_mask[nb + k], y);
+    }
+    out[(size_t)(nb + k) * C + ch] = y;
+  }
+#undef GT_VALUE
 }
 
 // GraphNorm with every intermediate in double (scene_graph_encoder.py:99-102).
@@ -170,6 +211,7 @@ __global__ __launch_bounds__(512) void global_attn_pool_kernel(const float *__re
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const float *col = xn + (size_t)nb * C + ch;
     float sum = 0.f;
+#pragma unroll ISG_TAIL_UNROLL
     for (int k = 0; k < n; ++k) {
       float v = col[(size_t)k * C];
       if (node_mask) v = __fmul_rn(v, node_mask[nb + k]);
@@ -199,7 +241,7 @@ extern "C" int isg_scatter_attention(const float *query, const float *key, const
   if (st != ISG_OK) return st;
   if (B == 0) return ISG_OK;
   if (!query || !key || !value || !ptr || !out) return ISG_EINVAL;
-  graph_tail_kernel<0><<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(
+  graph_tail_kernel<0><<<(unsigned)B, std::max(256, block_for(C)), 0, as_stream(stream)>>>(
       query, key, value, ptr, nullptr, nullptr, nullptr, 0.f, nullptr, out, C, (float)sqrt((double)C));
   return check_launch();
 }
@@ -228,7 +270,8 @@ extern "C" int isg_instr_attn_graphnorm_residual(const float *ins, const float *
   if (B == 0) return ISG_OK;
   if (!ins || !c || !h || !ptr || !weight || !bias || !mean_scale || !h_out) return ISG_EINVAL;
   // scatter_scaled_dot_product.py:11 divides by math.sqrt(C): a double rounded to fp32 by the tensor op
-  graph_tail_kernel<2><<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(
+  // at least four waves: phase A keeps 16 of the graph's rows in flight, the last pass spreads the rows over the spare threads
+  graph_tail_kernel<2><<<(unsigned)B, std::max(256, block_for(C)), 0, as_stream(stream)>>>(
       ins, c, h, ptr, weight, bias, mean_scale, (float)eps, node_mask, h_out, C, (float)sqrt((double)C));
   return check_launch();
 }
@@ -240,7 +283,7 @@ extern "C" int isg_global_attn_pool(const float *xn, const float *q, const int32
   if (B == 0) return ISG_OK;
   if (!xn || !q || !ptr || !out || !gate) return ISG_EINVAL;
   // att_pooling.py:68 divides by torch.sqrt(torch.tensor(C)): fp32 sqrt
-  global_attn_pool_kernel<<<(unsigned)B, block_for(C), 0, as_stream(stream)>>>(xn, q, ptr, node_mask, out, gate, C,
+  global_attn_pool_kernel<<<(unsigned)B, std::max(256, block_for(C)), 0, as_stream(stream)>>>(xn, q, ptr, node_mask, out, gate, C,
                                                                               sqrtf((float)C));
   return check_launch();
 }

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void node_gate_kernel(const float4 *__restrict
     if (dbl) b = batch[min(b, (int64_t)N - 1)];   // batch[batch[n]] (quirk Q3)
     const float4 *xr = xn + (size_t)n * Q;
     const float4 *qr = q + (size_t)b * Q;
-    for (int c = l; c < Q; c += 16) part += dot4(xr[c], qr[c]);
+    for (int c = l; c < Q; c += 16) part += dot4_rn(xr[c], qr[c]);
   }
   const float dot = group_sum<16>(part);
   if (n < N && l == 0) gate[n] = gelu_libm(dot / denom);

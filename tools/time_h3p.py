@@ -25,6 +25,9 @@ SHAPES = [  # M, N, K, act, what
 ]
 if "--quick" in sys.argv:
     SHAPES = SHAPES[:4]
+if "--small" in sys.argv:       # the configs[1] step's classifier side (below ops.H3P_MIN_M rows)
+    SHAPES = [(4096, 256, 256, "gelu", "embedding"), (4096, 1840, 256, None, "logit_fc (1842)"), (4096, 1844, 256, None, "logit_fc (1842)"),
+              (8192, 1844, 256, None, "logit_fc x2"), (4096, 1844, 512, None, "logit_fc K=512")]
 
 
 def timed(fn, reps=7):

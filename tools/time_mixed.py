@@ -10,6 +10,11 @@ import torch
 
 from isubgvqa_amd import ops, synthetic
 
+only = None          # --only=mixed / --only=off: one mode (for a rocprofv3 kernel trace of it)
+for a in list(sys.argv[1:]):
+    if a.startswith("--only="):
+        only = a.split("=", 1)[1] == "mixed"
+        sys.argv.remove(a)
 graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda:0")
 ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES = 0.9, 0      # the gate open: this tool measures the mode itself
@@ -22,7 +27,7 @@ for nbig in ([int(sys.argv[2])] if len(sys.argv) > 2 else [0, 1, 8, 64]):
     wl = synthetic.make_workload(cfg).to(dev)
     model = synthetic.build_answer_model(cfg).to(dev).eval()
     line = f"{graphs} graphs, {nbig} beyond a tile (N={wl.x.size(0)}, max nodes {wl.max_nodes}, max edges {wl.max_edges}):"
-    for mode in (True, False, True, False):
+    for mode in ((True, False, True, False) if only is None else (only,)):
         ops.MIXED_DISPATCH = mode
         with torch.no_grad():
             for i in range(3):
@@ -31,7 +36,8 @@ for nbig in ([int(sys.argv[2])] if len(sys.argv) > 2 else [0, 1, 8, 64]):
             t0 = time.perf_counter()
             for i in range(20):
                 model(wl, seed=60 + i)
+            t_issue = (time.perf_counter() - t0) / 20          # the host's share: launches issued, nothing waited for
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 20
-        line += f"  {'mixed' if mode else 'off'} {dt * 1e3:.3f} ms"
+        line += f"  {'mixed' if mode else 'off'} {dt * 1e3:.3f} ms (host issue {t_issue * 1e3:.3f})"
     print(line, flush=True)
