@@ -91,6 +91,37 @@ __device__ __forceinline__ int wave_min_i(int v) {
   return v;
 }
 
+// One rounding per operation, whatever the compiler would like to contract: the reference's CPU kernels add and multiply in
+// separate steps (scatter sums, GraphNorm's statistics, the weighted aggregation), and results that must match them -- or each
+// other, between a per-graph kernel and its tile form -- cannot depend on where the backend finds an fma.  hipcc compiles device
+// code with -ffp-contract=fast-honor-pragmas, and its __fmul_rn / __fadd_rn / __fsub_rn are plain `x * y`, `x + y`, `x - y`
+// (__clang_hip_math.h) that the backend fuses at will -- the same source line came out as v_pk_mul + v_add in one kernel and as
+// v_pk_fma in its neighbour.  The pragma takes the `contract` flag off these operations, so nothing fuses with them.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ double dmul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double dadd_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ double dsub_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
@@ -100,7 +131,7 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
 // kernel and v_pk_fma chains in its neighbour).  For the per-graph attention logits and gates, whose per-graph and tile kernels
 // must agree bit for bit (isg_norm_pool.hip / isg_layer_tile.hip / isg_layer_conv.hip / isg_sampler.hip).
 __device__ __forceinline__ float dot4_rn(const float4 &a, const float4 &b) {
-  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)), __fmul_rn(a.z, b.z)), __fmul_rn(a.w, b.w));
+  return add_rn(add_rn(add_rn(mul_rn(a.x, b.x), mul_rn(a.y, b.y)), mul_rn(a.z, b.z)), mul_rn(a.w, b.w));
 }
 
 // exact (erf) GELU, the torch.nn.functional.gelu default used everywhere in the reference: 0.5 x (1 + erf(x / sqrt 2)).
@@ -183,10 +214,10 @@ struct Philox {
 __device__ __forceinline__ float gumbel_from_bits(uint32_t bits, float loc, float scale) {
   float u01 = (float)(bits >> 8) * (1.0f / 16777216.0f);
   const float lo = FLT_MIN, hi = 1.0f - FLT_EPSILON;
-  float u = __fadd_rn(lo, __fmul_rn(u01, hi - lo));
+  float u = add_rn(lo, mul_rn(u01, hi - lo));
   float l1 = (float)log((double)u);
   float l2 = (float)log((double)(-l1));
-  return __fsub_rn(loc, __fmul_rn(scale, l2));
+  return sub_rn(loc, mul_rn(scale, l2));
 }
 
 }  // namespace isg

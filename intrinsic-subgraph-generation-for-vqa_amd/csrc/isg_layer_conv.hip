@@ -572,7 +572,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
         for (int m = 0; m < 4; ++m) o[m] = make_float4(0.f, 0.f, 0.f, 0.f);
         int s = rb;
 #pragma unroll 1
-        while (true) {          // four in-edges per round (two and two), edge-id order, mul + add as the kernels this replaces compile them
+        while (true) {          // four in-edges per round (two and two), edge-id order, one fma per term like every kernel of the family
           {     // alpha: ONE store instruction per round, lane u of a node's eight writes in-edge u
             const float wsel = (j8 & 2) ? ((j8 & 1) ? e4[3] : e4[2]) : ((j8 & 1) ? e4[1] : e4[0]);
             const int esel = (j8 & 2) ? ((j8 & 1) ? rc4[3].y : rc4[2].y) : ((j8 & 1) ? rc4[1].y : rc4[0].y);
@@ -592,13 +592,13 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
               // slots past the segment's end carry weight 0 instead of a branch each: their rows are copies of the last slot's
               // (finite), and x + 0 * r = x exactly
               const float w = s + 2 * hp + u < re ? e4[2 * hp + u] * rden : 0.f;
-              const float wm = MASKED ? __fmul_rn(w, __int_as_float(rc4[2 * hp + u].w)) : w;
+              const float wm = MASKED ? mul_rn(w, __int_as_float(rc4[2 * hp + u].w)) : w;
 #pragma unroll
               for (int m = 0; m < 4; ++m) {
-                o[m].x = __fadd_rn(o[m].x, __fmul_rn(u2[u][m].x, wm));
-                o[m].y = __fadd_rn(o[m].y, __fmul_rn(u2[u][m].y, wm));
-                o[m].z = __fadd_rn(o[m].z, __fmul_rn(u2[u][m].z, wm));
-                o[m].w = __fadd_rn(o[m].w, __fmul_rn(u2[u][m].w, wm));
+                o[m].x = fmaf(u2[u][m].x, wm, o[m].x);
+                o[m].y = fmaf(u2[u][m].y, wm, o[m].y);
+                o[m].z = fmaf(u2[u][m].z, wm, o[m].z);
+                o[m].w = fmaf(u2[u][m].w, wm, o[m].w);
               }
             }
           }
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void readout_tile_kernel(RoArgs a) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const float t = (acc[i][4 * g + jj] * si) * wi4[g][jj] + bv4[g][jj];
-          v[jj] = a.node_mask ? __fmul_rn(t, mk) : t;      // att_pooling.py:63: x = node_nn(x) * node_mask
+          v[jj] = a.node_mask ? mul_rn(t, mk) : t;      // att_pooling.py:63: x = node_nn(x) * node_mask
         }
         *reinterpret_cast<hf32x4 *>(&sC[row][wave * 32 + 8 * g + 4 * hh]) = v;
       }
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void readout_tile_kernel(RoArgs a) {
       const int n = min(gi < RO_GPC ? s_gp[gi + 1] : a.ptr[g0 + gi + 1] - r0, nrows) - nb;
       float sum = 0.f;
 #pragma unroll 4
-      for (int k = 0; k < n; ++k) sum = __fadd_rn(sum, __fmul_rn(s_a[nb + k], sC[nb + k][ch]));
+      for (int k = 0; k < n; ++k) sum = add_rn(sum, mul_rn(s_a[nb + k], sC[nb + k][ch]));
       a.out[(int64_t)(g0 + gi) * RO_C + ch] = sum;
     }
   }

@@ -515,16 +515,16 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
         const float cnt = (float)n;
         float sum = 0.f;
 #pragma unroll 4
-        for (int k = 0; k < n; ++k) sum = __fadd_rn(sum, __fmul_rn(s_a[nb + k], sC[nb + k][ch]));
-        const float mean_ms = __fmul_rn(sum / cnt, ms);
+        for (int k = 0; k < n; ++k) sum = add_rn(sum, mul_rn(s_a[nb + k], sC[nb + k][ch]));
+        const float mean_ms = mul_rn(sum / cnt, ms);
         float sq = 0.f;
 #pragma unroll 4
         for (int k = 0; k < n; ++k) {
-          const float o = __fsub_rn(__fmul_rn(s_a[nb + k], sC[nb + k][ch]), mean_ms);
-          sq = __fadd_rn(sq, __fmul_rn(o, o));
+          const float o = sub_rn(mul_rn(s_a[nb + k], sC[nb + k][ch]), mean_ms);
+          sq = add_rn(sq, mul_rn(o, o));
         }
         s_mean[gi - gb][ch] = mean_ms;
-        s_std[gi - gb][ch] = sqrtf(__fadd_rn(sq / cnt, a.eps));
+        s_std[gi - gb][ch] = sqrtf(add_rn(sq / cnt, a.eps));
       }
     }
     __syncthreads();
@@ -549,10 +549,10 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
         hf32x4 y4, g4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float o = __fsub_rn(__fmul_rn(an, cv[j]), mv[j]);
-          float y = __fadd_rn(__fmul_rn(wv[j], o) / dv[j], bv[j]);
-          y = __fadd_rn(y, rh[u][j]);
-          if (a.node_mask) y = __fmul_rn(mk, y);
+          const float o = sub_rn(mul_rn(an, cv[j]), mv[j]);
+          float y = add_rn(mul_rn(wv[j], o) / dv[j], bv[j]);
+          y = add_rn(y, rh[u][j]);
+          if (a.node_mask) y = mul_rn(mk, y);
           y4[j] = y;
         }
         if (a.xg_out || a.xp_out) {
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
       for (int s = rb; s < re; ++s) den += __builtin_amdgcn_exp2f((s_lg[s] - mx) * 1.4426950408889634f);
       const float w = __builtin_amdgcn_exp2f((s_lg[tid] - mx) * 1.4426950408889634f) * __builtin_amdgcn_rcpf(den + 1e-16f);
       a.alpha[(int64_t)rc.y * a.H + hd] = w;
-      s_w[tid] = MASKED ? __fmul_rn(w, __int_as_float(rc.w)) : w;
+      s_w[tid] = MASKED ? mul_rn(w, __int_as_float(rc.w)) : w;
     }
     int4 rec_n;                 // the next tile's inputs: defined and consumed inside this iteration
     int rp_n, sraw_n = 0, draw_n = 0;
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
     TC_REQUEST_TILE(desc_n)     // (unconditional: a zero descriptor requests row 0 and nothing else) the next tile's records, row pointers, x_l slice, edge ids: in flight under C2
     __syncthreads();
     TC_STAMP(6)              // weights
-    // C2, a half-wave per destination node, lane = float4 column: x_l rows from LDS in edge-id order, unfused mul + add
+    // C2, a half-wave per destination node, lane = float4 column: x_l rows from LDS in edge-id order, one fma per term
 #pragma unroll 1
     for (int k = 2 * tw + hh; k < nrows; k += 8) {
       const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
@@ -965,10 +965,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
       for (int s = rb; s < re; ++s) {
         const float wm = s_w[s];
         const float4 u4 = *reinterpret_cast<const float4 *>(&sXl[s_tab[s].x][fr * 4]);
-        o.x = __fadd_rn(o.x, __fmul_rn(u4.x, wm));
-        o.y = __fadd_rn(o.y, __fmul_rn(u4.y, wm));
-        o.z = __fadd_rn(o.z, __fmul_rn(u4.z, wm));
-        o.w = __fadd_rn(o.w, __fmul_rn(u4.w, wm));
+        o.x = fmaf(u4.x, wm, o.x);
+        o.y = fmaf(u4.y, wm, o.y);
+        o.z = fmaf(u4.z, wm, o.z);
+        o.w = fmaf(u4.w, wm, o.w);
       }
       if (a.bias) { o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w; }
       hf32x4 o4 = {o.x, o.y, o.z, o.w};

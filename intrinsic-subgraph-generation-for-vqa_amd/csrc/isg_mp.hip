@@ -11,8 +11,9 @@
 //   * per-head attention logits are a G-lane DPP butterfly (no LDS), kept in an LDS strip per
 //     wave (overflow for in-degree > MP_LCAP goes through the alpha output buffer)
 //   * softmax is the exact three-step form of torch_geometric.utils.softmax (max, exp-sum + 1e-16,
-//     divide) and the aggregation adds messages in ascending edge id, unfused mul+add, i.e. the
-//     summation order and roundings of the reference's CPU scatter
+//     divide) and the aggregation adds messages in ascending edge id, i.e. in the summation order of
+//     the reference's CPU scatter, ONE fma per term (a single rounding where the CPU's multiply and
+//     add round twice; written as fmaf so that it does not depend on the compiler's contraction)
 #include "isg_mp.hpp"
 
 #include <stdlib.h>
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(MP_WAVES * 64) void gatv2_mp_kernel(MpArgs a) {
     }
     den += 1e-16f;
 
-    // ---- pass 3: alpha out + weighted aggregation (unfused mul, add: the CPU's roundings) ------
+    // ---- pass 3: alpha out + weighted aggregation (edge-id order, one fma per term) ------
     float4 acc[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -147,17 +148,17 @@ __global__ __launch_bounds__(MP_WAVES * 64) void gatv2_mp_kernel(MpArgs a) {
       const float w = expf(lg - mx) / den;
       if (l == 0) a.alpha[(size_t)e * H + g] = w;
       float wm = w;
-      if (mode == 1) wm = __fmul_rn(w, a.node_mask[j] * mi);
-      else if (mode == 2) wm = __fmul_rn(w, a.edge_mask[e]);
+      if (mode == 1) wm = mul_rn(w, a.node_mask[j] * mi);
+      else if (mode == 2) wm = mul_rn(w, a.edge_mask[e]);
       const float4 *xl = a.x_l + (size_t)j * a.ldl4;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         if (ok[p]) {
           float4 u = xl[off[p]];
-          acc[p].x = __fadd_rn(acc[p].x, __fmul_rn(u.x, wm));
-          acc[p].y = __fadd_rn(acc[p].y, __fmul_rn(u.y, wm));
-          acc[p].z = __fadd_rn(acc[p].z, __fmul_rn(u.z, wm));
-          acc[p].w = __fadd_rn(acc[p].w, __fmul_rn(u.w, wm));
+          acc[p].x = fmaf(u.x, wm, acc[p].x);
+          acc[p].y = fmaf(u.y, wm, acc[p].y);
+          acc[p].z = fmaf(u.z, wm, acc[p].z);
+          acc[p].w = fmaf(u.w, wm, acc[p].w);
         }
       }
     }

@@ -16,7 +16,7 @@
 //            and U x_r rows are requested together, x_l[j] comes from LDS; per-head logit = G-lane DPP
 //            butterfly -> LDS logit table                                                              (1 barrier)
 //   phase C  NODE-parallel: a wave owns a destination node: max / exp-sum(+1e-16) / normalise over its segment of
-//            the logit table, alpha out, aggregation of LDS-resident x_l rows in edge-id order with unfused mul+add,
+//            the logit table, alpha out, aggregation of LDS-resident x_l rows in edge-id order, one fma per term,
 //            + bias, row store.  No global loads in this phase.
 // Ablation (profiles/r01_c_mp_ablation.md) showed the first version instruction-issue bound, not HBM bound
 // (phases add up instead of overlapping, SIMDs ~95 % busy).  Hence: every wave-uniform value (slot record, row
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
           if (nt_al) __builtin_nontemporal_store(w, a.alpha + (size_t)uni(rec.y) * a.H + hd);
           else a.alpha[(size_t)uni(rec.y) * a.H + hd] = w;
         }
-        const float wm = MASKED ? __fmul_rn(w, unif(__int_as_float(rec.w))) : w;
+        const float wm = MASKED ? mul_rn(w, unif(__int_as_float(rec.w))) : w;
         const int jl = uni(rec.x);
         const bool in_lds = jl < rows;
         const float4 *xl_s = s_xl + (in_lds ? jl : 0) * RQ;
@@ -231,10 +231,10 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_kernel(MpArgs a) {
           if (ok[p]) {
             float4 u4 = xl_s[off[p]];
             if (!in_lds) u4 = ldq<F16>(a.x_l, (size_t)(nb + jl) * a.ldl4 + hoff + off[p]);
-            acc[p].x = __fadd_rn(acc[p].x, __fmul_rn(u4.x, wm));
-            acc[p].y = __fadd_rn(acc[p].y, __fmul_rn(u4.y, wm));
-            acc[p].z = __fadd_rn(acc[p].z, __fmul_rn(u4.z, wm));
-            acc[p].w = __fadd_rn(acc[p].w, __fmul_rn(u4.w, wm));
+            acc[p].x = fmaf(u4.x, wm, acc[p].x);
+            acc[p].y = fmaf(u4.y, wm, acc[p].y);
+            acc[p].z = fmaf(u4.z, wm, acc[p].z);
+            acc[p].w = fmaf(u4.w, wm, acc[p].w);
           }
         }
       }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_flat_kernel(MpArgs 
       for (int hh = 0; hh < HS; ++hh) {
         w[hh] = __builtin_amdgcn_exp2f((s_lg[t * HS + hh] - mx[hh]) * 1.4426950408889634f) * rden[hh];
         if (lane == 0) a.alpha[(size_t)uni(rec.y) * a.H + hg * HS + hh] = w[hh];
-        if (MASKED) w[hh] = __fmul_rn(w[hh], unif(__int_as_float(rec.w)));
+        if (MASKED) w[hh] = mul_rn(w[hh], unif(__int_as_float(rec.w)));
       }
       const int jl = uni(rec.x);
       const bool in_lds = jl < rows;
@@ -442,10 +442,10 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_flat_kernel(MpArgs 
           float wm = w[0];
 #pragma unroll
           for (int hh = 1; hh < HS; ++hh) wm = hof[p] == hh ? w[hh] : wm;
-          acc[p].x = __fadd_rn(acc[p].x, __fmul_rn(u4.x, wm));
-          acc[p].y = __fadd_rn(acc[p].y, __fmul_rn(u4.y, wm));
-          acc[p].z = __fadd_rn(acc[p].z, __fmul_rn(u4.z, wm));
-          acc[p].w = __fadd_rn(acc[p].w, __fmul_rn(u4.w, wm));
+          acc[p].x = fmaf(u4.x, wm, acc[p].x);
+          acc[p].y = fmaf(u4.y, wm, acc[p].y);
+          acc[p].z = fmaf(u4.z, wm, acc[p].z);
+          acc[p].w = fmaf(u4.w, wm, acc[p].w);
         }
       }
     }

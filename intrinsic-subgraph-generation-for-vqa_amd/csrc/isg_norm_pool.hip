@@ -22,33 +22,45 @@ namespace isg {
 constexpr int GN_NCAP = 1024;  // nodes per graph the LDS strip holds (host rejects larger graphs)
 constexpr int GN_CMAX = 512;    // channels whose per-graph statistics fit the LDS strips of the layer tail's last pass
 
-// phase A: s_a[k] = <q, key[nb+k] (* mask)> / denom.  A wave takes FOUR nodes per round: their loads are in flight together (one
+#ifndef ISG_PL_U
+#define ISG_PL_U 4
+#endif
+#ifndef ISG_GT_U
+#define ISG_GT_U 16
+#endif
+constexpr int PL_U = ISG_PL_U;   // nodes a wave has in flight in phase A
+constexpr int GT_U = ISG_GT_U;   // nodes a thread has in flight in the node-ordered passes of phase C
+
+// phase A: s_a[k] = <q, key[nb+k] (* mask)> / denom.  A wave takes PL_U nodes per round: their loads are in flight together (one
 // node per round was one exposed memory round trip per node and wave -- 100 of them in a row for a 200-node graph on two waves).
 // A lane's partial sum still runs over its float4 columns in ascending order and the 64-lane butterfly is the same: same bits.
 __device__ __forceinline__ void phase_logits(const float4 *__restrict__ q4, const float4 *__restrict__ key4,
                                              const float *__restrict__ node_mask, int nb, int n, int Q, float denom,
                                              float *s_a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int k0 = 4 * wave; k0 < n; k0 += 4 * nw) {
-    float part[4] = {0.f, 0.f, 0.f, 0.f}, m[4];
+  for (int k0 = PL_U * wave; k0 < n; k0 += PL_U * nw) {
+    float part[PL_U], m[PL_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) m[u] = node_mask ? node_mask[nb + min(k0 + u, n - 1)] : 1.f;
+    for (int u = 0; u < PL_U; ++u) {
+      part[u] = 0.f;
+      m[u] = node_mask ? node_mask[nb + min(k0 + u, n - 1)] : 1.f;
+    }
     for (int c = lane; c < Q; c += 64) {
-      float4 v[4];
+      float4 v[PL_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = key4[(size_t)(nb + min(k0 + u, n - 1)) * Q + c];
+      for (int u = 0; u < PL_U; ++u) v[u] = key4[(size_t)(nb + min(k0 + u, n - 1)) * Q + c];
       const float4 qv = q4[c];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < PL_U; ++u) {
         if (node_mask) {
-          v[u].x = __fmul_rn(v[u].x, m[u]); v[u].y = __fmul_rn(v[u].y, m[u]);
-          v[u].z = __fmul_rn(v[u].z, m[u]); v[u].w = __fmul_rn(v[u].w, m[u]);
+          v[u].x = mul_rn(v[u].x, m[u]); v[u].y = mul_rn(v[u].y, m[u]);
+          v[u].z = mul_rn(v[u].z, m[u]); v[u].w = mul_rn(v[u].w, m[u]);
         }
         part[u] += dot4_rn(v[u], qv);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PL_U; ++u) {
       const float dot = wave_sum(part[u]);
       if (lane == 0 && k0 + u < n) s_a[k0 + u] = dot / denom;
     }
@@ -105,26 +117,42 @@ __global__ __launch_bounds__(512) void graph_tail_kernel(const float *__restrict
   if (MODE == 0) {   // h carries `value` here
     for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
       const float *val = h + (size_t)nb * C + ch;
-      for (int k = 0; k < n; ++k) out[(size_t)(nb + k) * C + ch] = __fmul_rn(s_a[k], val[(size_t)k * C]);
+      for (int k = 0; k < n; ++k) out[(size_t)(nb + k) * C + ch] = mul_rn(s_a[k], val[(size_t)k * C]);
     }
     return;
   }
   const float cnt = (float)n;
   const bool strips = C <= GN_CMAX && (int)blockDim.x >= C;     // the statistics go through LDS, the last pass runs on every thread
-#define GT_VALUE(k, src) (MODE == 2 ? __fmul_rn(s_a[k], (src)) : (src))
+#define GT_VALUE(k, src) (MODE == 2 ? mul_rn(s_a[k], (src)) : (src))
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const float *col = key + (size_t)nb * C + ch;
+    // blocks of GT_U nodes with every load of a block in flight, the last block's too (indices clamped, sums predicated): an
+    // unrolled loop's remainder ran one exposed load per node
     float sum = 0.f;
-#pragma unroll ISG_TAIL_UNROLL
-    for (int k = 0; k < n; ++k) sum = __fadd_rn(sum, GT_VALUE(k, col[(size_t)k * C]));
-    const float mean_ms = __fmul_rn(sum / cnt, mean_scale[ch]);
-    float sq = 0.f;
-#pragma unroll ISG_TAIL_UNROLL
-    for (int k = 0; k < n; ++k) {
-      const float o = __fsub_rn(GT_VALUE(k, col[(size_t)k * C]), mean_ms);
-      sq = __fadd_rn(sq, __fmul_rn(o, o));
+    for (int k0 = 0; k0 < n; k0 += GT_U) {
+      float v[GT_U];
+#pragma unroll
+      for (int u = 0; u < GT_U; ++u) v[u] = col[(size_t)min(k0 + u, n - 1) * C];
+#pragma unroll
+      for (int u = 0; u < GT_U; ++u) {
+        const float t = add_rn(sum, GT_VALUE(min(k0 + u, n - 1), v[u]));
+        sum = k0 + u < n ? t : sum;
+      }
     }
-    const float stdv = sqrtf(__fadd_rn(sq / cnt, eps));
+    const float mean_ms = mul_rn(sum / cnt, mean_scale[ch]);
+    float sq = 0.f;
+    for (int k0 = 0; k0 < n; k0 += GT_U) {
+      float v[GT_U];
+#pragma unroll
+      for (int u = 0; u < GT_U; ++u) v[u] = col[(size_t)min(k0 + u, n - 1) * C];
+#pragma unroll
+      for (int u = 0; u < GT_U; ++u) {
+        const float o = sub_rn(GT_VALUE(min(k0 + u, n - 1), v[u]), mean_ms);
+        const float t = add_rn(sq, mul_rn(o, o));
+        sq = k0 + u < n ? t : sq;
+      }
+    }
+    const float stdv = sqrtf(add_rn(sq / cnt, eps));
     if (strips) {
       s_mean[ch] = mean_ms;
       s_std[ch] = stdv;
@@ -133,11 +161,11 @@ __global__ __launch_bounds__(512) void graph_tail_kernel(const float *__restrict
     const float w = weight[ch], b = bias[ch];
 #pragma unroll ISG_TAIL_UNROLL
     for (int k = 0; k < n; ++k) {
-      const float o = __fsub_rn(GT_VALUE(k, col[(size_t)k * C]), mean_ms);
-      float y = __fadd_rn(__fmul_rn(w, o) / stdv, b);
+      const float o = sub_rn(GT_VALUE(k, col[(size_t)k * C]), mean_ms);
+      float y = add_rn(mul_rn(w, o) / stdv, b);
       if (MODE == 2) {
-        y = __fadd_rn(y, h[(size_t)(nb + k) * C + ch]);
-        if (node_mask) y = __fmul_rn(node_mask[nb + k], y);
+        y = add_rn(y, h[(size_t)(nb + k) * C + ch]);
+        if (node_mask) y = mul_rn(node_mask[nb + k], y);
       }
       out[(size_t)(nb + k) * C + ch] = y;
     }
@@ -149,15 +177,26 @@ __global__ __launch_bounds__(512) void graph_tail_kernel(const float *__restrict
   if (rl >= nrl) return;
   const float *col = key + (size_t)nb * C + ch;
   const float mean_ms = s_mean[ch], stdv = s_std[ch], w = weight[ch], b = bias[ch];
-#pragma unroll ISG_TAIL_UNROLL
-  for (int k = rl; k < n; k += nrl) {
-    const float o = __fsub_rn(GT_VALUE(k, col[(size_t)k * C]), mean_ms);
-    float y = __fadd_rn(__fmul_rn(w, o) / stdv, b);
-    if (MODE == 2) {
-      y = __fadd_rn(y, h[(size_t)(nb + k) * C + ch]);
-      if (node_mask) y = __fmul_rn(node_mask[nb + k], y);
+  for (int k0 = rl; k0 < n; k0 += nrl * GT_U) {
+    float v[GT_U], hv[GT_U];
+#pragma unroll
+    for (int u = 0; u < GT_U; ++u) {
+      const int k = min(k0 + u * nrl, n - 1);
+      v[u] = col[(size_t)k * C];
+      hv[u] = MODE == 2 ? h[(size_t)(nb + k) * C + ch] : 0.f;
     }
-    out[(size_t)(nb + k) * C + ch] = y;
+#pragma unroll
+    for (int u = 0; u < GT_U; ++u) {
+      const int k = k0 + u * nrl;
+      if (k >= n) break;
+      const float o = sub_rn(GT_VALUE(k, v[u]), mean_ms);
+      float y = add_rn(mul_rn(w, o) / stdv, b);
+      if (MODE == 2) {
+        y = add_rn(y, hv[u]);
+        if (node_mask) y = mul_rn(node_mask[nb + k], y);
+      }
+      out[(size_t)(nb + k) * C + ch] = y;
+    }
   }
 #undef GT_VALUE
 }
@@ -175,18 +214,18 @@ __global__ __launch_bounds__(512) void graph_norm_f64_kernel(const float *__rest
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const float *col = x + (size_t)nb * C + ch;
     double sum = 0.0;
-    for (int k = 0; k < n; ++k) sum = __dadd_rn(sum, (double)col[(size_t)k * C]);
-    const double mean_ms = __dmul_rn(sum / cnt, (double)mean_scale[ch]);
+    for (int k = 0; k < n; ++k) sum = dadd_rn(sum, (double)col[(size_t)k * C]);
+    const double mean_ms = dmul_rn(sum / cnt, (double)mean_scale[ch]);
     double sq = 0.0;
     for (int k = 0; k < n; ++k) {
-      const double o = __dsub_rn((double)col[(size_t)k * C], mean_ms);
-      sq = __dadd_rn(sq, __dmul_rn(o, o));
+      const double o = dsub_rn((double)col[(size_t)k * C], mean_ms);
+      sq = dadd_rn(sq, dmul_rn(o, o));
     }
-    const double stdv = sqrt(__dadd_rn(sq / cnt, eps));
+    const double stdv = sqrt(dadd_rn(sq / cnt, eps));
     const double w = (double)weight[ch], b = (double)bias[ch];
     for (int k = 0; k < n; ++k) {
-      const double o = __dsub_rn((double)col[(size_t)k * C], mean_ms);
-      out[(size_t)(nb + k) * C + ch] = (float)__dadd_rn(__dmul_rn(w, o) / stdv, b);
+      const double o = dsub_rn((double)col[(size_t)k * C], mean_ms);
+      out[(size_t)(nb + k) * C + ch] = (float)dadd_rn(dmul_rn(w, o) / stdv, b);
     }
   }
 }
@@ -211,11 +250,17 @@ __global__ __launch_bounds__(512) void global_attn_pool_kernel(const float *__re
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const float *col = xn + (size_t)nb * C + ch;
     float sum = 0.f;
-#pragma unroll ISG_TAIL_UNROLL
-    for (int k = 0; k < n; ++k) {
-      float v = col[(size_t)k * C];
-      if (node_mask) v = __fmul_rn(v, node_mask[nb + k]);
-      sum = __fadd_rn(sum, __fmul_rn(s_a[k], v));
+    for (int k0 = 0; k0 < n; k0 += GT_U) {
+      float v[GT_U];
+#pragma unroll
+      for (int u = 0; u < GT_U; ++u) v[u] = col[(size_t)min(k0 + u, n - 1) * C];
+#pragma unroll
+      for (int u = 0; u < GT_U; ++u) {
+        const int k = min(k0 + u, n - 1);
+        if (node_mask) v[u] = mul_rn(v[u], node_mask[nb + k]);
+        const float t = add_rn(sum, mul_rn(s_a[k], v[u]));
+        sum = k0 + u < n ? t : sum;
+      }
     }
     out[(size_t)g * C + ch] = sum;
   }

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(RowArgs a) {
       if (a.noise_scale != 0.f) {
         const float g = a.noise ? a.noise[(size_t)b * a.nmax_host + j]
                                 : gumbel_from_bits(Philox::draw(a.seed, (uint32_t)b, (uint32_t)j), 0.f, 0.3f);
-        x = __fadd_rn(x, __fmul_rn(g, a.noise_scale));                         // aimle.py:109,117 (mul, then add)
+        x = add_rn(x, mul_rn(g, a.noise_scale));                         // aimle.py:109,117 (mul, then add)
       }
     }
     v[s] = x;

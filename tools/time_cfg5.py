@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configs[4]'s generator at C = 128 with fp32 rows: mixed dispatch on / off, ms per step.
-  python3 tools/time_cfg5.py [graphs] [--off]   (under rocprofv3 for the per-kernel split)"""
+  python3 tools/time_cfg5.py [graphs] [--off] [--order=desc|asc]   (under rocprofv3 for the per-kernel split)"""
 import os
 import sys
 import time
@@ -15,6 +15,11 @@ graphs = int(args[0]) if args else 2048
 dev = torch.device("cuda:0")
 ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES = 0.9, 0      # the gate open: this tool measures the mode itself
 cfg = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": graphs})
+order = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--order=")]       # the same graphs, largest / smallest first
+if order:
+    sizes = sorted(synthetic.graph_sizes(cfg, torch.Generator().manual_seed(cfg.seed)).tolist(), reverse=order[0] == "desc")
+    cfg = synthetic.WorkloadConfig(**{**cfg.__dict__, "sizes": tuple(sizes)})
+    print(f"graphs ordered by size ({order[0]}): {sizes[:3]} ... {sizes[-3:]}")
 wl = synthetic.make_workload(cfg).to(dev)
 model = synthetic.build_answer_model(cfg).to(dev).eval()
 for mode in ([False] if "--off" in sys.argv else [True] if "--on" in sys.argv else [True, False, True, False]):
