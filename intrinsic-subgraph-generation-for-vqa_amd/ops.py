@@ -299,10 +299,42 @@ class GraphPlan:
             return "tiles"
         if not MIXED_DISPATCH or torch.cuda.is_current_stream_capturing():
             return "none"
-        sub = self.oversize(node_cap, edge_cap)
-        if sub is None:
+        if self.N < MIXED_MIN_NODES:
+            return "none"                   # decided before the device-to-host sync below: a small batch never pays for it
+        st = self._oversize_stats(node_cap, edge_cap)
+        if st is None or st["stats"][0] == 0:
             return "tiles"                  # the hints overstated the batch
-        return "mixed" if (sub.nodes.numel() <= MIXED_MAX_FRACTION * self.N and self.N >= MIXED_MIN_NODES) else "none"
+        # (the LIST of such graphs -- ~30 launches -- is only built for a batch that then uses it)
+        return "mixed" if st["stats"][1] <= MIXED_MAX_FRACTION * self.N else "none"
+
+    def _oversize_stats(self, node_cap: int, edge_cap: int) -> Optional[dict]:
+        """How many graphs of the batch lie beyond a tile, with their node / edge totals and maxima: ONE device-to-host sync, paid
+        only by batches whose bounds say there is such a graph; cached per (plan, caps)."""
+        ecap = int(edge_cap) if self.rowptr is not None else 0
+        key = ("stats", int(node_cap), ecap)
+        if self._oversize is None:
+            self._oversize = {}
+        if key in self._oversize:
+            return self._oversize[key]
+        res = None
+        if self.nmax > int(node_cap) or (ecap > 0 and self.emax > ecap):
+            ptr = self.ptr.long()
+            n = ptr[1:] - ptr[:-1]
+            big = n > int(node_cap)
+            e = eptr = None
+            if ecap > 0:
+                eptr = self.eptr.long()
+                e = eptr[1:] - eptr[:-1]
+                big = big | (e > ecap)
+            zero = n.new_zeros(())
+            nb = torch.where(big, n, zero)
+            stats = [big.sum(), nb.sum(), nb.max()]
+            if e is not None:
+                eb = torch.where(big, e, zero)
+                stats += [eb.sum(), eb.max()]
+            res = {"stats": [int(v) for v in torch.stack(stats).tolist()], "ptr": ptr, "n": n, "big": big, "eptr": eptr, "e": e}
+        self._oversize[key] = res
+        return res
 
     def oversize(self, node_cap: int = 64, edge_cap: int = 256) -> Optional["OversizeGraphs"]:
         """The graphs of this batch beyond a tile (more than node_cap nodes or edge_cap in-edges) as a batch of their own: graph
@@ -316,24 +348,10 @@ class GraphPlan:
         if key in self._oversize:
             return self._oversize[key]
         res = None
-        if self.nmax > key[0] or (ecap > 0 and self.emax > ecap):
+        st = self._oversize_stats(node_cap, edge_cap)        # ONE device-to-host sync: how many such graphs, their nodes / edges
+        if st is not None:
             dev = self.ptr.device
-            ptr = self.ptr.long()
-            n = ptr[1:] - ptr[:-1]
-            big = n > key[0]
-            e = None
-            if ecap > 0:
-                eptr = self.eptr.long()
-                e = eptr[1:] - eptr[:-1]
-                big = big | (e > ecap)
-            # ONE device-to-host sync: how many such graphs, their nodes / edges in total and at most
-            zero = n.new_zeros(())
-            nb = torch.where(big, n, zero)
-            stats = [big.sum(), nb.sum(), nb.max()]
-            if e is not None:
-                eb = torch.where(big, e, zero)
-                stats += [eb.sum(), eb.max()]
-            stats = [int(v) for v in torch.stack(stats).tolist()]
+            stats, ptr, n, big, eptr, e = st["stats"], st["ptr"], st["n"], st["big"], st["eptr"], st["e"]
             G = stats[0]
             if G > 0:
                 gids = torch.nonzero_static(big, size=G).squeeze(1)
