@@ -116,12 +116,14 @@ class SceneGraphBatch:
     num_graphs: int
     max_nodes: int
     max_edges: int
+    graph_sizes: Optional[Tensor] = None      # HOST int64 [2, B] nodes / in-edges per graph, when some graph lies beyond a graph tile
+                                              # (ops.GraphPlan.build's hint: the list of such graphs is then made without a sync)
 
     def to(self, device, non_blocking: bool = True) -> "SceneGraphBatch":
         mv = lambda t: t.to(device, non_blocking=non_blocking)
         return SceneGraphBatch(mv(self.x), mv(self.edge_index), mv(self.edge_attr), mv(self.x_bbox),
                                mv(self.added_sym_edge), mv(self.batch), mv(self.ptr), self.num_graphs,
-                               self.max_nodes, self.max_edges)
+                               self.max_nodes, self.max_edges, self.graph_sizes)
 
 
 class BatchBuffers:
@@ -195,7 +197,11 @@ class SceneGraphStore:
         _check(lib.isg_sg_collate(self._h, slots.data_ptr(), B, x.data_ptr(), ei.data_ptr(), ea.data_ptr(),
                                   bb.data_ptr(), sym.data_ptr(), batch.data_ptr(), ptr.data_ptr(), bounds,
                                   int(threads)), "isg_sg_collate")
-        return SceneGraphBatch(x, ei, ea, bb, sym, batch, ptr, B, int(bounds[0]), int(bounds[1]))
+        sizes = None
+        if int(bounds[0]) > 64 or int(bounds[1]) > 256:      # a graph beyond the 64-node / 256-in-edge tiles of the kernels
+            sizes = torch.stack([ptr[1:] - ptr[:-1], torch.bincount(batch[ei[1]], minlength=B)]) if E > 0 else \
+                torch.stack([ptr[1:] - ptr[:-1], torch.zeros(B, dtype=torch.int64)])
+        return SceneGraphBatch(x, ei, ea, bb, sym, batch, ptr, B, int(bounds[0]), int(bounds[1]), sizes)
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:

@@ -72,10 +72,19 @@ class MGAT(torch.nn.Module):
         return (isinstance(lin, torch.nn.Linear) and isinstance(act, torch.nn.GELU) and act.approximate == "none" and
                 ops.MP_PLANES and ops.h3p_supported(rows, lin.weight.size(0), lin.weight.size(1)))
 
+    def on_tiles(self, plan, in_channels: int, edge_attr) -> bool:
+        """Will forward() run its convolutions on the graph-tile kernels for this batch?  (Then a model may send the graphs
+        beyond a tile through ops.run_split instead of having every layer fill their rows.)"""
+        if plan is None or edge_attr is None or edge_attr.dim() != 2 or torch.is_grad_enabled():
+            return False
+        return self.convs[0].dispatch(plan, in_channels, edge_attr.float()) in ("layer_conv", "tile_conv")
+
     def forward(self, x, edge_index, instr_vectors, global_language_feats, edge_attr, batch, return_masks=False,
                 explainer=False, explainer_stage=False, expl_bypass_x=False, plan: Optional[ops.GraphPlan] = None,
                 noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
-                return_attention: bool = False):
+                return_attention: bool = False, gate_feats: Optional[Tensor] = None):
+        # gate_feats [B, C]: the rows the masked layers' node gates read, given per graph (ops.run_split's sub-batch); default:
+        # global_language_feats under the reference's double index (masking.py:151-155, quirk Q3)
         if plan is None:
             plan = ops.GraphPlan.build(batch, edge_index, num_graphs=global_language_feats.size(0))
         h = x.float().contiguous()
@@ -103,7 +112,8 @@ class MGAT(torch.nn.Module):
                 x_gated = x_planes = None
             conv_res, mask, edge_att = self.convs[i](
                 x=h, edge_index=edge_index, edge_attr=edge_attr, instruction=ins, batch=batch,
-                return_masks=return_masks, return_attention_weights=True, imle_att=glf, all_instrs=instr_vectors,
+                return_masks=return_masks, return_attention_weights=True, imle_att=glf if gate_feats is None else gate_feats.contiguous(),
+                gate_rows_given=gate_feats is not None, all_instrs=instr_vectors,
                 plan=plan, noise=None if noises is None else noises.get(i),
                 seed=None if seed is None else seed + i,
                 e_proj=None if e_projs is None else e_projs[i], x_gated=x_gated, x_planes=x_planes,

@@ -112,7 +112,9 @@ class MaskingGATv2Conv(torch.nn.Module):
                 return_attention_weights: bool = None, return_masks: bool = None, all_instrs=None,
                 plan: Optional[ops.GraphPlan] = None, noise: Optional[Tensor] = None, seed: Optional[int] = None,
                 e_proj: Optional[Tensor] = None, x_gated: Optional[Tensor] = None,
-                x_planes: Optional["ops.NodePlanes"] = None, out_planes: bool = False):
+                x_planes: Optional["ops.NodePlanes"] = None, out_planes: bool = False, gate_rows_given: bool = False):
+        # gate_rows_given: imle_att[g] already IS the row the node gate of graph g reads (ops.run_split's sub-batch: the reference's
+        # double index batch[batch[n]], quirk Q3, refers to positions in the batch the graphs were taken from)
         # out_planes (inference): the caller feeds the result to a Linear + GELU on the planes32 engine (MGAT's x_proj.0) and
         # takes it as a segmented ops.Planes32 where the message-passing kernel can write that (H = 4, the flat kernel)
         H, C = self.heads, self.out_channels
@@ -147,7 +149,7 @@ class MaskingGATv2Conv(torch.nn.Module):
         mask = None
         if self.mask.masking_threshold != 1.0:                                           # :161
             mask = self.mask(x, imle_att, batch, edge_index, use_all_instrs=False, plan=plan, noise=noise,
-                             seed=seed, u_is_per_graph=True, x_planes=planes)             # :166-168
+                             seed=seed, u_is_per_graph=not gate_rows_given, x_planes=planes)             # :166-168
 
         def done(out, alpha):
             if isinstance(return_attention_weights, bool):

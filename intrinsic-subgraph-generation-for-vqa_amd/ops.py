@@ -84,8 +84,20 @@ def _rec(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_index: Optional[int] = None
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The current stream's hipStream_t.  torch.cuda.current_stream() builds a Stream object per call (~20 calls and 0.1-0.2 ms
+    of host time per step, which a host-bound step -- small batches, the sub-batch of run_split -- pays in full): the raw
+    handle of this process's device instead (one process per GPU; the index is read once)."""
+    global _dev_index
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()
+    return _raw_stream(_dev_index)
 
 
 def _chk(t: Optional[Tensor], name: str, dtype, shape=None, optional=False) -> int:
@@ -159,12 +171,12 @@ BOUNDS_TO_HOST = True    # isg_graph_plan_build writes the batch's true bounds i
 
 
 MIXED_DISPATCH = True       # graphs beyond a tile go to the per-graph kernels, the rest of the batch stays on the tile kernels
-MIXED_MAX_FRACTION = 0.05   # ... while at most this share of the batch's nodes sits in such graphs
-MIXED_MIN_NODES = 60000     # ... and the batch is large: the per-graph kernels on a handful of big graphs are ~35 launches per layer
-                            # and bound by their largest graph (~0.3 ms per layer whatever the batch), measured
-                            # (profiles/r04_p_mixed_dispatch.txt): 4096 graphs + 1..8 big ones 2.63-2.82 ms mixed vs 2.65-2.89 ms
-                            # with the per-graph kernels for everything (1.47 ms without big graphs); 1024 graphs 1.9 vs 1.0 ms.
-                            # Tests and tools lower both to force the mode.
+MIXED_MAX_FRACTION = 0.12   # ... while at most this share of the batch's nodes sits in such graphs
+MIXED_MIN_NODES = 60000     # ... and the batch is large: the big graphs are a chain of ~60 launches of a workgroup or a few each, ~1.8 ms
+                            # of HOST time per step whatever the batch.  Measured (profiles/r04_az_split_forward.txt), 4096
+                            # graphs + 1 / 8 / 64 big ones: 1.84-1.91 / 2.00 / 2.12 ms (run_split, sub-batch on its own stream)
+                            # against 2.35 / 2.49 / 2.63 ms with the per-graph kernels for everything (1.43 ms without big
+                            # graphs); 1024 graphs + 1: 1.83 vs 0.89 ms.  Tests and tools lower both to force the mode.
 
 
 class OversizeGraphs(NamedTuple):
@@ -205,6 +217,10 @@ class GraphPlan:
     _tiles: Optional[dict] = None
     _edge_planes: Optional[tuple] = None
     _oversize: Optional[dict] = None
+    sizes_host: Optional[Tensor] = None           # HOST int64 [2, B] nodes / in-edges per graph when the caller's collate gave them (a hint
+                                                  # like max_nodes / max_edges: lets oversize() count without a device-to-host sync)
+    no_tiles: bool = False                        # the plan of a batch's oversize graphs: the tile kernels are not asked again
+    holes: Optional["OversizeGraphs"] = None      # set by run_split: the tile kernels pass over these graphs and NOTHING fills their rows
 
     def edge_planes(self, edge_attr: Tensor) -> Tuple[Tensor, Tensor]:
         """(planes int16 [E, 2, 128], inv_scale fp32 [E]) of the batch's edge features in CSR slot order (isg_edge_planes): the
@@ -293,7 +309,7 @@ class GraphPlan:
         rows of the same outputs; "none" -- tiles do not pay (most nodes sit in oversize graphs) or the list cannot be made
         (inside a hipGraph capture: it takes a device-to-host sync)."""
         ecap = edge_cap if self.rowptr is not None else 0
-        if self.B <= 0 or self.nmax <= 0:
+        if self.B <= 0 or self.nmax <= 0 or self.no_tiles:
             return "none"
         if self.nmax <= node_cap and (ecap == 0 or self.emax <= ecap):
             return "tiles"
@@ -326,13 +342,23 @@ class GraphPlan:
                 eptr = self.eptr.long()
                 e = eptr[1:] - eptr[:-1]
                 big = big | (e > ecap)
-            zero = n.new_zeros(())
-            nb = torch.where(big, n, zero)
-            stats = [big.sum(), nb.sum(), nb.max()]
-            if e is not None:
-                eb = torch.where(big, e, zero)
-                stats += [eb.sum(), eb.max()]
-            res = {"stats": [int(v) for v in torch.stack(stats).tolist()], "ptr": ptr, "n": n, "big": big, "eptr": eptr, "e": e}
+            if self.sizes_host is not None:       # the collate's per-graph counts: no sync (verify_hints checks the bounds they imply)
+                nh, eh = self.sizes_host[0], self.sizes_host[1]
+                bh = nh > int(node_cap)
+                if ecap > 0:
+                    bh = bh | (eh > ecap)
+                st = [int(bh.sum()), int(nh[bh].sum()), int(nh[bh].max()) if bool(bh.any()) else 0]
+                if e is not None:
+                    st += [int(eh[bh].sum()), int(eh[bh].max()) if bool(bh.any()) else 0]
+            else:
+                zero = n.new_zeros(())
+                nb = torch.where(big, n, zero)
+                stats = [big.sum(), nb.sum(), nb.max()]
+                if e is not None:
+                    eb = torch.where(big, e, zero)
+                    stats += [eb.sum(), eb.max()]
+                st = [int(v) for v in torch.stack(stats).tolist()]
+            res = {"stats": st, "ptr": ptr, "n": n, "big": big, "eptr": eptr, "e": e}
         self._oversize[key] = res
         return res
 
@@ -354,24 +380,21 @@ class GraphPlan:
             stats, ptr, n, big, eptr, e = st["stats"], st["ptr"], st["n"], st["big"], st["eptr"], st["e"]
             G = stats[0]
             if G > 0:
-                gids = torch.nonzero_static(big, size=G).squeeze(1)
-                cnt = n[gids]
+                # flags -> compaction: every list comes out ascending (segment sums keep their order) without a sort
                 Ns, nmax_s = stats[1], stats[2]
-                ar = torch.arange(G, device=dev)
-                seg = torch.repeat_interleave(ar, cnt, output_size=Ns)
-                nodes = ptr[gids][seg] + (torch.arange(Ns, device=dev) - (cnt.cumsum(0) - cnt)[seg])
+                gids = torch.nonzero_static(big, size=G).squeeze(1)
+                node_big = big[self.batch]                                    # [N]: the node sits in such a graph
+                nodes = torch.nonzero_static(node_big, size=Ns).squeeze(1)
+                seg = (big.cumsum(0) - 1)[self.batch[nodes]]                  # local graph index of those nodes
                 edges = sub_ei = None
                 emax_s = None
                 if e is not None:
                     Es, emax_s = stats[3], stats[4]
-                    ce = e[gids]
-                    seg_e = torch.repeat_interleave(ar, ce, output_size=Es)
-                    slots = eptr[gids][seg_e] + (torch.arange(Es, device=dev) - (ce.cumsum(0) - ce)[seg_e])
-                    edges = torch.sort(self.eid.long()[slots]).values
-                    newid = torch.full((self.N,), -1, dtype=torch.int64, device=dev)
-                    newid[nodes] = torch.arange(Ns, device=dev)
+                    edges = torch.nonzero_static(node_big[self.edge_index[1]], size=Es).squeeze(1)      # by destination: edges stay
+                    newid = node_big.cumsum(0) - 1                                                    # inside their graph
                     sub_ei = newid[self.edge_index[:, edges]].contiguous()
                 sub_plan = GraphPlan.build(seg.contiguous(), sub_ei, num_graphs=G, max_nodes=nmax_s, max_edges=emax_s)
+                sub_plan.no_tiles = True
                 res = OversizeGraphs(gids, nodes, edges, seg, sub_ei, sub_plan)
         self._oversize[key] = res
         return res
@@ -396,7 +419,8 @@ class GraphPlan:
 
     @staticmethod
     def build(batch: Tensor, edge_index: Optional[Tensor] = None, num_graphs: Optional[int] = None,
-              max_nodes: Optional[int] = None, max_edges: Optional[int] = None) -> "GraphPlan":
+              max_nodes: Optional[int] = None, max_edges: Optional[int] = None,
+              graph_sizes: Optional[Tensor] = None) -> "GraphPlan":
         lib = _lib.load()
         _chk(batch, "batch", torch.int64)
         N = batch.numel()
@@ -408,6 +432,10 @@ class GraphPlan:
         bounds = torch.empty(2, dtype=torch.int32, device=dev)     # [max nodes per graph, max edges per graph]
         nmax_dev = bounds[:1]
         plan = GraphPlan(N=N, E=0, B=B, ptr=ptr, nmax_dev=nmax_dev, nmax=0, batch=batch)
+        if graph_sizes is not None:
+            if graph_sizes.device.type != "cpu" or graph_sizes.dim() != 2 or tuple(graph_sizes.shape) != (2, B):
+                raise ValueError("graph_sizes: a HOST tensor [2, num_graphs] (nodes, in-edges per graph)")
+            plan.sizes_host = graph_sizes.long()
         host_bounds = None
         if edge_index is not None:
             _chk(edge_index, "edge_index", torch.int64)
@@ -809,10 +837,109 @@ def _count_tile_nodes(plan: "GraphPlan", sub: Optional["OversizeGraphs"]) -> Non
 
 
 def _mixed_sub(plan: "GraphPlan") -> Optional["OversizeGraphs"]:
-    """The oversize graphs of a batch the tile kernels take in "mixed" mode (None in "tiles" mode)."""
+    """The oversize graphs of a batch the tile kernels take in "mixed" mode (None in "tiles" mode) -- and None when they run as a
+    batch of their own through the whole model (run_split: plan.holes), so that nobody fills their rows layer by layer."""
+    if plan.holes is not None:
+        _count_tile_nodes(plan, plan.holes)
+        return None
     sub = plan.oversize(TILE_CONV_NODES, TILE_CONV_EDGES) if plan.tile_mode(TILE_CONV_NODES, TILE_CONV_EDGES) == "mixed" else None
     _count_tile_nodes(plan, sub)
     return sub
+
+
+SPLIT_STREAM = True       # ... on a stream of its own, beside the whole batch's tile kernels (A/B switch)
+_side_streams: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+SPLIT_FORWARD = True      # "mixed" batches: the graphs beyond a tile run as a batch of their own through the WHOLE model (A/B switch;
+                          # off: every tile kernel's wrapper fills their rows with the per-graph kernels, layer by layer)
+
+
+def oversize_split(plan: "GraphPlan") -> Optional["OversizeGraphs"]:
+    """The graphs a model running on the graph-tile kernels should send through run_split (None: none, or not worth it)."""
+    if not SPLIT_FORWARD or plan.holes is not None or plan.rowptr is None:
+        return None
+    if plan.tile_mode(TILE_CONV_NODES, TILE_CONV_EDGES) != "mixed":
+        return None
+    return plan.oversize(TILE_CONV_NODES, TILE_CONV_EDGES)
+
+
+def run_split(plan: "GraphPlan", sub: "OversizeGraphs", core, x: Tensor, edge_index: Tensor, edge_attr: Tensor, batch: Tensor,
+              instr: Tensor, glf: Tensor, noises=None, seed=None, kinds: str = "gnn"):
+    """core(x, edge_index, edge_attr, batch, instr, glf, plan, noises, seed, gate_feats) -> tuple of tensors / lists / None, one per
+    letter of `kinds` ("g": a row per graph, "n": a row per node), run TWICE: on the whole batch with the tile kernels passing
+    over the graphs beyond a tile (their rows stay unwritten: plan.holes), and on those graphs as a batch of their own (per-graph
+    kernels; instr is [L, B, C]); the second result is then copied over the rows of the first.  Every op of the path is local to
+    a graph (or a row), so nothing of a hole reaches another graph -- with ONE exception that the reference itself makes: a masked
+    layer's node gate reads the question row batch[batch[n]] (masking.py:151-155, quirk Q3), i.e. for graph g the row of the graph
+    that holds NODE number g; the sub-batch is handed exactly those rows (gate_feats, to MGAT.forward).  A real GQA batch has a few such graphs (the reference caps
+    nothing: datasets/scene_graph.py:199-389); filling their rows after every tile kernel instead cost ~200 small launches per step
+    (profiles/r04_az_split_forward.txt).  Dense [B, nmax] noise is cut to the sub-batch; a seed draws the sub-batch's own noise."""
+    nmax_s = sub.plan.nmax
+
+    def run_side():
+        xs, es = x.index_select(0, sub.nodes), edge_attr.index_select(0, sub.edges)
+        instr_s, glf_s = instr.index_select(1, sub.gids), glf.index_select(0, sub.gids)
+        gate_s = glf.index_select(0, batch.index_select(0, sub.gids.clamp(max=max(plan.N - 1, 0))))
+        nz_s = None
+        if noises is not None:
+            nz_s = {}
+            for k, v in noises.items():
+                v = v.index_select(0, sub.gids)
+                nz_s[k] = (v[:, :nmax_s] if v.dim() == 2 else v[:, :, :nmax_s]).contiguous()
+        return core(xs, sub.edge_index, es, sub.batch, instr_s, glf_s, sub.plan, nz_s, seed, gate_s)
+
+    def run_main():
+        plan.holes = sub
+        try:
+            return core(x, edge_index, edge_attr, batch, instr, glf, plan, noises, seed, None)
+        finally:
+            plan.holes = None
+
+    if SPLIT_STREAM and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        # The sub-batch is a chain of ~60 launches of one or a few workgroups each (0.65 ms of GPU time for ONE 100-node graph):
+        # on a stream of its own it runs beside the tile kernels instead of behind them.  The main pass is issued FIRST (the GPU
+        # starts on it while the host is still issuing the sub-batch).
+        cur = torch.cuda.current_stream()
+        side_stream = _side_stream(x.device)
+        side_stream.wait_stream(cur)                 # inputs and the lists of `sub` are complete
+        main = run_main()
+        with torch.cuda.stream(side_stream):
+            side = run_side()
+        cur.wait_stream(side_stream)
+
+        def keep(t):                                 # results made on the side stream, read on this one
+            if isinstance(t, Tensor):
+                t.record_stream(cur)
+            elif isinstance(t, (list, tuple)):
+                for u in t:
+                    keep(u)
+        keep(side)
+    else:
+        main = run_main()
+        side = run_side()
+    if len(main) != len(kinds) or len(side) != len(kinds):
+        raise ValueError("run_split: one letter of `kinds` per result")
+
+    def merge(m, s_, kind):
+        if m is None:
+            return None
+        if isinstance(m, (list, tuple)):
+            return type(m)(merge(a, b, kind) for a, b in zip(m, s_))
+        idx = sub.gids if kind == "g" else sub.nodes
+        if m.size(0) != (plan.B if kind == "g" else plan.N) or s_.size(0) != idx.numel():
+            raise ValueError(f"run_split: a '{kind}' result of {tuple(m.shape)} / {tuple(s_.shape)} rows")
+        if m.dim() == 2 and kind == "n" and s_.dim() == 2 and m.size(1) != s_.size(1):
+            raise ValueError("run_split: per-node results of different widths")
+        return m.index_copy_(0, idx, s_.to(m.dtype))
+    return tuple(merge(m, s_, k) for m, s_, k in zip(main, side, kinds))
 
 
 def _oversize_conv(sub: "OversizeGraphs", x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, heads: int,

@@ -60,10 +60,12 @@ class Workload:
     num_graphs: int = 0
     max_nodes: int = 0
     max_edges: int = 0
+    graph_sizes: Optional[Tensor] = None      # HOST int64 [2, B]: nodes / in-edges per graph (what a collate knows anyway); stays on the host
 
     def to(self, device) -> "Workload":
         return Workload(self.x.to(device), self.edge_index.to(device), self.edge_attr.to(device), self.batch.to(device),
-                        self.instr.to(device), self.glf.to(device), self.num_graphs, self.max_nodes, self.max_edges)
+                        self.instr.to(device), self.glf.to(device), self.num_graphs, self.max_nodes, self.max_edges,
+                        self.graph_sizes)
 
 
 def graph_sizes(cfg: WorkloadConfig, gen: torch.Generator) -> Tensor:
@@ -126,8 +128,10 @@ def make_workload(cfg: WorkloadConfig) -> Workload:
     edge_attr = torch.randn(E, C, generator=gen)
     instr = torch.randn(L, B, C, generator=gen)
     glf = torch.randn(B, C, generator=gen)
-    emax = int(torch.bincount(batch[edge_index[1]], minlength=B).max())
-    return Workload(x, edge_index, edge_attr, batch, instr, glf, B, nmax, emax)
+    epg = torch.bincount(batch[edge_index[1]], minlength=B)
+    emax = int(epg.max())
+    return Workload(x, edge_index, edge_attr, batch, instr, glf, B, nmax, emax,
+                    torch.stack([torch.bincount(batch, minlength=B), epg]))
 
 
 def gumbel_noise(shape, device) -> Tensor:
@@ -161,14 +165,23 @@ class AnswerModel(torch.nn.Module):
         if plan is None:
             plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=wl.glf.size(0),
                                        max_nodes=(wl.max_nodes or None) if use_hints else None,
-                                       max_edges=(wl.max_edges or None) if use_hints else None)
-        h, mask, _, _ = self.gat_seq(x=wl.x, edge_index=wl.edge_index, edge_attr=wl.edge_attr,
-                                     instr_vectors=wl.instr[:4], global_language_feats=wl.glf, batch=wl.batch,
-                                     return_masks=True, plan=plan, noises=noises, seed=seed)
-        embed, gate = self.graph_global_attention_pooling(x=h, u=wl.glf, batch=wl.batch, size=None, return_mask=True,
-                                                          node_mask=mask, plan=plan)
+                                       max_edges=(wl.max_edges or None) if use_hints else None,
+                                       graph_sizes=wl.graph_sizes if use_hints else None)
+        sub = ops.oversize_split(plan) if self.gat_seq.on_tiles(plan, wl.x.size(1), wl.edge_attr) else None
+        if sub is None:
+            return self._answer(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, plan, noises, seed, None)
+        # a few graphs beyond a graph tile: they run as a batch of their own, the rest stays on the tile kernels
+        return ops.run_split(plan, sub, self._answer, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, noises, seed,
+                             kinds="gnn")
+
+    def _answer(self, x, edge_index, edge_attr, batch, instr, glf, plan, noises, seed, gate_feats):
         from . import ops as _ops
-        feats = _ops.mlp(self.embedding, _ops.cat_mul(embed, wl.glf), want_rowmax=True)
+        h, mask, _, _ = self.gat_seq(x=x, edge_index=edge_index, edge_attr=edge_attr, instr_vectors=instr[:4],
+                                     global_language_feats=glf, batch=batch, return_masks=True, plan=plan, noises=noises, seed=seed,
+                                     gate_feats=gate_feats)
+        embed, gate = self.graph_global_attention_pooling(x=h, u=glf, batch=batch, size=None, return_mask=True,
+                                                          node_mask=mask, plan=plan)
+        feats = _ops.mlp(self.embedding, _ops.cat_mul(embed, glf), want_rowmax=True)
         return _ops.linear(feats, self.logit_fc.weight, self.logit_fc.bias), mask, gate
 
 

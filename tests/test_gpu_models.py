@@ -754,3 +754,37 @@ def test_mixed_dispatch_off_gives_the_same_answers(dev):
     (l0, m0, g0), (l1, m1, g1) = outs
     assert torch.equal(m0, m1)
     assert (l0 - l1).abs().max() < 2e-5
+
+
+def test_split_forward_variants_agree(dev):
+    """ops.run_split with the sub-batch on its own stream / on the current stream, with the collate's per-graph sizes as a hint /
+    counted on the device (one sync), and the first form (every tile kernel's wrapper fills the rows): same masks, logits to 2e-5."""
+    from isubgvqa_amd import ops, synthetic
+    sizes = (20,) * 150 + (130,) + (20,) * 100 + (90,) + (20,) * 50
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler="imle", seed=11)
+    wl = synthetic.make_workload(cfg).to(dev)
+    assert wl.graph_sizes is not None and wl.graph_sizes.device.type == "cpu"
+    model = synthetic.build_answer_model(cfg).eval().to(dev)
+    keep = ops.SPLIT_FORWARD, ops.SPLIT_STREAM
+    outs = {}
+    try:
+        for name, split, stream, hints in (("stream", True, True, True), ("inline", True, False, True), ("synced", True, True, False),
+                                           ("fill", False, False, True)):
+            ops.SPLIT_FORWARD, ops.SPLIT_STREAM = split, stream
+            w = wl if hints else synthetic.Workload(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, wl.num_graphs,
+                                                    wl.max_nodes, wl.max_edges, None)
+            ops.reset_counters()
+            with torch.no_grad():
+                outs[name] = _forced_mixed(lambda: model(w))
+            c = ops.counters()
+            assert c["oversize_nodes"] > 0 and c["tile_nodes"] > 0, (name, c)
+            torch.cuda.synchronize()
+    finally:
+        ops.SPLIT_FORWARD, ops.SPLIT_STREAM = keep
+    l0, m0, g0 = outs["stream"]
+    assert torch.isfinite(l0).all()
+    for name in ("inline", "synced"):
+        l, m, g = outs[name]
+        assert torch.equal(l, l0) and torch.equal(m, m0) and torch.equal(g, g0), name
+    l, m, g = outs["fill"]
+    assert torch.equal(m, m0) and (l - l0).abs().max() < 2e-5 and torch.allclose(g, g0, atol=1e-6)
