@@ -29,6 +29,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   full_model    the configs[2] stand-in (full model at C = 300) timed in the same run
   cfg5          BASELINE configs[4] on one GPU (skewed graphs, AIMLE, fp16 rows): ms/step, MP kernel GB/s on s = 2 bytes, the
                 imbalance of contiguous graph ranges over 8 ranks
+  mixed         the configs[1] batch with a few graphs beyond a graph tile (what real GQA batches are: the reference caps nothing):
+                ms/step with the tile kernels + the big graphs as a sub-batch (ops.run_split) and with the per-graph kernels for all
   fallbacks     launches per step that left this library's dense kernels (0 = none), extra row-maximum passes
   dense_err_vs_fp32   error of the exact-split dense kernels relative to a plain fp32 GEMM's (vs fp64)
   per_rank      (N > 1) every rank's own ms/step and its wait at the closing barrier
@@ -61,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the configs[4] leg (skewed graphs, AIMLE, fp16 rows)")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-dispatch leg (configs[1] + a few graphs beyond a tile)")
     ap.add_argument("--no-full-model", action="store_true", help="skip the configs[2] stand-in (full model at C = 300)")
     ap.add_argument("--full-model-graphs", type=int, default=4096)
     ap.add_argument("--cpu-sample-graphs", type=int, default=512)
@@ -349,7 +352,7 @@ def time_unfused_mp(wl, cfg, dev, launches: int = 20):
 # committed sample (profiles/r03_*bench.json)
 LINE_SCHEMA = {
     "": ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-         "dtype", "data", "config", "roofline", "cpu_baseline", "rccl", "fallbacks", "dense_err_vs_fp32", "cfg5", "full_model"],
+         "dtype", "data", "config", "roofline", "cpu_baseline", "rccl", "fallbacks", "dense_err_vs_fp32", "cfg5", "full_model", "mixed"],
     "config": ["workload", "graphs_per_gpu", "global_batch", "parallelism"],
     "roofline": ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us"],
     "cpu_baseline": ["value", "unit", "cores", "kind", "sample", "cfg1"],
@@ -358,6 +361,8 @@ LINE_SCHEMA = {
     "cfg5": ["workload", "graphs", "ms_per_step", "questions_per_s", "mp_kernel", "mp_avg_launch_us", "mp_achieved_GBps",
              "mp_frac_of_hbm_peak", "imbalance_world8_max_over_mean", "fp32_rows"],
     "full_model": ["workload", "graphs", "ms_per_step", "questions_per_s", "h3p_store_policy"],
+    "mixed": ["workload", "graphs", "big_graphs", "nodes", "ms_per_step", "host_issue_ms_per_step", "dispatch",
+              "tile_kernel_node_share", "per_graph_kernels_ms_per_step"],
 }
 
 
@@ -427,6 +432,50 @@ def dense_err_vs_fp32(dev):
             ((got - ref).abs().max() / (base - ref).abs().max().clamp_min(1e-30)).item(), 3)
     out["max"] = max(out.values())
     return out
+
+
+def mixed_leg(dev, graphs: int = 4096, big: int = 8, steps: int = 10):
+    """The configs[1] batch with `big` of its graphs replaced by graphs of 100-189 nodes, after the timed region: the default
+    dispatch (tile kernels for the graphs that fit a 64-node / 256-in-edge tile, the others as a batch of their own through the whole
+    model on the per-graph kernels and a second stream: ops.run_split) against the per-graph kernels for the whole batch."""
+    import torch
+    from isubgvqa_amd import ops, synthetic
+    gen = torch.Generator().manual_seed(3)
+    sizes = synthetic.graph_sizes(synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs}), gen).tolist()
+    for i in range(big):
+        sizes[(i * 977 + 13) % graphs] = 100 + (i * 37) % 90
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs, "sizes": tuple(sizes)})
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).to(dev).eval()
+    out = {}
+    keep = ops.MIXED_DISPATCH
+    try:
+        for name, on in (("mixed", True), ("per_graph", False)):
+            ops.MIXED_DISPATCH = on
+            with torch.no_grad():
+                for i in range(3):
+                    model(wl, seed=50 + i)
+                torch.cuda.synchronize()
+                ops.reset_counters()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    logits = model(wl, seed=60 + i)[0]
+                t_issue = (time.perf_counter() - t0) / steps
+                torch.cuda.synchronize()
+                out[name] = ((time.perf_counter() - t0) / steps, t_issue, ops.counters())
+            assert torch.isfinite(logits).all()
+    finally:
+        ops.MIXED_DISPATCH = keep
+    dt, t_issue, c = out["mixed"]
+    visits = c["tile_nodes"] + c["oversize_nodes"]
+    return {"workload": f"BASELINE configs[1] with {big} of its graphs replaced by graphs of 100-189 nodes (beyond a graph tile)",
+            "graphs": graphs, "big_graphs": big, "nodes": int(wl.x.size(0)), "max_nodes": int(wl.max_nodes),
+            "ms_per_step": round(dt * 1e3, 3), "questions_per_s": round(graphs / dt, 1),
+            "host_issue_ms_per_step": round(t_issue * 1e3, 3),
+            "dispatch": ("tile kernels + the big graphs as a sub-batch on the per-graph kernels (ops.run_split)" if c["oversize_nodes"]
+                         else ("tile kernels" if visits else "per-graph kernels")),
+            "tile_kernel_node_share": round(c["tile_nodes"] / visits, 4) if visits else 0.0,
+            "per_graph_kernels_ms_per_step": round(out["per_graph"][0] * 1e3, 3), "steps": steps}
 
 
 def cfg5_leg(dev, graphs: int = 2048, steps: int = 10):
@@ -803,6 +852,9 @@ def main(argv=None):
         if world == 1 and not args.no_cfg5:
             progress("cfg5 leg (skewed graphs, AIMLE, fp16 rows)")
             res["cfg5"] = cfg5_leg(dev)
+        if world == 1 and not args.no_mixed:
+            progress("mixed leg (configs[1] + 8 graphs beyond a tile)")
+            res["mixed"] = mixed_leg(dev)
         ops.check_plans()           # any understated GraphPlan hint of this run raises here
         if world == 1 and not args.no_cpu_baseline:
             progress("cpu_baseline leg (oracle on the host cores)")
@@ -811,7 +863,7 @@ def main(argv=None):
             res["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
         else:
             res["cpu_baseline"] = None
-        validate_line(res, full=world == 1 and not (args.no_cpu_baseline or args.no_full_model or args.no_cfg5))
+        validate_line(res, full=world == 1 and not (args.no_cpu_baseline or args.no_full_model or args.no_cfg5 or args.no_mixed))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
