@@ -849,6 +849,7 @@ def _mixed_sub(plan: "GraphPlan") -> Optional["OversizeGraphs"]:
 
 SPLIT_STREAM = True       # ... on a stream of its own, beside the whole batch's tile kernels (A/B switch)
 _side_streams: dict = {}
+_split_concurrent = 0     # > 0 while run_split has two passes in flight on two streams (derived_weight syncs what it builds then)
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -907,12 +908,17 @@ def run_split(plan: "GraphPlan", sub: "OversizeGraphs", core, x: Tensor, edge_in
         # The sub-batch is a chain of ~60 launches of one or a few workgroups each (0.65 ms of GPU time for ONE 100-node graph):
         # on a stream of its own it runs beside the tile kernels instead of behind them.  The main pass is issued FIRST (the GPU
         # starts on it while the host is still issuing the sub-batch).
+        global _split_concurrent
         cur = torch.cuda.current_stream()
         side_stream = _side_stream(x.device)
         side_stream.wait_stream(cur)                 # inputs and the lists of `sub` are complete
-        main = run_main()
-        with torch.cuda.stream(side_stream):
-            side = run_side()
+        _split_concurrent += 1
+        try:
+            main = run_main()
+            with torch.cuda.stream(side_stream):
+                side = run_side()
+        finally:
+            _split_concurrent -= 1
         cur.wait_stream(side_stream)
 
         def keep(t):                                 # results made on the side stream, read on this one
@@ -1632,6 +1638,10 @@ def derived_weight(tag: str, sources, build):
         return hit[2]
     with torch.no_grad():
         value = build()
+    if _split_concurrent:
+        # two streams of one step share this cache (run_split): whichever pass builds an entry first, the other may read it on
+        # its own stream right away -- a one-off device sync per entry instead of an event per use
+        torch.cuda.synchronize()
     if len(_DERIVED) > 256:
         for k in [k for k, v in _DERIVED.items() if any(r() is None for r in v[1])]:
             del _DERIVED[k]
