@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 15
+#define ISG_ABI_VERSION 16
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -538,6 +538,12 @@ int isg_split_f16x2_frag(const float *w, int64_t rows, int32_t K, uint16_t *plan
 int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias, float *d,
                      int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, int32_t out_cols,
                      int64_t out_stride, void *stream);
+/* isg_linear_f16x3 with the result rounded once (RNE) to half rows d uint16 (ldd, out_stride in halves): a model in "fp16
+ * features / fp32 accumulate" mode (BASELINE configs[4]; MaskingGATv2Conv.feature_dtype) projects x_l | x_r and e_proj with it
+ * (ISubGVQA/models/mgat_v2_conv.py:177-181, :259-261). */
+int isg_linear_f16x3_f16(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias, uint16_t *d,
+                         int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act, int32_t out_cols,
+                         int64_t out_stride, void *stream);
 
 /* The K >= 256 engine (csrc/isg_gemm_h3p.hip): the Linears of the question encoder / decoder
  * (ISubGVQA/models/question_encoder.py:20-38, question_decoder.py:25-71: nn.TransformerEncoder/DecoderLayer's in_proj,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -78,6 +78,8 @@ SIGNATURES = {
     "isg_split_f16x2_frag": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_linear_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                  c_int32, c_int32, c_int32, c_int64, c_void_p]),
+    "isg_linear_f16x3_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                     c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "isg_gatv2_mp_fwd_rowmax": (c_int, [c_void_p] * 13 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "isg_gatv2_edge_logits": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32,

@@ -51,11 +51,12 @@ __global__ void split_f16x2_frag_kernel(const float *__restrict__ w, int N, int 
   }
 }
 
-template <int ACT, int WTN>
+// F16D: the result as half rows (one RNE rounding of the fp32 value: BASELINE configs[4]'s "fp16 features / fp32 accumulate")
+template <int ACT, int WTN, bool F16D = false>
 __global__ __launch_bounds__(H3_THREADS, 2) void linear_f16x3_kernel(const float *__restrict__ A,
                                                                      const _Float16 *__restrict__ Wf,
                                                                      const float *__restrict__ w_inv,
-                                                                     const float *__restrict__ bias, float *__restrict__ D,
+                                                                     const float *__restrict__ bias, void *__restrict__ Dv,
                                                                      int M, int N, int K, int KS, int NT, int lda, int ldd,
                                                                      int nt_store, int out_cols, int64_t out_stride) {
   __shared__ __attribute__((aligned(16))) _Float16 sA[2][H3_BM][H3_LD];   // 34,816 B
@@ -172,9 +173,16 @@ __global__ __launch_bounds__(H3_THREADS, 2) void linear_f16x3_kernel(const float
     float v = (acc[i][j][r] * s_inv[rl]) * wi[j] + bv[j];     /* both scales are powers of two: exact */        \
     if (ACT == 1) v = gelu_exact(v);                                                                             \
     if (GUARD) {                                                                                                 \
-      float *dst = D + obase + (int64_t)row * ldd + col;                                                         \
-      if (nt_store) __builtin_nontemporal_store(v, dst);                                                         \
-      else *dst = v;                                                                                             \
+      if (F16D) {     /* the fp32 value first, THEN one rounding: the compiler would fold the last fma into a v_fma_mix */ \
+        asm volatile("" : "+v"(v));     /* (single rounding of the exact sum: differs from fp32-then-half on ties)        */ \
+        _Float16 *dst = reinterpret_cast<_Float16 *>(Dv) + obase + (int64_t)row * ldd + col;                     \
+        if (nt_store) __builtin_nontemporal_store((_Float16)v, dst);                                             \
+        else *dst = (_Float16)v;                                                                                 \
+      } else {                                                                                                   \
+        float *dst = reinterpret_cast<float *>(Dv) + obase + (int64_t)row * ldd + col;                           \
+        if (nt_store) __builtin_nontemporal_store(v, dst);                                                       \
+        else *dst = v;                                                                                           \
+      }                                                                                                          \
     }                                                                                                            \
   }
         if (rows_full && cols_full) H3_EPI(true)
@@ -207,9 +215,9 @@ extern "C" int isg_split_f16x2_frag(const float *w, int64_t rows, int32_t K, uin
   return check_launch();
 }
 
-extern "C" int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias,
-                                float *d, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
-                                int32_t out_cols, int64_t out_stride, void *stream) {
+static int linear_f16x3_launch(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias, void *d,
+                               bool d_f16, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                               int32_t out_cols, int64_t out_stride, void *stream) {
   if (M < 0 || N <= 0 || K <= 0 || lda < K || act < 0 || act > 1) return ISG_EINVAL;
   if (out_cols <= 0 || ldd < out_cols || (out_cols < N && (out_cols & 31) != 0) || N % out_cols != 0) return ISG_EINVAL;
   if (M == 0) return ISG_OK;
@@ -221,15 +229,35 @@ extern "C" int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const fl
   auto waste = [&](int w) { const int per = 4 * w; return ((NT + per - 1) / per) * per - NT; };
   const int wtn = waste(2) <= waste(1) + 1 ? 2 : 1;
   static const long long nt_b = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return (e ? atoll(e) : 128) * 1000000ll; }();
-  const int nt = nt_b >= 0 && (long long)M * N * 4 >= nt_b;
+  const int nt = nt_b >= 0 && (long long)M * N * (d_f16 ? 2 : 4) >= nt_b;
   const _Float16 *wf = reinterpret_cast<const _Float16 *>(w_frag);
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)panels), block(H3_THREADS);
-#define ISG_H3(ACT_, W_) linear_f16x3_kernel<ACT_, W_><<<grid, block, 0, st>>>(a, wf, w_inv_scale, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt, out_cols, (long long)out_stride)
-  if (act == 1) { if (wtn == 2) ISG_H3(1, 2); else ISG_H3(1, 1); }
-  else { if (wtn == 2) ISG_H3(0, 2); else ISG_H3(0, 1); }
+#define ISG_H3(ACT_, W_, F_) linear_f16x3_kernel<ACT_, W_, F_><<<grid, block, 0, st>>>(a, wf, w_inv_scale, bias, d, (int)M, N, K, KS, NT, lda, ldd, nt, out_cols, (long long)out_stride)
+  if (d_f16) {
+    if (act == 1) { if (wtn == 2) ISG_H3(1, 2, true); else ISG_H3(1, 1, true); }
+    else { if (wtn == 2) ISG_H3(0, 2, true); else ISG_H3(0, 1, true); }
+  } else {
+    if (act == 1) { if (wtn == 2) ISG_H3(1, 2, false); else ISG_H3(1, 1, false); }
+    else { if (wtn == 2) ISG_H3(0, 2, false); else ISG_H3(0, 1, false); }
+  }
 #undef ISG_H3
   return check_launch();
+}
+
+extern "C" int isg_linear_f16x3(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias,
+                                float *d, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                                int32_t out_cols, int64_t out_stride, void *stream) {
+  return linear_f16x3_launch(a, w_frag, w_inv_scale, bias, d, false, M, N, K, lda, ldd, act, out_cols, out_stride, stream);
+}
+
+// The same product with the result rounded ONCE to half rows (ldd / out_stride in halves): the projections of a model in
+// BASELINE configs[4]'s "fp16 features / fp32 accumulate" mode (x_l | x_r, e_proj), at half the matrix-core work of
+// isg_linear_panel's bf16 six-product form.
+extern "C" int isg_linear_f16x3_f16(const float *a, const uint16_t *w_frag, const float *w_inv_scale, const float *bias,
+                                    uint16_t *d, int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldd, int32_t act,
+                                    int32_t out_cols, int64_t out_stride, void *stream) {
+  return linear_f16x3_launch(a, w_frag, w_inv_scale, bias, d, true, M, N, K, lda, ldd, act, out_cols, out_stride, stream);
 }
 
 // =====================================================================================================================

@@ -1606,6 +1606,8 @@ def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional
 # ------------------------------------------------------------------------------------------------
 GEMM_BACKEND = "bf16x6"      # "bf16x6": this library's kernels; "torch": hipBLASLt fp32 through torch (A/B switch)
 _PLANES = {}                 # (id(weight), layout) -> (weakref, version, data_ptr, planes): static weights are split once
+F16X3_F16_OUT = True         # half-row results (configs[4]) of K <= 128 Linears on isg_linear_f16x3_f16 instead of the bf16 six-product
+                             # panel kernel (A/B switch)
 GEMM_KERNEL = "auto"         # "auto": per shape (below); "panel": isg_linear_panel; "tile": isg_linear_bf16x6 (A/B switch)
 
 
@@ -1910,6 +1912,15 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         if d_rowmax is not None:
             attach_row_maxima(out, d_rowmax)
         return out
+    if (_use_panel(M, N, K) and not relu and GEMM_F16X3 and K <= 128 and F16X3_F16_OUT and x.dtype == torch.float32
+            and out_dtype == torch.float16):
+        # fp32 rows in, half rows out (configs[4]'s x_l | x_r): the three-product kernel with one rounding at its store
+        planes, inv = _weight_planes(weight, cache_planes, "f16x3")
+        _lib.check(lib.isg_linear_f16x3_f16(
+            _chk(x, "x", torch.float32), planes.data_ptr(), inv.data_ptr(),
+            _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
+            out.data_ptr(), M, N, K, K, N, 1 if gelu else 0, N, 0, _stream()), "isg_linear_f16x3_f16")
+        return out
     if _use_panel(M, N, K) and not relu and GEMM_F16X3 and K <= 128 and not f16_io:
         planes, inv = _weight_planes(weight, cache_planes, "f16x3")
         _lib.check(lib.isg_linear_f16x3(
@@ -2163,10 +2174,12 @@ def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
     cat = derived_weight("linear_multi", tuple(weights), lambda: torch.cat([w.detach() for w in weights], 0).contiguous())
     L = len(weights)
     out = torch.empty(L, M, n, dtype=out_dtype, device=x.device)
-    if GEMM_F16X3 and K <= 128 and x.dtype == torch.float32 and out_dtype == torch.float32:
+    if GEMM_F16X3 and K <= 128 and x.dtype == torch.float32 and (out_dtype == torch.float32 or
+                                                                 (out_dtype == torch.float16 and F16X3_F16_OUT)):
         planes, inv = _weight_planes(cat, True, "f16x3")
-        _lib.check(lib.isg_linear_f16x3(_chk(x, "x", torch.float32), planes.data_ptr(), inv.data_ptr(), 0, out.data_ptr(),
-                                        M, L * n, K, K, n, 0, n, M * n, _stream()), "isg_linear_f16x3")
+        fn = lib.isg_linear_f16x3 if out_dtype == torch.float32 else lib.isg_linear_f16x3_f16
+        _lib.check(fn(_chk(x, "x", torch.float32), planes.data_ptr(), inv.data_ptr(), 0, out.data_ptr(),
+                      M, L * n, K, K, n, 0, n, M * n, _stream()), "isg_linear_f16x3")
         return tuple(out[i] for i in range(L))
     planes = _weight_planes(cat, True, "panel")
     _lib.check(lib.isg_linear_panel_multi(

@@ -1685,3 +1685,34 @@ def test_layer_conv_ignores_an_edge_whose_destination_is_out_of_range(dev):
     keep = torch.ones(ei_bad.size(1), dtype=torch.bool)
     keep[10] = False
     assert torch.equal(a0, a1[keep.to(dev)])
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(5000, 1024, 128, False), (333, 96, 36, True), (70000, 512, 128, False)])
+def test_linear_f16x3_half_rows_are_the_fp32_result_rounded_once(dev, M, N, K, gelu):
+    """isg_linear_f16x3_f16 (configs[4]'s x_l | x_r / e_proj as half rows) == isg_linear_f16x3's fp32 result rounded to half (RNE),
+    bit for bit; and the multi-layer form (one launch, L outputs)."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=gen) * torch.rand(M, 1, generator=gen).mul(3).exp()).to(dev)
+    w, b = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev), torch.randn(N, generator=gen).to(dev)
+    if not ops._use_panel(M, N, K):
+        pytest.skip("not a panel-kernel shape")
+    ref = ops.linear(x, w, b, gelu=gelu)
+    got = ops.linear(x, w, b, gelu=gelu, out_dtype=torch.float16)
+    assert got.dtype == torch.float16 and torch.equal(got, ref.half())
+    keep = ops.F16X3_F16_OUT
+    try:
+        ops.F16X3_F16_OUT = False                 # the bf16 six-product kernel it replaces: the same value to a half step
+        old = ops.linear(x, w, b, gelu=gelu, out_dtype=torch.float16)
+    finally:
+        ops.F16X3_F16_OUT = keep
+    # (a half step of the value, plus the two kernels' own fp32-level difference where a sum cancels)
+    step = ref.abs() * 2.0 ** -10 + 2e-6 * x.abs().amax(dim=1, keepdim=True) * w.abs().sum(dim=1).max()
+    assert ((old.float() - got.float()).abs() <= step).all()
+    if N % 64 == 0 and not gelu:
+        ws = [w[: N // 2], w[N // 2:]]
+        multi = ops.linear_multi(x, ws, out_dtype=torch.float16)
+        if multi is not None:
+            ref2 = ops.linear_multi(x, ws)
+            for a, r in zip(multi, ref2):
+                assert torch.equal(a, r.half())

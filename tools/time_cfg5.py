@@ -14,7 +14,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 graphs = int(args[0]) if args else 2048
 dev = torch.device("cuda:0")
 ops.MIXED_MAX_FRACTION, ops.MIXED_MIN_NODES = 0.9, 0      # the gate open: this tool measures the mode itself
-cfg = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": graphs})
+cfg = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": graphs,
+                                  "feature_dtype": "fp16" if "--fp16" in sys.argv else "fp32"})       # --fp16: configs[4]'s half rows
 order = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--order=")]       # the same graphs, largest / smallest first
 if order:
     sizes = sorted(synthetic.graph_sizes(cfg, torch.Generator().manual_seed(cfg.seed)).tolist(), reverse=order[0] == "desc")
