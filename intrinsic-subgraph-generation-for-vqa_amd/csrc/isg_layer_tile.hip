@@ -122,33 +122,69 @@ __device__ __forceinline__ void tile_plan_body(const int *__restrict__ ptr, cons
   // The same descriptors HEAVY TILES FIRST (by 32-slot half chunks, the unit of the layer kernel's edge loop; ties in tile order):
   // a persistent kernel whose workgroup w walks entries w, w + G, w + 2G, ... of THIS list gets one tile of every weight class
   // per round instead of whatever the batch order deals it -- at BASELINE configs[1] the slowest workgroup's share of the work
-  // drops from 1.062x to 1.029x the mean (tools/sim_tile_balance.py).  One wave, two passes of ballots over the list.
-  if (tile_info && tile_heavy_first && wave == 0) {          // (every tile_info entry is written and behind a barrier)
+  // drops from 1.062x to 1.029x the mean (tools/sim_tile_balance.py).  A stable counting sort over 9 classes on every wave of the
+  // workgroup: one pass of ballots counts, one pass places 1024 descriptors per round (one wave doing both took 15 us of the
+  // launch -- 48 dependent rounds of a global load and 9 ballots -- behind which the whole chip waited).
+  if (tile_info && tile_heavy_first) {          // (uniform; every tile_info entry is written and behind a barrier)
+    constexpr int NB = 9;                       // classes: 8, 7, ..., 0 half chunks (8 = a full 256-slot tile)
+    constexpr int NW = TP_CH / 64;
+    __shared__ int s_cnt[NW][NB];
+    __shared__ int s_start[NB];
+    __syncthreads();                            // s_base is final
     const int T = min(s_base, cap);
-    constexpr int NB = 9;                                     // classes: 8, 7, ..., 0 half chunks (8 = a full 256-slot tile)
-    int base[NB];
+    int mine[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) base[b] = 0;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-      const int t = t0 + lane;
+    for (int b = 0; b < NB; ++b) mine[b] = 0;
+    for (int t0 = 0; t0 < T; t0 += TP_CH) {      // every thread walks every round: the ballots need whole waves
+      const int t = t0 + i;
       const int cls = t < T ? NB - 1 - min((tile_info[t].w + 31) >> 5, NB - 1) : -1;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) base[b] += __popcll(__ballot(cls == b));
+      for (int b = 0; b < NB; ++b) mine[b] += __popcll(__ballot(cls == b));
     }
-    int run = 0;
+    if (lane == 0) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { const int c = base[b]; base[b] = run; run += c; }
-    for (int t0 = 0; t0 < T; t0 += 64) {
-      const int t = t0 + lane;
+      for (int b = 0; b < NB; ++b) s_cnt[wave][b] = mine[b];
+    }
+    __syncthreads();
+    if (i == 0) {
+      int run = 0;
+      for (int b = 0; b < NB; ++b) {
+        int c = 0;
+        for (int w = 0; w < NW; ++w) c += s_cnt[w][b];
+        s_start[b] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += TP_CH) {      // 1024 descriptors per round, wave w the 64 at t0 + 64 w: tile order within a class
+      const int t = t0 + i;
       int4 d = make_int4(0, 0, 0, 0);
       if (t < T) d = tile_info[t];
       const int cls = t < T ? NB - 1 - min((d.w + 31) >> 5, NB - 1) : -1;
+      int below = 0, wcnt[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const unsigned long long m = __ballot(cls == b);
-        if (cls == b) tile_heavy_first[base[b] + __popcll(m & ((1ull << lane) - 1ull))] = d;
-        base[b] += __popcll(m);
+        wcnt[b] = __popcll(m);
+        if (cls == b) below = __popcll(m & ((1ull << lane) - 1ull));
       }
+      if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) s_cnt[wave][b] = wcnt[b];
+      }
+      __syncthreads();
+      if (cls >= 0) {
+        int at = s_start[cls] + below;
+        for (int w = 0; w < wave; ++w) at += s_cnt[w][cls];
+        tile_heavy_first[at] = d;
+      }
+      __syncthreads();
+      if (i < NB) {
+        int c = 0;
+        for (int w = 0; w < NW; ++w) c += s_cnt[w][i];
+        s_start[i] += c;
+      }
+      __syncthreads();
     }
   }
 }
