@@ -85,19 +85,16 @@ def _rec(*tensors) -> bool:
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_dev_index: Optional[int] = None
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _stream() -> int:
     """The current stream's hipStream_t.  torch.cuda.current_stream() builds a Stream object per call (~20 calls and 0.1-0.2 ms
     of host time per step, which a host-bound step -- small batches, the sub-batch of run_split -- pays in full): the raw
-    handle of this process's device instead (one process per GPU; the index is read once)."""
-    global _dev_index
-    if _raw_stream is None:
+    handle of the current device's current stream instead."""
+    if _raw_stream is None or _get_device is None:
         return torch.cuda.current_stream().cuda_stream
-    if _dev_index is None:
-        _dev_index = torch.cuda.current_device()
-    return _raw_stream(_dev_index)
+    return _raw_stream(_get_device())
 
 
 def _chk(t: Optional[Tensor], name: str, dtype, shape=None, optional=False) -> int:
@@ -139,6 +136,7 @@ def _chk_rows(t: Tensor, name: str, dtype=torch.float32) -> int:
 # at check_plans().  An understated hint (which would size the LDS tables / sampler rows too small and truncate
 # graphs silently) therefore raises -- one step late, but loudly and without stalling the stream.
 _PENDING_HINTS = []      # (event, pinned int32[2] = true [max nodes, max edges], hinted max_nodes, hinted max_edges)
+_PENDING_SIZES = []      # (event, pinned int64[2 or 3] = graphs beyond a tile / their nodes / their edges counted on the device, the hint's counts)
 
 
 def check_plans(block: bool = True) -> None:
@@ -154,6 +152,19 @@ def check_plans(block: bool = True) -> None:
         if n_true > hn or (he is not None and e_true > he):
             bad = bad or (n_true, e_true, hn, he)
     _PENDING_HINTS[:] = keep
+    keep_s, bad_s = [], None
+    for ev, host, expect in _PENDING_SIZES:       # graph_sizes hints (GraphPlan._oversize_stats): counted on the device as well
+        if not block and not ev.query():
+            keep_s.append((ev, host, expect))
+            continue
+        ev.synchronize()
+        got = [int(v) for v in host.tolist()]
+        if got != expect:
+            bad_s = bad_s or (got, expect)
+    _PENDING_SIZES[:] = keep_s
+    if bad_s is not None:
+        raise _lib.IsgError(f"GraphPlan graph_sizes disagree with the batch: graphs beyond a tile / their nodes / their edges "
+                            f"counted on the device {bad_s[0]}, from the hint {bad_s[1]}; results of that batch are invalid")
     if bad is not None:
         raise _lib.IsgError(f"GraphPlan hints understate the batch: max_nodes={bad[2]} / max_edges={bad[3]} given, "
                             f"but a graph has {bad[0]} nodes / {bad[1]} edges; results of that batch are invalid")
@@ -350,6 +361,15 @@ class GraphPlan:
                 st = [int(bh.sum()), int(nh[bh].sum()), int(nh[bh].max()) if bool(bh.any()) else 0]
                 if e is not None:
                     st += [int(eh[bh].sum()), int(eh[bh].max()) if bool(bh.any()) else 0]
+                if not torch.cuda.is_current_stream_capturing():
+                    # the same counts on the device, copied to pinned memory behind the stream and compared at check_plans():
+                    # a wrong hint would size the lists below wrongly without any fault
+                    dev_cnt = torch.stack([big, big * n] + ([big * e] if e is not None else [])).sum(1)
+                    host = torch.empty(dev_cnt.numel(), dtype=torch.int64, pin_memory=True)
+                    host.copy_(dev_cnt, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    _PENDING_SIZES.append((ev, host, [st[0], st[1]] + ([st[3]] if e is not None else [])))
             else:
                 zero = n.new_zeros(())
                 nb = torch.where(big, n, zero)
@@ -486,7 +506,7 @@ class GraphPlan:
             plan._bounds_dev = bounds
             plan._hints = (int(max_nodes), None if edge_index is None else int(max_edges))
         else:                                       # hinted: verify later, without a sync (see check_plans)
-            if _PENDING_HINTS:
+            if _PENDING_HINTS or _PENDING_SIZES:
                 check_plans(block=False)
             if host_bounds is not None:
                 host = host_bounds

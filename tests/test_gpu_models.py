@@ -788,3 +788,26 @@ def test_split_forward_variants_agree(dev):
         assert torch.equal(l, l0) and torch.equal(m, m0) and torch.equal(g, g0), name
     l, m, g = outs["fill"]
     assert torch.equal(m, m0) and (l - l0).abs().max() < 2e-5 and torch.allclose(g, g0, atol=1e-6)
+
+
+def test_a_wrong_graph_sizes_hint_is_caught_at_check_plans(dev):
+    """GraphPlan.build(graph_sizes=) is trusted to keep the step free of a device-to-host sync; the same counts are made on the
+    device, copied to pinned memory behind the stream and compared at ops.check_plans(): a hint that misses a big graph raises."""
+    from isubgvqa_amd import _lib, ops, synthetic
+    sizes = (20,) * 50 + (130,) + (20,) * 50
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler="imle", seed=3)
+    wl = synthetic.make_workload(cfg).to(dev)
+    ops.check_plans()
+    good = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=cfg.num_graphs, max_nodes=wl.max_nodes, max_edges=wl.max_edges,
+                               graph_sizes=wl.graph_sizes)
+    assert _forced_mixed(lambda: good.tile_mode(64, 256)) == "mixed"
+    ops.check_plans()                                      # consistent: silent
+    wrong = wl.graph_sizes.clone()
+    wrong[0, 50] = 20                                      # the hint hides the 130-node graph's size (its edges still give it away)
+    wrong[1, 50] = 40
+    bad = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=cfg.num_graphs, max_nodes=wl.max_nodes, max_edges=wl.max_edges,
+                              graph_sizes=wrong)
+    _forced_mixed(lambda: bad.tile_mode(64, 256))
+    with pytest.raises(_lib.IsgError, match="graph_sizes disagree"):
+        ops.check_plans()
+    ops.check_plans()                                      # reported once
