@@ -997,7 +997,13 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
     for (int k = 2 * tw + hh; k < nrows; k += 8) {
       const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 2
+      // NOT unrolled.  With `#pragma unroll 2` (an odd first slot, then pairs: ds_read2_b32 of two weights, two ds_read_b128, four
+      // v_pk_fma_f32 of which two take their weight through op_sel) one launch in ~15 at 700 graphs x 4 heads left ONE register
+      // (o.x or o.z) of lanes 16-31 of one node's half-wave with a wrong sum -- the same inputs, two launches, different bits;
+      // isg_gatv2_layer_conv, which walks its in-edges by hand, never did (tools/repro_layer_conv_flake.py: 22 / 250 and 13 / 250
+      // launches before, 0 / 300 with this loop rolled).  The cause is not understood: every LDS access of the unrolled loop is
+      // behind its s_waitcnt, every buffer behind its barrier, a full vmcnt(0) before the hand-over changes nothing.
+#pragma unroll 1
       for (int s = rb; s < re; ++s) {
         const float wm = s_w[s];
         const float4 u4 = *reinterpret_cast<const float4 *>(&sXl[s_tab[s].x][fr * 4]);
