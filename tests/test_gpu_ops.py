@@ -1716,3 +1716,33 @@ def test_linear_f16x3_half_rows_are_the_fp32_result_rounded_once(dev, M, N, K, g
             ref2 = ops.linear_multi(x, ws)
             for a, r in zip(multi, ref2):
                 assert torch.equal(a, r.half())
+
+
+def test_tile_kernels_give_the_same_bits_on_every_launch(dev, monkeypatch):
+    """The same inputs, launch after launch: isg_gatv2_tile_conv and isg_gatv2_layer_conv must return the same bits every time
+    (700 random graphs, 4 heads).  isg_gatv2_tile_conv did not, in one launch of ~15, while its aggregation loop was unrolled by two
+    (one register of 16 lanes of one node: DESIGN.md 15.4, tools/repro_layer_conv_flake.py); 24 launches of each kernel here."""
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.models.layers import GlorotLinear
+    gen = torch.Generator().manual_seed(29)
+    H, C, K = 4, 128, 128
+    monkeypatch.setattr(ops, "GEMM_KERNEL", "panel")
+    torch.manual_seed(6)
+    lin_l, lin_r = GlorotLinear(128, H * C, bias=True).to(dev), GlorotLinear(128, H * C, bias=True).to(dev)
+    for rep in range(6):
+        sizes = torch.randint(8, 34, (700,), generator=gen).tolist()
+        batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=(7, 60))
+        N, E, B = batch.numel(), ei.size(1), len(sizes)
+        x = (torch.randn(N, 128, generator=gen) * torch.rand(N, 1, generator=gen).mul(3).exp()).to(dev)
+        ea, w = torch.randn(E, K, generator=gen).to(dev), (torch.randn(H * C, K, generator=gen) * 0.1).to(dev)
+        att, bias = torch.randn(1, H, C, generator=gen).to(dev), torch.randn(H * C, generator=gen).to(dev)
+        plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=B)
+        with torch.no_grad():
+            x_l, x_r = ops.linear_fused(x, (lin_l, lin_r))
+            f = [ops.gatv2_layer_conv(x, lin_l, lin_r, ea, w, att, plan, H, bias=bias) for _ in range(4)]
+            t = [ops.gatv2_tile_conv(x_l, x_r, ea, w, att, plan, H, bias=bias) for _ in range(4)]
+        for i in range(1, 4):
+            assert torch.equal(f[i][0], f[0][0]) and torch.equal(f[i][1], f[0][1]), ("layer_conv", rep, i)
+            assert torch.equal(t[i][0], t[0][0]) and torch.equal(t[i][1], t[0][1]), ("tile_conv", rep, i,
+                                                                                     (t[i][0] - t[0][0]).abs().max().item())
+        assert torch.equal(f[0][0], t[0][0]) and torch.equal(f[0][1], t[0][1])
