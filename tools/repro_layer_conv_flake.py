@@ -78,4 +78,30 @@ for it in range(iters):
                 srcs = ei[0][ei[1] == r].tolist()
                 print(f"      row {r} = node {r - first} of graph {gph} ({sizes[gph]} nodes), columns {cols}; in-edges from {[s_ - first for s_ in srcs]}")
                 print(f"      a: {a[r, cols[:4]].tolist()}  b: {b[r, cols[:4]].tolist()}")
+                if name.startswith("layer#") and "--explain" in sys.argv:      # a = the layer kernel (right), b = tile_conv (wrong)
+                    hd = cols[0] // C
+                    eids = (ei[1] == r).nonzero().flatten()
+                    al = t[0][1][eids.to(dev), hd].double().cpu()                    # alpha of the row's in-edges (edge-id order)
+                    xs = x_l[ei[0][eids].to(dev)][:, cols].double().cpu()             # their x_l values at the differing columns
+                    terms = al[:, None] * xs
+                    right = a[r, cols].double().cpu() - bias[cols].double().cpu()
+                    wrong = b[r, cols].double().cpu() - bias[cols].double().cpu()
+                    print(f"      in-degree {eids.numel()}, alpha {al.tolist()}")
+                    print(f"      sum of terms - right: {(terms.sum(0) - right).abs().max().item():.2e}")
+                    for j in range(eids.numel()):
+                        print(f"      without term {j}: max |.. - wrong| = {((terms.sum(0) - terms[j]) - wrong).abs().max().item():.3e};"
+                              f"  term {j} alone: {(terms[j] - wrong).abs().max().item():.3e};"
+                              f"  term {j} twice: {((terms.sum(0) + terms[j]) - wrong).abs().max().item():.3e}")
+                    # the half-wave's previous node (k - 8 of the tile) and the other component pair of the same lanes
+                    print(f"      wrong - right: {(wrong - right)[:6].tolist()}")
+                    for dr in (-8, -1, 1, 8):
+                        if 0 <= r + dr < N:
+                            other = a[r + dr, cols].double().cpu() - bias[cols].double().cpu()
+                            print(f"      right row {r + dr:+d}: max |wrong - that| = {(wrong - other).abs().max().item():.3e}; "
+                                  f"|wrong - right - that| = {(wrong - right - other).abs().max().item():.3e}")
+                    for dc in (-2, -1, 1, 2):
+                        cc = [c + dc for c in cols]
+                        if min(cc) >= 0 and max(cc) < H * C:
+                            other = a[r, cc].double().cpu() - bias[cc].double().cpu()
+                            print(f"      right columns {dc:+d}: max |wrong - that| = {(wrong - other).abs().max().item():.3e}")
 print(f"{bad} of {iters} iterations with a mismatch")
