@@ -95,22 +95,12 @@ class ISubGVQA(torch.nn.Module):
 
     def answer_graphs(self, x_encoded, edge_index, edge_attr_encoded, batch, instr_vectors, glf, plan,
                       return_masks=True, noises=None, seed=None, explainer=False, explainer_stage=False,
-                      expl_bypass_x=False, gate_feats=None):
+                      expl_bypass_x=False):
         """MGAT -> pooling -> classifier (isubgvqa.py:267-292)."""
-        if not explainer and isinstance(instr_vectors, Tensor):
-            # a few graphs beyond a graph tile (the reference caps nothing: datasets/scene_graph.py:199-389): they run as a batch
-            # of their own on the per-graph kernels, the rest of the batch stays on the tile kernels (ops.run_split)
-            sub = ops.oversize_split(plan) if self.gat_seq.on_tiles(plan, x_encoded.size(1), edge_attr_encoded) else None
-            if sub is not None:
-                core = lambda x, ei, ea, b, ins, g, pl, nz, sd, gf: self.answer_graphs(x, ei, ea, b, ins, g, pl, return_masks, nz, sd,
-                                                                                     gate_feats=gf)
-                return ops.run_split(plan, sub, core, x_encoded, edge_index, edge_attr_encoded, batch, instr_vectors, glf, noises,
-                                     seed, kinds="gnnn")
         x_mgat, imle_mask, node_logits_layers, _ = self.gat_seq(
             x=x_encoded, edge_index=edge_index, edge_attr=edge_attr_encoded, instr_vectors=instr_vectors[:4],
             global_language_feats=glf, batch=batch, return_masks=return_masks, explainer=explainer,
-            explainer_stage=explainer_stage, expl_bypass_x=expl_bypass_x, plan=plan, noises=noises, seed=seed,
-            gate_feats=gate_feats)
+            explainer_stage=explainer_stage, expl_bypass_x=expl_bypass_x, plan=plan, noises=noises, seed=seed)
         embed, gate = self.graph_global_attention_pooling(x=x_mgat, u=glf, batch=batch, size=None,
                                                           return_mask=True, node_mask=imle_mask, plan=plan)
         feats = ops.mlp(self.embedding, ops.cat_mul(embed, glf), want_rowmax=True)       # :288-291 (row maxima: for logit_fc)

@@ -228,22 +228,24 @@ class FullWorkload:
     att_mask: Tensor          # [B, T] 1 = real token
     max_nodes: int
     max_edges: int
+    graph_sizes: Optional[Tensor] = None      # HOST int64 [2, B] (nodes, in-edges per graph), as loader.collate hands them over
 
     def to(self, device) -> "FullWorkload":
         mv = lambda t: t.to(device)
         return FullWorkload(mv(self.x), mv(self.edge_index), mv(self.edge_attr), mv(self.batch), mv(self.x_bbox),
-                            mv(self.added_sym_edge), mv(self.questions), mv(self.att_mask), self.max_nodes, self.max_edges)
+                            mv(self.added_sym_edge), mv(self.questions), mv(self.att_mask), self.max_nodes, self.max_edges,
+                            self.graph_sizes)
 
     def scene_graphs(self):
         import argparse
         return argparse.Namespace(x_bbox=self.x_bbox, added_sym_edge=self.added_sym_edge, max_nodes=self.max_nodes,
-                                  max_edges=self.max_edges)
+                                  max_edges=self.max_edges, graph_sizes=self.graph_sizes)
 
 
 def make_full_workload(num_graphs: int, tokens: int = 12, seed: int = 7, sg_vocab: int = 2578,
-                       text_vocab: int = 49408) -> FullWorkload:
+                       text_vocab: int = 49408, sizes=None) -> FullWorkload:
     gen = torch.Generator().manual_seed(seed + 1)
-    cfg = WorkloadConfig(num_graphs=num_graphs, seed=seed)
+    cfg = WorkloadConfig(num_graphs=num_graphs, seed=seed, sizes=None if sizes is None else tuple(sizes))
     batch, ei, nmax = make_topology(cfg, gen)
     N, E = batch.numel(), ei.size(1)
     x = torch.randint(0, sg_vocab, (N, 4), generator=gen)
@@ -254,5 +256,6 @@ def make_full_workload(num_graphs: int, tokens: int = 12, seed: int = 7, sg_voca
     q = torch.randint(0, text_vocab, (num_graphs, tokens), generator=gen)
     lens = torch.randint(max(1, tokens // 2), tokens + 1, (num_graphs,), generator=gen)
     qmask = (torch.arange(tokens)[None] < lens[:, None]).long()
-    emax = int(torch.bincount(batch[ei[1]], minlength=num_graphs).max())
-    return FullWorkload(x, ei, edge_attr, batch, x_bbox, sym, q, qmask, nmax, emax)
+    epg = torch.bincount(batch[ei[1]], minlength=num_graphs)
+    return FullWorkload(x, ei, edge_attr, batch, x_bbox, sym, q, qmask, nmax, int(epg.max()),
+                        torch.stack([torch.bincount(batch, minlength=num_graphs), epg]))

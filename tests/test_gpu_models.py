@@ -811,3 +811,4 @@ def test_a_wrong_graph_sizes_hint_is_caught_at_check_plans(dev):
     with pytest.raises(_lib.IsgError, match="graph_sizes disagree"):
         ops.check_plans()
     ops.check_plans()                                      # reported once
+
