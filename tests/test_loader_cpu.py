@@ -174,3 +174,29 @@ def test_number_at_the_very_end_of_an_unterminated_buffer(L, g8):
     st.add_json(good)
     with pytest.raises(L.LoaderError):           # truncated right after the number: must fail inside the view, not read on
         st.add_json('{"a": {"width": 12')
+
+
+def test_collate_hands_over_per_graph_sizes_when_a_graph_lies_beyond_a_tile(L, g8):
+    """The reference caps nothing (datasets/scene_graph.py:199-389): a scene graph with 70 objects is beyond the 64-node tile of the
+    GPU kernels.  collate then carries graph_sizes = (nodes, in-edges) per graph on the HOST (ops.GraphPlan.build's hint: the list of
+    such graphs is made without a device-to-host sync); a batch of small graphs carries none."""
+    rng = random.Random(11)
+    names, attrs, rels = g8["token_lists"][0], g8["token_lists"][1], g8["token_lists"][2]
+    graphs = _random_graphs(rng, 20, names, attrs, rels)
+    ids = list(range(1, 71))
+    graphs["big"] = {"objects": {str(i): {"name": rng.choice(names), "attributes": [],
+                                          "relations": [{"object": str(rng.choice(ids)), "name": rng.choice(rels)} for _ in range(2)]}
+                                 for i in ids}, "width": 640}
+    st = L.SceneGraphStore(L.SceneGraphVocab(g8["token_lists"]))
+    st.add_json(json.dumps(graphs))
+    small = st.collate([k for k in graphs if k != "big"], pin_memory=False)
+    assert small.graph_sizes is None and small.max_nodes <= 64
+    keys = list(graphs)
+    b = st.collate(keys, pin_memory=False)
+    assert b.max_nodes == 70 and b.graph_sizes is not None and b.graph_sizes.device.type == "cpu"
+    assert tuple(b.graph_sizes.shape) == (2, len(keys))
+    assert torch.equal(b.graph_sizes[0], b.ptr[1:] - b.ptr[:-1])
+    assert torch.equal(b.graph_sizes[1], torch.bincount(b.batch[b.edge_index[1]], minlength=len(keys)))
+    assert int(b.graph_sizes[0].max()) == b.max_nodes and int(b.graph_sizes[1].max()) == b.max_edges
+    moved = b.to("cpu")
+    assert moved.graph_sizes is b.graph_sizes
