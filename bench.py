@@ -75,11 +75,14 @@ def parse(argv=None):
     ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
                     help="graph: the step (plan build included) captured once as a hipGraph and replayed; Gumbel noise from "
                          "torch's generator inside the graph (fresh on every replay); single GPU")
-    ap.add_argument("--gather", choices=["answers", "logits"], default="answers",
-                    help="N > 1: what every rank receives per step -- the arg-max answers [B_local] i64 of every peer (32 KB per "
-                         "rank; the path shards by graph with no data-path exchange, and the reference's evaluation loop moves "
-                         "counts only, utils/misc.py:40-48), or their fp32 logits [B_local,1842] (30 MB per rank per step at 4096 "
-                         "graphs: 211 MB received per step at N = 8, DESIGN §7 has the budget)")
+    ap.add_argument("--gather", choices=["logits", "answers"], default="logits",
+                    help="N > 1: what every rank receives per step -- the fp32 logits [B_local,1842] of every peer (BASELINE "
+                         "north_star / configs[3]: 30 MB per rank per step at 4096 graphs, 211 MB received at N = 8; the default), "
+                         "or only their arg-max answers [B_local] i64 (32 KB per rank: what the reference's evaluation loop "
+                         "needs, utils/misc.py:40-48; opt-in, reported as such in rccl.collective)")
+    ap.add_argument("--gather-depth", type=int, default=2,
+                    help="N > 1: all-gathers in flight (depth + 1 receive buffers): depth 2 hides a collective of up to two "
+                         "steps' length behind the following steps' kernels (DESIGN 7, option 2)")
     ap.add_argument("--no-fuse-logits", action="store_true",
                     help="A/B: lin_edge as its own GEMM + the message-passing kernel streaming e_proj (the round-1 boundary)")
     ap.add_argument("--features", choices=["fp32", "fp16"], default="fp32",
@@ -579,7 +582,6 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from isubgvqa_amd import ops, synthetic
-    from isubgvqa_amd.distributed import all_gather_logits
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -606,27 +608,14 @@ def main(argv=None):
     wl = synthetic.make_workload(cfg).to(dev)
     model = synthetic.build_answer_model(cfg).to(dev).eval()
     N, E = wl.x.size(0), wl.edge_index.size(1)
-    # two gather buffers: the all-gather of step i runs on the communicator's stream while step i+1 computes
-    gshape = (world * cfg.num_graphs, 1842) if args.gather == "logits" else (world * cfg.num_graphs,)
-    gathered = [torch.empty(gshape, dtype=torch.float32 if args.gather == "logits" else torch.int64, device=dev)
-                for _ in range(2)] if world > 1 else None
-    pending = []          # (work, logits kept alive) of the all-gather in flight
-
-    def drain():
-        while pending:
-            work, _keep = pending.pop(0)
-            work.wait()
+    # the per-step collective: up to --gather-depth all-gathers in flight on the communicator's stream beside the next steps' kernels
+    from isubgvqa_amd.distributed import GatherPipeline
+    pipe = GatherPipeline(cfg.num_graphs, 1842, dev, what=args.gather, depth=args.gather_depth)
+    drain = pipe.drain
 
     def step(i: int):
         logits, mask, gate = model(wl, seed=1000 + i, use_hints=not args.no_hints)   # in-kernel Philox noise
-        if world > 1:
-            drain()       # at most one collective in flight: its buffer is free again, its input may be released
-            if args.gather == "answers":
-                logits = logits.argmax(dim=1)
-            out, work = all_gather_logits(logits, gathered[i % 2], async_op=True)
-            pending.append((work, logits))
-            return out
-        return logits
+        return pipe.submit(i, logits)
 
     def fence():
         drain()
@@ -718,8 +707,7 @@ def main(argv=None):
         all_devs = [torch.empty_like(devs) for _ in range(world)]
         dist.all_gather(all_devs, devs)
         rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(),
-                "devices": [int(d.item()) for d in all_devs], "collective": "all_gather_into_tensor(logits[B_local,1842] f32)" if args.gather == "logits"
-                else "all_gather_into_tensor(answers[B_local] i64)"}
+                "devices": [int(d.item()) for d in all_devs], **pipe.describe()}
     else:
         rccl = {"backend": None, "world": 1, "devices": [int(devs.item())], "collective": None}
     rccl["gpu"] = torch.cuda.get_device_name(dev)

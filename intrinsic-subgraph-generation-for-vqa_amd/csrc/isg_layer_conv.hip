@@ -431,7 +431,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     const int slot = min(64 * (ch) + prow, ne - 1);                                                                  \
     const float sinv = s_einv[slot];                                                                                 \
     int4 rec = s_tab[slot];                                                                                          \
-    const float me = __int_as_float(rec.w);                                                                          \
+    const float me = own_reg(__int_as_float(rec.w));    /* a scalar: never the high dword of the record's (z, w) pair */  \
     float part[4];                                                                                                   \
     int cb = tw * 32 + 4 * hh;       /* laundered: hoisted out of the chunk loop, the 16 addresses below cost 16 registers */ \
     asm volatile("" : "+v"(cb));                                                                                     \

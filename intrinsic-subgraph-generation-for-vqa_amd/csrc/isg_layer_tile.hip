@@ -939,7 +939,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
         const int prow = i * 32 + fr;
         const float sinv = s_inv[prow];
         const int4 rec = s_tab[min(64 * c + prow, ne - 1)];
-        const float me = __int_as_float(rec.w);
+        const float me = own_reg(__int_as_float(rec.w));      // a scalar: never the high dword of the record's (z, w) pair
         float part[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -997,15 +997,15 @@ __global__ __launch_bounds__(TC_THREADS, 2) void gatv2_tile_conv_kernel(TcArgs a
     for (int k = 2 * tw + hh; k < nrows; k += 8) {
       const int rb = s_rp[k], re = min(s_rp[k + 1], ne);
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      // NOT unrolled.  With `#pragma unroll 2` (an odd first slot, then pairs: ds_read2_b32 of two weights, two ds_read_b128, four
-      // v_pk_fma_f32 of which two take their weight through op_sel) one launch in ~15 at 700 graphs x 4 heads left ONE register
-      // (o.x or o.z) of lanes 16-31 of one node's half-wave with a wrong sum -- the same inputs, two launches, different bits;
-      // isg_gatv2_layer_conv, which walks its in-edges by hand, never did (tools/repro_layer_conv_flake.py: 22 / 250 and 13 / 250
-      // launches before, 0 / 300 with this loop rolled).  The cause is not understood: every LDS access of the unrolled loop is
-      // behind its s_waitcnt, every buffer behind its barrier, a full vmcnt(0) before the hand-over changes nothing.
+      // One in-edge per trip, its weight in a register of its own (own_reg).  Round 4's `#pragma unroll 2` form let the second
+      // fma of a pair take its weight from the HIGH dword of a ds_read2_b32 result (v_pk_fma_f32 .. op_sel:[0,1,0]) and one launch
+      // in ~15 left o.x or o.z of lanes 16-31 of a half-wave without that in-edge's term.  tools/flake/ (DESIGN.md 16.1): 48-417
+      // wrong launches of 1600 in every variant with that operand form -- two accumulators, no loads in flight, 16 idle cycles
+      // behind the LDS reads alike -- and 0 of 1600 in the variants without it; tools/scan_pk_cross.py keeps the form out of the
+      // whole library.
 #pragma unroll 1
       for (int s = rb; s < re; ++s) {
-        const float wm = s_w[s];
+        const float wm = own_reg(s_w[s]);
         const float4 u4 = *reinterpret_cast<const float4 *>(&sXl[s_tab[s].x][fr * 4]);
         o.x = fmaf(u4.x, wm, o.x);
         o.y = fmaf(u4.y, wm, o.y);

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_flat_kernel(MpArgs 
           if (MASKED) { s.x *= me[u]; s.y *= me[u]; s.z *= me[u]; s.w *= me[u]; }
           s.x = leaky(s.x, slope); s.y = leaky(s.y, slope); s.z = leaky(s.z, slope); s.w = leaky(s.w, slope);
           if (MASKED) { s.x *= me[u]; s.y *= me[u]; s.z *= me[u]; s.w *= me[u]; }
-          const float d = dot4(s, att4[p]);
+          const float d = own_reg(dot4(s, att4[p]));     // a scalar: the head select below must not take it from a pair's high dword
 #pragma unroll
           for (int hh = 0; hh < HS; ++hh) part[hh] += hof[p] == hh ? d : 0.f;
         }

@@ -49,7 +49,8 @@ __device__ __forceinline__ void phase_logits(const float4 *__restrict__ q4, cons
       float4 v[PL_U];
 #pragma unroll
       for (int u = 0; u < PL_U; ++u) v[u] = key4[(size_t)(nb + min(k0 + u, n - 1)) * Q + c];
-      const float4 qv = q4[c];
+      float4 qv = q4[c];        // scalars of their own: the products of PL_U rows pair up across rows, never (q.y, q.x) out of one pair
+      qv.x = own_reg(qv.x); qv.y = own_reg(qv.y); qv.z = own_reg(qv.z); qv.w = own_reg(qv.w);
 #pragma unroll
       for (int u = 0; u < PL_U; ++u) {
         if (node_mask) {

@@ -90,3 +90,44 @@ def all_gather_logits_ragged(logits: Tensor, group=None) -> Tensor:
     out = torch.empty((world * m,) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
     dist.all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])
+
+
+class GatherPipeline:
+    """The per-step collective of the N > 1 path with up to `depth` all-gathers in flight (option 2): step i's
+    gather runs on the communicator's stream into buffer i % (depth + 1) while the following steps' kernels run, so a
+    collective up to `depth` steps long (a ring over per-link-bound xGMI) stays hidden.  `what` = "logits": BASELINE
+    north_star's collective, fp32 [B_local, A] per rank (main.py:72-94 is the reference's DDP shape); "answers": the arg-max
+    answers [B_local] i64 only (what the reference's evaluation reduces, utils/misc.py:40-48) -- opt-in."""
+
+    def __init__(self, b_local: int, answers: int, device, what: str = "logits", depth: int = 2, group=None):
+        import torch.distributed as dist
+        if what not in ("logits", "answers"):
+            raise ValueError(f"GatherPipeline: what = {what!r}")
+        self.what, self.depth, self.group = what, max(1, int(depth)), group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.b_local, self.answers = int(b_local), int(answers)
+        shape = (self.world * self.b_local, self.answers) if what == "logits" else (self.world * self.b_local,)
+        dtype = torch.float32 if what == "logits" else torch.int64
+        self.buffers = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth + 1)] if self.world > 1 else []
+        self.pending = []          # (work, input kept alive), oldest first
+
+    def drain(self, keep: int = 0) -> None:
+        while len(self.pending) > keep:
+            work, _keep = self.pending.pop(0)
+            work.wait()
+
+    def submit(self, i: int, logits: Tensor) -> Tensor:
+        """Queue step i's gather behind the producer of `logits`; returns the buffer it lands in (valid after drain())."""
+        if self.world == 1:
+            return logits
+        self.drain(self.depth - 1)     # the oldest gather's buffer is free again, its input may be released
+        src = logits if self.what == "logits" else logits.argmax(dim=1)
+        out, work = all_gather_logits(src, self.buffers[i % (self.depth + 1)], group=self.group, async_op=True)
+        self.pending.append((work, src))
+        return out
+
+    def describe(self) -> dict:
+        per = self.b_local * (self.answers * 4 if self.what == "logits" else 8)
+        return {"collective": f"all_gather_into_tensor(logits[B_local,{self.answers}] f32)" if self.what == "logits"
+                else "all_gather_into_tensor(answers[B_local] i64)",
+                "bytes_per_rank": per, "bytes_received_per_rank": (self.world - 1) * per, "in_flight": self.depth}

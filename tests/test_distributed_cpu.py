@@ -41,7 +41,7 @@ def _worker(rank, world, port, balance, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     from isubgvqa_amd import synthetic
-    from isubgvqa_amd.distributed import all_gather_logits, all_gather_logits_ragged, shard_workload
+    from isubgvqa_amd.distributed import GatherPipeline, all_gather_logits, all_gather_logits_ragged, shard_workload
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = _cfg(balance)
@@ -54,8 +54,18 @@ def _worker(rank, world, port, balance, q):
     ans, work = (None, None) if balance else all_gather_logits(local.argmax(dim=1), async_op=True)
     if work is not None:
         work.wait()
+    # bench.py's per-step collective with its DEFAULT arguments (north_star: the logits; two gathers in flight, three buffers)
+    import bench
+    args = bench.parse([])
+    piped = None
+    if not balance:
+        pipe = GatherPipeline(local.size(0), local.size(1), local.device, what=args.gather, depth=args.gather_depth)
+        outs = [pipe.submit(i, local + float(i)) for i in range(5)]
+        pipe.drain()
+        # buffers rotate over depth + 1 = 3: steps 2, 3, 4 are the ones still held
+        piped = (pipe.describe(), [o.clone() for o in outs[2:]], outs[4].data_ptr() == outs[1].data_ptr())
     if rank == 0:
-        q.put((full, shard.num_graphs, ans))
+        q.put((full, shard.num_graphs, ans, piped))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,7 +78,7 @@ def test_shard_compute_allgather_world2(balance):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, balance, q)) for r in range(2)]
     for p in procs:
         p.start()
-    full, n0, ans = q.get(timeout=120)
+    full, n0, ans, piped = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -81,6 +91,13 @@ def test_shard_compute_allgather_world2(balance):
     assert torch.allclose(full, ref, atol=1e-5)
     if not balance:
         assert ans.dtype == torch.int64 and torch.equal(ans, full.argmax(dim=1))
+        desc, held, rotated = piped
+        a = full.size(1)
+        assert desc["collective"] == f"all_gather_into_tensor(logits[B_local,{a}] f32)", desc       # the default IS the logits
+        assert desc["in_flight"] == 2 and desc["bytes_per_rank"] == n0 * a * 4 and desc["bytes_received_per_rank"] == n0 * a * 4
+        assert rotated
+        for i, got in zip((2, 3, 4), held):
+            assert torch.allclose(got, ref + float(i), atol=1e-5)
 
 
 def test_graph_ranges_balance_by_nodes_plus_edges():

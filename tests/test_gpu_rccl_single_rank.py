@@ -25,20 +25,21 @@ SCRIPT = textwrap.dedent("""
     assert dist.get_backend() == "nccl"
     g = torch.Generator(device=dev).manual_seed(0)
     logits = torch.randn(4096, 1842, device=dev, generator=g)              # one rank's answer logits (30 MB)
-    bufs = [torch.empty_like(logits) for _ in range(2)]
+    bufs = [torch.empty_like(logits) for _ in range(3)]
     pending, sent = [], []
-    for i in range(4):                                                      # bench.py's double-buffered async pattern
-        while pending:
+    for i in range(4):                              # distributed.GatherPipeline's pattern: two gathers in flight, three buffers
+        while len(pending) > 1:
             pending.pop(0)[0].wait()
-        w = dist.all_gather_into_tensor(bufs[i %% 2], logits, async_op=True)
+        w = dist.all_gather_into_tensor(bufs[i %% 3], logits, async_op=True)
         pending.append((w, logits))                                         # the input stays referenced until the wait
         sent.append(logits)
         logits = logits + 1.0                                               # next step's producer runs beside the collective
     while pending:
         pending.pop(0)[0].wait()
     torch.cuda.synchronize()
-    assert torch.equal(bufs[1], sent[3]) and torch.equal(bufs[0], sent[2]), "gathered logits differ from what was sent"
-    # the default collective of bench.py (--gather answers): every rank's arg-max answers, i64, async like the logits
+    assert torch.equal(bufs[0], sent[3]) and torch.equal(bufs[2], sent[2]) and torch.equal(bufs[1], sent[1]), \
+        "gathered logits differ from what was sent"
+    # the opt-in light collective of bench.py (--gather answers): every rank's arg-max answers, i64, async like the logits
     ans = sent[3].argmax(dim=1)
     abuf = torch.empty_like(ans)
     w = dist.all_gather_into_tensor(abuf, ans, async_op=True)

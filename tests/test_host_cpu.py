@@ -208,3 +208,26 @@ def test_docs_quote_the_headers_symbol_count_and_abi_version():
         for q in re.findall(r"(\d+) (?:`extern \"C\"` )?symbols", text) + re.findall(r"for all (\d+)\b", text):
             if 30 <= int(q) <= 200:      # counts of the device library (the loader's 15 are quoted too)
                 assert int(q) == n_sym, f"{name} quotes {q} symbols, include/isg.h declares {n_sym}"
+
+
+def test_library_holds_no_cross_selecting_packed_fp32_operation():
+    """on gfx950 a v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 that takes a LOW-half operand from the HIGH dword of
+    a register pair (op_sel:[..1..]) intermittently lost its low-half result in isg_gatv2_tile_conv (tools/flake/: 48-417 wrong
+    launches of 1600 in every variant with the form, 0 of 1600 without).  The form is the compiler's choice, so the guard reads the
+    BUILT library: every gfx950 code object is disassembled and must hold none (round 4 had 31 in five kernels)."""
+    import importlib.util
+    import __graft_entry__ as ge
+    ge.build()
+    spec = importlib.util.spec_from_file_location("scan_pk_cross", os.path.join(ROOT, "tools", "scan_pk_cross.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    # the scanner sees the form where it is (a line of round 4's failing loop) and only there
+    sample = ["0000 <_Zkernel>:", "\tv_pk_fma_f32 v[34:35], v[44:45], v[52:53], v[34:35] op_sel_hi:[1,0,1] // 0001: AA",
+              "\tv_pk_fma_f32 v[34:35], v[48:49], v[52:53], v[34:35] op_sel:[0,1,0] // 0002: BB",
+              "\tv_pk_mul_f32 v[20:21], v[228:229], v[20:21] op_sel:[1,0]", "\tv_pk_add_f32 v[2:3], v[4:5], v[6:7]",
+              "\tv_pk_fma_f16 v1, v2, v3, v4 op_sel:[0,1,0]"]
+    total, hits = scan.scan_text(sample, re.compile(r"^[0-9a-f]+ <(\S+)>:"))
+    assert total == 4 and [h[1].split()[0] for h in hits] == ["v_pk_fma_f32", "v_pk_mul_f32"] and hits[0][0] == "_Zkernel"
+    objects, total, hits = scan.scan_library()
+    assert objects >= 18 and total > 10000, (objects, total)         # the whole library was read, not an empty extraction
+    assert not hits, "\n".join(f"{scan.demangle(k)}: {t}" for k, t in hits[:10])
