@@ -324,10 +324,10 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       s_einv0[(b) * LC_ECAP + tid] = einv_n;                                                                         \
     }                                                                                                                \
     if (tid < LC_ROWS) s_inv[tid] = xinv_n;                                                                          \
-    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): the planes this wave asked for have landed, long ago (a builtin, */ \
-                                          /* not asm: the compiler must SEE the LDS-DMA retired or it drains every     */ \
-                                          /* later request early)                                                      */ \
   }
+  // the node planes this wave asked for have landed (a builtin, not asm: the compiler must SEE the LDS-DMA retired or it drains
+  // every later request early); behind the NEXT barrier every wave's have, and the next tile's node GEMM may read them
+#define LC_PLANES_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(0) */
 
   int4 desc = a.tile_info[t];
   {
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     LC_REQUEST_MASKS(desc)
     LC_REQUEST_PLANES(desc)
     LC_STORE_TILE(desc, 0)
+    LC_PLANES_LANDED()
   }
   __syncthreads();
   LC_STAMP(0)              // first tile's inputs (exposed once per workgroup)
@@ -383,6 +384,12 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       }
       ISG_DIAG_KEEP2(accn[0][0], accn[1][15])
       LC_STAMP(8)            // node GEMM: k loop
+      // THE HAND-OVER BARRIER sits here, behind the k loop (which reads only the planes, complete since the barrier that ended
+      // the previous tile's chunks, and this wave's registers): a wave that is done aggregating starts the next tile's products
+      // while the slowest waves still aggregate -- matrix work under the vector phase's imbalance.  Behind it: every wave is done
+      // with the previous tile's slices and tables; the next tile's tables and s_inv are complete.
+      __syncthreads();
+      LC_STAMP(7)            // hand-over barrier
       float(*dstx)[LC_LDX] = ct < 4 ? sXl : sXr;
       int frl = fr, hhl = hh;          // laundered: the addresses below, hoisted out of the tile loop, were spilled and came back
       asm volatile("" : "+v"(frl), "+v"(hhl));       // from scratch one dependent load at a time (700 cycles per tile)
@@ -403,7 +410,14 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
       }
     }
     LC_STAMP(9)              // node GEMM: epilogue
-    __syncthreads();         // x_l / x_r slices complete; the panel image is free for the edge chunks
+    // chunk 0's edge planes (requested before the previous tile's aggregation) into the panel image, free since the last chunk's
+    // barrier: ONE barrier covers the slices and the first panel
+    if (ne > 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
+    }
+    LC_STAMP(10)             // panel staging: the wait for the planes, LDS writes
+    __syncthreads();         // x_l / x_r slices and chunk 0's panel complete
     LC_STAMP(1)              // node GEMM: barrier
     // The next tile's rows, records and scales are requested in the LAST chunk, behind the last request for edge planes: any
     // earlier and the chunks' waits for their planes (counted from the youngest request) wait for these too; any later (before the
@@ -461,11 +475,13 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #define LC_EPILOGUE(ch) LC_EPILOGUE_(ch, SL01)
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
+      if (c > 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
-      LC_STAMP(10)           // panel staging: the wait for the planes, LDS writes
-      __syncthreads();
-      LC_STAMP(2)            // staging barrier
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<hf32x4 *>(&sA[sc4 >> 4][srow + 16 * u][(sc4 & 15) * 8]) = ra[u];
+        LC_STAMP(10)         // panel staging: the wait for the planes, LDS writes
+        __syncthreads();
+        LC_STAMP(2)          // staging barrier
+      }
       if (c == creq) LC_REQUEST_TILE(desc_n)
       if (c + 1 < nchunk) {      // the next chunk's planes: in flight under this chunk's product and epilogue
 #pragma unroll
@@ -507,6 +523,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     }
 #undef LC_EPILOGUE
 #undef LC_EPILOGUE_
+    LC_PLANES_LANDED()       // requested two chunks ago
     __syncthreads();
 
     // ---- softmax + aggregation (isg_mp_graph.hip phase C: same operations in the same order) ----------------------------------
@@ -514,9 +531,11 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     // weights (the logits are broadcast reads), so no weight table and no barrier between the softmax and the aggregation; the
     // first four in-edges (most segments) are read once and stay in registers for all three uses.
     LC_STAMP(11)             // last logit sums + barrier
-    if (nchunk == 0) {          // a tile without edges: nothing hid the requests
+    if (nchunk == 0) {          // a tile without edges: nothing hid the requests (uniform over the workgroup)
       LC_REQUEST_TILE(desc_n)
       LC_REQUEST_MASKS(desc_n)
+      LC_PLANES_LANDED()
+      __syncthreads();
     }
     LC_STORE_TILE(desc_n, cur ^ 1)      // panel image and scales are free since the last chunk's barrier; tables: the other set
     LC_REQUEST_PLANES(desc_n)
@@ -634,9 +653,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
     }
     LC_STAMP(6)              // softmax + aggregation, stores
     if (!has_next) break;
-    __syncthreads();         // every wave is done with this tile's slices; the next tile's planes and tables are complete
-    LC_STAMP(7)              // hand-over barrier
-    desc = desc_n;
+    desc = desc_n;           // (no barrier here: it waits behind the next tile's node products)
     t = t_next;
     cur ^= 1;
   }
@@ -644,6 +661,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
 #undef LC_REQUEST_PLANES
 #undef LC_REQUEST_MASKS
 #undef LC_STORE_TILE
+#undef LC_PLANES_LANDED
   ISG_DIAG_DUMP(g_lc_stamps, bid * 8 + wave, 12, )
 }
 
