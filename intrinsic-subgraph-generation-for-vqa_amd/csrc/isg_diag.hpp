@@ -18,6 +18,19 @@
 #ifndef ISG_DIAG_HPP
 #define ISG_DIAG_HPP
 
+// -DISG_DIAG_STRICT (a second switch, independent of the stamps): the SCHEDULE-FREE build of the hand-scheduled kernels.  Every
+// hand-counted wait ("all but the n youngest requests have landed") becomes vmcnt(0) lgkmcnt(0), every raw s_barrier a full
+// __syncthreads() (fences and the compiler's own waits included).  Arithmetic is untouched, so the strict build must return the
+// bits of the fast build on every input: when the two differ the fault is in a wait count or a missing barrier, not in the
+// arithmetic.  build() makes csrc/libisg_hip_strict.so beside the library; tests/test_gpu_strict.py compares the two.
+#ifdef ISG_DIAG_STRICT
+#define ISG_WAIT(imm) ((void)(imm), __builtin_amdgcn_s_waitcnt(0))
+#define ISG_BARRIER() __syncthreads()
+#else
+#define ISG_WAIT(imm) __builtin_amdgcn_s_waitcnt(imm)
+#define ISG_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+
 #ifdef ISG_DIAG
 #define ISG_DIAG_BUFFER(name) static __device__ long long *name = nullptr;
 #define ISG_DIAG_NOW() ((long long)__builtin_amdgcn_s_memtime())

@@ -179,18 +179,18 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
   }
   // end of a load segment: the three youngest quarters stay in flight; then the hand-over barrier
 #define P3_L_END                                                                                                   \
-  __builtin_amdgcn_s_waitcnt(0x0F76);   /* vmcnt(6) */                                                             \
+  ISG_WAIT(0x0F76);   /* vmcnt(6) */                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
-  __builtin_amdgcn_s_barrier();                                                                                    \
+  ISG_BARRIER();                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 #define P3_M(FB, ah, bh)                                                                                           \
-  __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0) */                                                           \
+  ISG_WAIT(0xC07F);   /* lgkmcnt(0) */                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   __builtin_amdgcn_s_setprio(1);                                                                                   \
   P3_MMA(FB, ah, bh)                                                                                               \
   __builtin_amdgcn_s_setprio(0);                                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
-  __builtin_amdgcn_s_barrier();                                                                                    \
+  ISG_BARRIER();                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 #define P3_TILE(t, buf)                                                                                            \
   {                                                                                                                \
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
   P3_STAGE(P3_ALO, 1, 1)
   P3_L_END
   if (wr == 1) {                         // the second wave group runs one barrier behind the first
-    __builtin_amdgcn_s_barrier();
+    ISG_BARRIER();
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll 1
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3p_kernel(const P3Args 
     if (t + 1 < nk) P3_TILE(t + 1, 1)
   }
   if (wr == 0) {
-    __builtin_amdgcn_s_barrier();
+    ISG_BARRIER();
     __builtin_amdgcn_sched_barrier(0);
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);    // the requests past the last k-tile have landed: nothing in flight at the end
+  ISG_WAIT(0x0F70);    // the requests past the last k-tile have landed: nothing in flight at the end
 #undef P3_TILE
 #undef P3_M
 #undef P3_L_END
@@ -627,12 +627,12 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   }
 #define Q3_BAR                                                                                                     \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
-  __builtin_amdgcn_s_barrier();                                                                                    \
+  ISG_BARRIER();                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 #define Q3_WAIT(n)                                                                                                 \
-  __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14));
+  ISG_WAIT(0x0F70 | ((n) & 15) | (((n) >> 4) << 14));
 #define Q3_M(ah)                                                                                                   \
-  __builtin_amdgcn_s_waitcnt(0xC07F);                                                                              \
+  ISG_WAIT(0xC07F);                                                                              \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   Q3_ST(3 + 7 * (ah))                                                                                              \
   __builtin_amdgcn_s_setprio(1);                                                                                   \
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
   // and stored behind the NEXT load segment's requests -- every segment then issues a store, dropped when nothing is pending,
   // and the K = 2048 shape lost 7 % to those.)
 #define Q3_M_PIECE(ah, TI, TJ, BQ0, BQ1, IB)                                                                        \
-  __builtin_amdgcn_s_waitcnt(0xC07F);                                                                              \
+  ISG_WAIT(0xC07F);                                                                              \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   Q3_ST(3 + 7 * (ah))                                                                                              \
   __builtin_amdgcn_s_setprio(1);                                                                                   \
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(P3_THREADS, 2) void linear_h3q_kernel(const Q3Args 
     cL = nL; cm0 = nm0; cn0 = nn0; cpar = npar;
   }
   if (wn == 0) { Q3_BAR }
-  __builtin_amdgcn_s_waitcnt(0x0F70);    // the requests past the last k-tile have landed: nothing in flight at the end
+  ISG_WAIT(0x0F70);    // the requests past the last k-tile have landed: nothing in flight at the end
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll

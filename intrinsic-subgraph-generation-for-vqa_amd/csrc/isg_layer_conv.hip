@@ -327,7 +327,7 @@ __global__ __launch_bounds__(LC_THREADS, 2) void gatv2_layer_conv_kernel(LcArgs 
   }
   // the node planes this wave asked for have landed (a builtin, not asm: the compiler must SEE the LDS-DMA retired or it drains
   // every later request early); behind the NEXT barrier every wave's have, and the next tile's node GEMM may read them
-#define LC_PLANES_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(0) */
+#define LC_PLANES_LANDED() ISG_WAIT(0x0F70);      /* vmcnt(0) */
 
   int4 desc = a.tile_info[t];
   {

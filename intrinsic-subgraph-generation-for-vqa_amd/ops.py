@@ -97,6 +97,30 @@ def _stream() -> int:
     return _raw_stream(_get_device())
 
 
+class _Ready:
+    """When a cached device tensor is safe to read: the stream that built it and an event behind the building launches.  A hit
+    from ANOTHER stream (run_split's side pass, a caller's own streams) makes that stream wait for the event -- once; the marker
+    is dropped when the event has completed.  A hit from the building stream is ordered by the stream itself and costs one
+    integer comparison."""
+    __slots__ = ("stream", "event")
+
+    def __init__(self, on_cuda: bool):
+        self.stream, self.event = None, None
+        if on_cuda and not torch.cuda.is_current_stream_capturing():
+            self.stream = _stream()
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def wait(self) -> None:
+        ev = self.event
+        if ev is None or _stream() == self.stream:
+            return
+        if ev.query():
+            self.event = None           # done for every stream from here on
+        else:
+            torch.cuda.current_stream().wait_event(ev)
+
+
 def _chk(t: Optional[Tensor], name: str, dtype, shape=None, optional=False) -> int:
     if t is None:
         if optional:
@@ -869,7 +893,6 @@ def _mixed_sub(plan: "GraphPlan") -> Optional["OversizeGraphs"]:
 
 SPLIT_STREAM = True       # ... on a stream of its own, beside the whole batch's tile kernels (A/B switch)
 _side_streams: dict = {}
-_split_concurrent = 0     # > 0 while run_split has two passes in flight on two streams (derived_weight syncs what it builds then)
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -928,17 +951,12 @@ def run_split(plan: "GraphPlan", sub: "OversizeGraphs", core, x: Tensor, edge_in
         # The sub-batch is a chain of ~60 launches of one or a few workgroups each (0.65 ms of GPU time for ONE 100-node graph):
         # on a stream of its own it runs beside the tile kernels instead of behind them.  The main pass is issued FIRST (the GPU
         # starts on it while the host is still issuing the sub-batch).
-        global _split_concurrent
         cur = torch.cuda.current_stream()
         side_stream = _side_stream(x.device)
         side_stream.wait_stream(cur)                 # inputs and the lists of `sub` are complete
-        _split_concurrent += 1
-        try:
-            main = run_main()
-            with torch.cuda.stream(side_stream):
-                side = run_side()
-        finally:
-            _split_concurrent -= 1
+        main = run_main()                            # (weight caches the two passes share: every entry carries its _Ready marker)
+        with torch.cuda.stream(side_stream):
+            side = run_side()
         cur.wait_stream(side_stream)
 
         def keep(t):                                 # results made on the side stream, read on this one
@@ -1657,17 +1675,14 @@ def derived_weight(tag: str, sources, build):
     ver = tuple((_ver(t), t.data_ptr()) for t in sources)
     hit = _DERIVED.get(key)
     if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[1], sources)):
+        hit[3].wait()               # built on another stream a moment ago (run_split's two passes share this cache)?
         return hit[2]
     with torch.no_grad():
         value = build()
-    if _split_concurrent:
-        # two streams of one step share this cache (run_split): whichever pass builds an entry first, the other may read it on
-        # its own stream right away -- a one-off device sync per entry instead of an event per use
-        torch.cuda.synchronize()
     if len(_DERIVED) > 256:
         for k in [k for k, v in _DERIVED.items() if any(r() is None for r in v[1])]:
             del _DERIVED[k]
-    _DERIVED[key] = (ver, tuple(weakref.ref(t) for t in sources), value)
+    _DERIVED[key] = (ver, tuple(weakref.ref(t) for t in sources), value, _Ready(any(t.is_cuda for t in sources)))
     return value
 
 
@@ -1751,6 +1766,7 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
     hit = _PLANES.get(key) if cache else None
     # the weak reference pins the identity: a freed weight's id (and even its address) can be reused by another model
     if hit is not None and hit[0]() is weight and hit[1] == _ver(weight) and hit[2] == weight.data_ptr():
+        hit[4].wait()
         return hit[3]
     lib = _lib.load()
     N, K = weight.shape
@@ -1781,7 +1797,7 @@ def _weight_planes(weight: Tensor, cache: bool = True, layout: str = "tile") -> 
         if len(_PLANES) > 256:
             for k in [k for k, v in _PLANES.items() if v[0]() is None]:
                 del _PLANES[k]
-        _PLANES[key] = (weakref.ref(weight), _ver(weight), weight.data_ptr(), planes)
+        _PLANES[key] = (weakref.ref(weight), _ver(weight), weight.data_ptr(), planes, _Ready(weight.is_cuda))
     return planes
 
 
@@ -2353,8 +2369,10 @@ def linear_fused(x: Tensor, layers, out_dtype=torch.float32) -> Tuple[Tensor, ..
         if len(_CAT) > 256:
             for k in [k for k, v in _CAT.items() if any(r() is None for r in v[3])]:
                 del _CAT[k]
-        hit = (ver, w, b, tuple(weakref.ref(m.weight) for m in layers))
+        hit = (ver, w, b, tuple(weakref.ref(m.weight) for m in layers), _Ready(w.is_cuda))
         _CAT[key] = hit
+    else:
+        hit[4].wait()
     y = linear(x, hit[1], hit[2], out_dtype=out_dtype)
     outs, o = [], 0
     for m in layers:

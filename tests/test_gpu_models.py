@@ -790,6 +790,39 @@ def test_split_forward_variants_agree(dev):
     assert torch.equal(m, m0) and (l - l0).abs().max() < 2e-5 and torch.allclose(g, g0, atol=1e-6)
 
 
+def test_split_forward_on_a_cold_weight_cache_matches_the_inline_pass(dev):
+    """run_split's two passes share the weight caches (planes of w_edge / x_proj / node_nn, the concatenated lin_l |
+    lin_r, the derived layouts).  On the FIRST mixed batch after a model load every entry is built by whichever pass asks first, on
+    that pass's stream, and the other pass hits it a moment later on ITS stream -- at a configs[1]-sized batch the GPU is far
+    behind the host and the planes are not written yet.  Every entry now carries the event behind its building launches
+    (ops._Ready); a cold stream-mode pass must give the bits of the inline pass."""
+    from isubgvqa_amd import ops, synthetic
+    sizes = (20,) * 2000 + (130,) + (20,) * 2095
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler="imle", seed=17)
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).eval().to(dev)
+    keep = ops.SPLIT_FORWARD, ops.SPLIT_STREAM
+    outs = {}
+    try:
+        for name, stream in (("stream", True), ("inline", False), ("stream_again", True)):
+            ops.SPLIT_FORWARD, ops.SPLIT_STREAM = True, stream
+            ops.invalidate_weight_cache()              # cold: every shared entry is built inside this forward
+            torch.cuda.synchronize()
+            ops.reset_counters()
+            with torch.no_grad():
+                outs[name] = _forced_mixed(lambda: model(wl))
+            c = ops.counters()
+            assert c["oversize_nodes"] > 0 and c["tile_nodes"] > 0, (name, c)
+            torch.cuda.synchronize()
+    finally:
+        ops.SPLIT_FORWARD, ops.SPLIT_STREAM = keep
+    l0, m0, g0 = outs["inline"]
+    assert torch.isfinite(l0).all()
+    for name in ("stream", "stream_again"):
+        l, m, g = outs[name]
+        assert torch.equal(l, l0) and torch.equal(m, m0) and torch.equal(g, g0), name
+
+
 def test_a_wrong_graph_sizes_hint_is_caught_at_check_plans(dev):
     """GraphPlan.build(graph_sizes=) is trusted to keep the step free of a device-to-host sync; the same counts are made on the
     device, copied to pinned memory behind the stream and compared at ops.check_plans(): a hint that misses a big graph raises."""

@@ -1,0 +1,146 @@
+"""The hand-scheduled kernels against their own SCHEDULE-FREE build.  csrc/libisg_hip_strict.so is the library
+compiled with -DISG_DIAG_STRICT (csrc/isg_diag.hpp): every hand-counted `s_waitcnt vmcnt(n)` is vmcnt(0) lgkmcnt(0), every raw
+`s_barrier` a full __syncthreads(); the arithmetic is the same.  Each case runs once on both libraries on the same inputs and
+demands EQUAL BITS: a difference is a wrong wait count or a missing barrier in the fast build (round 4 found two such defects by
+the timing of the full suite alone), never a rounding question.  Cases: the planes32 GEMM engine (counted waits on a three-slot
+LDS-DMA ring, raw barriers, a segmented operand, planes32 results), the layer convolution (LDS-DMA retired by hand), and the tile
+convolution / dense tail / read-out, whose barriers are the compiler's (the two builds agree there by construction)."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+from test_gpu_ops import _rand_graphs
+
+pytestmark = pytest.mark.gpu
+
+STRICT = os.path.join(ROOT, "intrinsic-subgraph-generation-for-vqa_amd", "csrc", "libisg_hip_strict.so")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X (run with -m gpu on the GPU box)"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def both():
+    """run(fn) -> (fast result, strict result): fn() once per library, the derived-weight caches shared (they are data)."""
+    from isubgvqa_amd import _lib
+    assert os.path.exists(STRICT), "csrc/libisg_hip_strict.so is missing: __graft_entry__.build() makes it beside the library"
+    fast = _lib.load()
+    strict = ctypes.CDLL(STRICT)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(strict, name)
+        fn.restype, fn.argtypes = res, args
+    assert strict.isg_abi_version() == _lib.ABI_VERSION
+
+    def run(fn):
+        outs = []
+        for lib in (fast, strict):
+            _lib._lib = lib
+            try:
+                with torch.no_grad():
+                    outs.append(fn())
+                torch.cuda.synchronize()
+            finally:
+                _lib._lib = fast
+        return outs
+    return run
+
+
+def _same(a, b, what):
+    if isinstance(a, torch.Tensor):
+        assert torch.equal(a, b), f"{what}: the strict and the fast build differ in {int((a != b).sum())} values, max |d| {(a.float() - b.float()).abs().max().item():.3e}"
+    elif a is None:
+        assert b is None
+    else:
+        assert len(a) == len(b)
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{what}[{i}]")
+
+
+@pytest.mark.parametrize("M,N,K,act,bias,planes_out", [
+    (4097, 1536, 512, None, True, False),       # the text encoder's in_proj: 16 k-tiles on the three-slot ring
+    (777, 300, 300, None, True, False),         # ragged rows / columns / k-tiles: the two-piece epilogue per k-tile
+    (5000, 1200, 600, "gelu", True, True),      # 19 k-tiles (head + odd body), planes32 result (the pair exchange)
+    (70001, 128, 512, "relu", False, False),    # more tiles than CUs: the stager runs across tile boundaries
+    (1031, 2048, 2048, "relu", True, False),    # long reduction: the trickled epilogue under 64 k-tiles
+    (300, 64, 128, None, True, False),          # K < 256: the one-tile form behind the same entry point
+])
+def test_linear_h3p_gives_the_strict_builds_bits(dev, both, M, N, K, act, bias, planes_out):
+    from isubgvqa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=dev, generator=g) * torch.rand(M, 1, device=dev, generator=g).mul(5).exp()
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(N, device=dev, generator=g) if bias else None
+
+    def fn():
+        y = ops.linear_h3p(x, w, b, gelu=act == "gelu", relu=act == "relu", planes_out=planes_out)
+        return ops.planes32_to_rows(y) if planes_out else y
+    fast, strict = both(fn)
+    assert torch.isfinite(fast).all()
+    _same(fast, strict, f"isg_linear_h3p {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("planes_out", [False, True])
+def test_linear_h3p_segmented_operand_gives_the_strict_builds_bits(dev, both, planes_out):
+    """x_proj.0 at C = 300 on a SEGMENTED planes32 operand (two half rows under their own scales, what isg_gatv2_mp_fwd_planes
+    writes; the accumulators change units at k-tile 19 of 38): the path whose in-place scale overwrite was round 4's race."""
+    from isubgvqa_amd import ops
+    M, N, seg = 9001, 600, 600
+    g = torch.Generator(device=dev).manual_seed(M + seg)
+    K = 2 * seg
+    x = torch.randn(M, K, device=dev, generator=g)
+    big = torch.rand(M, 1, device=dev, generator=g) < 0.5
+    x[:, :seg] *= torch.where(big, 512.0, 1.0)
+    x[:, seg:] *= torch.where(big, 1.0, 512.0) * torch.rand(M, 1, device=dev, generator=g).mul(3).exp()
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(N, device=dev, generator=g)
+
+    def fn():
+        halves = [ops.split_planes32(x[:, :seg].contiguous()), ops.split_planes32(x[:, seg:].contiguous())]
+        st = (seg + 31) // 32
+        pl = torch.cat([h.planes.view(M, st, 64) for h in halves], dim=1).contiguous().view(-1)
+        xs = ops.Planes32(pl, halves[1].inv, M, K, halves[0].inv, seg)
+        got = ops.linear_h3p(xs, w, b, gelu=True, planes_out=planes_out)
+        return ops.planes32_to_rows(ops.Planes32(got.planes, got.inv, M, (N + 31) // 32 * 32)) if planes_out else got
+    fast, strict = both(fn)
+    assert torch.isfinite(fast).all()
+    _same(fast, strict, "isg_linear_h3p on a segmented operand")
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_graph_tile_kernels_give_the_strict_builds_bits(dev, both, masked):
+    """isg_gatv2_layer_conv (LDS-DMA retired by a hand-placed wait), isg_gatv2_tile_conv, isg_mgat_dense_tail and isg_readout_tile
+    through one AnswerModel forward at 700 graphs with hubs -- the batch shape of round 4's intermittent failure."""
+    from isubgvqa_amd import ops, synthetic
+    cfg = synthetic.WorkloadConfig(num_graphs=700, channels=128, layers=3, masks=(1.0, 1.0, 0.15) if masked else (1.0, 1.0, 1.0),
+                                   sampler="imle", sample_k=5, nodes_mean=20.0, nodes_std=6.0, nodes_min=4, nodes_max=60,
+                                   edges_per_graph=50.0, seed=31)
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).eval().to(dev)
+
+    def fn():
+        ops.reset_counters()
+        out = model(wl)
+        assert ops.counters()["tile_nodes"] == 7 * wl.x.size(0)
+        return out
+    fast, strict = both(fn)
+    _same(fast, strict, "AnswerModel forward on the tile kernels")
+
+    gen = torch.Generator().manual_seed(23)
+    sizes = torch.randint(8, 34, (700,), generator=gen).tolist()
+    batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=(7, 60))
+    N, E, H, C = batch.numel(), ei.size(1), 4, 128
+    xl = torch.randn(N, H * C, generator=gen).to(dev)
+    xr = torch.randn(N, H * C, generator=gen).to(dev)
+    ea = torch.randn(E, 128, generator=gen).to(dev)
+    w = (torch.randn(H * C, 128, generator=gen) * 0.1).to(dev)
+    att, bias = torch.randn(1, H, C, generator=gen).to(dev), torch.randn(H * C, generator=gen).to(dev)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    nm = (torch.rand(N, generator=gen) < 0.6).float().to(dev) if masked else None
+    fast, strict = both(lambda: ops.gatv2_tile_conv(xl, xr, ea, w, att, plan, H, bias=bias, node_mask=nm, want_rowmax=True))
+    _same(fast, strict, "isg_gatv2_tile_conv")
