@@ -53,6 +53,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_COPY_GBPS = 6290.0
+MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA, ~2.5 PF (never the 2:1-sparsity headline)
 
 
 def parse(argv=None):
@@ -65,6 +66,8 @@ def parse(argv=None):
     ap.add_argument("--no-cfg5", action="store_true", help="skip the configs[4] leg (skewed graphs, AIMLE, fp16 rows)")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-dispatch leg (configs[1] + a few graphs beyond a tile)")
     ap.add_argument("--no-full-model", action="store_true", help="skip the configs[2] stand-in (full model at C = 300)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the sustained leg (>= --sustained-seconds of steps)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5)
     ap.add_argument("--full-model-graphs", type=int, default=4096)
     ap.add_argument("--cpu-sample-graphs", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -263,7 +266,33 @@ def full_model_rate(dev, graphs: int, steps: int = 10):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
     assert torch.isfinite(out).all()
-    return {"workload": "BASELINE configs[2] stand-in: full ISubGVQA model, C=300, 4 MGAT layers, I-MLE k=5, 12-token "
+    # the step's two dominant kernels against THEIR rooflines, from HIP events around every launch of three more steps (outside
+    # the timed loop: an event pair per launch costs host time): isg_linear_h3p against the dense fp16 MFMA peak (three fp16
+    # products per fp32 product: 6 M N K flops per launch), the flat message-passing kernel against HBM on SURVEY 8(d)'s bytes_mp
+    ops.H3P_TIMER, ops.MP_TIMER = ops.KernelTimer(), ops.KernelTimer()
+    with torch.no_grad():
+        for _ in range(3):
+            model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg)
+    torch.cuda.synchronize()
+    ht, mt = ops.H3P_TIMER, ops.MP_TIMER
+    ops.H3P_TIMER, ops.MP_TIMER = None, None
+    hd, md = ht.durations_ms(), mt.durations_ms()
+    flops = [6.0 * m["M"] * m["N"] * m["K"] for m in ht.meta]
+    k300 = [i for i, m in enumerate(ht.meta) if m["K"] <= 320]
+    mpb = [ops.mp_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"], m.get("feat_bytes", 4)) for m in mt.meta]
+    kernels = {
+        "linear_h3p": {"bound": "mfma", "launches_per_step": len(hd) // 3, "ms_per_step": round(sum(hd) / 3, 3),
+                       "achieved": round(sum(flops) / (sum(hd) * 1e-3) / 1e12, 1) if hd else 0.0, "peak": MFMA_F16_PEAK_TFLOPS,
+                       "unit": "TFLOP/s of fp16 products", "frac": round(sum(flops) / (sum(hd) * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if hd else 0.0,
+                       "k_le_320": {"launches_per_step": len(k300) // 3, "ms_per_step": round(sum(hd[i] for i in k300) / 3, 3),
+                                    "achieved": round(sum(flops[i] for i in k300) / max(sum(hd[i] for i in k300), 1e-9) / 1e9, 1)}},
+        "gatv2_mp_flat": {"bound": "hbm", "launches_per_step": len(md) // 3, "ms_per_step": round(sum(md) / 3, 3),
+                          "achieved": round(sum(mpb) / max(sum(md), 1e-9) / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": round(sum(mpb) / max(sum(md), 1e-9) / 1e6 / HBM_PEAK_GBPS, 4),
+                          "algorithmic_bytes_per_launch": int(sum(mpb) / max(len(mpb), 1))},
+    }
+    return {"kernels": kernels,
+            "workload": "BASELINE configs[2] stand-in: full ISubGVQA model, C=300, 4 MGAT layers, I-MLE k=5, 12-token "
                         "questions, GQA-shaped synthetic scene graphs (no GQA data in the container)",
             "graphs": graphs, "nodes": int(wl.x.size(0)), "edges": int(wl.edge_index.size(1)),
             "ms_per_step": round(dt * 1e3, 3), "questions_per_s": round(graphs / dt, 1), "steps": steps,
@@ -355,7 +384,8 @@ def time_unfused_mp(wl, cfg, dev, launches: int = 20):
 # committed sample (profiles/r03_*bench.json)
 LINE_SCHEMA = {
     "": ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-         "dtype", "data", "config", "roofline", "cpu_baseline", "rccl", "fallbacks", "dense_err_vs_fp32", "cfg5", "full_model", "mixed"],
+         "dtype", "data", "config", "roofline", "cpu_baseline", "rccl", "fallbacks", "dense_err_vs_fp32", "cfg5", "full_model", "mixed",
+         "sustained"],
     "config": ["workload", "graphs_per_gpu", "global_batch", "parallelism"],
     "roofline": ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us"],
     "cpu_baseline": ["value", "unit", "cores", "kind", "sample", "cfg1"],
@@ -363,7 +393,8 @@ LINE_SCHEMA = {
     "dense_err_vs_fp32": ["max"],
     "cfg5": ["workload", "graphs", "ms_per_step", "questions_per_s", "mp_kernel", "mp_avg_launch_us", "mp_achieved_GBps",
              "mp_frac_of_hbm_peak", "imbalance_world8_max_over_mean", "fp32_rows"],
-    "full_model": ["workload", "graphs", "ms_per_step", "questions_per_s", "h3p_store_policy"],
+    "full_model": ["workload", "graphs", "ms_per_step", "questions_per_s", "h3p_store_policy", "kernels"],
+    "sustained": ["seconds", "steps", "ms_per_step", "ratio_to_burst"],
     "mixed": ["workload", "graphs", "big_graphs", "nodes", "ms_per_step", "host_issue_ms_per_step", "dispatch",
               "tile_kernel_node_share", "per_graph_kernels_ms_per_step"],
 }
@@ -832,6 +863,19 @@ def main(argv=None):
             progress("dense_err_vs_fp32 leg")
             with torch.no_grad():
                 res["dense_err_vs_fp32"] = dense_err_vs_fp32(dev)
+        if world == 1 and not args.no_sustained:
+            # >= 2 s of back-to-back configs[1] steps: the clocks under load, and something the driver's busy sampler can see
+            progress("sustained leg (>= 2 s of steps)")
+            with torch.no_grad():
+                n_s = max(200, int(args.sustained_seconds / max(dt / args.steps, 1e-6)))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n_s):
+                    step(args.warmup + args.steps + i)
+                torch.cuda.synchronize()
+                ds = time.perf_counter() - t0
+            res["sustained"] = {"seconds": round(ds, 3), "steps": n_s, "ms_per_step": round(ds / n_s * 1e3, 4),
+                                "ratio_to_burst": round((ds / n_s) / (dt / args.steps), 4)}
         if world == 1 and not args.no_full_model:
             del model, wl
             torch.cuda.empty_cache()
@@ -851,7 +895,8 @@ def main(argv=None):
             res["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
         else:
             res["cpu_baseline"] = None
-        validate_line(res, full=world == 1 and not (args.no_cpu_baseline or args.no_full_model or args.no_cfg5 or args.no_mixed))
+        validate_line(res, full=world == 1 and not (args.no_cpu_baseline or args.no_full_model or args.no_cfg5 or args.no_mixed
+                                                    or args.no_sustained))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

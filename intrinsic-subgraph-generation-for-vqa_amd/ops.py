@@ -76,6 +76,7 @@ class KernelTimer:
 
 
 MP_TIMER: Optional[KernelTimer] = None   # set by bench.py around its timed region
+H3P_TIMER: Optional[KernelTimer] = None  # the same around every isg_linear_h3p launch (bench.py: the full model's dense share)
 
 
 def _rec(*tensors) -> bool:
@@ -2156,18 +2157,29 @@ def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = Fa
     ksplit = (seg + 31) // 32 * 32
     Kc = 2 * ksplit if seg else K                    # the k extent the kernel walks: both segments with their padding
     seg_args = (xp.inv_first.data_ptr(), ksplit) if seg else (0, 0)
+    timer = H3P_TIMER
+    if timer is not None:
+        ev0, ev1 = timer.bracket({"M": M, "N": N, "K": Kc, "planes_out": bool(planes_out)})
     if planes_out:
         dp = torch.empty(int(lib.isg_planes32_elems(M, N)), dtype=torch.int16, device=dev)
         dinv = torch.empty(M, dtype=torch.float32, device=dev)
+        if timer is not None:
+            ev0.record()
         _lib.check(lib.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), bptr, 0,
                                       dp.data_ptr(), dinv.data_ptr(), bound.data_ptr(), M, N, Kc, 0, act, *seg_args, _stream()),
                    "isg_linear_h3p")
+        if timer is not None:
+            ev1.record()
         return Planes32(dp, dinv, M, N)
     if _h3p_policy_state["chosen"] is None and M * N * 4 >= 128_000_000:
         _h3p_tune(dev)
     out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    if timer is not None:
+        ev0.record()
     _lib.check(lib.isg_linear_h3p(xp.planes.data_ptr(), xp.inv.data_ptr(), wp.data_ptr(), winv.data_ptr(), bptr,
                                   out.data_ptr(), 0, 0, 0, M, N, Kc, N, act, *seg_args, _stream()), "isg_linear_h3p")
+    if timer is not None:
+        ev1.record()
     return out
 
 

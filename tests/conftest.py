@@ -28,3 +28,20 @@ def golden_dir():
 def load_golden(name):
     import torch
     return torch.load(os.path.join(GOLDEN, name), map_location="cpu", weights_only=False)
+
+
+def parity_record(name: str, numbers: dict) -> None:
+    """Parity numbers a GPU test prints (graphs with a differing top-k mask, max |logit diff|, ...) also go on record: one JSON
+    object per test name in gpurun_out/parity_report.json (merged back from the GPU box by gpurun; beside the test log of whoever
+    runs the suite from the repository root) -- the counts are bounded by asserts, the report says what they WERE."""
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_report.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = numbers
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass                # a read-only checkout: the printed line stays
+    print(f"[parity] {name}: {json.dumps(numbers)}")

@@ -7,7 +7,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, parity_record
 
 pytestmark = pytest.mark.gpu
 
@@ -139,6 +139,8 @@ def test_cfg1_cpu_config_logits_and_masks_match_oracle(dev, sampler):
     from isubgvqa_amd import synthetic
     cfg = synthetic.WorkloadConfig(**{**synthetic.CFG1.__dict__, "sampler": sampler})
     wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    parity_record(f"cfg1_{sampler}", {"graphs": cfg.num_graphs, "mask_values_differing": int(((gm > 0.5) != (rm > 0.5)).sum()),
+                                      "max_abs_logit_diff": (gl - rl).abs().max().item(), "logit_tolerance": LOGIT_TOL})
     assert torch.equal(gm > 0.5, rm > 0.5), "top-k mask indices must be bit-exact"
     assert (gl - rl).abs().max() < LOGIT_TOL, (gl - rl).abs().max()
     assert torch.allclose(gg, rg, atol=1e-5)
@@ -177,6 +179,9 @@ def test_cfg2_full_size_logits_within_tolerance(dev):
     ok = ~bad_graph
     err = (gl[ok] - rl[ok]).abs().max().item()
     print(f"cfg2: max |logit diff| = {err:.3e}")
+    parity_record("cfg2_full_size", {"graphs": cfg.num_graphs, "graphs_with_a_differing_topk_mask": n_bad,
+                                     "max_abs_logit_diff": err, "logit_tolerance": LOGIT_TOL,
+                                     "max_abs_gate_diff": (gg[ok[wl.batch]] - rg[ok[wl.batch]]).abs().max().item()})
     assert err < LOGIT_TOL
     assert torch.allclose(gg[ok[wl.batch]], rg[ok[wl.batch]], atol=1e-5)
 
@@ -187,6 +192,8 @@ def test_cfg5_skewed_graphs_aimle(dev):
     cfg = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": 192, "channels": 64})
     wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
     assert wl.max_nodes > 100
+    parity_record("cfg5_skewed_aimle_fp32", {"graphs": cfg.num_graphs, "mask_values_differing": int((gm != rm).sum()),
+                                             "max_abs_logit_diff": (gl - rl).abs().max().item(), "logit_tolerance": LOGIT_TOL})
     assert torch.equal(gm, rm)
     assert (gl - rl).abs().max() < LOGIT_TOL, (gl - rl).abs().max()
 
@@ -206,6 +213,9 @@ def test_cfg5_skewed_graphs_aimle_fp16_features(dev):
     assert int(bad.sum()) <= 4, int(bad.sum())
     err = (gl[~bad] - rl[~bad]).abs().max()
     print(f"cfg5 fp16 features: max |logit diff| = {err:.2e}, graphs with a flipped mask: {int(bad.sum())}")
+    parity_record("cfg5_skewed_aimle_fp16_features", {"graphs": cfg.num_graphs, "graphs_with_a_flipped_mask": int(bad.sum()),
+                                                      "flipped_mask_cap": 4, "max_abs_logit_diff": float(err),
+                                                      "logit_tolerance": 1e-3})
     assert err < 1e-3
 
 
