@@ -8,6 +8,11 @@ without a backward refuses such an operand loudly.
 """
 from __future__ import annotations
 
+import contextlib
+import copy
+import dataclasses
+import sys
+import types
 import weakref
 from dataclasses import dataclass
 from typing import NamedTuple, Optional, Tuple
@@ -18,6 +23,88 @@ from torch import Tensor
 from . import _lib
 
 MAX_NODES_PER_GRAPH = 1024   # LDS strip / sampler row capacity of the kernels
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Every A/B switch of this module in ONE frozen object.  The functions below read `CFG.<field>`; nothing else in the module is
+# mutable configuration.  `ops.SPLIT_FORWARD = False` (tests, tools, bench.py: the historical spelling) is routed by the module's
+# __setattr__ to `CFG = dataclasses.replace(CFG, split_forward=False)` -- an atomic swap of the whole object, never a field
+# written in place -- and `ops.SPLIT_FORWARD` reads the field; `with ops.configured(split_forward=False): ...` restores it.
+@dataclasses.dataclass(frozen=True)
+class Switches:
+    plan_fused: bool = True
+    bounds_to_host: bool = True
+    mixed_dispatch: bool = True
+    mixed_max_fraction: float = 0.12
+    mixed_min_nodes: int = 60000
+    mp_kernel: str = "graph"
+    fuse_logits: bool = True
+    fuse_tile_conv: bool = True
+    fuse_layer_conv: bool = True
+    split_stream: bool = True
+    split_forward: bool = True
+    fuse_gate: bool = True
+    fuse_dense_tail: bool = True
+    dense_tail_rows: int = 64
+    fuse_readout: bool = True
+    gemm_backend: str = "bf16x6"
+    gemm_kernel: str = "auto"
+    panel_min_n: int = 256
+    embedding_sum: bool = True
+    ln_planes: bool = True
+    mp_planes: bool = True
+    gather_add_planes: bool = True
+    linear_multi: bool = True
+    tile_heavy_first: bool = True
+    mha_rows_planes: bool = True
+    mha_rows_max_tq: int = 16
+
+    f16x3_f16_out: bool = True
+    f16x3_tile: bool = True
+    gemm_f16x3: bool = True
+    h3p: bool = True
+    h3p_min_k: int = 256
+    h3p_chain: bool = True
+    h3p_min_m: int = 8192
+    h3p_store_policy: int = -1
+    linear_multi_h3p: bool = True
+
+CFG = Switches()
+_SWITCH_FIELDS = {f.name.upper(): f.name for f in dataclasses.fields(Switches)}
+
+
+@contextlib.contextmanager
+def configured(**fields):
+    """Run a block under a modified copy of the switches (restored afterwards, exceptions included)."""
+    global CFG
+    keep = CFG
+    CFG = dataclasses.replace(CFG, **fields)
+    try:
+        yield CFG
+    finally:
+        CFG = keep
+
+
+class _OpsModule(types.ModuleType):
+    def __getattr__(self, name):
+        f = _SWITCH_FIELDS.get(name)
+        if f is None:
+            raise AttributeError(f"module {self.__name__!r} has no attribute {name!r}")
+        return getattr(self.__dict__["CFG"], f)
+
+    def __setattr__(self, name, value):
+        f = _SWITCH_FIELDS.get(name)
+        if f is None:
+            super().__setattr__(name, value)
+        else:
+            self.__dict__["CFG"] = dataclasses.replace(self.__dict__["CFG"], **{f: value})
+
+    def __delattr__(self, name):              # monkeypatch of a name that "did not exist": nothing to delete
+        if name not in _SWITCH_FIELDS:
+            super().__delattr__(name)
+
+
+sys.modules[__name__].__class__ = _OpsModule
 
 # Launches that leave this library's own dense kernels, and extra passes a missing hand-off costs; bench.py prints them
 # per step ("no GEMM of the inference path runs on hipBLASLt" is then a number, not a sentence).
@@ -202,13 +289,13 @@ def _f32(t: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # Graph plan
 # ------------------------------------------------------------------------------------------------
-PLAN_FUSED = True     # isg_graph_plan_build (6 launches) instead of isg_graph_ptr + isg_csr_build + isg_graph_edge_ptr (14): A/B switch
-BOUNDS_TO_HOST = True    # isg_graph_plan_build writes the batch's true bounds into pinned host memory (hint check without a copy)
+# CFG.plan_fused (ops.PLAN_FUSED): isg_graph_plan_build (6 launches) instead of isg_graph_ptr + isg_csr_build + isg_graph_edge_ptr (14): A/B switch
+# CFG.bounds_to_host (ops.BOUNDS_TO_HOST): isg_graph_plan_build writes the batch's true bounds into pinned host memory (hint check without a copy)
 
 
-MIXED_DISPATCH = True       # graphs beyond a tile go to the per-graph kernels, the rest of the batch stays on the tile kernels
-MIXED_MAX_FRACTION = 0.12   # ... while at most this share of the batch's nodes sits in such graphs
-MIXED_MIN_NODES = 60000     # ... and the batch is large: the big graphs are a chain of ~60 launches of a workgroup or a few each, ~1.8 ms
+# CFG.mixed_dispatch (ops.MIXED_DISPATCH): graphs beyond a tile go to the per-graph kernels, the rest of the batch stays on the tile kernels
+# CFG.mixed_max_fraction (ops.MIXED_MAX_FRACTION): ... while at most this share of the batch's nodes sits in such graphs
+# CFG.mixed_min_nodes (ops.MIXED_MIN_NODES): ... and the batch is large: the big graphs are a chain of ~60 launches of a workgroup or a few each, ~1.8 ms
                             # of HOST time per step whatever the batch.  Measured (profiles/r04_az_split_forward.txt), 4096
                             # graphs + 1 / 8 / 64 big ones: 1.84-1.91 / 2.00 / 2.12 ms (run_split, sub-batch on its own stream)
                             # against 2.35 / 2.49 / 2.63 ms with the per-graph kernels for everything (1.43 ms without big
@@ -283,7 +370,7 @@ class GraphPlan:
         ekey = (id(edge_attr), edge_attr.data_ptr(), _ver(edge_attr), tuple(edge_attr.shape))
         have_t = self._tiles is not None and key in self._tiles
         have_e = self._edge_planes is not None and self._edge_planes[0] == ekey
-        if PLAN_FUSED and not have_t and not have_e and edge_cap > 0 and edge_attr.dim() == 2 and edge_attr.size(1) <= 128 \
+        if CFG.plan_fused and not have_t and not have_e and edge_cap > 0 and edge_attr.dim() == 2 and edge_attr.size(1) <= 128 \
                 and edge_attr.size(1) % 4 == 0 and edge_attr.dtype == torch.float32:
             lib = _lib.load()
             self.require_csr()
@@ -312,7 +399,7 @@ class GraphPlan:
         instead of 1.06x at BASELINE configs[1] (tools/sim_tile_balance.py).  Any order gives the same results."""
         self.tiles(node_cap, edge_cap)
         hit = self._tiles[(int(node_cap), int(edge_cap))]
-        return hit[4] if TILE_HEAVY_FIRST else hit[3]
+        return hit[4] if CFG.tile_heavy_first else hit[3]
 
     def tiles(self, node_cap: int = 64, edge_cap: int = 0) -> Tuple[Tensor, Tensor, int, Tensor]:
         """(tile_ptr int32[cap + 1], ntiles int32[1] on the device, cap, tile_info int32[cap, 4]): consecutive graphs packed greedily into tiles of
@@ -349,15 +436,15 @@ class GraphPlan:
             return "none"
         if self.nmax <= node_cap and (ecap == 0 or self.emax <= ecap):
             return "tiles"
-        if not MIXED_DISPATCH or torch.cuda.is_current_stream_capturing():
+        if not CFG.mixed_dispatch or torch.cuda.is_current_stream_capturing():
             return "none"
-        if self.N < MIXED_MIN_NODES:
+        if self.N < CFG.mixed_min_nodes:
             return "none"                   # decided before the device-to-host sync below: a small batch never pays for it
         st = self._oversize_stats(node_cap, edge_cap)
         if st is None or st["stats"][0] == 0:
             return "tiles"                  # the hints overstated the batch
         # (the LIST of such graphs -- ~30 launches -- is only built for a batch that then uses it)
-        return "mixed" if st["stats"][1] <= MIXED_MAX_FRACTION * self.N else "none"
+        return "mixed" if st["stats"][1] <= CFG.mixed_max_fraction * self.N else "none"
 
     def _oversize_stats(self, node_cap: int, edge_cap: int) -> Optional[dict]:
         """How many graphs of the batch lie beyond a tile, with their node / edge totals and maxima: ONE device-to-host sync, paid
@@ -497,9 +584,9 @@ class GraphPlan:
             plan.eptr = idx[n1 + 3 * e1:n1 + 3 * e1 + B + 1]
             ws_bytes = lib.isg_csr_workspace_bytes(N, E)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            if PLAN_FUSED:
+            if CFG.plan_fused:
                 # hinted and eager: the plan's last kernel stores the bounds into pinned host memory itself (no copy in the stream)
-                if (max_nodes is not None and max_edges is not None and BOUNDS_TO_HOST
+                if (max_nodes is not None and max_edges is not None and CFG.bounds_to_host
                         and not torch.cuda.is_current_stream_capturing()):
                     host_bounds = torch.empty(2, dtype=torch.int32, pin_memory=True)
                 _lib.check(lib.isg_graph_plan_build(batch.data_ptr(), edge_index.data_ptr(), N, E, B, ptr.data_ptr(),
@@ -624,7 +711,7 @@ def node_to_edge_mask(mask: Tensor, edge_index: Tensor, plan: Optional[GraphPlan
     return out.view(E, 1) if mask.dim() == 2 else out
 
 
-MP_KERNEL = "graph"    # "graph": per-graph LDS-resident kernel; "chunk": node-chunk kernel (A/B switch for bench/tests)
+# CFG.mp_kernel (ops.MP_KERNEL): "graph": per-graph LDS-resident kernel; "chunk": node-chunk kernel (A/B switch for bench/tests)
 
 
 def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphPlan, heads: int,
@@ -657,7 +744,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         raise TypeError(f"x_l / x_r / e_proj must share one dtype (fp32 or fp16), got {x_l.dtype}/{x_r.dtype}/{e_proj.dtype}")
     out = torch.empty(N, HC, dtype=fdt, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
-    use_graph = (kernel or MP_KERNEL) == "graph" and plan.B > 0 and plan.nmax > 0
+    use_graph = (kernel or CFG.mp_kernel) == "graph" and plan.B > 0 and plan.nmax > 0
     if fdt == torch.float16 and not use_graph:
         raise _lib.IsgError("fp16 feature rows need the per-graph kernel (a GraphPlan built with edge_index)")
     timer = MP_TIMER
@@ -665,7 +752,7 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
         ev0, ev1 = timer.bracket({"N": N, "E": E, "H": H, "C": C, "masked": node_mask is not None or edge_mask is not None,
                                   "feat_bytes": 2 if fdt == torch.float16 else 4})
         ev0.record()
-    if want_planes and MP_PLANES and use_graph and fdt == torch.float32 and E > 0 and H == 4 and C % 4 == 0:
+    if want_planes and CFG.mp_planes and use_graph and fdt == torch.float32 and E > 0 and H == 4 and C % 4 == 0:
         seg = 2 * C
         st = (seg + 31) // 32
         pl = torch.empty(N * 2 * st * 64, dtype=torch.int16, device=x_l.device)
@@ -722,12 +809,10 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
 
 
 # lin_edge folded into the attention logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is never written or read
-FUSE_LOGITS = True
-
-
+# CFG.fuse_logits (ops.FUSE_LOGITS): 
 def fused_logits_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
     """Shape test of isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits (inference, fp32 rows, per-graph kernel)."""
-    return (FUSE_LOGITS and GEMM_BACKEND == "bf16x6" and GEMM_F16X3 and MP_KERNEL == "graph" and channels % 32 == 0 and
+    return (CFG.fuse_logits and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3 and CFG.mp_kernel == "graph" and channels % 32 == 0 and
             heads * channels <= 2048 and 0 < edge_dim <= 128 and edge_dim % 4 == 0 and plan.B > 0 and plan.nmax > 0 and
             plan.rowptr is not None and plan.E > 0)
 
@@ -824,24 +909,24 @@ ISG_EUNSUPPORTED = -2      # include/isg.h
 
 # message + softmax + aggregation with lin_edge inside as ONE launch on graph-aligned tiles (csrc/isg_layer_tile.hip): the
 # head's x_l slice of a tile is staged once in LDS and serves the logit epilogue's row gathers and the aggregation
-FUSE_TILE_CONV = True
+# CFG.fuse_tile_conv (ops.FUSE_TILE_CONV): 
 TILE_CONV_NODES, TILE_CONV_EDGES = 64, 256
 
 
 def tile_conv_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
     """Shape test of isg_gatv2_tile_conv (inference, fp32 rows): C = 128, edge features <= 128 wide, every graph within one
     64-node / 256-slot tile -- or all but a few (GraphPlan.tile_mode: those go to the per-graph kernels)."""
-    return (FUSE_TILE_CONV and FUSE_LOGITS and GEMM_BACKEND == "bf16x6" and GEMM_F16X3 and MP_KERNEL == "graph" and
+    return (CFG.fuse_tile_conv and CFG.fuse_logits and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3 and CFG.mp_kernel == "graph" and
             channels == 128 and 0 < edge_dim <= 128 and edge_dim % 4 == 0 and heads <= 64 and plan.B > 0 and
             plan.rowptr is not None and plan.E > 0 and plan.tile_mode(TILE_CONV_NODES, TILE_CONV_EDGES) != "none")
 
 
-FUSE_LAYER_CONV = True     # ... and lin_l | lin_r inside as well (csrc/isg_layer_conv.hip): x_l / x_r never exist in memory
+# CFG.fuse_layer_conv (ops.FUSE_LAYER_CONV): ... and lin_l | lin_r inside as well (csrc/isg_layer_conv.hip): x_l / x_r never exist in memory
 
 
 def layer_conv_supported(plan: "GraphPlan", heads: int, channels: int, in_channels: int, edge_dim: int) -> bool:
     """Shape test of isg_gatv2_layer_conv: isg_gatv2_tile_conv's, and a 128-wide layer input."""
-    return FUSE_LAYER_CONV and in_channels == 128 and heads <= 16 and tile_conv_supported(plan, heads, channels, edge_dim)
+    return CFG.fuse_layer_conv and in_channels == 128 and heads <= 16 and tile_conv_supported(plan, heads, channels, edge_dim)
 
 
 class NodePlanes(NamedTuple):
@@ -892,7 +977,7 @@ def _mixed_sub(plan: "GraphPlan") -> Optional["OversizeGraphs"]:
     return sub
 
 
-SPLIT_STREAM = True       # ... on a stream of its own, beside the whole batch's tile kernels (A/B switch)
+# CFG.split_stream (ops.SPLIT_STREAM): ... on a stream of its own, beside the whole batch's tile kernels (A/B switch)
 _side_streams: dict = {}
 
 
@@ -903,13 +988,13 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return _side_streams[key]
 
 
-SPLIT_FORWARD = True      # "mixed" batches: the graphs beyond a tile run as a batch of their own through the WHOLE model (A/B switch;
+# CFG.split_forward (ops.SPLIT_FORWARD): "mixed" batches: the graphs beyond a tile run as a batch of their own through the WHOLE model (A/B switch;
                           # off: every tile kernel's wrapper fills their rows with the per-graph kernels, layer by layer)
 
 
 def oversize_split(plan: "GraphPlan") -> Optional["OversizeGraphs"]:
     """The graphs a model running on the graph-tile kernels should send through run_split (None: none, or not worth it)."""
-    if not SPLIT_FORWARD or plan.holes is not None or plan.rowptr is None:
+    if not CFG.split_forward or plan.holes is not None or plan.rowptr is None:
         return None
     if plan.tile_mode(TILE_CONV_NODES, TILE_CONV_EDGES) != "mixed":
         return None
@@ -942,13 +1027,11 @@ def run_split(plan: "GraphPlan", sub: "OversizeGraphs", core, x: Tensor, edge_in
         return core(xs, sub.edge_index, es, sub.batch, instr_s, glf_s, sub.plan, nz_s, seed, gate_s)
 
     def run_main():
-        plan.holes = sub
-        try:
-            return core(x, edge_index, edge_attr, batch, instr, glf, plan, noises, seed, None)
-        finally:
-            plan.holes = None
+        holed = copy.copy(plan)        # the SAME tensors and caches (dictionaries are shared), its own `holes`: the caller's plan is
+        holed.holes = sub              # not written to, and a second run_split on it (another thread, a re-entrant core) sees none
+        return core(x, edge_index, edge_attr, batch, instr, glf, holed, noises, seed, None)
 
-    if SPLIT_STREAM and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if CFG.split_stream and x.is_cuda and not torch.cuda.is_current_stream_capturing():
         # The sub-batch is a chain of ~60 launches of one or a few workgroups each (0.65 ms of GPU time for ONE 100-node graph):
         # on a stream of its own it runs beside the tile kernels instead of behind them.  The main pass is issued FIRST (the GPU
         # starts on it while the host is still issuing the sub-batch).
@@ -1305,12 +1388,12 @@ def node_gate(xn: Tensor, q: Tensor, batch: Tensor, double_index: bool, plan: Op
     return gate
 
 
-FUSE_GATE = True           # the masked layer's node gate from the layer input's planes, node_nn inside (A/B switch)
+# CFG.fuse_gate (ops.FUSE_GATE): the masked layer's node gate from the layer input's planes, node_nn inside (A/B switch)
 
 
 def node_gate_planes_supported(node_nn: torch.nn.Sequential, q: Tensor) -> bool:
     """Shape test of isg_node_gate_planes: inference, node_nn = Linear(128 -> 128) + exact GELU, 128-wide question rows."""
-    if not (FUSE_GATE and GEMM_BACKEND == "bf16x6" and GEMM_F16X3) or torch.is_grad_enabled():
+    if not (CFG.fuse_gate and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3) or torch.is_grad_enabled():
         return False
     mods = list(node_nn)
     if len(mods) != 2 or not isinstance(mods[0], torch.nn.Linear) or not isinstance(mods[1], torch.nn.GELU) \
@@ -1491,14 +1574,14 @@ def mgat_layer_tail(ins: Tensor, c: Tensor, h: Tensor, plan: GraphPlan, weight: 
     return out
 
 
-FUSE_DENSE_TAIL = True    # x_proj + layer tail + next instruction gate as one kernel on graph-aligned tiles (A/B switch)
-DENSE_TAIL_ROWS = 64      # nodes per tile of isg_mgat_dense_tail
+# CFG.fuse_dense_tail (ops.FUSE_DENSE_TAIL): x_proj + layer tail + next instruction gate as one kernel on graph-aligned tiles (A/B switch)
+# CFG.dense_tail_rows (ops.DENSE_TAIL_ROWS): nodes per tile of isg_mgat_dense_tail
 
 
 def dense_tail_supported(plan: GraphPlan, x_proj: torch.nn.Sequential, width_in: int, channels: int) -> bool:
     """Shape test of isg_mgat_dense_tail (csrc/isg_layer_tile.hip): inference, fp32, Linear(512 -> 256) GELU Linear(256 ->
     128) GELU (MGAT at C = 128, H = 4: BASELINE configs[1]), every graph within one 64-node tile."""
-    if not (FUSE_DENSE_TAIL and GEMM_BACKEND == "bf16x6" and GEMM_F16X3) or torch.is_grad_enabled():
+    if not (CFG.fuse_dense_tail and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3) or torch.is_grad_enabled():
         return False
     mods = list(x_proj)
     if len(mods) != 4 or not all(isinstance(m, torch.nn.GELU) and m.approximate == "none" for m in (mods[1], mods[3])):
@@ -1508,7 +1591,7 @@ def dense_tail_supported(plan: GraphPlan, x_proj: torch.nn.Sequential, width_in:
         return False
     return (width_in == 512 and channels == 128 and tuple(l0.weight.shape) == (256, 512) and
             tuple(l2.weight.shape) == (128, 256) and plan.B > 0 and plan.batch is not None and
-            plan.tile_mode(DENSE_TAIL_ROWS, TILE_CONV_EDGES) != "none")
+            plan.tile_mode(CFG.dense_tail_rows, TILE_CONV_EDGES) != "none")
 
 
 def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, h: Tensor, plan: GraphPlan, weight: Tensor,
@@ -1533,7 +1616,7 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
         [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
     # one tile plan per batch: the convolution's (64 nodes / 256 slots) serves this kernel too when it exists
     # one tile plan per batch, the convolution's (64 nodes / 256 slots): the same graphs are "oversize" for every tile kernel
-    tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if plan.rowptr is not None else 0)
+    tile_ptr, ntiles, cap, tile_info = plan.tiles(CFG.dense_tail_rows, TILE_CONV_EDGES if plan.rowptr is not None else 0)
     h_out = torch.empty_like(h)
     xg = torch.empty_like(h) if ins_next is not None and want_rows else None
     xp = None
@@ -1573,12 +1656,12 @@ def mgat_dense_tail(conv_out: Tensor, x_proj: torch.nn.Sequential, ins: Tensor, 
     return h_out, xg, xp
 
 
-FUSE_READOUT = True        # node_nn + mask + per-graph softmax pooling as one launch on graph-aligned tiles (A/B switch)
+# CFG.fuse_readout (ops.FUSE_READOUT): node_nn + mask + per-graph softmax pooling as one launch on graph-aligned tiles (A/B switch)
 
 
 def readout_tile_supported(plan: GraphPlan, node_nn: torch.nn.Sequential, width_in: int) -> bool:
     """Shape test of isg_readout_tile: inference, fp32, node_nn = Linear(128 -> 128) GELU Linear(128 -> 128), tiles of 64 nodes."""
-    if not (FUSE_READOUT and GEMM_BACKEND == "bf16x6" and GEMM_F16X3) or torch.is_grad_enabled():
+    if not (CFG.fuse_readout and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3) or torch.is_grad_enabled():
         return False
     mods = list(node_nn)
     if len(mods) != 3 or not isinstance(mods[1], torch.nn.GELU) or mods[1].approximate != "none":
@@ -1587,7 +1670,7 @@ def readout_tile_supported(plan: GraphPlan, node_nn: torch.nn.Sequential, width_
     if not (isinstance(l0, torch.nn.Linear) and isinstance(l2, torch.nn.Linear)) or l0.bias is None or l2.bias is None:
         return False
     return (width_in == 128 and tuple(l0.weight.shape) == (128, 128) and tuple(l2.weight.shape) == (128, 128) and plan.B > 0 and
-            plan.batch is not None and plan.tile_mode(DENSE_TAIL_ROWS, TILE_CONV_EDGES) != "none")
+            plan.batch is not None and plan.tile_mode(CFG.dense_tail_rows, TILE_CONV_EDGES) != "none")
 
 
 def readout_tile(x: Tensor, node_nn: torch.nn.Sequential, q: Tensor, plan: GraphPlan, node_mask: Optional[Tensor] = None):
@@ -1600,7 +1683,7 @@ def readout_tile(x: Tensor, node_nn: torch.nn.Sequential, q: Tensor, plan: Graph
     p2, inv2 = _weight_planes(l2.weight, True, "f16x3")
     ybound = derived_weight("dense_tail_bound", (l0.weight, l0.bias), lambda: torch.stack(
         [l0.weight.detach().abs().sum(dim=1).max(), l0.bias.detach().abs().max()]).float().contiguous())
-    tile_ptr, ntiles, cap, tile_info = plan.tiles(DENSE_TAIL_ROWS, TILE_CONV_EDGES if plan.rowptr is not None else 0)
+    tile_ptr, ntiles, cap, tile_info = plan.tiles(CFG.dense_tail_rows, TILE_CONV_EDGES if plan.rowptr is not None else 0)
     out = torch.empty(plan.B, C, dtype=torch.float32, device=x.device)
     gate = torch.empty(N, 1, dtype=torch.float32, device=x.device)
     rc = lib.isg_readout_tile(
@@ -1643,27 +1726,27 @@ def global_attn_pool(xn: Tensor, q: Tensor, plan: GraphPlan, node_mask: Optional
 # ------------------------------------------------------------------------------------------------
 # Dense projections: fp32 accuracy on the bf16 matrix cores (csrc/isg_gemm.hip)
 # ------------------------------------------------------------------------------------------------
-GEMM_BACKEND = "bf16x6"      # "bf16x6": this library's kernels; "torch": hipBLASLt fp32 through torch (A/B switch)
+# CFG.gemm_backend (ops.GEMM_BACKEND): "bf16x6": this library's kernels; "torch": hipBLASLt fp32 through torch (A/B switch)
 _PLANES = {}                 # (id(weight), layout) -> (weakref, version, data_ptr, planes): static weights are split once
-F16X3_F16_OUT = True         # half-row results (configs[4]) of K <= 128 Linears on isg_linear_f16x3_f16 instead of the bf16 six-product
+# CFG.f16x3_f16_out (ops.F16X3_F16_OUT): half-row results (configs[4]) of K <= 128 Linears on isg_linear_f16x3_f16 instead of the bf16 six-product
                              # panel kernel (A/B switch)
-GEMM_KERNEL = "auto"         # "auto": per shape (below); "panel": isg_linear_panel; "tile": isg_linear_bf16x6 (A/B switch)
+# CFG.gemm_kernel (ops.GEMM_KERNEL): "auto": per shape (below); "panel": isg_linear_panel; "tile": isg_linear_bf16x6 (A/B switch)
 
 
-F16X3_TILE = True     # ... and 128 < K <= 1024 when the producer of the input left its row maxima (isg_linear_f16x3_tile)
-GEMM_F16X3 = True     # K <= 128 panel shapes on the fp16 three-product kernel (isg_linear_f16x3) instead of bf16x6 (A/B switch)
+# CFG.f16x3_tile (ops.F16X3_TILE): ... and 128 < K <= 1024 when the producer of the input left its row maxima (isg_linear_f16x3_tile)
+# CFG.gemm_f16x3 (ops.GEMM_F16X3): K <= 128 panel shapes on the fp16 three-product kernel (isg_linear_f16x3) instead of bf16x6 (A/B switch)
 
 
-PANEL_MIN_N = 256       # narrowest Linear the row-panel kernels take (A/B: tools/ab_step.py)
+# CFG.panel_min_n (ops.PANEL_MIN_N): narrowest Linear the row-panel kernels take (A/B: tools/ab_step.py)
 
 
 def _use_panel(M: int, N: int, K: int) -> bool:
     """The row-panel kernel wins where an A panel is split once and serves many columns (K <= 128: lin_edge 182 vs 212 us,
     lin_l|lin_r 153 vs 166 us) and there are enough 64-row panels to fill the chip; the tile kernel elsewhere
     (profiles/r02_a_gemm_structures.md)."""
-    if GEMM_KERNEL != "auto":
-        return GEMM_KERNEL == "panel"
-    return K <= 128 and N >= PANEL_MIN_N and M >= 32768
+    if CFG.gemm_kernel != "auto":
+        return CFG.gemm_kernel == "panel"
+    return K <= 128 and N >= CFG.panel_min_n and M >= 32768
 
 
 _DERIVED = {}   # (tag, ids of the source tensors) -> (versions, weakrefs, value): weights re-laid-out once per model
@@ -1729,7 +1812,7 @@ def gather_add(A: Tensor, ia: Tensor, B: Optional[Tensor] = None, ib: Optional[T
     return Planes32(pl, pinv, E, C) if planes_out else out
 
 
-EMBEDDING_SUM = True            # sum of a node's token embeddings through isg_gather_add instead of gather + reduce (A/B switch)
+# CFG.embedding_sum (ops.EMBEDDING_SUM): sum of a node's token embeddings through isg_gather_add instead of gather + reduce (A/B switch)
 
 
 def embedding_sum(weight: Tensor, idx: Tensor) -> Tensor:
@@ -1737,7 +1820,7 @@ def embedding_sum(weight: Tensor, idx: Tensor) -> Tensor:
     intermediate -- isg_gather_add adds up to three gathered rows (and a dense term) per launch, so four tokens are two launches
     over a table that sits in L2 (1.5 MB) instead of a 79 us gather x 2 and a 116 us reduction at 82 k nodes.  Inference, fp32,
     4 | C; anything else: the torch ops.  (The sum runs ((t0 + t1) + t2) then + t3: equal to torch's to rounding.)"""
-    if (not EMBEDDING_SUM or _rec(weight) or weight.dtype != torch.float32 or idx.dim() != 2 or idx.size(1) < 2 or
+    if (not CFG.embedding_sum or _rec(weight) or weight.dtype != torch.float32 or idx.dim() != 2 or idx.size(1) < 2 or
             weight.size(1) % 4 != 0 or not weight.is_cuda or idx.dtype != torch.int64):
         return torch.sum(torch.nn.functional.embedding(idx, weight), dim=-2)
     w = weight.detach()
@@ -1844,7 +1927,7 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], norm: torch.nn.LayerNor
     rm = torch.empty(M, 1, dtype=torch.float32, device=x.device) if want_rowmax else None
     # the consumers of a LayerNorm result are Linears: where they run on the planes32 engine the kernel writes the planes too
     pl = None
-    if LN_PLANES and H3P and D % 32 == 0 and D >= H3P_MIN_K and M >= H3P_MIN_M:
+    if CFG.ln_planes and CFG.h3p and D % 32 == 0 and D >= CFG.h3p_min_k and M >= CFG.h3p_min_m:
         pl = Planes32(torch.empty(M * D * 2, dtype=torch.int16, device=x.device),
                       torch.empty(M, dtype=torch.float32, device=x.device), M, D)
     rc = lib.isg_add_layernorm(_chk_rows(x, "x"), x.stride(0), 0 if residual is None else _chk_rows(residual, "residual"),
@@ -1880,17 +1963,17 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         return linear_h3p(x, weight, bias, gelu=gelu, relu=relu, cache_planes=cache_planes)
     M, K = x.shape
     f16_io = x.dtype == torch.float16 or out_dtype == torch.float16
-    if f16_io and (GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or _rec(x, weight, bias)):
+    if f16_io and (CFG.gemm_backend != "bf16x6" or (K & 3) != 0 or _rec(x, weight, bias)):
         raise _lib.IsgError("fp16 feature rows are an inference feature of the bf16x6 kernel (K % 4 == 0, no autograd)")
     if relu and (gelu or f16_io):
         raise ValueError("relu excludes gelu and fp16 rows")
-    if relu and (_rec(x, weight, bias) or GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or M == 0):
+    if relu and (_rec(x, weight, bias) or CFG.gemm_backend != "bf16x6" or (K & 3) != 0 or M == 0):
         return _linear_torch(x, weight, bias, False, True)
-    if _rec(x, weight, bias) and GEMM_BACKEND == "bf16x6" and (K & 3) == 0 and M > 0:
+    if _rec(x, weight, bias) and CFG.gemm_backend == "bf16x6" and (K & 3) == 0 and M > 0:
         from . import autograd
         return autograd.linear(x, weight, bias, gelu)
     N = weight.size(0)
-    if GEMM_BACKEND != "bf16x6" or (K & 3) != 0 or M == 0:
+    if CFG.gemm_backend != "bf16x6" or (K & 3) != 0 or M == 0:
         if M == 0:
             return x.new_empty(0, N)
         return _linear_torch(x, weight, bias, gelu, False)
@@ -1903,7 +1986,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     if a_rowmax is not None and (a_rowmax.dim() != 2 or a_rowmax.size(0) != M or a_rowmax.size(1) > 64 or
                                  a_rowmax.stride(1) != 1):
         a_rowmax = None
-    f16x3_tile = GEMM_F16X3 and F16X3_TILE and GEMM_KERNEL == "auto" and K > 128 and not f16_io and M < (1 << 23)
+    f16x3_tile = CFG.gemm_f16x3 and CFG.f16x3_tile and CFG.gemm_kernel == "auto" and K > 128 and not f16_io and M < (1 << 23)
     nchunk = (K + 639) // 640              # chains of at most 640: 2.75x an fp32 GEMM's error at 1024-long chains, < 2x here
     step = (K + nchunk - 1) // nchunk
     step = (step + 31) // 32 * 32
@@ -1949,7 +2032,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         if d_rowmax is not None:
             attach_row_maxima(out, d_rowmax)
         return out
-    if (_use_panel(M, N, K) and not relu and GEMM_F16X3 and K <= 128 and F16X3_F16_OUT and x.dtype == torch.float32
+    if (_use_panel(M, N, K) and not relu and CFG.gemm_f16x3 and K <= 128 and CFG.f16x3_f16_out and x.dtype == torch.float32
             and out_dtype == torch.float16):
         # fp32 rows in, half rows out (configs[4]'s x_l | x_r): the three-product kernel with one rounding at its store
         planes, inv = _weight_planes(weight, cache_planes, "f16x3")
@@ -1958,7 +2041,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
             _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
             out.data_ptr(), M, N, K, K, N, 1 if gelu else 0, N, 0, _stream()), "isg_linear_f16x3_f16")
         return out
-    if _use_panel(M, N, K) and not relu and GEMM_F16X3 and K <= 128 and not f16_io:
+    if _use_panel(M, N, K) and not relu and CFG.gemm_f16x3 and K <= 128 and not f16_io:
         planes, inv = _weight_planes(weight, cache_planes, "f16x3")
         _lib.check(lib.isg_linear_f16x3(
             _chk(x, "x", torch.float32), planes.data_ptr(), inv.data_ptr(),
@@ -2066,16 +2149,13 @@ def _h3p_weight(weight: Tensor, bias: Optional[Tensor], cache: bool = True, seg_
     return derived_weight(f"h3p{seg_cols or ''}", (weight,) if bias is None else (weight, bias), build)
 
 
-H3P = True            # Linears with K >= H3P_MIN_K over at least H3P_MIN_M rows on isg_linear_h3p (A/B switch)
-H3P_MIN_K = 256
-LN_PLANES = True      # isg_add_layernorm writes its result as planes32 too where Linears on the engine read it (A/B switch)
-H3P_CHAIN = True      # linear1 -> linear2 of the Transformer layers through planes (no fp32 intermediate): A/B switch
-H3P_MIN_M = 8192
-
-
+# CFG.h3p (ops.H3P): Linears with K >= CFG.h3p_min_k over at least CFG.h3p_min_m rows on isg_linear_h3p (A/B switch)
+# CFG.h3p_min_k (ops.H3P_MIN_K): CFG.ln_planes (ops.LN_PLANES): isg_add_layernorm writes its result as planes32 too where Linears on the engine read it (A/B switch)
+# CFG.h3p_chain (ops.H3P_CHAIN): linear1 -> linear2 of the Transformer layers through planes (no fp32 intermediate): A/B switch
+# CFG.h3p_min_m (ops.H3P_MIN_M): 
 def h3p_supported(M: int, N: int, K: int) -> bool:
-    return (H3P and GEMM_BACKEND == "bf16x6" and GEMM_KERNEL == "auto" and GEMM_F16X3 and K >= H3P_MIN_K and (K & 3) == 0 and
-            (N & 3) == 0 and M >= H3P_MIN_M and M * ((K + 31) // 32) * 128 < (1 << 31) and N * ((K + 31) // 32) * 128 < (1 << 31)
+    return (CFG.h3p and CFG.gemm_backend == "bf16x6" and CFG.gemm_kernel == "auto" and CFG.gemm_f16x3 and K >= CFG.h3p_min_k and (K & 3) == 0 and
+            (N & 3) == 0 and M >= CFG.h3p_min_m and M * ((K + 31) // 32) * 128 < (1 << 31) and N * ((K + 31) // 32) * 128 < (1 << 31)
             and M * ((N + 31) // 32 * 32) * 4 < (1 << 32) - 16)       # the result through a buffer descriptor: 32-bit byte offsets
 
 
@@ -2085,10 +2165,10 @@ def h3p_supported(M: int, N: int, K: int) -> bool:
 # (the same way in every process on a box); in the full model, on a box where it wins in isolation, every policy gives the same
 # step (20.09-20.29 ms: profiles/r04_ag_h3p_store_policy.txt) -- what the producer gains by not leaving its result in L2 / the
 # Infinity Cache its consumer loses.  So the default is the library's choice and "auto" stays an experiment.
-H3P_STORE_POLICY = -1
-LINEAR_MULTI_H3P = True        # the layers' lin_edge over the shared edge features as one engine launch (A/B switch)
-MP_PLANES = True               # the flat message-passing kernel hands x_proj.0 its operand as segmented planes32 (A/B switch)
-GATHER_ADD_PLANES = True       # isg_gather_add hands its rows to the Linear behind it as planes32 (A/B switch)
+# CFG.h3p_store_policy (ops.H3P_STORE_POLICY): 
+# CFG.linear_multi_h3p (ops.LINEAR_MULTI_H3P): the layers' lin_edge over the shared edge features as one engine launch (A/B switch)
+# CFG.mp_planes (ops.MP_PLANES): the flat message-passing kernel hands x_proj.0 its operand as segmented planes32 (A/B switch)
+# CFG.gather_add_planes (ops.GATHER_ADD_PLANES): isg_gather_add hands its rows to the Linear behind it as planes32 (A/B switch)
 _h3p_policy_state = {"chosen": None, "us": None}
 
 
@@ -2102,9 +2182,9 @@ def _h3p_tune(dev) -> None:
     result), the library's own choice against write-through streaming stores, median of three launches each.  ~3 ms, once per
     process; skipped (library's choice) while a stream is being captured."""
     lib = _lib.load()
-    if H3P_STORE_POLICY != "auto":
-        _lib.check(lib.isg_linear_h3p_store_policy(int(H3P_STORE_POLICY)), "isg_linear_h3p_store_policy")
-        _h3p_policy_state.update(chosen=int(H3P_STORE_POLICY), us=None)
+    if CFG.h3p_store_policy != "auto":
+        _lib.check(lib.isg_linear_h3p_store_policy(int(CFG.h3p_store_policy)), "isg_linear_h3p_store_policy")
+        _h3p_policy_state.update(chosen=int(CFG.h3p_store_policy), us=None)
         return
     if torch.cuda.is_current_stream_capturing():
         return
@@ -2196,20 +2276,20 @@ def planes32_to_rows(p: Planes32) -> Tensor:
     return ((v[:, :, 0] + v[:, :, 1]).reshape(p.rows, KT * 32)[:, :p.cols] * p.inv[:, None]).contiguous()
 
 
-LINEAR_MULTI = True     # A/B switch (tools/ab_step.py)
+# CFG.linear_multi (ops.LINEAR_MULTI): A/B switch (tools/ab_step.py)
 
 
 def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
     """x @ W_i^T for several bias-free Linears of one shape over the same rows, as ONE launch of the row-panel kernel
     (isg_linear_panel_multi): a tuple of dense [M, n] tensors, or None when the shape is not the panel kernel's (the caller
     then projects layer by layer).  MGAT's per-layer lin_edge projections of the shared edge features use it."""
-    if not LINEAR_MULTI or GEMM_BACKEND != "bf16x6" or _rec(x, *weights) or len(weights) < 2:
+    if not CFG.linear_multi or CFG.gemm_backend != "bf16x6" or _rec(x, *weights) or len(weights) < 2:
         return None
     M, K = x.shape
     n = weights[0].size(0)
     if any(tuple(w.shape) != (n, K) for w in weights):
         return None
-    if (LINEAR_MULTI_H3P and x.dtype == torch.float32 and out_dtype == torch.float32 and (n & 3) == 0 and
+    if (CFG.linear_multi_h3p and x.dtype == torch.float32 and out_dtype == torch.float32 and (n & 3) == 0 and
             h3p_supported(M, len(weights) * n, K) and x.stride(1) == 1 and (x.stride(0) & 3) == 0 and (x.data_ptr() & 15) == 0):
         # K >= 256 (the reference's default width): ONE launch of the planes32 engine over the concatenated weights -- the shared
         # rows are read once instead of once per layer (262 MB per layer at 205 k edges); the layers' results are column slices
@@ -2222,8 +2302,8 @@ def linear_multi(x: Tensor, weights, out_dtype=torch.float32):
     cat = derived_weight("linear_multi", tuple(weights), lambda: torch.cat([w.detach() for w in weights], 0).contiguous())
     L = len(weights)
     out = torch.empty(L, M, n, dtype=out_dtype, device=x.device)
-    if GEMM_F16X3 and K <= 128 and x.dtype == torch.float32 and (out_dtype == torch.float32 or
-                                                                 (out_dtype == torch.float16 and F16X3_F16_OUT)):
+    if CFG.gemm_f16x3 and K <= 128 and x.dtype == torch.float32 and (out_dtype == torch.float32 or
+                                                                 (out_dtype == torch.float16 and CFG.f16x3_f16_out)):
         planes, inv = _weight_planes(cat, True, "f16x3")
         fn = lib.isg_linear_f16x3 if out_dtype == torch.float32 else lib.isg_linear_f16x3_f16
         _lib.check(fn(_chk(x, "x", torch.float32), planes.data_ptr(), inv.data_ptr(), 0, out.data_ptr(),
@@ -2243,16 +2323,16 @@ def mha_small_supported(t_kv: int, head_dim: int) -> bool:
     return head_dim <= 64 and head_dim % 4 == 0 and t_kv <= 128 and (t_kv * (3 * head_dim + 4) + 4 * 128) * 4 <= 64 * 1024
 
 
-TILE_HEAVY_FIRST = True        # persistent tile kernels walk the tile list heavy tiles first (A/B switch)
-MHA_ROWS_PLANES = True         # attention results as planes32 where the all-heads form fits (A/B switch)
-MHA_ROWS_MAX_TQ = 16           # ... up to this many query rows per batch item
+# CFG.tile_heavy_first (ops.TILE_HEAVY_FIRST): persistent tile kernels walk the tile list heavy tiles first (A/B switch)
+# CFG.mha_rows_planes (ops.MHA_ROWS_PLANES): attention results as planes32 where the all-heads form fits (A/B switch)
+# CFG.mha_rows_max_tq (ops.MHA_ROWS_MAX_TQ): ... up to this many query rows per batch item
 
 
 def mha_rows_supported(t_q: int, t_kv: int, heads: int, head_dim: int) -> bool:
     """The all-heads form of isg_mha_small (one workgroup per batch item, the result rows assembled in LDS and written as
     planes32): a head's Q / K / V, the score strips and t_q whole rows within 64 KB -- 12-token questions and the decoder's 4
     queries at d = 512, not CLIP's 77 tokens."""
-    return (MHA_ROWS_PLANES and t_q <= MHA_ROWS_MAX_TQ and mha_small_supported(max(t_q, t_kv), head_dim) and
+    return (CFG.mha_rows_planes and t_q <= CFG.mha_rows_max_tq and mha_small_supported(max(t_q, t_kv), head_dim) and
             (t_kv * (2 * head_dim + 4) + t_q * head_dim + (4 if t_q <= 4 else 8 if t_q <= 8 else 12) * 128 +
              t_q * heads * head_dim) * 4 <= 64 * 1024)
 
@@ -2338,7 +2418,7 @@ def mlp(seq: torch.nn.Sequential, x: Tensor, want_rowmax: bool = False) -> Tenso
             tail = want_rowmax and not any(hasattr(t, "weight") and getattr(t.weight, "dim", lambda: 0)() == 2 for t in mods[nxt:]) \
                 and all(isinstance(t, torch.nn.Dropout) and not t.training for t in mods[nxt:])   # only identities follow
             rows_in = x.rows if isinstance(x, Planes32) else x.size(0)
-            chain = (more and H3P_CHAIN and not _rec(m.weight, mods[nxt].weight) and not torch.is_grad_enabled() and
+            chain = (more and CFG.h3p_chain and not _rec(m.weight, mods[nxt].weight) and not torch.is_grad_enabled() and
                      (isinstance(x, Planes32) or x.dtype == torch.float32) and
                      h3p_supported(rows_in, m.weight.size(0), m.weight.size(1)) and
                      h3p_supported(rows_in, mods[nxt].weight.size(0), mods[nxt].weight.size(1)))
