@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 16
+#define ISG_ABI_VERSION 17
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -181,7 +181,8 @@ int isg_node_gate_planes(const uint16_t *x_planes, const float *x_inv_scale, con
  * noise: explicit fp32 noise laid out [B, nmax_host] (the reference draws [B,Nmax] for Gumbel,
  * gumbel_scheme.py:65-69, and [B,1,Nmax,1] for I-MLE/AIMLE, wrapper.py:84-91, aimle.py:93-106 --
  * the same memory layout), or NULL to generate it in-kernel with Philox4x32-10 keyed by
- * (seed, b, j). */
+ * (seed, g, j) with g = graph_ids[b] if graph_ids != NULL (int32[B]: a sub-batch whose rows keep the noise
+ * streams of the graphs they were cut from, ops.run_split) else g = b. */
 
 /* Relaxed Gumbel top-k with straight-through hard mask: GumbelSampler.forward, policy
  * 'edge_candid', ISubGVQA/sampling/methods/gumbel_scheme.py:55-58,63-104.
@@ -189,8 +190,8 @@ int isg_node_gate_planes(const uint16_t *x_planes, const float *x_inv_scale, con
  *   onehot = softmax(flat/tau); khot += onehot };  hard = top-k(khot);  out = (hard-khot)+khot
  * khot_out (optional) fp32[B,Nmax_host-strided] receives khot for inspection. */
 int isg_topk_gumbel(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
-                    const int32_t *nmax_dev, const float *noise, uint64_t seed, int32_t k, float tau,
-                    float *out, float *khot_out, void *stream);
+                    const int32_t *nmax_dev, const float *noise, uint64_t seed, const int32_t *graph_ids,
+                    int32_t k, float tau, float *out, float *khot_out, void *stream);
 
 /* Threshold top-k used by I-MLE / AIMLE at inference:  select_from_edge_candidates,
  * ISubGVQA/sampling/methods/deterministic_scheme.py:36-43, applied to scores + noise*noise_scale
@@ -202,7 +203,7 @@ int isg_topk_gumbel(const float *scores, const int32_t *ptr, int64_t B, int32_t 
  * the batch's longest graph (the AIMLE backward counts flipped slots over the whole padded row, target_aimle.py:137). */
 int isg_topk_threshold(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
                        const int32_t *nmax_dev, const float *noise, float noise_scale, uint64_t seed,
-                       int32_t k, float *out, float *dense_out, void *stream);
+                       const int32_t *graph_ids, int32_t k, float *out, float *dense_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-graph attention / normalisation / pooling
@@ -348,7 +349,7 @@ int isg_global_attn_pool(const float *xn, const float *q, const int32_t *ptr, co
  * scores ragged [N] with ptr or dense [B,nmax]; uniform fp32[B,n] (the torch.rand draw) or NULL for the in-kernel
  * Philox stream of `seed`; out in the layout of scores; marg_out optional fp32[B,nmax].  k <= 16, nmax <= 1024. */
 int isg_simple_topk(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax, const float *uniform,
-                    uint64_t seed, int32_t k, float *out, float *marg_out, void *stream);
+                    uint64_t seed, const int32_t *graph_ids, int32_t k, float *out, float *marg_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward (training of the hot path)
@@ -371,8 +372,8 @@ int isg_gatv2_mp_bwd(const float *x_l, const float *x_r, const float *e_proj, co
  * scores / noise / seed / k / tau must be the forward's.  ISG_EUNSUPPORTED when k * row length exceeds the 64 KB LDS
  * history (k * nmax_slots > 4096). */
 int isg_topk_gumbel_bwd(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
-                        const int32_t *nmax_dev, const float *noise, uint64_t seed, int32_t k, float tau,
-                        const float *d_out, float *d_scores, void *stream);
+                        const int32_t *nmax_dev, const float *noise, uint64_t seed, const int32_t *graph_ids,
+                        int32_t k, float tau, const float *d_out, float *d_scores, void *stream);
 
 /* Backward of isg_instr_attn_graphnorm_residual (autograd over mgat.py:168-177 in the reference).  grad_out fp32[N,C].
  * d_ins fp32[B,C], d_c / d_h fp32[N,C], d_mask fp32[N] or NULL; partial fp32[B,3,C]: per-graph rows of

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -34,17 +34,17 @@ SIGNATURES = {
     "isg_graph_edge_ptr": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "isg_scatter_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_node_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
-    "isg_topk_gumbel": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_int32,
+    "isg_topk_gumbel": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_void_p, c_int32,
                                 c_float, c_void_p, c_void_p, c_void_p]),
     "isg_topk_threshold": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_float, c_uint64,
-                                   c_int32, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_scatter_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "isg_graph_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int32, c_void_p,
                                c_int64, c_int32, c_void_p]),
     "isg_instr_attn_graphnorm_residual": (c_int, [c_void_p] * 7 + [c_double, c_void_p, c_void_p, c_int64, c_int32,
                                                                   c_void_p]),
-    "isg_simple_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_uint64, c_int32, c_void_p, c_void_p,
-                                c_void_p]),
+    "isg_simple_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_uint64, c_void_p, c_int32, c_void_p,
+                                c_void_p, c_void_p]),
     "isg_instr_attn_graphnorm_residual_bwd": (c_int, [c_void_p] * 7 + [c_double] + [c_void_p] * 7 + [c_int64, c_int32, c_void_p]),
     "isg_global_attn_pool_bwd": (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_void_p]),
     "isg_instr_gate_bwd": (c_int, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
@@ -53,7 +53,7 @@ SIGNATURES = {
     "isg_linear_wgrad_splits": (c_int64, [c_int64, c_int32, c_int32]),
     "isg_linear_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int64,
                                  c_void_p]),
-    "isg_topk_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_int32,
+    "isg_topk_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_uint64, c_void_p, c_int32,
                                     c_float, c_void_p, c_void_p, c_void_p]),
     "isg_gatv2_mp_bwd": (c_int, [c_void_p] * 19 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "isg_node_to_edge_mask_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

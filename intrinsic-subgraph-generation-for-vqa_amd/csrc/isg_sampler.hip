@@ -42,6 +42,7 @@ struct RowArgs {
   int B, nmax_host, k;
   float tau, noise_scale;
   uint64_t seed;
+  const int *gids;      // NULL -> row b draws the Philox stream of graph b; else of graph gids[b] (a sub-batch keeps its graphs' streams)
 };
 
 template <int SLOTS>
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void topk_gumbel_kernel(RowArgs a) {
     if (j < nmax) {
       const float sc = j < n ? a.scores[base + j] : 0.f;                       // pad = 0.0 (quirk Q1)
       const float g = a.noise ? a.noise[(size_t)b * a.nmax_host + j]
-                              : gumbel_from_bits(Philox::draw(a.seed, (uint32_t)b, (uint32_t)j), 0.f, 1.f);
+                              : gumbel_from_bits(Philox::draw(a.seed, (uint32_t)(a.gids ? a.gids[b] : b), (uint32_t)j), 0.f, 1.f);
       v = sc + g;                                                              // gumbel_scheme.py:70
     }
     flat[s] = v;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(RowArgs a) {
       x = j < n ? a.scores[base + j] : 0.f;
       if (a.noise_scale != 0.f) {
         const float g = a.noise ? a.noise[(size_t)b * a.nmax_host + j]
-                                : gumbel_from_bits(Philox::draw(a.seed, (uint32_t)b, (uint32_t)j), 0.f, 0.3f);
+                                : gumbel_from_bits(Philox::draw(a.seed, (uint32_t)(a.gids ? a.gids[b] : b), (uint32_t)j), 0.f, 0.3f);
         x = add_rn(x, mul_rn(g, a.noise_scale));                         // aimle.py:109,117 (mul, then add)
       }
     }
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void topk_gumbel_bwd_kernel(RowArgs a, const f
     if (j < nmax) {
       const float sc = j < n ? a.scores[base + j] : 0.f;
       const float g = a.noise ? a.noise[(size_t)b * a.nmax_host + j]
-                              : gumbel_from_bits(Philox::draw(a.seed, (uint32_t)b, (uint32_t)j), 0.f, 1.f);
+                              : gumbel_from_bits(Philox::draw(a.seed, (uint32_t)(a.gids ? a.gids[b] : b), (uint32_t)j), 0.f, 1.f);
       v = sc + g;
     }
     flat[s] = v;
@@ -286,13 +287,13 @@ static int check_rows(const float *scores, int64_t B, int32_t nmax_host, int32_t
 }
 
 extern "C" int isg_topk_gumbel(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
-                               const int32_t *nmax_dev, const float *noise, uint64_t seed, int32_t k, float tau,
-                               float *out, float *khot_out, void *stream) {
+                               const int32_t *nmax_dev, const float *noise, uint64_t seed, const int32_t *graph_ids,
+                               int32_t k, float tau, float *out, float *khot_out, void *stream) {
   int st = check_rows(scores, B, nmax_host, k, out);
   if (st != ISG_OK) return st;
   if (B == 0 || nmax_host == 0) return ISG_OK;
   if (!(tau > 0.f)) return ISG_EINVAL;
-  RowArgs a{scores, ptr, nmax_dev, noise, out, khot_out, (int)B, nmax_host, k, tau, 0.f, seed};
+  RowArgs a{scores, ptr, nmax_dev, noise, out, khot_out, (int)B, nmax_host, k, tau, 0.f, seed, graph_ids};
   dim3 grid((unsigned)((B + 3) / 4)), block(256);
   hipStream_t s = as_stream(stream);
   switch (pick_slots(nmax_host)) {
@@ -308,11 +309,11 @@ extern "C" int isg_topk_gumbel(const float *scores, const int32_t *ptr, int64_t 
 
 extern "C" int isg_topk_threshold(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
                                   const int32_t *nmax_dev, const float *noise, float noise_scale, uint64_t seed,
-                                  int32_t k, float *out, float *dense_out, void *stream) {
+                                  const int32_t *graph_ids, int32_t k, float *out, float *dense_out, void *stream) {
   int st = check_rows(scores, B, nmax_host, k, out);
   if (st != ISG_OK) return st;
   if (B == 0 || nmax_host == 0) return ISG_OK;
-  RowArgs a{scores, ptr, nmax_dev, noise, out, dense_out, (int)B, nmax_host, k, 1.f, noise_scale, seed};
+  RowArgs a{scores, ptr, nmax_dev, noise, out, dense_out, (int)B, nmax_host, k, 1.f, noise_scale, seed, graph_ids};
   dim3 grid((unsigned)((B + 3) / 4)), block(256);
   hipStream_t s = as_stream(stream);
   switch (pick_slots(nmax_host)) {
@@ -327,8 +328,8 @@ extern "C" int isg_topk_threshold(const float *scores, const int32_t *ptr, int64
 }
 
 extern "C" int isg_topk_gumbel_bwd(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax_host,
-                                   const int32_t *nmax_dev, const float *noise, uint64_t seed, int32_t k, float tau,
-                                   const float *d_out, float *d_scores, void *stream) {
+                                   const int32_t *nmax_dev, const float *noise, uint64_t seed, const int32_t *graph_ids,
+                                   int32_t k, float tau, const float *d_out, float *d_scores, void *stream) {
   int st = check_rows(scores, B, nmax_host, k, d_scores);
   if (st != ISG_OK) return st;
   if (B == 0 || nmax_host == 0) return ISG_OK;
@@ -337,7 +338,7 @@ extern "C" int isg_topk_gumbel_bwd(const float *scores, const int32_t *ptr, int6
   if (slots == 0) return ISG_EUNSUPPORTED;
   const size_t lds = (size_t)4 * k * slots * 64 * sizeof(float);
   if (lds > 64 * 1024) return ISG_EUNSUPPORTED;   // k * row length beyond the LDS history
-  RowArgs a{scores, ptr, nmax_dev, noise, nullptr, nullptr, (int)B, nmax_host, k, tau, 0.f, seed};
+  RowArgs a{scores, ptr, nmax_dev, noise, nullptr, nullptr, (int)B, nmax_host, k, tau, 0.f, seed, graph_ids};
   dim3 grid((unsigned)((B + 3) / 4)), block(256);
   hipStream_t s = as_stream(stream);
   switch (slots) {

@@ -35,6 +35,7 @@ struct SimpleArgs {
   float *marg_out;       // optional dense [B, nmax]
   int B, nmax;
   uint64_t seed;
+  const int *gids;       // NULL -> row b draws graph b's stream; else graph gids[b]'s
 };
 
 __device__ __forceinline__ float sm_log1mexp(float x) {   // simple.py:45-57: log(1 - exp(-|x|))
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void simple_kernel(SimpleArgs a, SimpleTables 
   // Gumbel top-k sample of the raw scores (simple.py:99-118): keys = w + (-log(-log(u))), k largest -> 1
   // keys live in W's leaf slots 0 (no longer needed), marginals are exp(M(0, i, 1))
   for (int i = lane; i < n; i += 64) {
-    const float u = a.uniform ? a.uniform[(size_t)b * n + i] : (float)(Philox::draw(a.seed, (uint32_t)b, (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
+    const float u = a.uniform ? a.uniform[(size_t)b * n + i] : (float)(Philox::draw(a.seed, (uint32_t)(a.gids ? a.gids[b] : b), (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
     W[i * K1 + 0] = flat(i) + (-logf(-logf(u)));
     W[i * K1 + 1] = 0.f;                                // hot flag
   }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void simple_kernel(SimpleArgs a, SimpleTables 
 using namespace isg;
 
 extern "C" int isg_simple_topk(const float *scores, const int32_t *ptr, int64_t B, int32_t nmax, const float *uniform,
-                               uint64_t seed, int32_t k, float *out, float *marg_out, void *stream) {
+                               uint64_t seed, const int32_t *graph_ids, int32_t k, float *out, float *marg_out, void *stream) {
   if (B < 0 || nmax < 0 || k <= 0) return ISG_EINVAL;
   if (B == 0 || nmax == 0) return ISG_OK;
   if (!scores || !out) return ISG_EINVAL;
@@ -191,7 +192,7 @@ extern "C" int isg_simple_topk(const float *scores, const int32_t *ptr, int64_t 
   if (rows > 4) rows = 4;
   if (rows < 1) rows = 1;
   if (row_bytes > 150 * 1024) return ISG_EUNSUPPORTED;
-  SimpleArgs a{scores, ptr, uniform, out, marg_out, (int)B, nmax, seed};
+  SimpleArgs a{scores, ptr, uniform, out, marg_out, (int)B, nmax, seed, graph_ids};
   if (rows * row_bytes > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void *>(simple_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(rows * row_bytes)) != hipSuccess)

@@ -343,6 +343,8 @@ class GraphPlan:
     sizes_host: Optional[Tensor] = None           # HOST int64 [2, B] nodes / in-edges per graph when the caller's collate gave them (a hint
                                                   # like max_nodes / max_edges: lets oversize() count without a device-to-host sync)
     no_tiles: bool = False                        # the plan of a batch's oversize graphs: the tile kernels are not asked again
+    graph_ids: Optional[Tensor] = None            # int32 [B]: this plan's graphs are a CUT of a larger batch and these are their numbers
+                                                  # there -- the samplers' in-kernel noise is keyed by them (ops._gid_ptr)
     holes: Optional["OversizeGraphs"] = None      # set by run_split: the tile kernels pass over these graphs and NOTHING fills their rows
 
     def edge_planes(self, edge_attr: Tensor) -> Tuple[Tensor, Tensor]:
@@ -527,6 +529,8 @@ class GraphPlan:
                     sub_ei = newid[self.edge_index[:, edges]].contiguous()
                 sub_plan = GraphPlan.build(seg.contiguous(), sub_ei, num_graphs=G, max_nodes=nmax_s, max_edges=emax_s)
                 sub_plan.no_tiles = True
+                own = self.graph_ids                        # a cut of a cut keeps the ORIGINAL batch's numbers
+                sub_plan.graph_ids = (gids if own is None else own.long()[gids]).to(torch.int32).contiguous()
                 res = OversizeGraphs(gids, nodes, edges, seg, sub_ei, sub_plan)
         self._oversize[key] = res
         return res
@@ -1011,7 +1015,7 @@ def run_split(plan: "GraphPlan", sub: "OversizeGraphs", core, x: Tensor, edge_in
     layer's node gate reads the question row batch[batch[n]] (masking.py:151-155, quirk Q3), i.e. for graph g the row of the graph
     that holds NODE number g; the sub-batch is handed exactly those rows (gate_feats, to MGAT.forward).  A real GQA batch has a few such graphs (the reference caps
     nothing: datasets/scene_graph.py:199-389); filling their rows after every tile kernel instead cost ~200 small launches per step
-    (profiles/r04_az_split_forward.txt).  Dense [B, nmax] noise is cut to the sub-batch; a seed draws the sub-batch's own noise."""
+    (profiles/r04_az_split_forward.txt).  Dense [B, nmax] noise is cut to the sub-batch; under a seed every graph of the sub-batch draws the stream of its number in the WHOLE batch (plan.graph_ids), so a seeded mask does not depend on the dispatch."""
     nmax_s = sub.plan.nmax
 
     def run_side():
@@ -1431,6 +1435,18 @@ def _rows(scores: Tensor, plan: Optional[GraphPlan]):
     return scores, 0, scores.size(0), scores.size(1), 0
 
 
+def _gid_ptr(plan: Optional["GraphPlan"]) -> int:
+    """The graph-id table of a plan that is a CUT of a larger batch (run_split's sub-batch: plan.graph_ids = int32 [B], the graphs'
+    numbers in the batch they came from): row b of a sampler then draws the Philox stream of graph graph_ids[b], i.e. the noise
+    that graph gets when the batch is not split (seeded masks do not depend on the dispatch).  0: row b draws stream b."""
+    g = None if plan is None else plan.graph_ids
+    if g is None:
+        return 0
+    if g.dtype != torch.int32 or g.numel() != plan.B or not g.is_contiguous():
+        raise ValueError("plan.graph_ids must be a contiguous int32 [B] tensor")
+    return g.data_ptr()
+
+
 def _noise_ptr(noise: Optional[Tensor], B: int, nmax: int) -> int:
     if noise is None:
         return 0
@@ -1456,7 +1472,7 @@ def topk_gumbel(scores: Tensor, k: int, tau: float = 0.1, plan: Optional[GraphPl
     out = torch.empty_like(flat)
     khot = torch.empty(B, nmax, dtype=torch.float32, device=scores.device) if return_khot else None
     _lib.check(lib.isg_topk_gumbel(_chk(flat, "scores", torch.float32), ptr, B, nmax, nmax_dev,
-                                   _noise_ptr(noise, B, nmax), int(seed) & (2 ** 64 - 1), int(k), float(tau),
+                                   _noise_ptr(noise, B, nmax), int(seed) & (2 ** 64 - 1), _gid_ptr(plan), int(k), float(tau),
                                    out.data_ptr(), 0 if khot is None else khot.data_ptr(), _stream()),
                "isg_topk_gumbel")
     out = out.view(scores.shape)
@@ -1474,8 +1490,8 @@ def topk_threshold(scores: Tensor, k: int, plan: Optional[GraphPlan] = None, noi
     out = torch.empty_like(flat)
     dense = torch.empty(B, nmax, dtype=torch.float32, device=scores.device) if return_dense else None
     _lib.check(lib.isg_topk_threshold(_chk(flat, "scores", torch.float32), ptr, B, nmax, nmax_dev,
-                                      _noise_ptr(noise, B, nmax), float(noise_scale), int(seed) & (2 ** 64 - 1), int(k),
-                                      out.data_ptr(), 0 if dense is None else dense.data_ptr(), _stream()),
+                                      _noise_ptr(noise, B, nmax), float(noise_scale), int(seed) & (2 ** 64 - 1), _gid_ptr(plan),
+                                      int(k), out.data_ptr(), 0 if dense is None else dense.data_ptr(), _stream()),
                "isg_topk_threshold")
     out = out.view(scores.shape)
     return (out, dense) if return_dense else out
@@ -1498,7 +1514,7 @@ def simple_topk(scores: Tensor, k: int, plan: Optional[GraphPlan] = None, unifor
     marg = torch.empty(B, nmax, dtype=torch.float32, device=scores.device) if return_marginals else None
     _lib.check(lib.isg_simple_topk(_chk(flat, "scores", torch.float32), ptr, B, nmax,
                                    0 if uniform is None else _chk(uniform.reshape(B, n), "uniform", torch.float32),
-                                   int(seed) & (2 ** 64 - 1), int(k), out.data_ptr(),
+                                   int(seed) & (2 ** 64 - 1), _gid_ptr(plan), int(k), out.data_ptr(),
                                    0 if marg is None else marg.data_ptr(), _stream()), "isg_simple_topk")
     out = out.view(scores.shape)
     return (out, marg) if return_marginals else out
@@ -1513,7 +1529,7 @@ def topk_gumbel_backward(scores: Tensor, grad_out: Tensor, k: int, tau: float = 
     g = grad_out.reshape(flat.shape).contiguous()
     out = torch.empty_like(flat)
     _lib.check(lib.isg_topk_gumbel_bwd(_chk(flat, "scores", torch.float32), ptr, B, nmax, nmax_dev,
-                                       _noise_ptr(noise, B, nmax), int(seed) & (2 ** 64 - 1), int(k), float(tau),
+                                       _noise_ptr(noise, B, nmax), int(seed) & (2 ** 64 - 1), _gid_ptr(plan), int(k), float(tau),
                                        _chk(g, "grad_out", torch.float32), out.data_ptr(), _stream()),
                "isg_topk_gumbel_bwd")
     return out.view(scores.shape)

@@ -833,6 +833,30 @@ def test_split_forward_on_a_cold_weight_cache_matches_the_inline_pass(dev):
         assert torch.equal(l, l0) and torch.equal(m, m0) and torch.equal(g, g0), name
 
 
+@pytest.mark.parametrize("sampler", ["gumbel", "aimle"])
+def test_seeded_masks_do_not_depend_on_the_split(dev, sampler):
+    """the samplers key their in-kernel Philox noise by (seed, graph, slot).  run_split's sub-batch used to number its
+    graphs from 0, so oversize graph #k drew the noise of the main batch's graph k -- correlated with it, and different from what
+    the same graph draws when the batch is not split.  The sub-plan now carries the graphs' numbers in the whole batch
+    (GraphPlan.graph_ids -> the kernels' graph_ids table): a seeded forward gives the SAME masks split or not."""
+    from isubgvqa_amd import ops, synthetic
+    sizes = (20,) * 150 + (130,) + (20,) * 100 + (90,) + (20,) * 50
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler=sampler, seed=13)
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).eval().to(dev)
+    with torch.no_grad():
+        ops.reset_counters()
+        ls, ms, gs = _forced_mixed(lambda: model(wl, seed=77))
+        assert ops.counters()["oversize_nodes"] > 0 and ops.counters()["tile_nodes"] > 0
+        with ops.configured(mixed_dispatch=False):          # the whole batch on the per-graph kernels, one pass
+            ops.reset_counters()
+            lw, mw, gw = model(wl, seed=77)
+            assert ops.counters()["tile_nodes"] == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ms > 0.5, mw > 0.5), f"{int(((ms > 0.5) != (mw > 0.5)).sum())} mask values differ between the split and the one-pass forward"
+    assert (ls - lw).abs().max() < 2e-5
+
+
 def test_a_wrong_graph_sizes_hint_is_caught_at_check_plans(dev):
     """GraphPlan.build(graph_sizes=) is trusted to keep the step free of a device-to-host sync; the same counts are made on the
     device, copied to pinned memory behind the stream and compared at ops.check_plans(): a hint that misses a big graph raises."""
