@@ -14,8 +14,10 @@ A step = one pass of the hot path over one resident batch: BASELINE.json configs
 Gumbel top-k k=5, then attention pooling and the 1842-way classifier), i.e. ISubGVQA.forward from
 `gat_seq` down (ISubGVQA/models/isubgvqa.py:267-292) including the per-batch graph plan (CSR build).  Inputs
 are in HBM before the timed region.  With N ranks every rank owns its own 4096-graph shard (weak scaling) and
-each step ends with the RCCL all-gather of answer logits -- the only collective of the path; it is issued asynchronously and
-overlaps the next step's kernels (the last one is waited for inside the timed region).
+each step ends with the RCCL all-gather of answer logits [B_local, 1842] fp32 -- the only collective of the path (BASELINE
+north_star / configs[3]; --gather answers moves the arg-max answers instead and says so in rccl.collective); up to
+--gather-depth (2) of them are in flight on the communicator's stream beside the next steps' kernels (the last ones are
+waited for inside the timed region).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      the reference's message + aggregate: algorithmic bytes (e_proj included) / mean duration measured
@@ -26,7 +28,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 replayed from the committed PMC summary of exactly those kernels (profiles/*_mp_traffic.json)
   cpu_baseline  the CPU oracle (oracle/model.py, a port of the reference's PyG CPU path) timed on this host's usable
                 cores on a bounded sample of the same workload; .cfg1 = BASELINE configs[0] exactly
-  full_model    the configs[2] stand-in (full model at C = 300) timed in the same run
+  full_model    the configs[2] stand-in (full model at C = 300) timed in the same run; .kernels = its two dominant kernels against
+                their rooflines from HIP events around every launch of three extra steps (isg_linear_h3p: TFLOP/s of fp16
+                products vs the 2.5 PF dense MFMA peak; the flat message-passing kernel: SURVEY 8(d)'s bytes at H C = 1200 vs HBM)
+  sustained     >= 2.5 s of back-to-back configs[1] steps behind the timed burst: ms/step and its ratio to the burst's
   cfg5          BASELINE configs[4] on one GPU (skewed graphs, AIMLE, fp16 rows): ms/step, MP kernel GB/s on s = 2 bytes, the
                 imbalance of contiguous graph ranges over 8 ranks
   mixed         the configs[1] batch with a few graphs beyond a graph tile (what real GQA batches are: the reference caps nothing):
