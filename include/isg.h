@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 17
+#define ISG_ABI_VERSION 18
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -433,8 +433,12 @@ int isg_gatv2_mp_fwd_rowmax(const float *x_l, const float *x_r, const float *e_p
  * the endpoints, NodeMaskToEdgeMask) or both NULL.  logits fp32 [E, H] in SLOT order.  The product is the fp16
  * three-term form of isg_linear_f16x3 and never leaves the accumulators.  head_stride_l / _r: distance in floats between
  * the head slices of one node (0 = C: heads side by side in a row of H*C; N*C with ldl = C for a head-major [H][N][C]
- * tensor, whose 512-byte rows keep a gather instruction inside a few pages).  ISG_EUNSUPPORTED unless 32 | C, K <= 128,
- * 4 | K, H * C <= 2048, 16-byte aligned rows. */
+ * tensor, whose 512-byte rows keep a gather instruction inside a few pages).  A head dimension that is not a multiple of 32
+ * (the reference's C = 300) runs on heads PADDED to Cp = 32 * ceil(C / 32) channels: w_frag / w_inv_scale are then those of
+ * the [H*Cp, K] matrix with zero rows behind every head's C-th; att, x_l, x_r stay unpadded.  128 < K <= 320 runs the rows
+ * kernel (a wave keeps its 32 slots' edge rows in registers, the weight tiles stream through LDS once per 256 slots): w_frag /
+ * w_inv_scale are then those of the [H*Cp, 320] matrix (zero columns behind the K-th).  ISG_EUNSUPPORTED unless 4 | C, K <= 320,
+ * 4 | K, H * Cp <= 2048, 16-byte aligned rows. */
 int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
                           const float *x_l, int32_t ldl, int64_t head_stride_l, const float *x_r, int32_t ldr,
                           int64_t head_stride_r, const float *att, const int32_t *eid, const int32_t *src, const int32_t *dst,
@@ -462,6 +466,14 @@ int isg_gatv2_mp_fwd_logits(const float *x_l, const float *logits, const float *
                             int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
                             const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
                             int32_t emax_host, int32_t ld_l, void *stream);
+/* The same with the result as the segmented planes32 operand of isg_linear_h3p (isg_gatv2_mp_fwd_planes's output contract:
+ * H = 4, the flat per-graph kernel): a C = 300 layer with neither e_proj nor fp32 convolution rows in memory. */
+int isg_gatv2_mp_fwd_logits_planes(const float *x_l, const float *logits, const float *att, const float *bias,
+                                   const int32_t *rowptr, const int32_t *eid, const int32_t *src, const float *node_mask,
+                                   const float *edge_mask, uint16_t *out_planes, float *out_inv, float *alpha, int64_t N,
+                                   int64_t E, int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
+                                   const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
+                                   int32_t emax_host, int32_t ld_l, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense projections (fp32 accuracy on the bf16 matrix cores)

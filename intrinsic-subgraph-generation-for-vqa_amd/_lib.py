@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -87,6 +87,8 @@ SIGNATURES = {
                                       c_int32, c_int32, c_int32, c_float, c_void_p]),
     "isg_gatv2_mp_fwd_logits": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_gatv2_mp_fwd_logits_planes": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                                               c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "isg_split_f16x2_rows": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "isg_linear_f16x3_tile": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

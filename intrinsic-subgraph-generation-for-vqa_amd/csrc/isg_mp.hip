@@ -434,3 +434,19 @@ extern "C" int isg_gatv2_mp_fwd_logits(const float *x_l, const float *logits, co
   return mp_fwd(x_l, nullptr, nullptr, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
                 negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, 0, 0, stream, 0, rowmax, logits);
 }
+
+// isg_gatv2_mp_fwd_logits whose result leaves as the SEGMENTED planes32 operand of isg_linear_h3p (isg_gatv2_mp_fwd_planes's
+// output contract: H = 4, the flat per-graph kernel): the C = 300 layer without e_proj AND without fp32 conv rows.
+extern "C" int isg_gatv2_mp_fwd_logits_planes(const float *x_l, const float *logits, const float *att, const float *bias,
+                                              const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                              const float *node_mask, const float *edge_mask, uint16_t *out_planes,
+                                              float *out_inv, float *alpha, int64_t N, int64_t E, int32_t H, int32_t C,
+                                              float negative_slope, const int32_t *graph_ptr, const int32_t *graph_eptr,
+                                              const int32_t *dst, int64_t B, int32_t nmax_host, int32_t emax_host,
+                                              int32_t ld_l, void *stream) {
+  if ((!logits && E > 0) || !out_planes || !out_inv) return ISG_EINVAL;
+  if (E == 0 || (reinterpret_cast<uintptr_t>(out_planes) & 15) != 0 || H != 4) return ISG_EUNSUPPORTED;
+  return mp_fwd(x_l, nullptr, nullptr, att, bias, rowptr, eid, src, node_mask, edge_mask, nullptr, alpha, N, E, H, C,
+                negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, 0, 0, stream, 0, nullptr, logits,
+                out_planes, out_inv);
+}

@@ -328,6 +328,9 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_flat_kernel(MpArgs 
 #pragma unroll
     for (int k = 0; k < RECS; ++k)
       if (tid + k * GK_THREADS < ne) s_tab[tid + k * GK_THREADS] = rec[k];
+    if (a.logits)     // logits formed by isg_gatv2_edge_logits (slot order): this workgroup's HS heads of its graph's slots
+      for (int t = tid; t < ne * HS; t += GK_THREADS)
+        s_lg[t] = a.logits[(size_t)(e0 + t / HS) * a.H + hg * HS + (t % HS)];
   }
   __syncthreads();
 
@@ -344,9 +347,9 @@ __global__ __launch_bounds__(GK_THREADS) void gatv2_mp_graph_flat_kernel(MpArgs 
   }
   const float slope = a.slope;
 
-  // ---- phase B: edge-parallel logits ---------------------------------------------------------------------------------
+  // ---- phase B: edge-parallel logits (skipped when the logits were handed in: neither e_proj nor x_r is touched) ----------
 #pragma unroll 1
-  for (int tb = wave * U; tb < ne; tb += GK_WAVES * U) {
+  for (int tb = a.logits ? ne : wave * U; tb < ne; tb += GK_WAVES * U) {
     float4 epv[U][P], xrv[U][P];
     int jl[U];
     float me[U];
@@ -597,7 +600,7 @@ int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   static const bool no_flat = getenv("ISG_MP_NO_FLAT") != nullptr;
   if (HS == 1 && a.H > 1 && P == 2 && Q * 10 < G * P * 7 && !force_graph) {
     // head dimension that fills < 70 % of two passes (the reference's C = 300): flat lane mapping over two heads
-    if (!no_flat && !a.rowmax && !a.logits) {
+    if (!no_flat && !a.rowmax) {
       const int rc = launch_mp_graph_flat(a, nmax_host, emax_host, st);
       if (rc != ISG_EUNSUPPORTED) return rc;
     }

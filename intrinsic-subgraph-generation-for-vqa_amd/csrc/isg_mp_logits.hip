@@ -24,13 +24,14 @@
 // W never touches LDS (fragment-major planes from L2, one k-step ahead), exactly as in isg_linear_f16x3.
 #include "isg_f16x3.hpp"
 #include "isg_mp.hpp"
+#include "isg_diag.hpp"
 
 #include <stdlib.h>
 
 
 namespace isg {
 
-constexpr int EL_BM = 64, EL_KC = 128, EL_LD = EL_KC + 8, EL_THREADS = 512;
+constexpr int EL_BM = 64, EL_KC = 128, EL_THREADS = 512;
 
 struct ElArgs {
   const float *edge_attr;           // rows by EDGE ID, stride lda
@@ -42,6 +43,7 @@ struct ElArgs {
   const float *edge_mask, *node_mask;
   float *logits;                    // [E, H], slot order
   int E, H, C, K, KS, NT, lda, ldl, ldr;
+  int Cp, LD;                       // channels per head padded to whole 32-channel tiles (== C when 32 | C); panel row pitch in halfs
   int64_t hsl, hsr;                 // distance between a row's consecutive HEAD slices in x_l / x_r (floats): C when the heads
                                     // lie side by side in one row (row-major [N, H*C]); N * C for a head-major [H][N][C] tensor
   float slope;
@@ -75,31 +77,44 @@ struct ElArgs {
 // isg_gatv2_mp_fwd, and the configs[1] step 2.20-2.22 ms against 2.24-2.29 ms on the same box.
 // (A form that also computed x_r = lin_r(x) here, from a second panel of x[dst] rows, was built in round 2 and measured 2.255 vs
 // 2.235 ms per step: removed in round 4.)
-template <bool MASKED>
+// PASSES: 128-column passes of the panel staging (1: K <= 128, the only instantiation: wider edge rows take the rows kernel below).
+// Head dimensions that are not a multiple of 32 (the reference's C = 300) run on heads PADDED to Cp = 320 channels: the caller's W
+// fragments are those of the weight with zero rows behind every head's C-th (isg_split_f16x2_frag of the padded matrix), att is
+// staged with zeros there, and the row gathers skip the float4 pieces beyond a head's last channel (C % 4 == 0: a piece is whole
+// or absent) -- the padding contributes exact zeros to the logit.
+template <bool MASKED, int PASSES>
 __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs a) {
-  __shared__ __attribute__((aligned(16))) _Float16 sA[2][EL_BM][EL_LD];   // 34,816 B
   __shared__ float s_inv[EL_BM];
-  extern __shared__ __attribute__((aligned(16))) float s_cw[];            // att [H*C], w_inv [H*C], partial logits [4][64][H]
+  extern __shared__ __attribute__((aligned(16))) unsigned char el_smem[];     // panel [2][64][LD] halfs, then att / w_inv / partials
+  const int LD = a.LD;
+  _Float16 *sA = reinterpret_cast<_Float16 *>(el_smem);
+#define EL_SA(q, row, k) (sA + ((q) * EL_BM + (row)) * LD + (k))
+  float *s_cw = reinterpret_cast<float *>(el_smem + (size_t)2 * EL_BM * LD * 2);     // att [H*Cp], w_inv [H*Cp], partial logits [4][64][H]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave >> 2, tw = wave & 3;     // which 32 slots of the panel; which channel tiles (tw, tw + 4, ...)
   const int m0 = blockIdx.x * EL_BM;
   const int fr = lane & 31, hh = lane >> 5, fk = hh * 8;
-  const int HC = a.H * a.C;
+  const int HC = a.H * a.Cp;                      // PADDED width: the index space of att / w_inv in LDS and of the channel tiles
 
   // ---- stage the edge panel once: rows gathered by edge id -> row scale -> (hi, mid) planes -------------------------------
   {
-    float4 ra[4];
+    const int KP4 = a.KS * 4;                     // float4 columns of the padded panel (zeros beyond K)
+    float4 ra[4][PASSES];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = tid + EL_THREADS * u;
       const int row = i >> 5, c4 = i & 31;
       const int e = a.eid[min(m0 + row, a.E - 1)];
-      const int gk = min(c4 * 4, a.K - 4);
-      ra[u] = *reinterpret_cast<const float4 *>(a.edge_attr + (int64_t)e * a.lda + gk);
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int gk = min((c4 + 32 * ps) * 4, a.K - 4);
+        ra[u][ps] = *reinterpret_cast<const float4 *>(a.edge_attr + (int64_t)e * a.lda + gk);
+      }
     }
     for (int c = tid; c < HC; c += EL_THREADS) {
-      s_cw[c] = a.att[c];
+      const int hd = c / a.Cp, ch = c - hd * a.Cp;
+      s_cw[c] = ch < a.C ? a.att[hd * a.C + ch] : 0.f;
       s_cw[HC + c] = a.w_inv[c];
     }
     for (int c = tid; c < 4 * EL_BM * a.H; c += EL_THREADS) s_cw[2 * HC + c] = 0.f;      // the waves' partial logits
@@ -107,18 +122,28 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
     for (int u = 0; u < 4; ++u) {
       const int i = tid + EL_THREADS * u;
       const int row = i >> 5, c4 = i & 31;       // the 32 lanes of a half-wave hold one row
-      float4 v = ra[u];
-      if (m0 + row >= a.E || c4 * 4 >= a.K) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float mx = group_max<32>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      float mx = 0.f;
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        float4 &v = ra[u][ps];
+        if (m0 + row >= a.E || (c4 + 32 * ps) * 4 >= a.K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
+      mx = group_max<32>(mx);
       float s, inv;
       h3_scale(mx, s, inv);
       if (c4 == 0) s_inv[row] = inv;
-      v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-      hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-      hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
-                    (_Float16)(v.w - (float)hi[3])};
-      *reinterpret_cast<hf16x4 *>(&sA[0][row][c4 * 4]) = hi;
-      *reinterpret_cast<hf16x4 *>(&sA[1][row][c4 * 4]) = mid;
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        if (c4 + 32 * ps >= KP4) continue;
+        float4 v = ra[u][ps];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        hf16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        hf16x4 mid = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
+                      (_Float16)(v.w - (float)hi[3])};
+        *reinterpret_cast<hf16x4 *>(EL_SA(0, row, (c4 + 32 * ps) * 4)) = hi;
+        *reinterpret_cast<hf16x4 *>(EL_SA(1, row, (c4 + 32 * ps) * 4)) = mid;
+      }
     }
   }
 
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.Wf), 0, (int)(2u * plane_b), 0x00020000);
   const int voff = lane * 16;
-  const int tph = a.C >> 5;            // channel tiles per head
+  const int tph = a.Cp >> 5;           // channel tiles per (padded) head
   const float slope = a.slope;
 
   // In round r the four tile-waves of a half take channel tiles 4 r .. 4 r + 3.  A wave's partial logits (its tiles of a
@@ -162,10 +187,15 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
     const int cb = nt * 32 + 4 * hh;         // this lane's channels of the tile: cb + 8 * g + j, g = r >> 2, j = r & 3
     const int64_t col_l = (int64_t)hd * a.hsl + (nt - hd * tph) * 32, col_r = (int64_t)hd * a.hsr + (nt - hd * tph) * 32;
     float4 xl[4], xr[4];
+    const int cin = (nt - hd * tph) * 32 + 4 * hh;          // this lane's first channel of the tile inside its head
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      xl[g] = *reinterpret_cast<const float4 *>(a.x_l + xl_off + col_l + 8 * g);
-      xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
+      if (cin + 8 * g < a.C) {                               // (always, when 32 | C)
+        xl[g] = *reinterpret_cast<const float4 *>(a.x_l + xl_off + col_l + 8 * g);
+        xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
+      } else {
+        xl[g] = xr[g] = make_float4(0.f, 0.f, 0.f, 0.f);     // a padded channel: W rows and att are zero there
+      }
     }
     hf32x16 acc;
 #pragma unroll
@@ -178,7 +208,7 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
           wrsrc, voff, (int)(wb + q * plane_b + (unsigned)(s) * 1024u), 0));
 #define EL_LOAD_A(Afr, ksl)                                                                                      \
   _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                  \
-      Afr[q] = *reinterpret_cast<const hf16x8 *>(&sA[q][prow][(ksl) * 16 + fk]);
+      Afr[q] = *reinterpret_cast<const hf16x8 *>(EL_SA(q, prow, (ksl) * 16 + fk));
     // transposed product: W fragment = A operand (rows = channels), edge panel = B operand (columns = edges)
 #define EL_MMA(Afr, W)                                                                                           \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], Afr[1], acc, 0, 0, 0);                                      \
@@ -193,7 +223,7 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
       EL_LOAD_A(a1, ks + 1)
       EL_MMA(a0, w0)
       EL_LOAD_W(w0, min(ks + 2, KS - 1))
-      EL_LOAD_A(a0, min(ks + 2, 7))
+      EL_LOAD_A(a0, min(ks + 2, KS - 1))
       EL_MMA(a1, w1)
     }
     if (ks < KS) { EL_MMA(a0, w0) }
@@ -226,6 +256,154 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
     const int slot = m0 + c / a.H;
     if (slot < a.E) a.logits[(int64_t)slot * a.H + (c % a.H)] = v;
   }
+#undef EL_SA
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same logits for WIDE layers (the reference's own: C = 300, 300 edge features).  The panel kernel above streams all of
+// lin_edge's fragments from L2 once per 64 slots; at H Cp = 1280, K = 304 that is 1.56 MB per workgroup, 5 GB per launch, and with an
+// 80 KB panel only one workgroup fits a CU: 0.9-1.1 ms per launch against 0.6 ms for lin_edge as a plain GEMM (profiles/
+// r05_u_edge_logits_wide.txt).  Here the roles are swapped: a wave keeps ITS 32 slots' edge rows -- scaled and split -- in
+// registers for the whole kernel (K padded to 16 KS_T: 8 KS_T registers), and the weight tiles stream through LDS, each fetched
+// ONCE per 256 slots by LDS-DMA into a two-buffer ring and read by all eight waves.  A wave owns every channel of its slots: a
+// (slot, head) logit is finished in-lane, no cross-wave sums.  W fragments are those of the weight padded to [H Cp, 16 KS_T].
+constexpr int ER_THREADS = 512, ER_SLOTS = 256;
+
+template <bool MASKED, int KS_T>
+__global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(ElArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char er_smem[];
+  constexpr int TILE_B = 2 * KS_T * 1024;            // one 32-channel tile's fragments: [plane][k step][lane] x 16 bytes
+  float *s_cw = reinterpret_cast<float *>(er_smem + 2 * TILE_B);      // att [H*Cp] (zeros in the padding), w_inv [H*Cp]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, hh = lane >> 5;
+  const int HC = a.H * a.Cp, NT = a.NT;
+  const unsigned plane_b = (unsigned)NT * (unsigned)KS_T * 1024u;
+  const unsigned char *Wb = reinterpret_cast<const unsigned char *>(a.Wf);
+  typedef __attribute__((address_space(3))) void er_lds_t;
+  const unsigned lds0 = (unsigned)(unsigned long long)(er_lds_t *)er_smem;
+  // a tile's 2 KS_T one-KB pieces, every eighth by this wave, by LDS-DMA from inline asm (invisible to the compiler, which would
+  // otherwise drain vmcnt in front of every LDS read it cannot bound; completion: ER_W_LANDED + the tile's barrier)
+#define ER_STAGE_W(nt_, buf_)                                                                                    \
+  for (int c = wave; c < 2 * KS_T; c += 8) {                                                                     \
+    const unsigned char *g_ = Wb + (size_t)(c >= KS_T ? plane_b : 0u) + ((size_t)(nt_) * KS_T + (c >= KS_T ? c - KS_T : c)) * 1024u + lane * 16; \
+    const unsigned l_ = lds0 + (unsigned)(buf_) * TILE_B + (unsigned)c * 1024u;                                  \
+    unsigned m0_keep;                                                                                            \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(m0_keep) : "v"(g_), "s"(l_) : "memory");                                                \
+  }
+#define ER_W_LANDED() ISG_WAIT(0x0F70);              /* vmcnt(0): this wave's pieces (and its gathers) have landed */
+  ER_STAGE_W(0, 0)
+  for (int c = tid; c < HC; c += ER_THREADS) {
+    const int hd = c / a.Cp, ch = c - hd * a.Cp;
+    s_cw[c] = ch < a.C ? a.att[hd * a.C + ch] : 0.f;
+    s_cw[HC + c] = a.w_inv[c];
+  }
+
+  // ---- this lane's slot: endpoints, mask, and its half of the edge row (k = 16 ks + 8 hh + 0..7) -> scale -> (hi, mid) ----------
+  const int slot = blockIdx.x * ER_SLOTS + wave * 32 + fr;
+  const int sl = min(slot, a.E - 1);
+  const int s_node = a.src[sl], d_node = a.dst[sl], e_id = a.eid[sl];
+  const int64_t xl_off = (int64_t)s_node * a.ldl + 4 * hh, xr_off = (int64_t)d_node * a.ldr + 4 * hh;
+  float me = 1.f;
+  if (MASKED) me = a.edge_mask ? a.edge_mask[e_id] : a.node_mask[s_node] * a.node_mask[d_node];
+  hf16x8 ph[KS_T], pm[KS_T];
+  float sinv;
+  {
+    const float *row = a.edge_attr + (int64_t)e_id * a.lda + 8 * hh;
+    float4 r0[KS_T], r1[KS_T];
+    float mx = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS_T; ++ks) {
+      const int k0 = ks * 16 + 8 * hh;
+      r0[ks] = k0 < a.K ? *reinterpret_cast<const float4 *>(row + ks * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r1[ks] = k0 + 4 < a.K ? *reinterpret_cast<const float4 *>(row + ks * 16 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS_T; ++ks)
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(r0[ks].x), fabsf(r0[ks].y)), fmaxf(fabsf(r0[ks].z), fabsf(r0[ks].w))),
+                           fmaxf(fmaxf(fabsf(r1[ks].x), fabsf(r1[ks].y)), fmaxf(fabsf(r1[ks].z), fabsf(r1[ks].w)))));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));              // the row's other half sits in lane ^ 32
+    float s;
+    h3_scale(mx, s, sinv);
+#pragma unroll
+    for (int ks = 0; ks < KS_T; ++ks) {
+      const float v[8] = {r0[ks].x * s, r0[ks].y * s, r0[ks].z * s, r0[ks].w * s, r1[ks].x * s, r1[ks].y * s, r1[ks].z * s, r1[ks].w * s};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ph[ks][j] = (_Float16)v[j];
+        pm[ks][j] = (_Float16)(v[j] - (float)ph[ks][j]);
+      }
+    }
+  }
+  const int tph = a.Cp >> 5;
+  const float slope = a.slope;
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int nt = 0; nt < NT; ++nt) {
+    ER_W_LANDED()
+    __syncthreads();          // tile nt's fragments are in buffer nt & 1 (every wave's pieces); every wave is done with tile nt - 1
+    if (nt + 1 < NT) ER_STAGE_W(nt + 1, (nt + 1) & 1)
+    const int hd = nt / tph;
+    const int cin = (nt - hd * tph) * 32 + 4 * hh;           // this lane's first channel of the tile inside its head
+    const int64_t col_l = (int64_t)hd * a.hsl + (nt - hd * tph) * 32, col_r = (int64_t)hd * a.hsr + (nt - hd * tph) * 32;
+    float4 xl[4], xr[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (cin + 8 * g < a.C) {
+        xl[g] = *reinterpret_cast<const float4 *>(a.x_l + xl_off + col_l + 8 * g);
+        xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
+      } else {
+        xl[g] = xr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    hf32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const unsigned char *wt = er_smem + (nt & 1) * TILE_B + lane * 16;
+    hf16x8 wq[2][2];          // [stage][plane]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wq[0][q] = *reinterpret_cast<const hf16x8 *>(wt + q * (KS_T * 1024));
+#pragma unroll
+    for (int ks = 0; ks < KS_T; ++ks) {
+      if (ks + 1 < KS_T) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) wq[(ks + 1) & 1][q] = *reinterpret_cast<const hf16x8 *>(wt + q * (KS_T * 1024) + (ks + 1) * 1024);
+      }
+      // transposed product: W fragment = A operand (rows = channels), the edge rows = B operand (columns = slots)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][0], pm[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][1], ph[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][0], ph[ks], acc, 0, 0, 0);
+    }
+    const int cb = nt * 32 + 4 * hh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 at4 = *reinterpret_cast<const float4 *>(&s_cw[cb + 8 * g]);
+      const float4 wi4 = *reinterpret_cast<const float4 *>(&s_cw[HC + cb + 8 * g]);
+      const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w};
+      const float lv[4] = {xl[g].x, xl[g].y, xl[g].z, xl[g].w};
+      const float rv[4] = {xr[g].x, xr[g].y, xr[g].z, xr[g].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = (acc[g * 4 + j] * sinv) * wiv[j];     // both scales are powers of two: exact
+        float z = (rv[j] + lv[j]) + e;
+        if (MASKED) z *= me;
+        z = leaky(z, slope);
+        if (MASKED) z *= me;
+        part[g] = fmaf(z, atv[j], part[g]);
+      }
+    }
+    if (nt + 1 == (hd + 1) * tph) {          // the head's last tile: its logit is complete in this lane pair
+      const float mine = (part[0] + part[1]) + (part[2] + part[3]);
+      const float tot = mine + __shfl_xor(mine, 32);
+      if (hh == 0 && slot < a.E) a.logits[(int64_t)slot * a.H + hd] = tot;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) part[g] = 0.f;
+    }
+  }
+#undef ER_STAGE_W
+#undef ER_W_LANDED
 }
 
 }  // namespace isg
@@ -246,20 +424,42 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   if (E == 0) return ISG_OK;
   if (!edge_attr || !w_frag || !w_inv_scale || !x_l || !x_r || !att || !eid || !src || !dst || !logits) return ISG_EINVAL;
   auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if ((C & 31) != 0 || H > 32 || K > EL_KC || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (head_stride_l & 3) != 0 || (head_stride_r & 3) != 0 || mis(edge_attr) ||
-      mis(x_l) || mis(x_r) || mis(att) || mis(w_inv_scale) || H * C > 2048 || E >= (1ll << 31) - EL_BM)
+  const int Cp = (C + 31) / 32 * 32;             // heads padded to whole 32-channel tiles (w_frag / w_inv_scale are the PADDED weight's)
+  if ((C & 3) != 0 || H > 32 || K > 320 || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (head_stride_l & 3) != 0 || (head_stride_r & 3) != 0 || mis(edge_attr) ||
+      mis(x_l) || mis(x_r) || mis(att) || mis(w_inv_scale) || H * Cp > 2048 || E >= (1ll << 31) - EL_BM)
     return ISG_EUNSUPPORTED;
   ElArgs a;
   a.edge_attr = edge_attr; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
   a.x_l = x_l; a.x_r = x_r; a.att = att; a.eid = eid; a.src = src; a.dst = dst;
   a.edge_mask = edge_mask; a.node_mask = node_mask; a.logits = logits;
-  a.E = (int)E; a.H = H; a.C = C; a.K = K; a.KS = (K + 15) / 16; a.NT = H * C / 32;
+  a.E = (int)E; a.H = H; a.C = C; a.K = K; a.KS = (K + 15) / 16; a.NT = H * Cp / 32; a.Cp = Cp;
+  a.LD = EL_KC + 8;
   a.lda = lda; a.ldl = ldl; a.ldr = ldr; a.hsl = head_stride_l; a.hsr = head_stride_r; a.slope = negative_slope;
-  const unsigned grid = (unsigned)((E + EL_BM - 1) / EL_BM);
-  const size_t dyn = ((size_t)2 * H * C + (size_t)4 * EL_BM * H) * sizeof(float);
   hipStream_t st = as_stream(stream);
-  if (edge_mask || node_mask) gatv2_edge_logits_kernel<true><<<grid, EL_THREADS, dyn, st>>>(a);
-  else gatv2_edge_logits_kernel<false><<<grid, EL_THREADS, dyn, st>>>(a);
+  const bool masked = edge_mask || node_mask;
+  if (K > EL_KC) {             // the rows kernel: w_frag is the split of the weight padded to [H * Cp, 320] (20 k steps)
+    constexpr int KST = 20;
+    a.KS = KST;
+    const unsigned grid = (unsigned)((E + ER_SLOTS - 1) / ER_SLOTS);
+    const size_t dyn = (size_t)2 * (2 * KST * 1024) + (size_t)2 * H * Cp * sizeof(float);
+    if (masked) {
+      if (!dyn_lds_ok<&gatv2_edge_logits_rows_kernel<true, KST>>((int)dyn)) return ISG_EUNSUPPORTED;
+      gatv2_edge_logits_rows_kernel<true, KST><<<grid, ER_THREADS, dyn, st>>>(a);
+    } else {
+      if (!dyn_lds_ok<&gatv2_edge_logits_rows_kernel<false, KST>>((int)dyn)) return ISG_EUNSUPPORTED;
+      gatv2_edge_logits_rows_kernel<false, KST><<<grid, ER_THREADS, dyn, st>>>(a);
+    }
+    return check_launch();
+  }
+  const unsigned grid = (unsigned)((E + EL_BM - 1) / EL_BM);
+  const size_t dyn = (size_t)2 * EL_BM * a.LD * 2 + ((size_t)2 * H * Cp + (size_t)4 * EL_BM * H) * sizeof(float);
+  if (masked) {
+    if (!dyn_lds_ok<&gatv2_edge_logits_kernel<true, 1>>((int)dyn)) return ISG_EUNSUPPORTED;
+    gatv2_edge_logits_kernel<true, 1><<<grid, EL_THREADS, dyn, st>>>(a);
+  } else {
+    if (!dyn_lds_ok<&gatv2_edge_logits_kernel<false, 1>>((int)dyn)) return ISG_EUNSUPPORTED;
+    gatv2_edge_logits_kernel<false, 1><<<grid, EL_THREADS, dyn, st>>>(a);
+  }
   return check_launch();
 }
 

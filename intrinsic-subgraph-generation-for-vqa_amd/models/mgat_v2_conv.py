@@ -183,7 +183,7 @@ class MaskingGATv2Conv(torch.nn.Module):
         if how in ("tile_conv", "pair"):
             # lin_edge folded into the logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is neither written nor read
             res = ops.gatv2_mp_edge_logits(x_l, x_r, edge_attr.float().contiguous(), self.lin_edge.weight, self.att, plan, H,
-                                           want_rowmax=True, **kw)                       # :215-232, :243-279
+                                           want_rowmax=True, want_planes=out_planes, **kw)          # :215-232, :243-279
             if res is not None:
                 return done(*res)
         if e_proj is None:

@@ -39,6 +39,7 @@ class Switches:
     mixed_min_nodes: int = 60000
     mp_kernel: str = "graph"
     fuse_logits: bool = True
+    fuse_logits_wide: bool = True          # ... also at head dimensions / edge widths beyond the tile shapes (C = 300, K = 300: round 5)
     fuse_tile_conv: bool = True
     fuse_layer_conv: bool = True
     split_stream: bool = True
@@ -816,9 +817,29 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
 # CFG.fuse_logits (ops.FUSE_LOGITS): 
 def fused_logits_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
     """Shape test of isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits (inference, fp32 rows, per-graph kernel)."""
-    return (CFG.fuse_logits and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3 and CFG.mp_kernel == "graph" and channels % 32 == 0 and
-            heads * channels <= 2048 and 0 < edge_dim <= 128 and edge_dim % 4 == 0 and plan.B > 0 and plan.nmax > 0 and
-            plan.rowptr is not None and plan.E > 0)
+    cp = (channels + 31) // 32 * 32       # round 5: heads padded to whole 32-channel tiles (the reference's C = 300 -> 320), K <= 320
+    wide = channels % 32 != 0 or edge_dim > 128
+    return (CFG.fuse_logits and (CFG.fuse_logits_wide or not wide) and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3 and
+            CFG.mp_kernel == "graph" and channels % 4 == 0 and heads * cp <= 2048 and 0 < edge_dim <= 320 and edge_dim % 4 == 0 and
+            plan.B > 0 and plan.nmax > 0 and plan.rowptr is not None and plan.E > 0)
+
+
+def _edge_logits_weight(w_edge: Tensor, heads: int):
+    """lin_edge.weight [H*C, K] as the fragment planes isg_gatv2_edge_logits reads: the weight itself when 32 | C and K <= 128; else
+    with zero rows behind every head's C-th up to the next multiple of 32 (C = 300 -> 320: a channel tile never straddles heads)
+    and, for K > 128 (the rows kernel: 20 k steps), zero columns up to 320."""
+    HC, K = w_edge.shape
+    C = HC // heads
+    cp = (C + 31) // 32 * 32
+    kp = K if K <= 128 else 320
+    if cp == C and kp == K:
+        return _weight_planes(w_edge, True, "f16x3")
+
+    def build():
+        w = torch.zeros(heads, cp, kp, dtype=torch.float32, device=w_edge.device)
+        w[:, :C, :K] = w_edge.detach().view(heads, C, K)
+        return w.view(heads * cp, kp)
+    return _weight_planes(derived_weight(f"edge_logits_pad{heads}", (w_edge,), build), True, "f16x3")
 
 
 def gatv2_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan", heads: int,
@@ -830,7 +851,7 @@ def gatv2_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tenso
     N, HC = x_l.shape
     H = int(heads)
     E, K = edge_attr.shape
-    planes, inv = _weight_planes(w_edge, True, "f16x3")
+    planes, inv = _edge_logits_weight(w_edge, H)
     logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     rc = lib.isg_gatv2_edge_logits(
         _chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(),
@@ -847,7 +868,8 @@ def gatv2_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tenso
 
 def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tensor, att: Tensor, plan: "GraphPlan",
                          heads: int, bias: Optional[Tensor] = None, node_mask: Optional[Tensor] = None,
-                         edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_rowmax: bool = False):
+                         edge_mask: Optional[Tensor] = None, negative_slope: float = 0.2, want_rowmax: bool = False,
+                         want_planes: bool = False):
     """gatv2_mp(x_l, x_r, lin_edge(edge_attr), ...) as two launches that never materialise lin_edge's output
     (mgat_v2_conv.py:243-279 with :259-261 inside): isg_gatv2_edge_logits forms the logits [E, H] in the epilogue of the
     edge GEMM, isg_gatv2_mp_fwd_logits does softmax + aggregation.  Returns (out, alpha), or None when the per-graph kernel
@@ -864,11 +886,13 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Te
         raise TypeError("gatv2_mp_edge_logits: fp32 rows")
     if tuple(x_r.shape) != (N, HC) or x_r.dtype != torch.float32:
         raise ValueError("gatv2_mp_edge_logits: x_r must be fp32 [N, H*C]")
-    planes, inv = _weight_planes(w_edge, True, "f16x3")
+    planes, inv = _edge_logits_weight(w_edge, H)
     logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
-    out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
-    rowmax = torch.empty(N, H, dtype=torch.float32, device=x_l.device) if want_rowmax else None
+    # the result as the segmented planes32 operand of x_proj.0 (the flat kernel, H = 4: the reference's C = 300) -- or fp32 rows
+    as_planes = bool(want_planes and CFG.mp_planes and H == 4 and C % 32 != 0)
+    out = None if as_planes else torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
+    rowmax = torch.empty(N, H, dtype=torch.float32, device=x_l.device) if want_rowmax and not as_planes and C % 32 == 0 else None
     nm = _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True)
     em = _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True)
     attp = _chk(att.reshape(-1), "att", torch.float32, (HC,))
@@ -891,6 +915,23 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Te
     _lib.check(rc, "isg_gatv2_edge_logits")
     if timer is not None:
         evm.record()
+    if as_planes:
+        seg = 2 * C
+        st = (seg + 31) // 32
+        pl = torch.empty(N * 2 * st * 64, dtype=torch.int16, device=x_l.device)
+        pinv = torch.empty(2, N, dtype=torch.float32, device=x_l.device)
+        rc = lib.isg_gatv2_mp_fwd_logits_planes(
+            _chk_rows(x_l, "x_l"), logits.data_ptr(), attp,
+            _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+            plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), nm, em, pl.data_ptr(), pinv.data_ptr(),
+            alpha.data_ptr(), N, E, H, C, float(negative_slope), plan.ptr.data_ptr(), plan.eptr.data_ptr(), plan.dst.data_ptr(),
+            plan.B, plan.nmax, plan.emax, x_l.stride(0), _stream())
+        if rc != ISG_EUNSUPPORTED:
+            _lib.check(rc, "isg_gatv2_mp_fwd_logits_planes")
+            if timer is not None:
+                ev1.record()
+            return Planes32(pl, pinv[1], N, HC, pinv[0], seg), alpha
+        out = torch.empty(N, HC, dtype=torch.float32, device=x_l.device)
     rc = lib.isg_gatv2_mp_fwd_logits(
         _chk_rows(x_l, "x_l"), logits.data_ptr(), attp,
         _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),

@@ -16,15 +16,16 @@ if os.environ.get("ISG_TOOL_LIB"):        # A/B against another build of the lib
 graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 dev = torch.device("cuda:0")
-cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs})
+chan = int(sys.argv[3]) if len(sys.argv) > 3 else 128          # channels per head (K stays <= 128: the edge-logits kernel's limit)
+cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs, "channels": chan})
 wl = synthetic.make_workload(cfg).to(dev)
 N, E, H, C = wl.x.size(0), wl.edge_index.size(1), cfg.heads, cfg.channels
-K = wl.edge_attr.size(1)
+K = min(wl.edge_attr.size(1), int(sys.argv[4]) if len(sys.argv) > 4 else 128)
 plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=graphs, max_nodes=wl.max_nodes, max_edges=wl.max_edges)
 g = torch.Generator(device=dev).manual_seed(0)
 x_lr = torch.randn(N, 2 * H * C, device=dev, generator=g)
 x_l, x_r = x_lr[:, :H * C], x_lr[:, H * C:]
-ea = wl.edge_attr.float().contiguous()
+ea = wl.edge_attr.float()[:, :K].contiguous()
 w = torch.randn(H * C, K, device=dev, generator=g) / K ** 0.5
 att = torch.randn(1, H, C, device=dev, generator=g)
 bias = torch.randn(H * C, device=dev, generator=g)
