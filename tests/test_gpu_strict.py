@@ -113,6 +113,27 @@ def test_linear_h3p_segmented_operand_gives_the_strict_builds_bits(dev, both, pl
 
 
 @pytest.mark.parametrize("masked", [False, True])
+def test_wide_edge_logits_give_the_strict_builds_bits(dev, both, masked):
+    """isg_gatv2_edge_logits at the reference's own width (H = 4, C = 300, K = 300): the rows kernel, whose weight tiles reach LDS
+    by LDS-DMA issued from inline asm and are retired by a hand-placed wait + barrier per tile."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(41)
+    sizes = torch.randint(8, 34, (300,), generator=gen).tolist()
+    batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=(7, 60))
+    N, E, H, C, K = batch.numel(), ei.size(1), 4, 300, 300
+    xl = torch.randn(N, H * C, generator=gen).to(dev)
+    xr = torch.randn(N, H * C, generator=gen).to(dev)
+    ea = torch.randn(E, K, generator=gen).to(dev)
+    w = (torch.randn(H * C, K, generator=gen) * 0.05).to(dev)
+    att = torch.randn(1, H, C, generator=gen).to(dev)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    nm = (torch.rand(N, generator=gen) < 0.6).float().to(dev) if masked else None
+    fast, strict = both(lambda: ops.gatv2_edge_logits(xl, xr, ea, w, att, plan, H, node_mask=nm))
+    assert fast is not None and torch.isfinite(fast).all()
+    _same(fast, strict, "isg_gatv2_edge_logits (rows kernel)")
+
+
+@pytest.mark.parametrize("masked", [False, True])
 def test_graph_tile_kernels_give_the_strict_builds_bits(dev, both, masked):
     """isg_gatv2_layer_conv (LDS-DMA retired by a hand-placed wait), isg_gatv2_tile_conv, isg_mgat_dense_tail and isg_readout_tile
     through one AnswerModel forward at 700 graphs with hubs -- the batch shape of round 4's intermittent failure."""
