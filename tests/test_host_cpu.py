@@ -231,3 +231,28 @@ def test_library_holds_no_cross_selecting_packed_fp32_operation():
     objects, total, hits = scan.scan_library()
     assert objects >= 18 and total > 10000, (objects, total)         # the whole library was read, not an empty extraction
     assert not hits, "\n".join(f"{scan.demangle(k)}: {t}" for k, t in hits[:10])
+
+
+def test_switches_are_one_frozen_object_swapped_atomically():
+    """ops' A/B switches live in ONE frozen dataclass (ops.CFG): the historical spelling `ops.NAME = value` (tests, tools, bench.py)
+    replaces the whole object, `ops.NAME` reads the field, `with ops.configured(...)` restores; a field cannot be written in place."""
+    import dataclasses
+    from isubgvqa_amd import ops
+    before = ops.CFG
+    assert dataclasses.is_dataclass(before) and ops.SPLIT_FORWARD is before.split_forward
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        before.split_forward = False
+    try:
+        ops.SPLIT_FORWARD = not before.split_forward
+        assert ops.CFG is not before and ops.CFG.split_forward == (not before.split_forward) and before.split_forward != ops.SPLIT_FORWARD
+        assert ops.CFG.mixed_min_nodes == before.mixed_min_nodes            # every other field carried over
+        with ops.configured(mixed_min_nodes=7, gemm_kernel="panel") as cfg:
+            assert ops.MIXED_MIN_NODES == 7 and ops.GEMM_KERNEL == "panel" and cfg is ops.CFG
+        assert ops.MIXED_MIN_NODES == before.mixed_min_nodes and ops.GEMM_KERNEL == before.gemm_kernel
+        with pytest.raises(TypeError):
+            with ops.configured(no_such_switch=1):
+                pass
+        assert not hasattr(ops, "NO_SUCH_SWITCH")
+    finally:
+        ops.CFG = before
+    assert ops.CFG is before
