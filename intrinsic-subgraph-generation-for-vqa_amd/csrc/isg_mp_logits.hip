@@ -265,46 +265,79 @@ __global__ __launch_bounds__(EL_THREADS, 4) void gatv2_edge_logits_kernel(ElArgs
 // 80 KB panel only one workgroup fits a CU: 0.9-1.1 ms per launch against 0.6 ms for lin_edge as a plain GEMM (profiles/
 // r05_u_edge_logits_wide.txt).  Here the roles are swapped: a wave keeps ITS 32 slots' edge rows -- scaled and split -- in
 // registers for the whole kernel (K padded to 16 KS_T: 8 KS_T registers), and the weight tiles stream through LDS, each fetched
-// ONCE per 256 slots by LDS-DMA into a two-buffer ring and read by all eight waves.  A wave owns every channel of its slots: a
-// (slot, head) logit is finished in-lane, no cross-wave sums.  W fragments are those of the weight padded to [H Cp, 16 KS_T].
-constexpr int ER_THREADS = 512, ER_SLOTS = 256;
+// ONCE per workgroup by LDS-DMA into a THREE-slot ring and read by all the computing waves.  A wave owns every channel of its
+// slots: a (slot, head) logit is finished in-lane, no cross-wave sums.  W fragments are those of the weight padded to [H Cp, 16 KS_T].
+//
+// The ring's lead is what the kernel's speed hangs on: an LDS-DMA request takes ~2.7 us (~5 800 cycles) to land with a CU's ring
+// in flight, a tile's products ~3 650, and vector-memory operations retire IN ORDER per wave: a wave that both
+// requests fragments and gathers its slots' x_l / x_r rows drains its requests every time it waits for a gather -- once per tile,
+// whatever the order (the first form of this kernel: 800 us, 2 000 cycles of every tile spent waiting at its barrier).  So the
+// requests have a wave of their OWN: wave 7 of the workgroup computes nothing, requests tile nt + 2 behind the barrier that frees
+// its slot and arrives at a tile's barrier once that tile has landed (a counted wait: only the younger tile may still fly) -- two
+// tile periods of lead; waves 0-6 (224 slots) never see a request, and their waits are the compiler's, for their gathers alone.
+// One raw barrier per tile (csrc/isg_diag.hpp: -DISG_DIAG_STRICT turns wait and barrier into a full wait and __syncthreads()).
+constexpr int ER_THREADS = 512, ER_WAVES = 8, ER_SLOTS = 32 * (ER_WAVES - 1), ER_RING = 3;
+typedef __attribute__((address_space(3))) void er_lds_t;
+typedef __attribute__((address_space(1))) void er_glb_t;
+typedef float er_f4 __attribute__((ext_vector_type(4)));
+
+ISG_DIAG_BUFFER(g_er_stamps)            // -DISG_DIAG builds only (tools/stamp_edge_logits_rows.py): [workgroups * 8 waves][16] int64
 
 template <bool MASKED, int KS_T>
 __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(ElArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char er_smem[];
-  constexpr int TILE_B = 2 * KS_T * 1024;            // one 32-channel tile's fragments: [plane][k step][lane] x 16 bytes
-  float *s_cw = reinterpret_cast<float *>(er_smem + 2 * TILE_B);      // att [H*Cp] (zeros in the padding), w_inv [H*Cp]
+  constexpr int PIECES = 2 * KS_T;                   // one-KB pieces of a tile: [plane][k step] x (lane x 16 bytes)
+  constexpr int TILE_B = PIECES * 1024;
+  static_assert(PIECES < 64, "the counted wait below is vmcnt(PIECES)");
+  float *s_cw = reinterpret_cast<float *>(er_smem + ER_RING * TILE_B);      // att [H*Cp] (zeros in the padding), w_inv [H*Cp]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, hh = lane >> 5;
   const int HC = a.H * a.Cp, NT = a.NT;
-  const unsigned plane_b = (unsigned)NT * (unsigned)KS_T * 1024u;
-  const unsigned char *Wb = reinterpret_cast<const unsigned char *>(a.Wf);
-  typedef __attribute__((address_space(3))) void er_lds_t;
-  const unsigned lds0 = (unsigned)(unsigned long long)(er_lds_t *)er_smem;
-  // a tile's 2 KS_T one-KB pieces, every eighth by this wave, by LDS-DMA from inline asm (invisible to the compiler, which would
-  // otherwise drain vmcnt in front of every LDS read it cannot bound; completion: ER_W_LANDED + the tile's barrier)
-#define ER_STAGE_W(nt_, buf_)                                                                                    \
-  for (int c = wave; c < 2 * KS_T; c += 8) {                                                                     \
-    const unsigned char *g_ = Wb + (size_t)(c >= KS_T ? plane_b : 0u) + ((size_t)(nt_) * KS_T + (c >= KS_T ? c - KS_T : c)) * 1024u + lane * 16; \
-    const unsigned l_ = lds0 + (unsigned)(buf_) * TILE_B + (unsigned)c * 1024u;                                  \
-    unsigned m0_keep;                                                                                            \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(m0_keep) : "v"(g_), "s"(l_) : "memory");                                                \
-  }
-#define ER_W_LANDED() ISG_WAIT(0x0F70);              /* vmcnt(0): this wave's pieces (and its gathers) have landed */
-  ER_STAGE_W(0, 0)
+  ISG_DIAG_BEGIN()
   for (int c = tid; c < HC; c += ER_THREADS) {
     const int hd = c / a.Cp, ch = c - hd * a.Cp;
     s_cw[c] = ch < a.C ? a.att[hd * a.C + ch] : 0.f;
     s_cw[HC + c] = a.w_inv[c];
   }
 
+  if (wave == ER_WAVES - 1) {           // ---- the requesting wave ---------------------------------------------------------
+    const unsigned plane_b = (unsigned)NT * (unsigned)KS_T * 1024u;
+    const unsigned char *Wb = reinterpret_cast<const unsigned char *>(a.Wf) + lane * 16;
+#define ER_STAGE_W(nt_, slot_)                                                                                   \
+    _Pragma("unroll") for (int c = 0; c < PIECES; ++c)                                                           \
+      __builtin_amdgcn_global_load_lds((er_glb_t *)(Wb + (size_t)(c >= KS_T ? plane_b : 0u) +                    \
+                                                    ((size_t)(nt_) * KS_T + (c >= KS_T ? c - KS_T : c)) * 1024u), \
+                                       (er_lds_t *)(er_smem + (slot_) * TILE_B + c * 1024), 16, 0, 0);
+    // (past the last tile the requests fetch it again into a slot nobody reads: the wait below is one count on every path)
+    ER_STAGE_W(0, 0)
+    ER_STAGE_W(min(1, NT - 1), 1)
+    ISG_WAIT(0xC07F);                   // lgkmcnt(0): my att / w_inv writes
+    ISG_DIAG_ADD(0)
+    int slot = 2;
+#pragma unroll 1
+    for (int nt = 0; nt < NT; ++nt) {
+      ISG_WAIT(((PIECES >> 4) << 14) | 0x0F70 | (PIECES & 15));      // vmcnt(PIECES): tile nt has landed, tile nt + 1 may still fly
+      ISG_DIAG_ADD(1)
+      __builtin_amdgcn_sched_barrier(0);
+      ISG_BARRIER();                    // tile nt is handed over; every computing wave is done with tile nt - 1: its slot is free
+      __builtin_amdgcn_sched_barrier(0);
+      ISG_DIAG_ADD(2)
+      ER_STAGE_W(min(nt + 2, NT - 1), slot)
+      slot = slot == ER_RING - 1 ? 0 : slot + 1;
+      ISG_DIAG_ADD(3)
+    }
+    ISG_WAIT(0x0F70);                   // nothing in flight at the end
+    ISG_DIAG_DUMP(g_er_stamps, blockIdx.x * ER_WAVES + wave, 12, )
+#undef ER_STAGE_W
+    return;
+  }
+
   // ---- this lane's slot: endpoints, mask, and its half of the edge row (k = 16 ks + 8 hh + 0..7) -> scale -> (hi, mid) ----------
   const int slot = blockIdx.x * ER_SLOTS + wave * 32 + fr;
   const int sl = min(slot, a.E - 1);
   const int s_node = a.src[sl], d_node = a.dst[sl], e_id = a.eid[sl];
-  const int64_t xl_off = (int64_t)s_node * a.ldl + 4 * hh, xr_off = (int64_t)d_node * a.ldr + 4 * hh;
+  const int64_t xl_off = (int64_t)s_node * a.ldl, xr_off = (int64_t)d_node * a.ldr;
   float me = 1.f;
   if (MASKED) me = a.edge_mask ? a.edge_mask[e_id] : a.node_mask[s_node] * a.node_mask[d_node];
   hf16x8 ph[KS_T], pm[KS_T];
@@ -339,76 +372,139 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
   const int tph = a.Cp >> 5;
   const float slope = a.slope;
   float part[4] = {0.f, 0.f, 0.f, 0.f};
+  ISG_WAIT(0xC07F);                     // lgkmcnt(0): my att / w_inv writes are in LDS before the first tile's barrier
+  ISG_DIAG_ADD(0)
 
-#pragma unroll 1
-  for (int nt = 0; nt < NT; ++nt) {
-    ER_W_LANDED()
-    __syncthreads();          // tile nt's fragments are in buffer nt & 1 (every wave's pieces); every wave is done with tile nt - 1
-    if (nt + 1 < NT) ER_STAGE_W(nt + 1, (nt + 1) & 1)
-    const int hd = nt / tph;
-    const int cin = (nt - hd * tph) * 32 + 4 * hh;           // this lane's first channel of the tile inside its head
-    const int64_t col_l = (int64_t)hd * a.hsl + (nt - hd * tph) * 32, col_r = (int64_t)hd * a.hsr + (nt - hd * tph) * 32;
-    float4 xl[4], xr[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (cin + 8 * g < a.C) {
-        xl[g] = *reinterpret_cast<const float4 *>(a.x_l + xl_off + col_l + 8 * g);
-        xr[g] = *reinterpret_cast<const float4 *>(a.x_r + xr_off + col_r + 8 * g);
-      } else {
-        xl[g] = xr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    hf32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const unsigned char *wt = er_smem + (nt & 1) * TILE_B + lane * 16;
-    hf16x8 wq[2][2];          // [stage][plane]
-#pragma unroll
-    for (int q = 0; q < 2; ++q) wq[0][q] = *reinterpret_cast<const hf16x8 *>(wt + q * (KS_T * 1024));
-#pragma unroll
-    for (int ks = 0; ks < KS_T; ++ks) {
-      if (ks + 1 < KS_T) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) wq[(ks + 1) & 1][q] = *reinterpret_cast<const hf16x8 *>(wt + q * (KS_T * 1024) + (ks + 1) * 1024);
-      }
-      // transposed product: W fragment = A operand (rows = channels), the edge rows = B operand (columns = slots)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][0], pm[ks], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][1], ph[ks], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][0], ph[ks], acc, 0, 0, 0);
-    }
-    const int cb = nt * 32 + 4 * hh;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 at4 = *reinterpret_cast<const float4 *>(&s_cw[cb + 8 * g]);
-      const float4 wi4 = *reinterpret_cast<const float4 *>(&s_cw[HC + cb + 8 * g]);
-      const float atv[4] = {at4.x, at4.y, at4.z, at4.w}, wiv[4] = {wi4.x, wi4.y, wi4.z, wi4.w};
-      const float lv[4] = {xl[g].x, xl[g].y, xl[g].z, xl[g].w};
-      const float rv[4] = {xr[g].x, xr[g].y, xr[g].z, xr[g].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float e = (acc[g * 4 + j] * sinv) * wiv[j];     // both scales are powers of two: exact
-        float z = (rv[j] + lv[j]) + e;
-        if (MASKED) z *= me;
-        z = leaky(z, slope);
-        if (MASKED) z *= me;
-        part[g] = fmaf(z, atv[j], part[g]);
-      }
-    }
-    if (nt + 1 == (hd + 1) * tph) {          // the head's last tile: its logit is complete in this lane pair
-      const float mine = (part[0] + part[1]) + (part[2] + part[3]);
-      const float tot = mine + __shfl_xor(mine, 32);
-      if (hh == 0 && slot < a.E) a.logits[(int64_t)slot * a.H + hd] = tot;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) part[g] = 0.f;
-    }
+  // The two waves of a SIMD (w and w + 4) run their tile periods in OPPOSITE phase: waves 0-3 do products, then epilogue; waves
+  // 4-6 first the epilogue of the PREVIOUS tile, then the products -- behind one barrier per tile every wave would otherwise be in
+  // its products at the same time (the matrix core shared, the vector ALU idle) and in its epilogue at the same time (the matrix
+  // core idle: 1 460 of a tile's 7 500 cycles in the first form).  No register is added: a late wave's accumulators and gathers
+  // just live across the barrier instead of across nothing.
+  const bool late = wave >= 4;
+  er_f4 xl[4], xr[4];
+  hf32x16 acc;
+#define ER_EPILOGUE()                                                                                              \
+  {                                                                                                                \
+    /* the gathers are not to be touched before this point (whole 16-byte registers: no early copies of their parts either) */ \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(xl[g]), "+v"(xr[g]));                     \
+    ISG_DIAG_ADD(4)                                                                                                \
+    const int cb = e_cb;                                                                                           \
+    /* ALL of the tile's att / w_inv in one go (one LDS round trip under the other waves' fragment reads, not four); the      */ \
+    /* arithmetic is SCALAR fp32 (the file is built with -fno-slp-vectorize): beside another wave's MFMAs a packed fp32      */ \
+    /* operation costs more issue time than the two scalar ones it replaces (MI355X_MICROARCH.md, constants table)           */ \
+    er_f4 at4[4], wi4[4];                                                                                          \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+      at4[g] = *reinterpret_cast<const er_f4 *>(&s_cw[cb + 8 * g]);                                                \
+      wi4[g] = *reinterpret_cast<const er_f4 *>(&s_cw[HC + cb + 8 * g]);                                           \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+        const float e = (acc[g * 4 + j] * sinv) * wi4[g][j];  /* both scales are powers of two: exact */           \
+        float z = (xr[g][j] + xl[g][j]) + e;                                                                       \
+        if (MASKED) z *= me;                                                                                       \
+        z = leaky(z, slope);                                                                                       \
+        if (MASKED) z *= me;                                                                                       \
+        part[g] = fmaf(z, at4[g][j], part[g]);                                                                     \
+      }                                                                                                            \
+    }                                                                                                              \
+    e_cb += 32;                                                                                                    \
+    if (++e_tin == tph) {                    /* the head's last tile: its logit is complete in this lane pair */   \
+      const float mine = (part[0] + part[1]) + (part[2] + part[3]);                                                \
+      const float tot = mine + __shfl_xor(mine, 32);                                                               \
+      if (hh == 0 && slot < a.E) a.logits[(int64_t)slot * a.H + e_hd] = tot;                                       \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) part[g] = 0.f;                                                 \
+      e_tin = 0;                                                                                                   \
+      ++e_hd;                                                                                                      \
+    }                                                                                                              \
+    ISG_DIAG_KEEP2(part[0], part[3])                                                                               \
+    ISG_DIAG_ADD(5)                                                                                                \
   }
-#undef ER_STAGE_W
-#undef ER_W_LANDED
+  int rslot = 0;
+  // running state instead of a division per tile: the tile's place in its head (products / epilogue), the lane's x_l / x_r
+  // pointers at the tile's first channel, the epilogue's place in att / w_inv
+  const float *pl = a.x_l + xl_off + 4 * hh, *pr = a.x_r + xr_off + 4 * hh;
+  int p_tin = 0, e_tin = 0, e_hd = 0, e_cb = 4 * hh;
+  // one tile's gathers and products
+#define ER_PRODUCTS()                                                                                              \
+  {                                                                                                                \
+    /* UNCONDITIONAL gathers (a branch per group makes the compiler wait for each group inside its branch).  A tile inside   */ \
+    /* the head: one address per operand, the groups at constant offsets; the head's last tile (wave-uniform): the padding's */ \
+    /* channels read the head's last four, and att is zero there                                                            */ \
+    if (p_tin * 32 + 32 <= a.C) {                                                                                  \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
+        xl[g] = *reinterpret_cast<const er_f4 *>(pl + 8 * g);                                                      \
+        xr[g] = *reinterpret_cast<const er_f4 *>(pr + 8 * g);                                                      \
+      }                                                                                                            \
+    } else {                                                                                                       \
+      const int room = a.C - 4 - (p_tin * 32 + 4 * hh);      /* floats from this lane's first channel to the head's last four */ \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
+        xl[g] = *reinterpret_cast<const er_f4 *>(pl + min(8 * g, room));                                           \
+        xr[g] = *reinterpret_cast<const er_f4 *>(pr + min(8 * g, room));                                           \
+      }                                                                                                            \
+    }                                                                                                              \
+    if (++p_tin == tph) {                                                                                          \
+      p_tin = 0;                                                                                                   \
+      pl += a.hsl - (tph - 1) * 32;                                                                                \
+      pr += a.hsr - (tph - 1) * 32;                                                                                \
+    } else {                                                                                                       \
+      pl += 32;                                                                                                    \
+      pr += 32;                                                                                                    \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);        /* (the scheduler would sink the gathers below the products, or add them up in front) */ \
+    ISG_DIAG_ADD(2)                                                                                                \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                                   \
+    const unsigned char *wt = er_smem + rslot * TILE_B + lane * 16;                                                \
+    rslot = rslot == ER_RING - 1 ? 0 : rslot + 1;                                                                  \
+    hf16x8 wq[2][2];          /* [stage][plane] */                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) wq[0][q] = *reinterpret_cast<const hf16x8 *>(wt + q * (KS_T * 1024)); \
+    _Pragma("unroll") for (int ks = 0; ks < KS_T; ++ks) {                                                          \
+      if (ks + 1 < KS_T) {                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                              \
+          wq[(ks + 1) & 1][q] = *reinterpret_cast<const hf16x8 *>(wt + q * (KS_T * 1024) + (ks + 1) * 1024);       \
+      }                                                                                                            \
+      /* transposed product: W fragment = A operand (rows = channels), the edge rows = B operand (columns = slots) */ \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][0], pm[ks], acc, 0, 0, 0);                           \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][1], ph[ks], acc, 0, 0, 0);                           \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[ks & 1][0], ph[ks], acc, 0, 0, 0);                           \
+    }                                                                                                              \
+    ISG_DIAG_KEEP2(acc[0], acc[15])                                                                                \
+    ISG_DIAG_ADD(3)                                                                                                \
+  }
+#define ER_TILE_BARRIER()                     /* tile nt's fragments are in ring slot nt % 3 */                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  ISG_BARRIER();                                                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  ISG_DIAG_ADD(1)
+  if (!late) {                // (two loops, not one with two branches: each gets its own register allocation)
+#pragma unroll 1
+    for (int nt = 0; nt < NT; ++nt) {
+      ER_TILE_BARRIER()
+      ER_PRODUCTS()
+      ER_EPILOGUE()
+    }
+  } else {
+    ER_TILE_BARRIER()
+    ER_PRODUCTS()
+#pragma unroll 1
+    for (int nt = 1; nt < NT; ++nt) {
+      ER_TILE_BARRIER()
+      ER_EPILOGUE()
+      ER_PRODUCTS()
+    }
+    ER_EPILOGUE()
+  }
+#undef ER_PRODUCTS
+#undef ER_TILE_BARRIER
+#undef ER_EPILOGUE
+  ISG_DIAG_DUMP(g_er_stamps, blockIdx.x * ER_WAVES + wave, 12, )
 }
 
 }  // namespace isg
 
 using namespace isg;
+
+ISG_DIAG_SETTER(isg_er_set_stamp_buffer, g_er_stamps)
 
 extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
                                      const float *x_l, int32_t ldl, int64_t head_stride_l, const float *x_r, int32_t ldr,
@@ -425,7 +521,7 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   if (!edge_attr || !w_frag || !w_inv_scale || !x_l || !x_r || !att || !eid || !src || !dst || !logits) return ISG_EINVAL;
   auto mis = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int Cp = (C + 31) / 32 * 32;             // heads padded to whole 32-channel tiles (w_frag / w_inv_scale are the PADDED weight's)
-  if ((C & 3) != 0 || H > 32 || K > 320 || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (head_stride_l & 3) != 0 || (head_stride_r & 3) != 0 || mis(edge_attr) ||
+  if ((C & 3) != 0 || H > 32 || K > 304 || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (head_stride_l & 3) != 0 || (head_stride_r & 3) != 0 || mis(edge_attr) ||
       mis(x_l) || mis(x_r) || mis(att) || mis(w_inv_scale) || H * Cp > 2048 || E >= (1ll << 31) - EL_BM)
     return ISG_EUNSUPPORTED;
   ElArgs a;
@@ -437,11 +533,11 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   a.lda = lda; a.ldl = ldl; a.ldr = ldr; a.hsl = head_stride_l; a.hsr = head_stride_r; a.slope = negative_slope;
   hipStream_t st = as_stream(stream);
   const bool masked = edge_mask || node_mask;
-  if (K > EL_KC) {             // the rows kernel: w_frag is the split of the weight padded to [H * Cp, 320] (20 k steps)
-    constexpr int KST = 20;
+  if (K > EL_KC) {             // the rows kernel: w_frag is the split of the weight padded to [H * Cp, 304] (19 k steps)
+    constexpr int KST = 19;
     a.KS = KST;
     const unsigned grid = (unsigned)((E + ER_SLOTS - 1) / ER_SLOTS);
-    const size_t dyn = (size_t)2 * (2 * KST * 1024) + (size_t)2 * H * Cp * sizeof(float);
+    const size_t dyn = (size_t)ER_RING * (2 * KST * 1024) + (size_t)2 * H * Cp * sizeof(float);
     if (masked) {
       if (!dyn_lds_ok<&gatv2_edge_logits_rows_kernel<true, KST>>((int)dyn)) return ISG_EUNSUPPORTED;
       gatv2_edge_logits_rows_kernel<true, KST><<<grid, ER_THREADS, dyn, st>>>(a);

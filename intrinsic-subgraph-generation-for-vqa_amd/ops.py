@@ -817,21 +817,21 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
 # CFG.fuse_logits (ops.FUSE_LOGITS): 
 def fused_logits_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
     """Shape test of isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits (inference, fp32 rows, per-graph kernel)."""
-    cp = (channels + 31) // 32 * 32       # round 5: heads padded to whole 32-channel tiles (the reference's C = 300 -> 320), K <= 320
+    cp = (channels + 31) // 32 * 32       # round 5: heads padded to whole 32-channel tiles (the reference's C = 300 -> 320), K <= 304
     wide = channels % 32 != 0 or edge_dim > 128
     return (CFG.fuse_logits and (CFG.fuse_logits_wide or not wide) and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3 and
-            CFG.mp_kernel == "graph" and channels % 4 == 0 and heads * cp <= 2048 and 0 < edge_dim <= 320 and edge_dim % 4 == 0 and
+            CFG.mp_kernel == "graph" and channels % 4 == 0 and heads * cp <= 2048 and 0 < edge_dim <= 304 and edge_dim % 4 == 0 and
             plan.B > 0 and plan.nmax > 0 and plan.rowptr is not None and plan.E > 0)
 
 
 def _edge_logits_weight(w_edge: Tensor, heads: int):
     """lin_edge.weight [H*C, K] as the fragment planes isg_gatv2_edge_logits reads: the weight itself when 32 | C and K <= 128; else
     with zero rows behind every head's C-th up to the next multiple of 32 (C = 300 -> 320: a channel tile never straddles heads)
-    and, for K > 128 (the rows kernel: 20 k steps), zero columns up to 320."""
+    and, for K > 128 (the rows kernel: 19 k steps), zero columns up to 304."""
     HC, K = w_edge.shape
     C = HC // heads
     cp = (C + 31) // 32 * 32
-    kp = K if K <= 128 else 320
+    kp = K if K <= 128 else 304
     if cp == C and kp == K:
         return _weight_planes(w_edge, True, "f16x3")
 

@@ -788,7 +788,7 @@ def test_edge_logits_pair_matches_the_unfused_kernels_and_the_oracle(dev, mask, 
     (mgat_v2_conv.py:243-279): masks of both kinds, E not a multiple of the 64-slot panel, graphs with more than 64 edges,
     an isolated target, a 1-node graph, x_l / x_r as column slices of one fused projection, odd k-step counts.  Round 5: head
     dimensions that are not a multiple of 32 (heads padded to whole channel tiles inside the kernel: the reference's C = 300) and
-    edge widths up to 320 (the rows kernel: its 300 edge features); at H = 4 the result also as segmented planes32."""
+    edge widths up to 304 (the rows kernel: its 300 edge features); at H = 4 the result also as segmented planes32."""
     from isubgvqa_amd import ops
     from oracle import model as OM
     gen = torch.Generator().manual_seed(70 + K + C)
