@@ -435,9 +435,9 @@ int isg_gatv2_mp_fwd_rowmax(const float *x_l, const float *x_r, const float *e_p
  * the head slices of one node (0 = C: heads side by side in a row of H*C; N*C with ldl = C for a head-major [H][N][C]
  * tensor, whose 512-byte rows keep a gather instruction inside a few pages).  A head dimension that is not a multiple of 32
  * (the reference's C = 300) runs on heads PADDED to Cp = 32 * ceil(C / 32) channels: w_frag / w_inv_scale are then those of
- * the [H*Cp, K] matrix with zero rows behind every head's C-th; att, x_l, x_r stay unpadded.  128 < K <= 304 runs the rows
- * kernel (a wave keeps its 32 slots' edge rows in registers, the weight tiles stream through LDS once per 224 slots, requested by a wave of their own): w_frag /
- * w_inv_scale are then those of the [H*Cp, 304] matrix (zero columns behind the K-th).  ISG_EUNSUPPORTED unless 4 | C, K <= 304,
+ * the [H*Cp, K] matrix with zero rows behind every head's C-th; att, x_l, x_r stay unpadded.  K = 128 and 128 < K <= 304 run the rows
+ * kernel (a wave keeps its 32 slots' edge rows in registers, the weight tiles stream through LDS once per 224 slots, requested by a wave of their own): for
+ * K > 128 w_frag / w_inv_scale are those of the [H*Cp, 304] matrix (zero columns behind the K-th).  ISG_EUNSUPPORTED unless 4 | C, K <= 304,
  * 4 | K, H * Cp <= 2048, 16-byte aligned rows. */
 int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
                           const float *x_l, int32_t ldl, int64_t head_stride_l, const float *x_r, int32_t ldr,

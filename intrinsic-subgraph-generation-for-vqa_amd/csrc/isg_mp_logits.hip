@@ -27,6 +27,7 @@
 #include "isg_diag.hpp"
 
 #include <stdlib.h>
+#include <type_traits>
 
 
 namespace isg {
@@ -371,7 +372,16 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
   }
   const int tph = a.Cp >> 5;
   const float slope = a.slope;
-  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  // K = 128 (KS_T = 8) is also what the graph-tile kernels and the panel kernel above run, and a batch split between those
+  // and this one must not show it (tests/test_gpu_ops.py: the tile convolution against the pair, bit for bit): the logit is then
+  // summed in THEIR order -- tile nt's channels go to partial sums nt & 3 (the panel kernel's four tile-waves), added pairwise at
+  // the head's end; the tile loop is unrolled by four so that nt & 3 is a constant.  Wider K has nobody to agree with: one set.
+  constexpr int NP = KS_T == 8 ? 4 : 1;
+  float part[NP][4];
+#pragma unroll
+  for (int u = 0; u < NP; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) part[u][g] = 0.f;
   ISG_WAIT(0xC07F);                     // lgkmcnt(0): my att / w_inv writes are in LDS before the first tile's barrier
   ISG_DIAG_ADD(0)
 
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
   const bool late = wave >= 4;
   er_f4 xl[4], xr[4];
   hf32x16 acc;
-#define ER_EPILOGUE()                                                                                              \
+#define ER_EPILOGUE(U)                                                                                             \
   {                                                                                                                \
     /* the gathers are not to be touched before this point (whole 16-byte registers: no early copies of their parts either) */ \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(xl[g]), "+v"(xr[g]));                     \
@@ -405,19 +415,23 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
         if (MASKED) z *= me;                                                                                       \
         z = leaky(z, slope);                                                                                       \
         if (MASKED) z *= me;                                                                                       \
-        part[g] = fmaf(z, at4[g][j], part[g]);                                                                     \
+        part[U][g] = fmaf(z, at4[g][j], part[U][g]);                                                               \
       }                                                                                                            \
     }                                                                                                              \
     e_cb += 32;                                                                                                    \
     if (++e_tin == tph) {                    /* the head's last tile: its logit is complete in this lane pair */   \
-      const float mine = (part[0] + part[1]) + (part[2] + part[3]);                                                \
-      const float tot = mine + __shfl_xor(mine, 32);                                                               \
-      if (hh == 0 && slot < a.E) a.logits[(int64_t)slot * a.H + e_hd] = tot;                                       \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) part[g] = 0.f;                                                 \
+      float tot[NP];                                                                                               \
+      _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                             \
+        const float mine = (part[u][0] + part[u][1]) + (part[u][2] + part[u][3]);                                  \
+        tot[u] = mine + __shfl_xor(mine, 32);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) part[u][g] = 0.f;                                            \
+      }                                                                                                            \
+      const float sum = NP == 4 ? (tot[0] + tot[1 % NP]) + (tot[2 % NP] + tot[3 % NP]) : tot[0];                   \
+      if (hh == 0 && slot < a.E) a.logits[(int64_t)slot * a.H + e_hd] = sum;                                       \
       e_tin = 0;                                                                                                   \
       ++e_hd;                                                                                                      \
     }                                                                                                              \
-    ISG_DIAG_KEEP2(part[0], part[3])                                                                               \
+    ISG_DIAG_KEEP2(part[0][0], part[0][3])                                                                         \
     ISG_DIAG_ADD(5)                                                                                                \
   }
   int rslot = 0;
@@ -476,23 +490,49 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
   ISG_BARRIER();                                                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   ISG_DIAG_ADD(1)
-  if (!late) {                // (two loops, not one with two branches: each gets its own register allocation)
+  if constexpr (NP == 1) {
+    if (!late) {              // (two loops, not one with two branches: each gets its own register allocation)
 #pragma unroll 1
-    for (int nt = 0; nt < NT; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
+        ER_TILE_BARRIER()
+        ER_PRODUCTS()
+        ER_EPILOGUE(0)
+      }
+    } else {
       ER_TILE_BARRIER()
       ER_PRODUCTS()
-      ER_EPILOGUE()
+#pragma unroll 1
+      for (int nt = 1; nt < NT; ++nt) {
+        ER_TILE_BARRIER()
+        ER_EPILOGUE(0)
+        ER_PRODUCTS()
+      }
+      ER_EPILOGUE(0)
     }
   } else {
-    ER_TILE_BARRIER()
-    ER_PRODUCTS()
+    if (!late) {
 #pragma unroll 1
-    for (int nt = 1; nt < NT; ++nt) {
-      ER_TILE_BARRIER()
-      ER_EPILOGUE()
-      ER_PRODUCTS()
+      for (int nt = 0; nt < NT; nt += 4) {
+        { ER_TILE_BARRIER() ER_PRODUCTS() ER_EPILOGUE(0) }
+        if (nt + 1 < NT) { ER_TILE_BARRIER() ER_PRODUCTS() ER_EPILOGUE(1) }
+        if (nt + 2 < NT) { ER_TILE_BARRIER() ER_PRODUCTS() ER_EPILOGUE(2) }
+        if (nt + 3 < NT) { ER_TILE_BARRIER() ER_PRODUCTS() ER_EPILOGUE(3) }
+      }
+    } else {                  // a late wave's epilogue is the PREVIOUS tile's: (nt - 1) & 3
+#pragma unroll 1
+      for (int nt = 0; nt < NT; nt += 4) {
+        { ER_TILE_BARRIER() if (nt > 0) ER_EPILOGUE(3) ER_PRODUCTS() }
+        if (nt + 1 < NT) { ER_TILE_BARRIER() ER_EPILOGUE(0) ER_PRODUCTS() }
+        if (nt + 2 < NT) { ER_TILE_BARRIER() ER_EPILOGUE(1) ER_PRODUCTS() }
+        if (nt + 3 < NT) { ER_TILE_BARRIER() ER_EPILOGUE(2) ER_PRODUCTS() }
+      }
+      switch ((NT - 1) & 3) {
+        case 0: ER_EPILOGUE(0) break;
+        case 1: ER_EPILOGUE(1) break;
+        case 2: ER_EPILOGUE(2) break;
+        default: ER_EPILOGUE(3) break;
+      }
     }
-    ER_EPILOGUE()
   }
 #undef ER_PRODUCTS
 #undef ER_TILE_BARRIER
@@ -533,8 +573,10 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   a.lda = lda; a.ldl = ldl; a.ldr = ldr; a.hsl = head_stride_l; a.hsr = head_stride_r; a.slope = negative_slope;
   hipStream_t st = as_stream(stream);
   const bool masked = edge_mask || node_mask;
-  if (K > EL_KC) {             // the rows kernel: w_frag is the split of the weight padded to [H * Cp, 304] (19 k steps)
-    constexpr int KST = 19;
+  // the rows kernel: w_frag is the split of the weight padded to [H * Cp, 16 KST]: 304 columns (19 k steps) for K > 128, and for
+  // K = 128 exactly its own 128 (8 k steps; a narrower K stays on the panel kernel, whose k loop is as long as K)
+  auto rows = [&](auto kst) -> int {
+    constexpr int KST = decltype(kst)::value;
     a.KS = KST;
     const unsigned grid = (unsigned)((E + ER_SLOTS - 1) / ER_SLOTS);
     const size_t dyn = (size_t)ER_RING * (2 * KST * 1024) + (size_t)2 * H * Cp * sizeof(float);
@@ -546,7 +588,9 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
       gatv2_edge_logits_rows_kernel<false, KST><<<grid, ER_THREADS, dyn, st>>>(a);
     }
     return check_launch();
-  }
+  };
+  if (K > EL_KC) return rows(std::integral_constant<int, 19>{});
+  if (K == EL_KC) return rows(std::integral_constant<int, 8>{});        // 177 against 228 us on the panel kernel (BASELINE configs[1] topology)
   const unsigned grid = (unsigned)((E + EL_BM - 1) / EL_BM);
   const size_t dyn = (size_t)2 * EL_BM * a.LD * 2 + ((size_t)2 * H * Cp + (size_t)4 * EL_BM * H) * sizeof(float);
   if (masked) {

@@ -113,14 +113,16 @@ def test_linear_h3p_segmented_operand_gives_the_strict_builds_bits(dev, both, pl
 
 
 @pytest.mark.parametrize("masked", [False, True])
-def test_wide_edge_logits_give_the_strict_builds_bits(dev, both, masked):
-    """isg_gatv2_edge_logits at the reference's own width (H = 4, C = 300, K = 300): the rows kernel, whose weight tiles reach LDS
-    by LDS-DMA issued from inline asm and are retired by a hand-placed wait + barrier per tile."""
+@pytest.mark.parametrize("C,K", [(300, 300), (128, 128), (96, 128)])
+def test_rows_kernel_edge_logits_give_the_strict_builds_bits(dev, both, masked, C, K):
+    """isg_gatv2_edge_logits' rows kernel (K = 128 and 128 < K <= 304; H = 4, C = 300 / K = 300 is the reference's own width): the
+    weight tiles reach a three-slot LDS ring by LDS-DMA from a requesting wave of their own, handed over by one counted wait and one
+    raw barrier per tile; at K = 128 the tile loop is unrolled by four (the panel kernel's summation order)."""
     from isubgvqa_amd import ops
     gen = torch.Generator().manual_seed(41)
     sizes = torch.randint(8, 34, (300,), generator=gen).tolist()
     batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=(7, 60))
-    N, E, H, C, K = batch.numel(), ei.size(1), 4, 300, 300
+    N, E, H = batch.numel(), ei.size(1), 4
     xl = torch.randn(N, H * C, generator=gen).to(dev)
     xr = torch.randn(N, H * C, generator=gen).to(dev)
     ea = torch.randn(E, K, generator=gen).to(dev)
