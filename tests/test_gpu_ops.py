@@ -781,7 +781,8 @@ def test_long_reductions_take_slices_of_the_producers_partial_maxima(dev):
 
 @pytest.mark.parametrize("mask", [None, "node", "edge"])
 @pytest.mark.parametrize("H,C,K", [(4, 128, 128), (4, 128, 36), (4, 64, 20), (8, 32, 128), (2, 256, 64),
-                                   (4, 300, 300), (4, 300, 128), (4, 128, 300), (2, 76, 52), (4, 44, 260)])
+                                   (4, 300, 300), (4, 300, 128), (4, 128, 300), (2, 76, 52), (4, 44, 260),
+                                   (4, 300, 304), (2, 76, 132), (4, 36, 128), (1, 64, 128)])
 def test_edge_logits_pair_matches_the_unfused_kernels_and_the_oracle(dev, mask, H, C, K):
     """isg_gatv2_edge_logits (lin_edge folded into the logits: transposed fp16 three-product tile, row gathers in the
     epilogue) + isg_gatv2_mp_fwd_logits against the un-fused pair isg_linear_* + isg_gatv2_mp_fwd and against the oracle
