@@ -30,7 +30,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 cores on a bounded sample of the same workload; .cfg1 = BASELINE configs[0] exactly
   full_model    the configs[2] stand-in (full model at C = 300) timed in the same run; .kernels = its two dominant kernels against
                 their rooflines from HIP events around every launch of three extra steps (isg_linear_h3p: TFLOP/s of fp16
-                products vs the 2.5 PF dense MFMA peak; the flat message-passing kernel: SURVEY 8(d)'s bytes at H C = 1200 vs HBM)
+                products vs the 2.5 PF dense MFMA peak; the message-passing pair -- edge logits + flat kernel from logits --: SURVEY 8(d)'s
+                bytes at H C = 1200 vs HBM)
   sustained     >= 2.5 s of back-to-back configs[1] steps behind the timed burst: ms/step and its ratio to the burst's
   cfg5          BASELINE configs[4] on one GPU (skewed graphs, AIMLE, fp16 rows): ms/step, MP kernel GB/s on s = 2 bytes, the
                 imbalance of contiguous graph ranges over 8 ranks
@@ -273,7 +274,7 @@ def full_model_rate(dev, graphs: int, steps: int = 10):
     assert torch.isfinite(out).all()
     # the step's two dominant kernels against THEIR rooflines, from HIP events around every launch of three more steps (outside
     # the timed loop: an event pair per launch costs host time): isg_linear_h3p against the dense fp16 MFMA peak (three fp16
-    # products per fp32 product: 6 M N K flops per launch), the flat message-passing kernel against HBM on SURVEY 8(d)'s bytes_mp
+    # products per fp32 product: 6 M N K flops per launch), the message-passing pair against HBM on SURVEY 8(d)'s bytes_mp
     ops.H3P_TIMER, ops.MP_TIMER = ops.KernelTimer(), ops.KernelTimer()
     with torch.no_grad():
         for _ in range(3):
@@ -285,13 +286,19 @@ def full_model_rate(dev, graphs: int, steps: int = 10):
     flops = [6.0 * m["M"] * m["N"] * m["K"] for m in ht.meta]
     k300 = [i for i, m in enumerate(ht.meta) if m["K"] <= 320]
     mpb = [ops.mp_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"], m.get("feat_bytes", 4)) for m in mt.meta]
+    sp = mt.split_ms()
     kernels = {
         "linear_h3p": {"bound": "mfma", "launches_per_step": len(hd) // 3, "ms_per_step": round(sum(hd) / 3, 3),
                        "achieved": round(sum(flops) / (sum(hd) * 1e-3) / 1e12, 1) if hd else 0.0, "peak": MFMA_F16_PEAK_TFLOPS,
                        "unit": "TFLOP/s of fp16 products", "frac": round(sum(flops) / (sum(hd) * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if hd else 0.0,
                        "k_le_320": {"launches_per_step": len(k300) // 3, "ms_per_step": round(sum(hd[i] for i in k300) / 3, 3),
                                     "achieved": round(sum(flops[i] for i in k300) / max(sum(hd[i] for i in k300), 1e-9) / 1e9, 1)}},
-        "gatv2_mp_flat": {"bound": "hbm", "launches_per_step": len(md) // 3, "ms_per_step": round(sum(md) / 3, 3),
+        # (since round 5 the C = 300 layers run the edge-logits pair: the bracket holds isg_gatv2_edge_logits -- lin_edge inside --
+        # AND the flat kernel from logits; bytes_mp still counts e_proj, which neither writes nor reads: a lower bound, as at C = 128)
+        "gatv2_mp_pair": {"bound": "hbm", "what": "isg_gatv2_edge_logits (rows kernel, lin_edge inside) + isg_gatv2_mp_fwd_logits_planes "
+                                                  "(flat kernel from logits) against SURVEY 8(d)'s bytes_mp at H C = 1200",
+                          "launches_per_step": len(md) // 3, "ms_per_step": round(sum(md) / 3, 3),
+                          "parts_us": [round(sum(p[i] for p in sp) / max(len(sp), 1) * 1e3, 1) for i in (0, 1)] if sp else None,
                           "achieved": round(sum(mpb) / max(sum(md), 1e-9) / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": round(sum(mpb) / max(sum(md), 1e-9) / 1e6 / HBM_PEAK_GBPS, 4),
                           "algorithmic_bytes_per_launch": int(sum(mpb) / max(len(mpb), 1))},
@@ -841,7 +848,7 @@ def main(argv=None):
                          "pipe and LDS add up instead of overlapping",
                 "hbm_frac_on_own_bytes": res["roofline"]["own_frac"],
                 "mfma_frac_of_dense_fp16_peak": round(flops / (mp_ms * 1e-3) / 1e12 / 2500.0, 4),
-                "evidence": "profiles/r03_bm_tile_kernels_sq_counters.txt (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.42), "
+                "evidence": "profiles/r05_q_tile_kernels_sq_counters.txt (round 5: matrix cores 31 % busy, LDS 34 %, SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.43), "
                             "profiles/r03_bg_layer_conv_ablation.md (the phases add)"}
             if layer_conv:     # the launch also IS lin_l | lin_r: the bytes the reference's projection moves beside bytes_mp
                 proj = sum(4 * m["N"] * m["K_in"] + 8 * m["N"] * m["H"] * m["C"] for m in timer.meta) / len(timer.meta)

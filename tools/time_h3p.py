@@ -25,6 +25,9 @@ SHAPES = [  # M, N, K, act, what
 ]
 if "--quick" in sys.argv:
     SHAPES = SHAPES[:4]
+if "--n300" in sys.argv:       # the full model's Linears with 300 result columns (256-wide column tiles: the second 44 columns full)
+    SHAPES = [(204753, 300, 300, None, "edge encoder"), (82189, 300, 600, "gelu", "x_proj.2"), (82189, 300, 300, None, "node 300x300"),
+              (82189, 320, 300, None, "(N = 320)"), (82189, 256, 300, None, "(N = 256)"), (82189, 512, 300, None, "(N = 512)")]
 if "--small" in sys.argv:       # the configs[1] step's classifier side (below ops.H3P_MIN_M rows)
     SHAPES = [(4096, 256, 256, "gelu", "embedding"), (4096, 1840, 256, None, "logit_fc (1842)"), (4096, 1844, 256, None, "logit_fc (1842)"),
               (8192, 1844, 256, None, "logit_fc x2"), (4096, 1844, 512, None, "logit_fc K=512")]
