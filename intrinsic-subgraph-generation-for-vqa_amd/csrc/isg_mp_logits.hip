@@ -22,6 +22,11 @@
 //   epilogue   per tile: e = acc * s_row * s_col (exact powers of two), z = (x_r[i] + x_l[j]) + e, mask, leaky, mask,
 //              z * att accumulated per lane; the 2 x 4 x 16 B row gathers of a tile are issued before its MFMA loop
 // W never touches LDS (fragment-major planes from L2, one k-step ahead), exactly as in isg_linear_f16x3.
+//
+// Round 5: that is the PANEL kernel, which now serves K < 128 only.  K = 128 and 128 < K <= 304 run the ROWS kernel further down
+// (gatv2_edge_logits_rows_kernel): the roles swapped -- edge rows resident in registers, W tiles through a three-slot LDS ring
+// requested by a wave of their own, once per 224 slots -- which is the "W tile kept in LDS across several panels" the notes
+// below ask for: 180 us against 228 at K = 128, 520 against 1 110 at the reference's own C = 300 / K = 300.
 #include "isg_f16x3.hpp"
 #include "isg_mp.hpp"
 #include "isg_diag.hpp"
