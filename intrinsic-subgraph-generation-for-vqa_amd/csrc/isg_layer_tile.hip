@@ -265,15 +265,27 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
   }
   float4 ra[8];
   DT_LOAD_CHUNK(0)               // in flight under the tile's bookkeeping
+  // Every other input of the header is requested HERE, unconditionally (clamped indices), before anything is used: a load inside
+  // `if (tid < 64) { ... s_x[tid] = p[i]; }` is waited for inside its branch, and the header was eight such round trips in a row
+  // (9 900 cycles of a workgroup's 90 000: profiles/r03_g_dense_tail_stamps.txt); now it is the one behind tile_info / tile_ptr.
+  const int ng = g1 - g0;
+  const int hrow = min(r0 + min(tid, nrows - 1), a.N - 1);          // the row whose scales thread tid < DT_ROWS files
+  const float *rm = a.a_rowmax + (int64_t)hrow * a.ldp;
+  float rmv[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) rmv[p] = rm[min(p, a.P - 1)];
+  const int h_gid = (int)a.batch[hrow];
+  float h_mask = 1.f;
+  if (a.node_mask) h_mask = a.node_mask[hrow];                      // (wave-uniform: the pointer is a kernel argument)
+  const int h_gp = a.ptr[g0 + min(tid, ng)];
+  const int gi = tid >> 5, c4 = tid & 31;
+  const int gi_c = min(gi, max(min(ng, DT_GST) - 1, 0));
+  const float4 h_ins = *reinterpret_cast<const float4 *>(a.ins + (int64_t)(g0 + gi_c) * DT_C + c4 * 4);
+  float4 h_insn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.ins_next) h_insn = *reinterpret_cast<const float4 *>(a.ins_next + (int64_t)(g0 + gi_c) * DT_C + c4 * 4);
   if (tid < DT_ROWS) {     // the row's scale from the producer's partial maxima: one round of loads per tile
-    const int gr = min(r0 + min(tid, nrows - 1), a.N - 1);
-    const float *rm = a.a_rowmax + (int64_t)gr * a.ldp;
-    float mx = 0.f;
-    if (a.P == 4) {
-      mx = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
-    } else {
-      for (int p = 0; p < a.P; ++p) mx = fmaxf(mx, rm[p]);
-    }
+    float mx = fmaxf(fmaxf(rmv[0], rmv[1]), fmaxf(rmv[2], rmv[3]));      // (P < 4: the clamped reads repeat the last one)
+    for (int p = 4; p < a.P; ++p) mx = fmaxf(mx, rm[p]);
     float s, inv;
     h3_scale(mx, s, inv);
     s_rmax[tid] = s;                    // a strip nothing else uses
@@ -284,21 +296,15 @@ __global__ __launch_bounds__(256, 2) void mgat_dense_tail_kernel(DtArgs a) {
     h3_scale(fmaf(mx, a.y_bound[0], a.y_bound[1]), s, inv);
     s_scale2[tid] = s;
     s_inv2[tid] = inv;
-    s_gid[tid] = (int)a.batch[gr];
-    s_mask[tid] = a.node_mask ? a.node_mask[gr] : 1.f;
+    s_gid[tid] = h_gid;
+    s_mask[tid] = h_mask;
   }
-  const int ng = g1 - g0;
   int *s_gp = reinterpret_cast<int *>(s_f + 2688);      // node offsets of the tile's first DT_GPC graphs: the tail's loops read these
-  if (tid <= min(ng, DT_GPC)) s_gp[tid] = a.ptr[g0 + tid] - r0;
-  {   // the instruction rows of the tile's first DT_GST graphs (this layer's and the next one's): 32 lanes per row
-    const int gi = tid >> 5, c4 = tid & 31;
-    if (gi < min(ng, DT_GST)) {
-      *reinterpret_cast<float4 *>(&s_ins[gi * DT_C + c4 * 4]) =
-          *reinterpret_cast<const float4 *>(a.ins + (int64_t)(g0 + gi) * DT_C + c4 * 4);
-      if (a.ins_next)
-        *reinterpret_cast<float4 *>(&s_insn[gi * DT_C + c4 * 4]) =
-            *reinterpret_cast<const float4 *>(a.ins_next + (int64_t)(g0 + gi) * DT_C + c4 * 4);
-    }
+  if (tid <= min(ng, DT_GPC)) s_gp[tid] = h_gp - r0;
+  // the instruction rows of the tile's first DT_GST graphs (this layer's and the next one's): 32 lanes per row
+  if (gi < min(ng, DT_GST)) {
+    *reinterpret_cast<float4 *>(&s_ins[gi * DT_C + c4 * 4]) = h_ins;
+    if (a.ins_next) *reinterpret_cast<float4 *>(&s_insn[gi * DT_C + c4 * 4]) = h_insn;
   }
   __syncthreads();
   float sa[8];
