@@ -779,6 +779,44 @@ def test_long_reductions_take_slices_of_the_producers_partial_maxima(dev):
     assert err <= 2.0 * err32
 
 
+@pytest.mark.parametrize("C,K", [(300, 300), (128, 128), (128, 64)])
+@pytest.mark.parametrize("sizes,extra", [((2,), 0), ((1, 3), 1), ((7, 2, 5), 2), ((33,) * 9, 3)])
+def test_edge_logits_on_tiny_and_ragged_batches(dev, sizes, extra, C, K):
+    """isg_gatv2_edge_logits where a launch is mostly padding: 2-30 edges (one partly filled wave of the rows kernel's seven, or a
+    partly filled 64-slot panel), and ~1 100 edges (a last workgroup with 4 of its 224 slots in use) -- against an fp64 evaluation
+    of att . leaky(x_l[src] + x_r[dst] + lin_edge(edge_attr)) in slot order; E = 0 returns an empty tensor."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(len(sizes) * 100 + extra + K)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    src, dst, off = [], [], 0
+    for n in sizes:
+        for v in range(n):
+            src.append(off + v); dst.append(off + (v + 1) % n)
+        m = extra * n
+        src += (off + torch.randint(0, n, (m,), generator=gen)).tolist()
+        dst += (off + torch.randint(0, n, (m,), generator=gen)).tolist()
+        off += n
+    ei = torch.tensor([src, dst])
+    N, E, H = batch.numel(), ei.size(1), 4
+    xl, xr = torch.randn(N, H * C, generator=gen), torch.randn(N, H * C, generator=gen)
+    ea = torch.randn(E, K, generator=gen)
+    w = torch.randn(H * C, K, generator=gen) / K ** 0.5
+    att = torch.randn(1, H, C, generator=gen)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    got = ops.gatv2_edge_logits(xl.to(dev), xr.to(dev), ea.to(dev), w.to(dev), att.to(dev), plan, H)
+    assert got is not None and got.shape == (E, H) and torch.isfinite(got).all()
+    eid, s_, d_ = plan.eid.cpu().long(), plan.src.cpu().long(), plan.dst.cpu().long()
+    z = xl.double()[s_] + xr.double()[d_] + (ea.double() @ w.double().t())[eid]
+    z = torch.where(z > 0, z, 0.2 * z).view(E, H, C)
+    ref = (z * att.double().view(1, H, C)).sum(-1)
+    scale = (z.abs() * att.double().abs().view(1, H, C)).sum(-1)            # what the sum is made of: the bound is relative to it
+    err = ((got.cpu().double() - ref).abs() / scale.clamp_min(1e-30)).max().item()
+    assert err < 2e-6, f"logits off by {err:.2e} of their terms' magnitude (E = {E})"
+    empty = ops.GraphPlan.build(batch.to(dev), torch.zeros(2, 0, dtype=torch.long, device=dev), num_graphs=len(sizes))
+    none = ops.gatv2_edge_logits(xl.to(dev), xr.to(dev), ea[:0].to(dev), w.to(dev), att.to(dev), empty, H)
+    assert none is not None and none.shape == (0, H)
+
+
 @pytest.mark.parametrize("mask", [None, "node", "edge"])
 @pytest.mark.parametrize("H,C,K", [(4, 128, 128), (4, 128, 36), (4, 64, 20), (8, 32, 128), (2, 256, 64),
                                    (4, 300, 300), (4, 300, 128), (4, 128, 300), (2, 76, 52), (4, 44, 260),
