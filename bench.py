@@ -601,13 +601,20 @@ def cfg5_leg(dev, graphs: int = 2048, steps: int = 10):
     mp_ms = sum(durs) / max(len(durs), 1)
     gbps = (sum(byt) / max(len(byt), 1)) / (mp_ms * 1e-3) / 1e9 if durs else 0.0
     small = wl.max_nodes <= 64 and wl.max_edges <= 256
+    fused = bool(timer.meta) and all(m.get("fused_logits") for m in timer.meta)
+    parts = timer.split_ms()
     return {"workload": "BASELINE configs[4] on one GPU: skewed graphs (8-200 nodes, Pareto sizes, power-law in-degree), AIMLE k=5, "
                         "fp16 feature rows / fp32 arithmetic, 3 layers C=128 H=4",
             "graphs": graphs, "nodes": int(wl.x.size(0)), "edges": int(wl.edge_index.size(1)), "max_nodes": int(wl.max_nodes),
             "max_edges": int(wl.max_edges), "max_in_degree": int(deg.max()), "ms_per_step": round(dt * 1e3, 3),
             "questions_per_s": round(graphs / dt, 1),
-            "mp_kernel": ("gatv2_mp_graph_kernel<.., 64, 256, f16>" if small else "gatv2_mp_graph_kernel<.., 256, 1024, f16> (per-graph "
-                          "tables for hub graphs)") + " (isg_gatv2_mp_fwd_f16; e_proj streamed as half rows)",
+            # since round 5 (ABI v19) the layers run the pair on half rows: ONE bracket holds isg_gatv2_edge_logits_f16 (lin_edge inside,
+            # e_proj rounded to half in registers) and isg_gatv2_mp_fwd_logits_f16; bytes_mp (s = 2) still counts e_proj: a lower bound
+            "mp_kernel": ("isg_gatv2_edge_logits_f16 (rows kernel) + isg_gatv2_mp_fwd_logits_f16 (gatv2_mp_graph_kernel<.., "
+                          + ("64, 256" if small else "256, 1024: per-graph tables for hub graphs") + ", f16>)") if fused else
+                         (("gatv2_mp_graph_kernel<.., 64, 256, f16>" if small else "gatv2_mp_graph_kernel<.., 256, 1024, f16> (per-graph "
+                           "tables for hub graphs)") + " (isg_gatv2_mp_fwd_f16; e_proj streamed as half rows)"),
+            "mp_parts_us": [round(sum(p[i] for p in parts) / len(parts) * 1e3, 1) for i in (0, 1)] if parts else None,
             "mp_avg_launch_us": round(mp_ms * 1e3, 2), "mp_algorithmic_bytes_per_launch_s2": int(sum(byt) / max(len(byt), 1)),
             "mp_achieved_GBps": round(gbps, 1), "mp_frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
             "imbalance_world8_max_over_mean": imb, "steps": steps, "fp32_rows": fp32_rows}

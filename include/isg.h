@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 18
+#define ISG_ABI_VERSION 19
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -444,6 +444,15 @@ int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w
                           int64_t head_stride_r, const float *att, const int32_t *eid, const int32_t *src, const int32_t *dst,
                           const float *edge_mask, const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C,
                           int32_t K, float negative_slope, void *stream);
+/* The same with x_l / x_r as HALF rows (BASELINE configs[4]: fp16 feature rows, fp32 arithmetic; ldl / ldr / head strides count
+ * halves): the edge projection is rounded to half before it enters the logit, which is how isg_linear_f16x3_f16 stores e_proj for
+ * isg_gatv2_mp_fwd_f16 -- the pair then computes what the un-fused fp16 path computes.  The rows kernel only: K >= 128
+ * (ISG_EUNSUPPORTED below).  Replaces mgat_v2_conv.py:259-261 + the logit half of :243-270 on half rows. */
+int isg_gatv2_edge_logits_f16(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
+                              const uint16_t *x_l, int32_t ldl, int64_t head_stride_l, const uint16_t *x_r, int32_t ldr,
+                              int64_t head_stride_r, const float *att, const int32_t *eid, const int32_t *src,
+                              const int32_t *dst, const float *edge_mask, const float *node_mask, float *logits, int64_t E,
+                              int32_t H, int32_t C, int32_t K, float negative_slope, void *stream);
 /* isg_gatv2_mp_fwd whose result leaves as the SEGMENTED planes32 operand of isg_linear_h3p instead of fp32 rows: H = 4 and a head
  * dimension served by the flat per-graph kernel (the reference's C = 300); ISG_EUNSUPPORTED wherever that kernel does not run --
  * the caller then takes isg_gatv2_mp_fwd and isg_split_planes32.  out_planes uint16 [N][2 * ceil(2 C / 32)][64]; out_inv fp32
@@ -466,6 +475,13 @@ int isg_gatv2_mp_fwd_logits(const float *x_l, const float *logits, const float *
                             int32_t H, int32_t C, float negative_slope, const int32_t *graph_ptr,
                             const int32_t *graph_eptr, const int32_t *dst, int64_t B, int32_t nmax_host,
                             int32_t emax_host, int32_t ld_l, void *stream);
+/* The same on HALF feature rows (x_l in, out; ld_l counts halves; no row maxima): behind isg_gatv2_edge_logits_f16, BASELINE
+ * configs[4]'s storage.  The grouped per-graph kernel only (mgat_v2_conv.py:270-279, :215-232). */
+int isg_gatv2_mp_fwd_logits_f16(const uint16_t *x_l, const float *logits, const float *att, const float *bias,
+                                const int32_t *rowptr, const int32_t *eid, const int32_t *src, const float *node_mask,
+                                const float *edge_mask, uint16_t *out, float *alpha, int64_t N, int64_t E, int32_t H, int32_t C,
+                                float negative_slope, const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst,
+                                int64_t B, int32_t nmax_host, int32_t emax_host, int32_t ld_l, void *stream);
 /* The same with the result as the segmented planes32 operand of isg_linear_h3p (isg_gatv2_mp_fwd_planes's output contract:
  * H = 4, the flat per-graph kernel): a C = 300 layer with neither e_proj nor fp32 convolution rows in memory. */
 int isg_gatv2_mp_fwd_logits_planes(const float *x_l, const float *logits, const float *att, const float *bias,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -85,8 +85,13 @@ SIGNATURES = {
     "isg_gatv2_edge_logits": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "isg_gatv2_edge_logits_f16": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32,
+                                          c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                          c_int32, c_int32, c_int32, c_float, c_void_p]),
     "isg_gatv2_mp_fwd_logits": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "isg_gatv2_mp_fwd_logits_f16": (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                                            c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "isg_gatv2_mp_fwd_logits_planes": (c_int, [c_void_p] * 12 + [c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                                c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "isg_split_f16x2_rows": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

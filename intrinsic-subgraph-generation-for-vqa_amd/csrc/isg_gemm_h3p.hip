@@ -915,7 +915,7 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   const long long tm = (M + P3_T - 1) / P3_T, tn = (N + P3_T - 1) / P3_T;
   const long long blocks = tn * ((tm + 7) / 8 * 8);
   if (blocks >= (1ll << 31)) return ISG_EUNSUPPORTED;
-  P3Args a;
+  P3Args a = {};
   a.A = reinterpret_cast<const _Float16 *>(a_planes); a.W = reinterpret_cast<const _Float16 *>(w_planes);
   a.a_inv = a_inv; a.w_inv = w_inv; a.bias = bias; a.D = d; a.Dp = reinterpret_cast<_Float16 *>(d_planes); a.d_inv = d_inv;
   a.d_bound = d_bound; a.M = (int)M; a.N = N; a.KT = KT; a.ldd = ldd; a.tiles_n = (int)tn;
@@ -934,7 +934,7 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
     // the result is addressed through a buffer descriptor with 32-bit byte offsets
     if ((planes_out ? M * (int64_t)(((N + 31) & ~31) * 4) : M * (int64_t)ldd * 4) >= (1ll << 32) - 16) return ISG_EUNSUPPORTED;
     const int ncu = device_cus();
-    Q3Args q;
+    Q3Args q = {};
     q.p = a;
     q.tiles_m = (int)tm;
     const long long tn2 = (N + Q3_BN - 1) / Q3_BN;

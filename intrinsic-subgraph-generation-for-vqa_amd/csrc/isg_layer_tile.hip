@@ -674,7 +674,7 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
       ((xg_out || xp_out) && !ins_next) || (xp_out && !xinv_out))
     return ISG_EINVAL;
   if (!dyn_lds_ok<&mgat_dense_tail_kernel>(DT_SMEM_BYTES)) return ISG_EUNSUPPORTED;
-  DtArgs a;
+  DtArgs a = {};
   a.a = conv_out; a.a_rowmax = a_rowmax; a.w1f = reinterpret_cast<const _Float16 *>(w1_frag); a.w1_inv = w1_inv_scale;
   a.b1 = b1; a.y_bound = y_bound; a.w2f = reinterpret_cast<const _Float16 *>(w2_frag); a.w2_inv = w2_inv_scale; a.b2 = b2; a.ins = ins; a.h = h;
   a.gn_w = gn_weight; a.gn_b = gn_bias; a.gn_ms = gn_mean_scale; a.node_mask = node_mask; a.ins_next = ins_next;
@@ -1066,7 +1066,7 @@ extern "C" int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x
   if (!x_l || !x_r || (E > 0 && (!edge_planes || !edge_inv_scale || !eid || !src || !dst || !alpha)) || !w_frag || !w_inv_scale || !att || !rowptr ||
       !tile_info || !ntiles || !out)
     return ISG_EINVAL;
-  TcArgs a;
+  TcArgs a = {};
   a.x_l = x_l; a.x_r = x_r; a.ep = reinterpret_cast<const _Float16 *>(edge_planes); a.ep_inv = edge_inv_scale; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
   a.att = att; a.bias = bias; a.rowptr = rowptr; a.eid = eid; a.src = src; a.dst = dst;
   a.tile_info = reinterpret_cast<const int4 *>(tile_info); a.ntiles = ntiles; a.edge_mask = edge_mask; a.node_mask = node_mask;

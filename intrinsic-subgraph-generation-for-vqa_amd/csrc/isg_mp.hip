@@ -288,7 +288,7 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
   if (ld_e == 0) ld_e = H * C;
   if (ld_l < H * C || ld_r < H * C || ld_e < H * C) return ISG_EINVAL;
   if ((ld_l & 3) != 0 || (ld_r & 3) != 0 || (ld_e & 3) != 0) return ISG_EUNSUPPORTED;
-  MpArgs a;
+  MpArgs a = {};
   a.x_l = (const float4 *)x_l; a.x_r = (const float4 *)x_r; a.e_proj = (const float4 *)e_proj;
   a.att = (const float4 *)att; a.bias = (const float4 *)bias;
   a.rowptr = rowptr; a.eid = eid; a.src = src;
@@ -433,6 +433,20 @@ extern "C" int isg_gatv2_mp_fwd_logits(const float *x_l, const float *logits, co
   if (E == 0) return ISG_EUNSUPPORTED;
   return mp_fwd(x_l, nullptr, nullptr, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
                 negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, 0, 0, stream, 0, rowmax, logits);
+}
+
+// isg_gatv2_mp_fwd_logits with HALF feature rows (x_l in, out; ld_l in halves): BASELINE configs[4]'s storage behind
+// isg_gatv2_edge_logits_f16.  The grouped per-graph kernel only.
+extern "C" int isg_gatv2_mp_fwd_logits_f16(const uint16_t *x_l, const float *logits, const float *att, const float *bias,
+                                           const int32_t *rowptr, const int32_t *eid, const int32_t *src,
+                                           const float *node_mask, const float *edge_mask, uint16_t *out, float *alpha,
+                                           int64_t N, int64_t E, int32_t H, int32_t C, float negative_slope,
+                                           const int32_t *graph_ptr, const int32_t *graph_eptr, const int32_t *dst, int64_t B,
+                                           int32_t nmax_host, int32_t emax_host, int32_t ld_l, void *stream) {
+  if (!logits && E > 0) return ISG_EINVAL;
+  if (E == 0) return ISG_EUNSUPPORTED;
+  return mp_fwd(x_l, nullptr, nullptr, att, bias, rowptr, eid, src, node_mask, edge_mask, out, alpha, N, E, H, C,
+                negative_slope, graph_ptr, graph_eptr, dst, B, nmax_host, emax_host, ld_l, 0, 0, stream, 1, nullptr, logits);
 }
 
 // isg_gatv2_mp_fwd_logits whose result leaves as the SEGMENTED planes32 operand of isg_linear_h3p (isg_gatv2_mp_fwd_planes's

@@ -283,7 +283,7 @@ extern "C" int isg_gatv2_mp_bwd(const float *x_l, const float *x_r, const float 
   if (!x_l || !x_r || !att || !grad_out || !rowptr || !rowptr_s || !d_x_l || !d_x_r || !d_att_partial) return ISG_EINVAL;
   if (E > 0 && (!e_proj || !alpha || !eid || !src || !eid_s || !dst_s || !d_e_proj)) return ISG_EINVAL;
   if ((C & 3) != 0 || N >= (1ll << 31) || E >= (1ll << 31)) return ISG_EUNSUPPORTED;
-  MpBwdArgs a;
+  MpBwdArgs a = {};
   a.x_l = (const float4 *)x_l; a.x_r = (const float4 *)x_r; a.e_proj = (const float4 *)e_proj;
   a.att = (const float4 *)att; a.grad_out = (const float4 *)grad_out; a.alpha = alpha;
   a.rowptr = rowptr; a.eid = eid; a.src = src;

@@ -584,7 +584,6 @@ static int launch_one(const MpArgs &a, int nmax_host, int emax_host, hipStream_t
 // then uses the node-chunk kernel).
 int launch_mp_graph(MpArgs a, int nmax_host, int emax_host, hipStream_t st) {
   const int Q = a.C >> 2;
-  if (a.logits && a.f16) return ISG_EUNSUPPORTED;
   if (nmax_host <= 0 || nmax_host > GK_NCAP_L || emax_host < 0 || emax_host > GK_ECAP_L) return ISG_EUNSUPPORTED;
   // heads per workgroup: the largest HS | H with a row slice of at most 1280 bytes (at least one head)
   int HS = 1;

@@ -289,8 +289,12 @@ typedef float er_f4 __attribute__((ext_vector_type(4)));
 
 ISG_DIAG_BUFFER(g_er_stamps)            // -DISG_DIAG builds only (tools/stamp_edge_logits_rows.py): [workgroups * 8 waves][16] int64
 
-template <bool MASKED, int KS_T>
+// F16: x_l / x_r are HALF rows (BASELINE configs[4]: fp16 feature rows, fp32 arithmetic; strides in halfs) and the edge projection
+// is rounded to half before it is used, as the un-fused path stores it (isg_linear_f16x3_f16 -> isg_gatv2_mp_fwd_f16).
+template <bool MASKED, int KS_T, bool F16 = false>
 __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(ElArgs a) {
+  typedef typename std::conditional<F16, _Float16, float>::type er_x_t;
+  typedef er_x_t er_x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char er_smem[];
   constexpr int PIECES = 2 * KS_T;                   // one-KB pieces of a tile: [plane][k step] x (lane x 16 bytes)
   constexpr int TILE_B = PIECES * 1024;
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
   // core idle: 1 460 of a tile's 7 500 cycles in the first form).  No register is added: a late wave's accumulators and gathers
   // just live across the barrier instead of across nothing.
   const bool late = wave >= 4;
-  er_f4 xl[4], xr[4];
+  er_x4 xl[4], xr[4];
   hf32x16 acc;
 #define ER_EPILOGUE(U)                                                                                             \
   {                                                                                                                \
@@ -415,8 +419,9 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
-        const float e = (acc[g * 4 + j] * sinv) * wi4[g][j];  /* both scales are powers of two: exact */           \
-        float z = (xr[g][j] + xl[g][j]) + e;                                                                       \
+        float e = (acc[g * 4 + j] * sinv) * wi4[g][j];        /* both scales are powers of two: exact */           \
+        if (F16) e = (float)(_Float16)e;                      /* e_proj as the un-fused path stores it */          \
+        float z = ((float)xr[g][j] + (float)xl[g][j]) + e;                                                         \
         if (MASKED) z *= me;                                                                                       \
         z = leaky(z, slope);                                                                                       \
         if (MASKED) z *= me;                                                                                       \
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
   int rslot = 0;
   // running state instead of a division per tile: the tile's place in its head (products / epilogue), the lane's x_l / x_r
   // pointers at the tile's first channel, the epilogue's place in att / w_inv
-  const float *pl = a.x_l + xl_off + 4 * hh, *pr = a.x_r + xr_off + 4 * hh;
+  const er_x_t *pl = reinterpret_cast<const er_x_t *>(a.x_l) + xl_off + 4 * hh, *pr = reinterpret_cast<const er_x_t *>(a.x_r) + xr_off + 4 * hh;
   int p_tin = 0, e_tin = 0, e_hd = 0, e_cb = 4 * hh;
   // one tile's gathers and products
 #define ER_PRODUCTS()                                                                                              \
@@ -452,14 +457,14 @@ __global__ __launch_bounds__(ER_THREADS, 2) void gatv2_edge_logits_rows_kernel(E
     /* channels read the head's last four, and att is zero there                                                            */ \
     if (p_tin * 32 + 32 <= a.C) {                                                                                  \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
-        xl[g] = *reinterpret_cast<const er_f4 *>(pl + 8 * g);                                                      \
-        xr[g] = *reinterpret_cast<const er_f4 *>(pr + 8 * g);                                                      \
+        xl[g] = *reinterpret_cast<const er_x4 *>(pl + 8 * g);                                                      \
+        xr[g] = *reinterpret_cast<const er_x4 *>(pr + 8 * g);                                                      \
       }                                                                                                            \
     } else {                                                                                                       \
       const int room = a.C - 4 - (p_tin * 32 + 4 * hh);      /* floats from this lane's first channel to the head's last four */ \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
-        xl[g] = *reinterpret_cast<const er_f4 *>(pl + min(8 * g, room));                                           \
-        xr[g] = *reinterpret_cast<const er_f4 *>(pr + min(8 * g, room));                                           \
+        xl[g] = *reinterpret_cast<const er_x4 *>(pl + min(8 * g, room));                                           \
+        xr[g] = *reinterpret_cast<const er_x4 *>(pr + min(8 * g, room));                                           \
       }                                                                                                            \
     }                                                                                                              \
     if (++p_tin == tph) {                                                                                          \
@@ -551,12 +556,12 @@ using namespace isg;
 
 ISG_DIAG_SETTER(isg_er_set_stamp_buffer, g_er_stamps)
 
-extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
-                                     const float *x_l, int32_t ldl, int64_t head_stride_l, const float *x_r, int32_t ldr,
-                                     int64_t head_stride_r, const float *att,
-                                     const int32_t *eid, const int32_t *src, const int32_t *dst, const float *edge_mask,
-                                     const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C, int32_t K,
-                                     float negative_slope, void *stream) {
+static int edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
+                       const void *x_l, int32_t ldl, int64_t head_stride_l, const void *x_r, int32_t ldr,
+                       int64_t head_stride_r, const float *att,
+                       const int32_t *eid, const int32_t *src, const int32_t *dst, const float *edge_mask,
+                       const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C, int32_t K,
+                       float negative_slope, void *stream, bool f16) {
   if (head_stride_l == 0) head_stride_l = C;
   if (head_stride_r == 0) head_stride_r = C;
   if (E < 0 || H <= 0 || C <= 0 || K <= 0 || lda < K || ldl < C || head_stride_l < C) return ISG_EINVAL;
@@ -569,9 +574,10 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   if ((C & 3) != 0 || H > 32 || K > 304 || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (head_stride_l & 3) != 0 || (head_stride_r & 3) != 0 || mis(edge_attr) ||
       mis(x_l) || mis(x_r) || mis(att) || mis(w_inv_scale) || H * Cp > 2048 || E >= (1ll << 31) - EL_BM)
     return ISG_EUNSUPPORTED;
-  ElArgs a;
+  ElArgs a = {};
   a.edge_attr = edge_attr; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
-  a.x_l = x_l; a.x_r = x_r; a.att = att; a.eid = eid; a.src = src; a.dst = dst;
+  a.x_l = static_cast<const float *>(x_l); a.x_r = static_cast<const float *>(x_r);      // (half rows when f16: the kernel casts)
+  a.att = att; a.eid = eid; a.src = src; a.dst = dst;
   a.edge_mask = edge_mask; a.node_mask = node_mask; a.logits = logits;
   a.E = (int)E; a.H = H; a.C = C; a.K = K; a.KS = (K + 15) / 16; a.NT = H * Cp / 32; a.Cp = Cp;
   a.LD = EL_KC + 8;
@@ -585,17 +591,23 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
     a.KS = KST;
     const unsigned grid = (unsigned)((E + ER_SLOTS - 1) / ER_SLOTS);
     const size_t dyn = (size_t)ER_RING * (2 * KST * 1024) + (size_t)2 * H * Cp * sizeof(float);
-    if (masked) {
-      if (!dyn_lds_ok<&gatv2_edge_logits_rows_kernel<true, KST>>((int)dyn)) return ISG_EUNSUPPORTED;
-      gatv2_edge_logits_rows_kernel<true, KST><<<grid, ER_THREADS, dyn, st>>>(a);
-    } else {
-      if (!dyn_lds_ok<&gatv2_edge_logits_rows_kernel<false, KST>>((int)dyn)) return ISG_EUNSUPPORTED;
-      gatv2_edge_logits_rows_kernel<false, KST><<<grid, ER_THREADS, dyn, st>>>(a);
+    // (the attribute is set once per kernel: to the most any shape asks for -- H Cp <= 2048 -- not to the first caller's size)
+    constexpr int dyn_max = ER_RING * (2 * KST * 1024) + 2 * 2048 * (int)sizeof(float);
+#define ER_LAUNCH(M_, F_)                                                                                          \
+    {                                                                                                              \
+      if (!dyn_lds_ok<&gatv2_edge_logits_rows_kernel<M_, KST, F_>>(dyn_max)) return ISG_EUNSUPPORTED;             \
+      gatv2_edge_logits_rows_kernel<M_, KST, F_><<<grid, ER_THREADS, dyn, st>>>(a);                               \
     }
+    if (masked && f16) ER_LAUNCH(true, true)
+    else if (masked) ER_LAUNCH(true, false)
+    else if (f16) ER_LAUNCH(false, true)
+    else ER_LAUNCH(false, false)
+#undef ER_LAUNCH
     return check_launch();
   };
   if (K > EL_KC) return rows(std::integral_constant<int, 19>{});
   if (K == EL_KC) return rows(std::integral_constant<int, 8>{});        // 177 against 228 us on the panel kernel (BASELINE configs[1] topology)
+  if (f16) return ISG_EUNSUPPORTED;            // half rows: the rows kernel only (K >= 128)
   const unsigned grid = (unsigned)((E + EL_BM - 1) / EL_BM);
   const size_t dyn = (size_t)2 * EL_BM * a.LD * 2 + ((size_t)2 * H * Cp + (size_t)4 * EL_BM * H) * sizeof(float);
   if (masked) {
@@ -608,3 +620,24 @@ extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const 
   return check_launch();
 }
 
+extern "C" int isg_gatv2_edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
+                                     const float *x_l, int32_t ldl, int64_t head_stride_l, const float *x_r, int32_t ldr,
+                                     int64_t head_stride_r, const float *att,
+                                     const int32_t *eid, const int32_t *src, const int32_t *dst, const float *edge_mask,
+                                     const float *node_mask, float *logits, int64_t E, int32_t H, int32_t C, int32_t K,
+                                     float negative_slope, void *stream) {
+  return edge_logits(edge_attr, lda, w_frag, w_inv_scale, x_l, ldl, head_stride_l, x_r, ldr, head_stride_r, att, eid, src, dst,
+                     edge_mask, node_mask, logits, E, H, C, K, negative_slope, stream, false);
+}
+
+// The same with x_l / x_r as HALF rows (strides and head strides in halfs), BASELINE configs[4]'s feature storage: the edge
+// projection is rounded to half before it enters the logit, as isg_linear_f16x3_f16 stores it for isg_gatv2_mp_fwd_f16.  K >= 128.
+extern "C" int isg_gatv2_edge_logits_f16(const float *edge_attr, int32_t lda, const uint16_t *w_frag, const float *w_inv_scale,
+                                         const uint16_t *x_l, int32_t ldl, int64_t head_stride_l, const uint16_t *x_r,
+                                         int32_t ldr, int64_t head_stride_r, const float *att, const int32_t *eid,
+                                         const int32_t *src, const int32_t *dst, const float *edge_mask, const float *node_mask,
+                                         float *logits, int64_t E, int32_t H, int32_t C, int32_t K, float negative_slope,
+                                         void *stream) {
+  return edge_logits(edge_attr, lda, w_frag, w_inv_scale, x_l, ldl, head_stride_l, x_r, ldr, head_stride_r, att, eid, src, dst,
+                     edge_mask, node_mask, logits, E, H, C, K, negative_slope, stream, true);
+}

@@ -81,14 +81,18 @@ class MaskingGATv2Conv(torch.nn.Module):
         needs_rows all ask here):
           "layer_conv"  lin_l | lin_r, lin_edge, logits, softmax, aggregation as one persistent launch on graph tiles
           "tile_conv"   the same with x_l / x_r projected before it (a layer input that is not 128 wide)
-          "pair"        lin_edge folded into the logits, softmax + aggregation from them (two launches, per-graph kernel)
-          "unfused"     lin_edge as a Linear (e_proj in memory) + the message-passing kernel (any width, fp16 rows, training)"""
+          "pair"        lin_edge folded into the logits, softmax + aggregation from them (two launches, per-graph kernel; also on
+                        fp16 feature rows when the edge width is one the rows kernel takes)
+          "unfused"     lin_edge as a Linear (e_proj in memory) + the message-passing kernel (any width, narrow fp16 rows, training)"""
         if (e_proj is not None or edge_attr is None or self.lin_edge is None or edge_attr.dim() != 2
-                or self.feature_dtype != torch.float32 or torch.is_grad_enabled() or plan is None):
+                or torch.is_grad_enabled() or plan is None):
             return "unfused"
         H, C = self.heads, self.out_channels
         if not ops.fused_logits_supported(plan, H, C, edge_attr.size(1)):
             return "unfused"
+        if self.feature_dtype != torch.float32:
+            # fp16 feature rows (BASELINE configs[4]): the pair exists on the rows kernel (K >= 128), the tile kernels do not
+            return "pair" if self.feature_dtype == torch.float16 and edge_attr.size(1) >= 128 else "unfused"
         if not self.share_weights and ops.layer_conv_supported(plan, H, C, in_channels, edge_attr.size(1)):
             return "layer_conv"
         if ops.tile_conv_supported(plan, H, C, edge_attr.size(1)):

@@ -882,11 +882,54 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Te
     E, K = edge_attr.shape
     if N != plan.N or E != plan.E or tuple(w_edge.shape) != (HC, K):
         raise ValueError("gatv2_mp_edge_logits: operand shapes do not match the plan")
-    if x_l.dtype != torch.float32 or edge_attr.dtype != torch.float32:
-        raise TypeError("gatv2_mp_edge_logits: fp32 rows")
-    if tuple(x_r.shape) != (N, HC) or x_r.dtype != torch.float32:
-        raise ValueError("gatv2_mp_edge_logits: x_r must be fp32 [N, H*C]")
+    if x_l.dtype not in (torch.float32, torch.float16) or edge_attr.dtype != torch.float32:
+        raise TypeError("gatv2_mp_edge_logits: x_l / x_r as fp32 or fp16 rows, fp32 edge rows")
+    if tuple(x_r.shape) != (N, HC) or x_r.dtype != x_l.dtype:
+        raise ValueError("gatv2_mp_edge_logits: x_r must be [N, H*C] of x_l's type")
     planes, inv = _edge_logits_weight(w_edge, H)
+    if x_l.dtype == torch.float16:
+        # BASELINE configs[4]'s storage (fp16 feature rows, fp32 arithmetic): the rows kernel gathers half rows and rounds the edge
+        # projection to half as the un-fused path stores it; the result row leaves as half.  K >= 128 (the rows kernel only).
+        if K < 128:
+            return None
+        logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+        alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
+        out = torch.empty(N, HC, dtype=torch.float16, device=x_l.device)
+        nm = _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True)
+        em = _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True)
+        attp = _chk(att.reshape(-1), "att", torch.float32, (HC,))
+        timer = MP_TIMER
+        if timer is not None:
+            ev0, evm, ev1 = timer.bracket3({"N": N, "E": E, "H": H, "C": C, "K": K,
+                                            "masked": node_mask is not None or edge_mask is not None, "feat_bytes": 2,
+                                            "fused_logits": True})
+            ev0.record()
+        rc = lib.isg_gatv2_edge_logits_f16(
+            _chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(),
+            _chk_rows(x_l, "x_l", torch.float16), x_l.stride(0), 0, _chk_rows(x_r, "x_r", torch.float16), x_r.stride(0), 0, attp,
+            plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(), em, nm, logits.data_ptr(), E, H, C, K,
+            float(negative_slope), _stream())
+        if rc == ISG_EUNSUPPORTED:
+            if timer is not None:
+                timer.drop_last()
+            return None
+        _lib.check(rc, "isg_gatv2_edge_logits_f16")
+        if timer is not None:
+            evm.record()
+        rc = lib.isg_gatv2_mp_fwd_logits_f16(
+            _chk_rows(x_l, "x_l", torch.float16), logits.data_ptr(), attp,
+            _chk(None if bias is None else bias.reshape(-1), "bias", torch.float32, (HC,), optional=True),
+            plan.rowptr.data_ptr(), plan.eid.data_ptr(), plan.src.data_ptr(), nm, em, out.data_ptr(), alpha.data_ptr(),
+            N, E, H, C, float(negative_slope), plan.ptr.data_ptr(), plan.eptr.data_ptr(), plan.dst.data_ptr(),
+            plan.B, plan.nmax, plan.emax, x_l.stride(0), _stream())
+        if rc == ISG_EUNSUPPORTED:
+            if timer is not None:
+                timer.drop_last()
+            return None
+        _lib.check(rc, "isg_gatv2_mp_fwd_logits_f16")
+        if timer is not None:
+            ev1.record()
+        return out, alpha
     logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     alpha = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
     # the result as the segmented planes32 operand of x_proj.0 (the flat kernel, H = 4: the reference's C = 300) -- or fp32 rows

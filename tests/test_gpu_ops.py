@@ -779,6 +779,42 @@ def test_long_reductions_take_slices_of_the_producers_partial_maxima(dev):
     assert err <= 2.0 * err32
 
 
+@pytest.mark.parametrize("mask", [None, "node", "edge"])
+@pytest.mark.parametrize("H,C,K", [(4, 128, 128), (4, 128, 300), (2, 96, 128)])
+def test_edge_logits_pair_on_fp16_rows_matches_the_unfused_fp16_kernels(dev, mask, H, C, K):
+    """BASELINE configs[4]'s storage (x_l / x_r / e_proj / out as HALF rows, fp32 arithmetic): isg_gatv2_edge_logits_f16 +
+    isg_gatv2_mp_fwd_logits_f16 against isg_linear_f16x3_f16 + isg_gatv2_mp_fwd_f16.  The rows kernel rounds the edge projection
+    to half where the un-fused path stores it; the fp32 sums the two round are the same three-product sums accumulated in a
+    different order, so about one element in 5 000 sits close enough to a half-precision rounding boundary to round the other way
+    (2^-11 of |e_proj| ~ 1): the logits then differ by ~5e-4 on those edges, alpha by its share of that, the output row by a
+    few half-precision ulps.  The bounds say exactly that much and no more."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(9 + H + C + K)
+    sizes = torch.randint(3, 40, (60,), generator=gen).tolist()
+    batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=(5, 40))
+    N, E, HC = batch.numel(), ei.size(1), H * C
+    x_lr = torch.randn(N, 2 * HC, generator=gen).half().to(dev)
+    x_l, x_r = x_lr[:, :HC], x_lr[:, HC:]
+    ea = torch.randn(E, K, generator=gen).to(dev)
+    w = (torch.randn(HC, K, generator=gen) / K ** 0.5).to(dev)
+    att, bias = torch.randn(1, H, C, generator=gen).to(dev), torch.randn(HC, generator=gen).to(dev)
+    nm = (torch.rand(N, generator=gen) < 0.6).float().to(dev) if mask == "node" else None
+    em = (torch.rand(E, generator=gen) < 0.6).float().to(dev) if mask == "edge" else None
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    res = ops.gatv2_mp_edge_logits(x_l, x_r, ea, w, att, plan, H, bias=bias, node_mask=nm, edge_mask=em)
+    assert res is not None, "the fp16 pair has no kernel for this shape"
+    out_f, alpha_f = res
+    assert out_f.dtype == torch.float16
+    e_proj = ops.linear(ea, w, None, out_dtype=torch.float16)
+    out_u, alpha_u = ops.gatv2_mp(x_l, x_r, e_proj, att, plan, H, bias=bias, node_mask=nm, edge_mask=em)
+    assert out_u.dtype == torch.float16
+    da = (alpha_f - alpha_u).abs().max().item()
+    do = (out_f.float() - out_u.float()).abs().max().item()
+    scale = out_u.float().abs().max().item()
+    print(f"fp16 pair H={H} C={C} K={K} mask={mask}: alpha vs un-fused {da:.2e}, out vs un-fused {do:.2e} (|out| <= {scale:.1f})")
+    assert da < 2e-3 and do <= 2.0 ** -9 * max(scale, 1.0)       # out: two half-precision ulps of its largest value, at most
+
+
 @pytest.mark.parametrize("C,K", [(300, 300), (128, 128), (128, 64)])
 @pytest.mark.parametrize("sizes,extra", [((2,), 0), ((1, 3), 1), ((7, 2, 5), 2), ((33,) * 9, 3)])
 def test_edge_logits_on_tiny_and_ragged_batches(dev, sizes, extra, C, K):
