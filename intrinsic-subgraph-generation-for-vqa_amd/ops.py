@@ -853,9 +853,11 @@ def gatv2_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Tenso
     E, K = edge_attr.shape
     planes, inv = _edge_logits_weight(w_edge, H)
     logits = torch.empty(E, H, dtype=torch.float32, device=x_l.device)
-    rc = lib.isg_gatv2_edge_logits(
+    fdt = x_l.dtype                      # fp32 rows, or half rows (isg_gatv2_edge_logits_f16: BASELINE configs[4]'s storage, K >= 128)
+    entry = lib.isg_gatv2_edge_logits if fdt == torch.float32 else lib.isg_gatv2_edge_logits_f16
+    rc = entry(
         _chk_rows(edge_attr, "edge_attr"), edge_attr.stride(0), planes.data_ptr(), inv.data_ptr(),
-        _chk_rows(x_l, "x_l"), x_l.stride(0), 0, _chk_rows(x_r, "x_r"), x_r.stride(0), 0,
+        _chk_rows(x_l, "x_l", fdt), x_l.stride(0), 0, _chk_rows(x_r, "x_r", fdt), x_r.stride(0), 0,
         _chk(att.reshape(-1), "att", torch.float32, (HC,)), plan.eid.data_ptr(), plan.src.data_ptr(), plan.dst.data_ptr(),
         _chk(None if edge_mask is None else edge_mask.reshape(-1), "edge_mask", torch.float32, (E,), optional=True),
         _chk(None if node_mask is None else node_mask.reshape(-1), "node_mask", torch.float32, (N,), optional=True),

@@ -113,8 +113,8 @@ def test_linear_h3p_segmented_operand_gives_the_strict_builds_bits(dev, both, pl
 
 
 @pytest.mark.parametrize("masked", [False, True])
-@pytest.mark.parametrize("C,K", [(300, 300), (128, 128), (96, 128)])
-def test_rows_kernel_edge_logits_give_the_strict_builds_bits(dev, both, masked, C, K):
+@pytest.mark.parametrize("C,K,half", [(300, 300, False), (128, 128, False), (96, 128, False), (128, 128, True), (128, 300, True)])
+def test_rows_kernel_edge_logits_give_the_strict_builds_bits(dev, both, masked, C, K, half):
     """isg_gatv2_edge_logits' rows kernel (K = 128 and 128 < K <= 304; H = 4, C = 300 / K = 300 is the reference's own width): the
     weight tiles reach a three-slot LDS ring by LDS-DMA from a requesting wave of their own, handed over by one counted wait and one
     raw barrier per tile; at K = 128 the tile loop is unrolled by four (the panel kernel's summation order)."""
@@ -125,6 +125,8 @@ def test_rows_kernel_edge_logits_give_the_strict_builds_bits(dev, both, masked, 
     N, E, H = batch.numel(), ei.size(1), 4
     xl = torch.randn(N, H * C, generator=gen).to(dev)
     xr = torch.randn(N, H * C, generator=gen).to(dev)
+    if half:                 # BASELINE configs[4]'s half feature rows (isg_gatv2_edge_logits_f16)
+        xl, xr = xl.half(), xr.half()
     ea = torch.randn(E, K, generator=gen).to(dev)
     w = (torch.randn(H * C, K, generator=gen) * 0.05).to(dev)
     att = torch.randn(1, H, C, generator=gen).to(dev)
