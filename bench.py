@@ -67,7 +67,14 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU (BASELINE configs[1]: 4096)")
+    ap.add_argument("--graphs", type=int, default=None,
+                    help="graphs per GPU (default: 4096 = BASELINE configs[1]; 2048 with --workload cfg5)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg5"], default="cfg2",
+                    help="cfg2 (default): BASELINE configs[1] / configs[3], every rank its own 4096-graph batch.  cfg5: BASELINE "
+                         "configs[4] -- ONE generated batch of N x --graphs skewed graphs (8-200 nodes, power-law in-degree, AIMLE k=5, "
+                         "fp16 feature rows) sharded into contiguous graph ranges balanced by sum(nodes + edges) "
+                         "(distributed.shard_workload(balance=True)); ranks then hold different graph counts and the logits "
+                         "all-gather is the ragged GatherPipeline (row counts exchanged once, rows padded to the largest shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the configs[4] leg (skewed graphs, AIMLE, fp16 rows)")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-dispatch leg (configs[1] + a few graphs beyond a tile)")
@@ -94,9 +101,14 @@ def parse(argv=None):
                          "steps' length behind the following steps' kernels (DESIGN 7, option 2)")
     ap.add_argument("--no-fuse-logits", action="store_true",
                     help="A/B: lin_edge as its own GEMM + the message-passing kernel streaming e_proj (the round-1 boundary)")
-    ap.add_argument("--features", choices=["fp32", "fp16"], default="fp32",
-                    help="storage of the projected rows (fp16 = BASELINE configs[4]'s variant; NOT the headline config)")
-    return ap.parse_args(argv)
+    ap.add_argument("--features", choices=["fp32", "fp16"], default=None,
+                    help="storage of the projected rows (default: fp32; fp16 with --workload cfg5 = BASELINE configs[4]'s storage)")
+    args = ap.parse_args(argv)
+    if args.graphs is None:
+        args.graphs = 4096 if args.workload == "cfg2" else 2048
+    if args.features is None:
+        args.features = "fp32" if args.workload == "cfg2" else "fp16"
+    return args
 
 
 def launcher_argv(gpus: int, script_args, port: int):
@@ -395,7 +407,7 @@ def time_unfused_mp(wl, cfg, dev, launches: int = 20):
 # keys of the ONE JSON line (N = 1, default flags); validate_line() runs before the line is printed and in a CPU test over the
 # committed sample (profiles/r03_*bench.json)
 LINE_SCHEMA = {
-    "": ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+    "": ["metric", "value", "unit", "summary", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
          "dtype", "data", "config", "roofline", "cpu_baseline", "rccl", "fallbacks", "dense_err_vs_fp32", "cfg5", "full_model", "mixed",
          "sustained"],
     "config": ["workload", "graphs_per_gpu", "global_batch", "parallelism"],
@@ -653,14 +665,29 @@ def main(argv=None):
     ops.MP_KERNEL = args.mp_kernel
     ops.GEMM_BACKEND = args.gemm
     ops.FUSE_LOGITS = not args.no_fuse_logits
-    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": args.graphs,
-                                      "seed": synthetic.CFG2.seed + rank, "feature_dtype": args.features})
-    wl = synthetic.make_workload(cfg).to(dev)
+    from isubgvqa_amd.distributed import GatherPipeline, shard_workload
+    cfg5 = args.workload == "cfg5"
+    shard_cost = None
+    if cfg5:
+        # BASELINE configs[4]: every rank generates the SAME batch of world x --graphs skewed graphs on the host (seeded) and keeps
+        # its contiguous range, balanced by sum(nodes + edges); the ranks' graph counts differ
+        import dataclasses
+        cfg_all = synthetic.WorkloadConfig(**{**synthetic.CFG5.__dict__, "num_graphs": world * args.graphs,
+                                              "feature_dtype": args.features})
+        wl_host = shard_workload(synthetic.make_workload(cfg_all), rank, world, balance=True)
+        cfg = dataclasses.replace(cfg_all, num_graphs=wl_host.num_graphs)
+        shard_cost = int(wl_host.x.size(0) + wl_host.edge_index.size(1))
+        wl = wl_host.to(dev)
+        del wl_host
+    else:
+        cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": args.graphs,
+                                          "seed": synthetic.CFG2.seed + rank, "feature_dtype": args.features})
+        wl = synthetic.make_workload(cfg).to(dev)
     model = synthetic.build_answer_model(cfg).to(dev).eval()
     N, E = wl.x.size(0), wl.edge_index.size(1)
+    total_graphs = world * args.graphs                  # cfg2: world x B_local; cfg5: the one batch all ranks share
     # the per-step collective: up to --gather-depth all-gathers in flight on the communicator's stream beside the next steps' kernels
-    from isubgvqa_amd.distributed import GatherPipeline
-    pipe = GatherPipeline(cfg.num_graphs, 1842, dev, what=args.gather, depth=args.gather_depth)
+    pipe = GatherPipeline(cfg.num_graphs, 1842, dev, what=args.gather, depth=args.gather_depth, ragged=cfg5)
     drain = pipe.drain
 
     def step(i: int):
@@ -751,6 +778,13 @@ def main(argv=None):
         per_rank = {"ms_per_step": [round(float(v[0]), 4) for v in allr],
                     "closing_barrier_wait_ms": [round(float(v[1]), 3) for v in allr],
                     "host_issue_ms_per_step": [round(float(v[2]), 4) for v in allr]}
+        if cfg5:       # what the balanced partition gave every rank: graphs, sum(nodes + edges), and the imbalance of the latter
+            mine = torch.tensor([cfg.num_graphs, shard_cost], dtype=torch.int64, device=dev)
+            allc = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allc, mine)
+            costs = [int(v[1]) for v in allc]
+            per_rank.update(graphs=[int(v[0]) for v in allc], nodes_plus_edges=costs,
+                            imbalance_max_over_mean=round(max(costs) / (sum(costs) / len(costs)), 4))
     # evidence that the communicator saw every rank: backend, world size, each rank's device index and GPU name
     devs = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=dev)
     if world > 1:
@@ -780,8 +814,9 @@ def main(argv=None):
     parts = None
     if fused:
         split = timer.split_ms()
-        own = [(ops.edge_logits_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["K"], m["masked"]),
-                ops.mp_logits_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"])) for m in timer.meta]
+        own = [(ops.edge_logits_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["K"], m["masked"], feat_bytes=m.get("feat_bytes", 4)),
+                ops.mp_logits_algorithmic_bytes(m["N"], m["E"], m["H"], m["C"], m["masked"], feat_bytes=m.get("feat_bytes", 4)))
+               for m in timer.meta]
         n = max(len(split), 1)
         t0, t1 = sum(a for a, _ in split) / n, sum(b for _, b in split) / n
         b0, b1 = sum(a for a, _ in own) / n, sum(b for _, b in own) / n
@@ -793,7 +828,7 @@ def main(argv=None):
                   "own_achieved_GBps": round(b1 / (t1 * 1e-3) / 1e9, 1), "own_frac": round(b1 / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}]
     # continuity with round 1: the UN-fused message-passing kernel on the same batch, timed here outside the timed region
     unfused = None
-    if (fused or tile_conv) and rank == 0:
+    if (fused or tile_conv) and rank == 0 and not cfg5:
         unfused = time_unfused_mp(wl, cfg, dev)
 
     if rank == 0:
@@ -801,18 +836,27 @@ def main(argv=None):
                                                                                    ("logits_pair" if fused else args.mp_kernel)),
                                             with_source=True)
         res = {
-            "metric": "GQA questions/sec", "value": round(world * cfg.num_graphs * args.steps / dt, 1),
-            "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "GQA questions/sec", "value": round(total_graphs * args.steps / dt, 1),
+            "unit": "questions/s",
+            # the other legs' headline numbers, flat and at the FRONT of the line (filled in below as the legs run): a record that
+            # keeps only the head of the line keeps them
+            "summary": {"configs1_ms_per_step": round(dt / args.steps * 1e3, 4) if not cfg5 else None},
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: MGAT(3 masked-GATv2 layers, C=128, H=4, masks [1,1,0.15], Gumbel "
+            "vs_baseline": None, "dtype": "f32" if args.features == "fp32" else "f32 arithmetic on f16 feature rows", "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[4]: ONE batch of skewed synthetic scene graphs (8-200 nodes, Pareto sizes, power-law "
+                                    "in-degree) sharded into contiguous graph ranges balanced by sum(nodes + edges); MGAT(3 masked-GATv2 "
+                                    "layers, C=128, H=4, masks [1,1,0.15], AIMLE k=5, fp16 feature rows / fp32 arithmetic) + "
+                                    "GlobalAttention pooling + 1842-way classifier; graph plan (CSR) built every step; ragged logits "
+                                    "all-gather") if cfg5 else
+                                   "BASELINE configs[1]: MGAT(3 masked-GATv2 layers, C=128, H=4, masks [1,1,0.15], Gumbel "
                                    "top-k k=5) + GlobalAttention pooling + 1842-way classifier over synthetic "
                                    "GQA-shaped scene graphs (~20 nodes, ~50 edges); graph plan (CSR) built every step; "
                                    "question encoder/decoder not included (full model needs C=300, SURVEY §5.1)",
-                       "graphs_per_gpu": cfg.num_graphs, "global_batch": world * cfg.num_graphs,
+                       "graphs_per_gpu": args.graphs if cfg5 else cfg.num_graphs, "global_batch": total_graphs,
                        "nodes_per_gpu": N, "edges_per_gpu": E, "channels": cfg.channels, "heads": cfg.heads,
-                       "layers": cfg.layers, "sampler": "gumbel(in-kernel Philox noise)", "k": cfg.sample_k,
-                       "parallelism": f"dp{world} (graphs sharded, RCCL all-gather of logits)" if world > 1 else "dp1",
+                       "layers": cfg.layers, "sampler": ("aimle" if cfg5 else "gumbel") + "(in-kernel Philox noise)", "k": cfg.sample_k,
+                       "parallelism": (f"dp{world} (graphs sharded, RCCL all-gather of logits" + (", ragged shards" if cfg5 else "") + ")") if world > 1 else "dp1",
                        "feature_rows": args.features,
                        "launch": "eager" if graph is None else "hipgraph: one captured step (plan build + model) replayed; Gumbel noise from torch's generator inside the graph; the roofline's kernel durations from eager steps after the timed region", "edge_projection": "unfused" if args.no_fuse_logits else ("inside isg_gatv2_layer_conv (with lin_l | lin_r)" if layer_conv else "inside isg_gatv2_tile_conv" if tile_conv else "folded into the logits"), "layer_tail": "isg_mgat_dense_tail (x_proj + instruction attention + GraphNorm + residual + next gate, one launch per layer)" if ops.FUSE_DENSE_TAIL else "un-fused", "dense": ("exact-split fp32 Linears on MFMA: isg_linear_f16x3 / _f16x3_tile (2 fp16 planes, 3 products, per-row scales), isg_linear_bf16x6 for the small ones" if args.gemm == "bf16x6" else "hipBLASLt fp32 via torch")},
             "roofline": {"bound": "hbm",
@@ -830,6 +874,7 @@ def main(argv=None):
                          "algorithmic_bytes_per_launch": int(mp_bytes),
                          "avg_launch_us": round(mp_ms * 1e3, 2), "launches_timed": len(durs)},
         }
+        res["summary"].update(roofline_frac=res["roofline"]["frac"], mp_avg_launch_us=res["roofline"]["avg_launch_us"])
         if tile_conv:
             m0 = timer.meta[0]
             # own minimum: edge planes + (x_l and x_r, or with lin_l | lin_r inside: the gated node rows) in, out + alpha back, CSR
@@ -882,7 +927,7 @@ def main(argv=None):
             progress("dense_err_vs_fp32 leg")
             with torch.no_grad():
                 res["dense_err_vs_fp32"] = dense_err_vs_fp32(dev)
-        if world == 1 and not args.no_sustained:
+        if world == 1 and not cfg5 and not args.no_sustained:
             # >= 2 s of back-to-back configs[1] steps: the clocks under load, and something the driver's busy sampler can see
             progress("sustained leg (>= 2 s of steps)")
             with torch.no_grad():
@@ -895,26 +940,35 @@ def main(argv=None):
                 ds = time.perf_counter() - t0
             res["sustained"] = {"seconds": round(ds, 3), "steps": n_s, "ms_per_step": round(ds / n_s * 1e3, 4),
                                 "ratio_to_burst": round((ds / n_s) / (dt / args.steps), 4)}
-        if world == 1 and not args.no_full_model:
+            res["summary"]["sustained_ms_per_step"] = res["sustained"]["ms_per_step"]
+        if world == 1 and not cfg5 and not args.no_full_model:
             del model, wl
             torch.cuda.empty_cache()
             progress(f"configs[1] step timed: {dt / args.steps * 1e3:.3f} ms; full model leg ({args.full_model_graphs} graphs)")
             res["full_model"] = full_model_rate(dev, args.full_model_graphs)
-        if world == 1 and not args.no_cfg5:
+            fk = res["full_model"]["kernels"]
+            res["summary"].update(full_model_ms_per_step=res["full_model"]["ms_per_step"],
+                                  full_model_questions_per_s=res["full_model"]["questions_per_s"],
+                                  full_model_linear_h3p_frac_of_mfma_peak=fk["linear_h3p"]["frac"],
+                                  full_model_mp_pair_frac_of_hbm_peak=fk["gatv2_mp_pair"]["frac"])
+        if world == 1 and not cfg5 and not args.no_cfg5:
             progress("cfg5 leg (skewed graphs, AIMLE, fp16 rows)")
             res["cfg5"] = cfg5_leg(dev)
-        if world == 1 and not args.no_mixed:
+            res["summary"].update(cfg5_ms_per_step=res["cfg5"]["ms_per_step"], cfg5_mp_frac_of_hbm_peak=res["cfg5"]["mp_frac_of_hbm_peak"])
+        if world == 1 and not cfg5 and not args.no_mixed:
             progress("mixed leg (configs[1] + 8 graphs beyond a tile)")
             res["mixed"] = mixed_leg(dev)
+            res["summary"].update(mixed_ms_per_step=res["mixed"]["ms_per_step"],
+                                  mixed_host_issue_ms_per_step=res["mixed"]["host_issue_ms_per_step"])
         ops.check_plans()           # any understated GraphPlan hint of this run raises here
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not cfg5 and not args.no_cpu_baseline:
             progress("cpu_baseline leg (oracle on the host cores)")
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_graphs, args.cpu_seconds, args.cpu_threads)
             res["cpu_baseline"]["cpu"] = cpu_model_string()
             res["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
         else:
             res["cpu_baseline"] = None
-        validate_line(res, full=world == 1 and not (args.no_cpu_baseline or args.no_full_model or args.no_cfg5 or args.no_mixed
+        validate_line(res, full=world == 1 and not cfg5 and not (args.no_cpu_baseline or args.no_full_model or args.no_cfg5 or args.no_mixed
                                                     or args.no_sustained))
         print(json.dumps(res), flush=True)
     if world > 1:

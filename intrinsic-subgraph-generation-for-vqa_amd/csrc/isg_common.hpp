@@ -31,14 +31,19 @@ inline int device_cus() {
   return cus[d];
 }
 template <auto Kernel>
-inline bool dyn_lds_ok(int bytes) {       // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device)
-  static signed char state[64] = {};      // 0 unknown, 1 set, -1 refused
-  const int d = current_device();
-  if (d < 0) return false;
-  if (!state[d])
-    state[d] = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) ==
-                       hipSuccess ? 1 : -1;
-  return state[d] > 0;
+inline bool dyn_lds_ok(int bytes) {       // hipFuncAttributeMaxDynamicSharedMemorySize per (kernel, device): raised whenever a
+  static int granted[64] = {};            // caller asks for more than the largest size set so far (0 nothing set yet, -1 refused) --
+  const int d = current_device();         // a first caller with a small shape must not cap a later, larger one
+  if (d < 0 || bytes < 0) return false;
+  if (granted[d] < 0) return false;
+  if (bytes > granted[d] || granted[d] == 0) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+      if (granted[d] == 0) granted[d] = -1;        // never worked on this device: do not ask again on every launch
+      return false;
+    }
+    granted[d] = bytes > 0 ? bytes : 1;
+  }
+  return true;
 }
 
 // ---- cross-lane movement via DPP (no LDS traffic) --------------------------------------------

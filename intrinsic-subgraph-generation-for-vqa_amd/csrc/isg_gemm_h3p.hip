@@ -915,15 +915,18 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
   const long long tm = (M + P3_T - 1) / P3_T, tn = (N + P3_T - 1) / P3_T;
   const long long blocks = tn * ((tm + 7) / 8 * 8);
   if (blocks >= (1ll << 31)) return ISG_EUNSUPPORTED;
-  P3Args a = {};
-  a.A = reinterpret_cast<const _Float16 *>(a_planes); a.W = reinterpret_cast<const _Float16 *>(w_planes);
-  a.a_inv = a_inv; a.w_inv = w_inv; a.bias = bias; a.D = d; a.Dp = reinterpret_cast<_Float16 *>(d_planes); a.d_inv = d_inv;
-  a.d_bound = d_bound; a.M = (int)M; a.N = N; a.KT = KT; a.ldd = ldd; a.tiles_n = (int)tn;
-  a.a_inv0 = a_inv_first; a.kseg = k_split >> 5;
   static const long long nt_mb = [] { const char *e = getenv("ISG_GEMM_NT_MB"); return e ? atoll(e) : 128ll; }();
   const bool large = nt_mb >= 0 && (long long)M * N * 4 >= nt_mb * 1000000ll;
   const int forced = g_h3p_store_policy.load(std::memory_order_relaxed);
-  a.nt_store = !large || planes_out ? 0 : forced >= 0 ? forced : (KT >= 16 ? 1 : 0);      // a planes32 result: plain (measured)
+  // every field named, in declaration order: -Werror=missing-field-initializers (HIP_FLAGS) refuses a field left out
+  P3Args a = {
+      .A = reinterpret_cast<const _Float16 *>(a_planes), .W = reinterpret_cast<const _Float16 *>(w_planes), .a_inv = a_inv,
+      .w_inv = w_inv, .bias = bias, .D = d, .Dp = reinterpret_cast<_Float16 *>(d_planes), .d_inv = d_inv, .d_bound = d_bound,
+      .M = (int)M, .N = N, .KT = KT, .ldd = ldd, .tiles_n = (int)tn,
+      .nt_store = !large || planes_out ? 0 : forced >= 0 ? forced : (KT >= 16 ? 1 : 0),      // a planes32 result: plain (measured)
+      .a_inv0 = a_inv_first, .kseg = k_split >> 5};
+  if (!a.A || !a.W || !a.a_inv || !a.w_inv || (a.kseg && !a.a_inv0) || (planes_out ? (!a.Dp || !a.d_inv || !a.d_bound) : !a.D))
+    return ISG_EINVAL;                         // the struct the kernels dereference, not the parameters it was filled from
   hipStream_t st = as_stream(stream);
   static const int version = [] { const char *e = getenv("ISG_H3P_V"); return e ? atoi(e) : 2; }();
   if (planes_out && (N & 31) && (version == 1 || KT < Q3_HEAD)) return ISG_EUNSUPPORTED;   // the 256 x 256 form pads no columns
@@ -934,14 +937,11 @@ extern "C" int isg_linear_h3p(const uint16_t *a_planes, const float *a_inv, cons
     // the result is addressed through a buffer descriptor with 32-bit byte offsets
     if ((planes_out ? M * (int64_t)(((N + 31) & ~31) * 4) : M * (int64_t)ldd * 4) >= (1ll << 32) - 16) return ISG_EUNSUPPORTED;
     const int ncu = device_cus();
-    Q3Args q = {};
-    q.p = a;
-    q.tiles_m = (int)tm;
     const long long tn2 = (N + Q3_BN - 1) / Q3_BN;
     const long long total = tn2 * ((tm + 7) / 8 * 8);
     if (total >= (1ll << 31)) return ISG_EUNSUPPORTED;
+    Q3Args q = {.p = a, .tiles_m = (int)tm, .total_l = (int)total};
     q.p.tiles_n = (int)tn2;
-    q.total_l = (int)total;
     const unsigned grid = (unsigned)(total < ncu ? total : ncu);
 #define ISG_Q3H(ACT_, PO_, H_)                                                                                    \
   do {                                                                                                            \

@@ -51,11 +51,13 @@ struct LcArgs {
   const _Float16 *ep;               // edge features as scaled (hi, mid) planes in CSR slot order [E][2][128] (isg_edge_planes)
   const float *ep_inv;              // [E]
   const _Float16 *We;               // lin_edge.weight [H*C, K] fragment planes
-  const float *we_inv, *att, *bias; // [H*C]; bias may be NULL
+  const float *we_inv, *att;        // [H*C]
+  const float *bias;                // [H*C], optional
   const int *rowptr, *eid, *src, *dst, *ntiles;
   const int4 *tile_info;
-  const float *edge_mask, *node_mask;
-  float *out, *alpha, *rowmax;
+  const float *edge_mask, *node_mask;   // optional (NULL: the layer is not masked)
+  float *out, *alpha;
+  float *rowmax;                    // optional
   int N, E, H, KSE, NTE, ldo;
   float slope;
 };
@@ -726,14 +728,17 @@ extern "C" int isg_gatv2_layer_conv(const uint16_t *x_planes, const float *x_inv
       (E > 0 && (!edge_planes || !edge_inv_scale || !eid || !src || !dst || !alpha)) || !we_frag || !we_inv_scale || !att || !rowptr ||
       !tile_info || !ntiles || !out)
     return ISG_EINVAL;
-  LcArgs a;
-  a.xp = reinterpret_cast<const _Float16 *>(x_planes); a.xinv = x_inv_scale;
-  a.Wn = reinterpret_cast<const _Float16 *>(wn_frag); a.wn_inv = wn_inv_scale; a.bn = bn;
-  a.ep = reinterpret_cast<const _Float16 *>(edge_planes); a.ep_inv = edge_inv_scale;
-  a.We = reinterpret_cast<const _Float16 *>(we_frag); a.we_inv = we_inv_scale; a.att = att; a.bias = bias; a.rowptr = rowptr;
-  a.eid = eid; a.src = src; a.dst = dst; a.ntiles = ntiles; a.tile_info = reinterpret_cast<const int4 *>(tile_info);
-  a.edge_mask = edge_mask; a.node_mask = node_mask; a.out = out; a.alpha = alpha; a.rowmax = rowmax; a.N = (int)N; a.E = (int)E;
-  a.H = H; a.KSE = (K_edge + 15) / 16; a.NTE = H * C / 32; a.ldo = ldo; a.slope = negative_slope;
+  // every field named, in declaration order: -Werror=missing-field-initializers (HIP_FLAGS) refuses a field left out
+  LcArgs a = {
+      .xp = reinterpret_cast<const _Float16 *>(x_planes), .xinv = x_inv_scale, .Wn = reinterpret_cast<const _Float16 *>(wn_frag),
+      .wn_inv = wn_inv_scale, .bn = bn, .ep = reinterpret_cast<const _Float16 *>(edge_planes), .ep_inv = edge_inv_scale,
+      .We = reinterpret_cast<const _Float16 *>(we_frag), .we_inv = we_inv_scale, .att = att, .bias = bias, .rowptr = rowptr,
+      .eid = eid, .src = src, .dst = dst, .ntiles = ntiles, .tile_info = reinterpret_cast<const int4 *>(tile_info),
+      .edge_mask = edge_mask, .node_mask = node_mask, .out = out, .alpha = alpha, .rowmax = rowmax, .N = (int)N, .E = (int)E,
+      .H = H, .KSE = (K_edge + 15) / 16, .NTE = H * C / 32, .ldo = ldo, .slope = negative_slope};
+  if (!a.xp || !a.xinv || !a.Wn || !a.wn_inv || !a.bn || (a.E > 0 && (!a.ep || !a.ep_inv || !a.eid || !a.src || !a.dst || !a.alpha)) ||
+      !a.We || !a.we_inv || !a.att || !a.rowptr || !a.tile_info || !a.ntiles || !a.out)
+    return ISG_EINVAL;                         // the struct the kernel dereferences, not the parameters it was filled from
   const int cus = device_cus();
   int gpx = (cus / 8) / H;                                // groups per XCD: one workgroup per CU
   if (gpx < 1) gpx = 1;
@@ -1039,12 +1044,16 @@ extern "C" int isg_readout_tile(const float *x, int32_t ldx, const uint16_t *w1_
       !tile_ptr || !tile_info || !ntiles)
     return ISG_EINVAL;
   if (!isg::dyn_lds_ok<&isg::readout_tile_kernel>(isg::RO_SMEM_BYTES)) return ISG_EUNSUPPORTED;
-  isg::RoArgs a;
-  a.x = x; a.w1f = reinterpret_cast<const _Float16 *>(w1_frag); a.w2f = reinterpret_cast<const _Float16 *>(w2_frag);
-  a.w1_inv = w1_inv_scale; a.b1 = b1; a.w2_inv = w2_inv_scale; a.b2 = b2; a.y_bound = y_bound; a.q = q; a.node_mask = node_mask;
-  a.out = out; a.gate = gate; a.ptr = ptr; a.tile_ptr = tile_ptr; a.ntiles = ntiles;
-  a.tile_info = reinterpret_cast<const int4 *>(tile_info); a.batch = reinterpret_cast<const long long *>(batch);
-  a.N = (int)N; a.ldx = ldx; a.denom = sqrtf((float)C);      // att_pooling.py:68 divides by torch.sqrt(torch.tensor(C)): fp32 sqrt
+  // every field named, in declaration order: -Werror=missing-field-initializers (HIP_FLAGS) refuses a field left out
+  isg::RoArgs a = {
+      .x = x, .w1f = reinterpret_cast<const _Float16 *>(w1_frag), .w2f = reinterpret_cast<const _Float16 *>(w2_frag),
+      .w1_inv = w1_inv_scale, .b1 = b1, .w2_inv = w2_inv_scale, .b2 = b2, .y_bound = y_bound, .q = q, .node_mask = node_mask,
+      .out = out, .gate = gate, .ptr = ptr, .tile_ptr = tile_ptr, .ntiles = ntiles,
+      .tile_info = reinterpret_cast<const int4 *>(tile_info), .batch = reinterpret_cast<const long long *>(batch),
+      .N = (int)N, .ldx = ldx, .denom = sqrtf((float)C)};     // att_pooling.py:68 divides by torch.sqrt(torch.tensor(C)): fp32 sqrt
+  if (!a.x || !a.w1f || !a.w2f || !a.w1_inv || !a.b1 || !a.w2_inv || !a.b2 || !a.y_bound || !a.q || !a.out || !a.gate || !a.ptr ||
+      !a.tile_ptr || !a.ntiles || !a.tile_info || !a.batch)
+    return ISG_EINVAL;                         // the struct the kernel dereferences, not the parameters it was filled from
   isg::readout_tile_kernel<<<(unsigned)max_tiles, 256, isg::RO_SMEM_BYTES, isg::as_stream(stream)>>>(a);
   return isg::check_launch();
 }

@@ -219,8 +219,9 @@ struct DtArgs {
   const float *w2_inv, *b2;
   const float *ins, *h;    // [B, 128], [N, 128]
   const float *gn_w, *gn_b, *gn_ms;
-  const float *node_mask, *ins_next;
-  float *h_out, *xg_out, *xinv_out;
+  const float *node_mask, *ins_next;    // optional (ins_next: required with xg_out / xp_out, checked by the wrapper)
+  float *h_out;
+  float *xg_out, *xinv_out;         // optional
   _Float16 *xp_out;                 // the gated rows as scaled (hi, mid) planes [N][2][128] for isg_gatv2_layer_conv (optional)
   const int *ptr, *tile_ptr, *ntiles;
   const int4 *tile_info;   // {first node, nodes, ., .} per tile: the rows' loads start one round trip after the launch
@@ -674,14 +675,18 @@ extern "C" int isg_mgat_dense_tail(const float *conv_out, int32_t lda, const flo
       ((xg_out || xp_out) && !ins_next) || (xp_out && !xinv_out))
     return ISG_EINVAL;
   if (!dyn_lds_ok<&mgat_dense_tail_kernel>(DT_SMEM_BYTES)) return ISG_EUNSUPPORTED;
-  DtArgs a = {};
-  a.a = conv_out; a.a_rowmax = a_rowmax; a.w1f = reinterpret_cast<const _Float16 *>(w1_frag); a.w1_inv = w1_inv_scale;
-  a.b1 = b1; a.y_bound = y_bound; a.w2f = reinterpret_cast<const _Float16 *>(w2_frag); a.w2_inv = w2_inv_scale; a.b2 = b2; a.ins = ins; a.h = h;
-  a.gn_w = gn_weight; a.gn_b = gn_bias; a.gn_ms = gn_mean_scale; a.node_mask = node_mask; a.ins_next = ins_next;
-  a.h_out = h_out; a.xg_out = xg_out; a.xp_out = reinterpret_cast<_Float16 *>(xp_out); a.xinv_out = xinv_out; a.ptr = ptr; a.tile_ptr = tile_ptr; a.ntiles = ntiles;
-  a.tile_info = reinterpret_cast<const int4 *>(tile_info);
-  a.batch = reinterpret_cast<const long long *>(batch);
-  a.N = (int)N; a.lda = lda; a.P = P; a.ldp = ldp; a.eps = (float)eps; a.denom = (float)sqrt((double)DT_C);
+  // every field named, in declaration order: -Werror=missing-field-initializers (HIP_FLAGS) refuses a field left out
+  DtArgs a = {
+      .a = conv_out, .a_rowmax = a_rowmax, .w1f = reinterpret_cast<const _Float16 *>(w1_frag), .w1_inv = w1_inv_scale, .b1 = b1,
+      .y_bound = y_bound, .w2f = reinterpret_cast<const _Float16 *>(w2_frag), .w2_inv = w2_inv_scale, .b2 = b2, .ins = ins, .h = h,
+      .gn_w = gn_weight, .gn_b = gn_bias, .gn_ms = gn_mean_scale, .node_mask = node_mask, .ins_next = ins_next, .h_out = h_out,
+      .xg_out = xg_out, .xinv_out = xinv_out, .xp_out = reinterpret_cast<_Float16 *>(xp_out), .ptr = ptr, .tile_ptr = tile_ptr,
+      .ntiles = ntiles, .tile_info = reinterpret_cast<const int4 *>(tile_info), .batch = reinterpret_cast<const long long *>(batch),
+      .N = (int)N, .lda = lda, .P = P, .ldp = ldp, .eps = (float)eps, .denom = (float)sqrt((double)DT_C)};
+  if (!a.a || !a.a_rowmax || !a.w1f || !a.w1_inv || !a.b1 || !a.y_bound || !a.w2f || !a.w2_inv || !a.b2 || !a.ins || !a.h || !a.gn_w ||
+      !a.gn_b || !a.gn_ms || !a.h_out || !a.ptr || !a.tile_ptr || !a.ntiles || !a.tile_info || !a.batch ||
+      ((a.xg_out || a.xp_out) && !a.ins_next) || (a.xp_out && !a.xinv_out))
+    return ISG_EINVAL;                         // the struct the kernel dereferences, not the parameters it was filled from
   mgat_dense_tail_kernel<<<(unsigned)max_tiles, 256, DT_SMEM_BYTES, as_stream(stream)>>>(a);
   return check_launch();
 }
@@ -713,11 +718,13 @@ struct TcArgs {
   const _Float16 *ep;               // edge features as scaled (hi, mid) fp16 planes in CSR SLOT order: [E][2][128] (isg_edge_planes)
   const float *ep_inv;              // [E] inverse row scales, slot order
   const _Float16 *Wf;               // lin_edge.weight [H*C, K] as fragment-major (hi, mid) planes
-  const float *w_inv, *att, *bias;  // [H*C]; bias may be NULL
+  const float *w_inv, *att;         // [H*C]
+  const float *bias;                // [H*C], optional
   const int *rowptr, *eid, *src, *dst, *ntiles;
   const int4 *tile_info;            // {first node, nodes, first CSR slot, CSR slots} per tile (isg_tile_plan)
-  const float *edge_mask, *node_mask;
-  float *out, *alpha, *rowmax;      // [N, H*C] (stride ldo), [E, H], [N, H] or NULL
+  const float *edge_mask, *node_mask;   // optional (NULL: the layer is not masked)
+  float *out, *alpha;               // [N, H*C] (stride ldo), [E, H]
+  float *rowmax;                    // [N, H], optional
   int N, E, H, K, KS, NT, ldl, ldr, ldo;
   float slope;
 };
@@ -1066,12 +1073,16 @@ extern "C" int isg_gatv2_tile_conv(const float *x_l, int32_t ldl, const float *x
   if (!x_l || !x_r || (E > 0 && (!edge_planes || !edge_inv_scale || !eid || !src || !dst || !alpha)) || !w_frag || !w_inv_scale || !att || !rowptr ||
       !tile_info || !ntiles || !out)
     return ISG_EINVAL;
-  TcArgs a = {};
-  a.x_l = x_l; a.x_r = x_r; a.ep = reinterpret_cast<const _Float16 *>(edge_planes); a.ep_inv = edge_inv_scale; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
-  a.att = att; a.bias = bias; a.rowptr = rowptr; a.eid = eid; a.src = src; a.dst = dst;
-  a.tile_info = reinterpret_cast<const int4 *>(tile_info); a.ntiles = ntiles; a.edge_mask = edge_mask; a.node_mask = node_mask;
-  a.out = out; a.alpha = alpha; a.rowmax = rowmax; a.N = (int)N; a.E = (int)E; a.H = H; a.K = K; a.KS = (K + 15) / 16;
-  a.NT = H * C / 32; a.ldl = ldl; a.ldr = ldr; a.ldo = ldo; a.slope = negative_slope;
+  // every field named, in declaration order: -Werror=missing-field-initializers (HIP_FLAGS) refuses a field left out
+  TcArgs a = {
+      .x_l = x_l, .x_r = x_r, .ep = reinterpret_cast<const _Float16 *>(edge_planes), .ep_inv = edge_inv_scale,
+      .Wf = reinterpret_cast<const _Float16 *>(w_frag), .w_inv = w_inv_scale, .att = att, .bias = bias, .rowptr = rowptr, .eid = eid,
+      .src = src, .dst = dst, .ntiles = ntiles, .tile_info = reinterpret_cast<const int4 *>(tile_info), .edge_mask = edge_mask,
+      .node_mask = node_mask, .out = out, .alpha = alpha, .rowmax = rowmax, .N = (int)N, .E = (int)E, .H = H, .K = K,
+      .KS = (K + 15) / 16, .NT = H * C / 32, .ldl = ldl, .ldr = ldr, .ldo = ldo, .slope = negative_slope};
+  if (!a.x_l || !a.x_r || (a.E > 0 && (!a.ep || !a.ep_inv || !a.eid || !a.src || !a.dst || !a.alpha)) || !a.Wf || !a.w_inv || !a.att ||
+      !a.rowptr || !a.tile_info || !a.ntiles || !a.out)
+    return ISG_EINVAL;                         // the struct the kernel dereferences, not the parameters it was filled from
   // two workgroups per CU (LDS), 256 CUs: 8 XCDs x (groups per XCD) x H head-workgroups; fewer groups when there are few tiles
   const int gpx_max = device_cus();
   int gpx = (2 * gpx_max / 8) / H;                       // groups per XCD

@@ -288,23 +288,19 @@ static int mp_fwd(const void *x_l, const void *x_r, const void *e_proj, const fl
   if (ld_e == 0) ld_e = H * C;
   if (ld_l < H * C || ld_r < H * C || ld_e < H * C) return ISG_EINVAL;
   if ((ld_l & 3) != 0 || (ld_r & 3) != 0 || (ld_e & 3) != 0) return ISG_EUNSUPPORTED;
-  MpArgs a = {};
-  a.x_l = (const float4 *)x_l; a.x_r = (const float4 *)x_r; a.e_proj = (const float4 *)e_proj;
-  a.att = (const float4 *)att; a.bias = (const float4 *)bias;
-  a.rowptr = rowptr; a.eid = eid; a.src = src;
-  a.node_mask = node_mask; a.edge_mask = edge_mask;
-  a.out = (float4 *)out; a.alpha = alpha;
-  a.N = (int)N; a.C = C; a.H = H; a.slope = negative_slope;
-  a.ldl4 = ld_l >> 2; a.ldr4 = ld_r >> 2; a.lde4 = ld_e >> 2;
-  a.graph_ptr = graph_ptr; a.graph_eptr = graph_eptr; a.dst = dst; a.B = (int)B; a.lrows = 0;
-  a.f16 = f16;
-  a.rowmax = rowmax;
-  a.logits = logits;
-  a.planes = planes; a.planes_inv = planes_inv;
-  a.planes_kt = 2 * ((2 * (C >> 2) + 7) >> 3);      // two half rows of 2 C columns, each padded to whole 32-column lines
   static const int mp_flags = [] { const char *f = getenv("ISG_MP_FLAGS"); return f ? atoi(f) : ISG_MP_DEFAULT_FLAGS; }();
-  a.flags = mp_flags;          // experiment switch, read once; default = tuned setting
-  a.nchunks = 0;
+  // every field named, in declaration order: -Werror=missing-field-initializers (HIP_FLAGS) refuses a field left out
+  MpArgs a = {
+      .x_l = (const float4 *)x_l, .x_r = (const float4 *)x_r, .e_proj = (const float4 *)e_proj, .att = (const float4 *)att,
+      .bias = (const float4 *)bias, .rowptr = rowptr, .eid = eid, .src = src, .node_mask = node_mask, .edge_mask = edge_mask,
+      .out = (float4 *)out, .alpha = alpha, .N = (int)N, .C = C, .H = H, .lde4 = ld_e >> 2, .ldl4 = ld_l >> 2, .ldr4 = ld_r >> 2,
+      .slope = negative_slope, .graph_ptr = graph_ptr, .graph_eptr = graph_eptr, .dst = dst, .B = (int)B, .lrows = 0, .f16 = f16,
+      .flags = mp_flags,           // experiment switch, read once; default = tuned setting
+      .nchunks = 0, .logits = logits, .rowmax = rowmax, .planes = planes, .planes_inv = planes_inv,
+      .planes_kt = 2 * ((2 * (C >> 2) + 7) >> 3)};     // two half rows of 2 C columns, each padded to whole 32-column lines
+  if (!a.x_l || !a.att || !a.rowptr || (!a.out && !a.planes) || (E > 0 && (!a.eid || !a.src || !a.alpha)) ||
+      (!a.logits && (!a.x_r || (E > 0 && !a.e_proj))) || (a.planes && !a.planes_inv))
+    return ISG_EINVAL;                         // the struct the kernels dereference, not the parameters it was filled from
   hipStream_t st = as_stream(stream);
   if (graph_ptr && graph_eptr && (dst || E == 0) && B > 0 && B < (1ll << 31) && nmax_host > 0) {
     int rc = launch_mp_graph(a, nmax_host, emax_host, st);

@@ -11,9 +11,10 @@ constexpr int MP_ECAP = 1024;  // CSR slots staged in LDS per workgroup (rest re
 constexpr int MP_LCAP = 32;    // logits per wave kept in LDS (x heads of the wave)
 
 struct MpArgs {
-  const float4 *x_l, *x_r, *e_proj, *att, *bias;
+  const float4 *x_l, *x_r, *e_proj, *att;
+  const float4 *bias;     // optional
   const int *rowptr, *eid, *src;
-  const float *node_mask, *edge_mask;
+  const float *node_mask, *edge_mask;        // optional (NULL: the layer is not masked)
   float4 *out;
   float *alpha;
   int N, C, H;
@@ -22,7 +23,7 @@ struct MpArgs {
   int ldl4, ldr4;         // row stride of x_l / x_r in float4 (H*C/4 when dense; larger when they are column
                           // slices of one fused [N, 2*H*C] projection)
   float slope;
-  const int *graph_ptr, *graph_eptr, *dst;   // per-graph kernel only
+  const int *graph_ptr, *graph_eptr, *dst;   // per-graph kernel only (optional: NULL selects the node-chunk kernel)
   int B, lrows;           // graphs; x_l rows of a graph kept in LDS
   int f16;                // x_l / x_r / e_proj / out hold fp16 (per-graph kernel only)
   int flags;              // bit0: non-temporal e_proj loads / out stores; bit1: XCD-aware chunk mapping (chunk kernel);
@@ -33,7 +34,7 @@ struct MpArgs {
                           // NULL.  When given, the logit phase (and with it e_proj and x_r) is skipped
   float *rowmax;          // per-graph kernel, fp32 rows: largest |out| per (node, head) [N, H], or NULL: the row scales of
                           // the fp16 three-product GEMM that consumes `out` (isg_linear_f16x3_tile) come from here
-  uint16_t *planes;       // flat per-graph kernel (H = 4, two heads per workgroup), instead of `out`: the result as the SEGMENTED
+  uint16_t *planes;       // flat per-graph kernel (H = 4, two heads per workgroup), instead of `out` (or NULL): the result as the SEGMENTED
   float *planes_inv;      // planes32 operand of isg_linear_h3p -- columns [0, 2C) and [2C, 4C) each padded to whole 32-column
   int planes_kt;          // lines and each under its own row scale planes_inv[segment * N + node] (a workgroup owns two heads:
                           // it knows that half row's largest magnitude, not the whole row's); planes_kt = lines per row

@@ -25,7 +25,7 @@ struct MpBwdArgs {
   const float *alpha;
   const int *rowptr, *eid, *src;           // CSR by destination
   const int *rowptr_s, *eid_s, *dst_s;     // CSR by source (isg_csr_build on the flipped edge_index)
-  const float *node_mask, *edge_mask;
+  const float *node_mask, *edge_mask;      // optional (NULL: the layer is not masked)
   float4 *d_e_proj, *d_x_r, *d_x_l, *d_att_partial;
   float *d_edge_mask;                      // optional [E]
   int N, C, H;
@@ -283,16 +283,16 @@ extern "C" int isg_gatv2_mp_bwd(const float *x_l, const float *x_r, const float 
   if (!x_l || !x_r || !att || !grad_out || !rowptr || !rowptr_s || !d_x_l || !d_x_r || !d_att_partial) return ISG_EINVAL;
   if (E > 0 && (!e_proj || !alpha || !eid || !src || !eid_s || !dst_s || !d_e_proj)) return ISG_EINVAL;
   if ((C & 3) != 0 || N >= (1ll << 31) || E >= (1ll << 31)) return ISG_EUNSUPPORTED;
-  MpBwdArgs a = {};
-  a.x_l = (const float4 *)x_l; a.x_r = (const float4 *)x_r; a.e_proj = (const float4 *)e_proj;
-  a.att = (const float4 *)att; a.grad_out = (const float4 *)grad_out; a.alpha = alpha;
-  a.rowptr = rowptr; a.eid = eid; a.src = src;
-  a.rowptr_s = rowptr_s; a.eid_s = eid_s; a.dst_s = dst_s;
-  a.node_mask = node_mask; a.edge_mask = edge_mask;
-  a.d_e_proj = (float4 *)d_e_proj; a.d_x_r = (float4 *)d_x_r; a.d_x_l = (float4 *)d_x_l;
-  a.d_att_partial = (float4 *)d_att_partial;
-  a.d_edge_mask = d_edge_mask;
-  a.N = (int)N; a.C = C; a.H = H; a.slope = negative_slope;
+  // every field named, in declaration order: -Werror=missing-field-initializers (HIP_FLAGS) refuses a field left out
+  MpBwdArgs a = {
+      .x_l = (const float4 *)x_l, .x_r = (const float4 *)x_r, .e_proj = (const float4 *)e_proj, .att = (const float4 *)att,
+      .grad_out = (const float4 *)grad_out, .alpha = alpha, .rowptr = rowptr, .eid = eid, .src = src, .rowptr_s = rowptr_s,
+      .eid_s = eid_s, .dst_s = dst_s, .node_mask = node_mask, .edge_mask = edge_mask, .d_e_proj = (float4 *)d_e_proj,
+      .d_x_r = (float4 *)d_x_r, .d_x_l = (float4 *)d_x_l, .d_att_partial = (float4 *)d_att_partial, .d_edge_mask = d_edge_mask,
+      .N = (int)N, .C = C, .H = H, .slope = negative_slope};
+  if (!a.x_l || !a.x_r || !a.att || !a.grad_out || !a.rowptr || !a.rowptr_s || !a.d_x_l || !a.d_x_r || !a.d_att_partial ||
+      (E > 0 && (!a.e_proj || !a.alpha || !a.eid || !a.src || !a.eid_s || !a.dst_s || !a.d_e_proj)))
+    return ISG_EINVAL;                         // the struct the kernels dereference, not the parameters it was filled from
   hipStream_t st = as_stream(stream);
   switch (H) {
     case 1: return launch_bwd<1>(a, st);

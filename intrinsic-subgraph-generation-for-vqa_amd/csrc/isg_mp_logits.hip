@@ -46,7 +46,7 @@ struct ElArgs {
   const float *x_l, *x_r;           // rows by node id, strides ldl / ldr (column slices of the fused lin_l | lin_r output)
   const float *att;                 // [H * C]
   const int *eid, *src, *dst;       // CSR slot order
-  const float *edge_mask, *node_mask;
+  const float *edge_mask, *node_mask;   // optional (NULL: the layer is not masked)
   float *logits;                    // [E, H], slot order
   int E, H, C, K, KS, NT, lda, ldl, ldr;
   int Cp, LD;                       // channels per head padded to whole 32-channel tiles (== C when 32 | C); panel row pitch in halfs
@@ -574,14 +574,15 @@ static int edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_fr
   if ((C & 3) != 0 || H > 32 || K > 304 || (K & 3) != 0 || (lda & 3) != 0 || (ldl & 3) != 0 || (ldr & 3) != 0 || (head_stride_l & 3) != 0 || (head_stride_r & 3) != 0 || mis(edge_attr) ||
       mis(x_l) || mis(x_r) || mis(att) || mis(w_inv_scale) || H * Cp > 2048 || E >= (1ll << 31) - EL_BM)
     return ISG_EUNSUPPORTED;
-  ElArgs a = {};
-  a.edge_attr = edge_attr; a.Wf = reinterpret_cast<const _Float16 *>(w_frag); a.w_inv = w_inv_scale;
-  a.x_l = static_cast<const float *>(x_l); a.x_r = static_cast<const float *>(x_r);      // (half rows when f16: the kernel casts)
-  a.att = att; a.eid = eid; a.src = src; a.dst = dst;
-  a.edge_mask = edge_mask; a.node_mask = node_mask; a.logits = logits;
-  a.E = (int)E; a.H = H; a.C = C; a.K = K; a.KS = (K + 15) / 16; a.NT = H * Cp / 32; a.Cp = Cp;
-  a.LD = EL_KC + 8;
-  a.lda = lda; a.ldl = ldl; a.ldr = ldr; a.hsl = head_stride_l; a.hsr = head_stride_r; a.slope = negative_slope;
+  // every field named, in declaration order: -Werror=missing-field-initializers (HIP_FLAGS) refuses a field left out
+  ElArgs a = {
+      .edge_attr = edge_attr, .Wf = reinterpret_cast<const _Float16 *>(w_frag), .w_inv = w_inv_scale,
+      .x_l = static_cast<const float *>(x_l), .x_r = static_cast<const float *>(x_r),   // (half rows when f16: the kernel casts)
+      .att = att, .eid = eid, .src = src, .dst = dst, .edge_mask = edge_mask, .node_mask = node_mask, .logits = logits,
+      .E = (int)E, .H = H, .C = C, .K = K, .KS = (K + 15) / 16, .NT = H * Cp / 32, .lda = lda, .ldl = ldl, .ldr = ldr,
+      .Cp = Cp, .LD = EL_KC + 8, .hsl = head_stride_l, .hsr = head_stride_r, .slope = negative_slope};
+  if (!a.edge_attr || !a.Wf || !a.w_inv || !a.x_l || !a.x_r || !a.att || !a.eid || !a.src || !a.dst || !a.logits)
+    return ISG_EINVAL;                         // the struct the kernel dereferences, not the parameters it was filled from
   hipStream_t st = as_stream(stream);
   const bool masked = edge_mask || node_mask;
   // the rows kernel: w_frag is the split of the weight padded to [H * Cp, 16 KST]: 304 columns (19 k steps) for K > 128, and for
@@ -610,11 +611,15 @@ static int edge_logits(const float *edge_attr, int32_t lda, const uint16_t *w_fr
   if (f16) return ISG_EUNSUPPORTED;            // half rows: the rows kernel only (K >= 128)
   const unsigned grid = (unsigned)((E + EL_BM - 1) / EL_BM);
   const size_t dyn = (size_t)2 * EL_BM * a.LD * 2 + ((size_t)2 * H * Cp + (size_t)4 * EL_BM * H) * sizeof(float);
+  // the attribute is set to the most any accepted shape asks for (H Cp <= 2048, H <= 32: 83,968 bytes), not to the first caller's
+  // size -- a first launch at H = 4 (43 KB) must not leave H = 16 (67.6 KB, beyond the 64 KB default limit) unlaunchable
+  constexpr int dyn_max = 2 * EL_BM * (EL_KC + 8) * 2 + (2 * 2048 + 4 * EL_BM * 32) * (int)sizeof(float);
+  if (dyn > (size_t)dyn_max) return ISG_EUNSUPPORTED;
   if (masked) {
-    if (!dyn_lds_ok<&gatv2_edge_logits_kernel<true, 1>>((int)dyn)) return ISG_EUNSUPPORTED;
+    if (!dyn_lds_ok<&gatv2_edge_logits_kernel<true, 1>>(dyn_max)) return ISG_EUNSUPPORTED;
     gatv2_edge_logits_kernel<true, 1><<<grid, EL_THREADS, dyn, st>>>(a);
   } else {
-    if (!dyn_lds_ok<&gatv2_edge_logits_kernel<false, 1>>((int)dyn)) return ISG_EUNSUPPORTED;
+    if (!dyn_lds_ok<&gatv2_edge_logits_kernel<false, 1>>(dyn_max)) return ISG_EUNSUPPORTED;
     gatv2_edge_logits_kernel<false, 1><<<grid, EL_THREADS, dyn, st>>>(a);
   }
   return check_launch();

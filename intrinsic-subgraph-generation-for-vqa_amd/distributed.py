@@ -97,18 +97,42 @@ class GatherPipeline:
     gather runs on the communicator's stream into buffer i % (depth + 1) while the following steps' kernels run, so a
     collective up to `depth` steps long (a ring over per-link-bound xGMI) stays hidden.  `what` = "logits": BASELINE
     north_star's collective, fp32 [B_local, A] per rank (main.py:72-94 is the reference's DDP shape); "answers": the arg-max
-    answers [B_local] i64 only (what the reference's evaluation reduces, utils/misc.py:40-48) -- opt-in."""
+    answers [B_local] i64 only (what the reference's evaluation reduces, utils/misc.py:40-48) -- opt-in.
 
-    def __init__(self, b_local: int, answers: int, device, what: str = "logits", depth: int = 2, group=None):
+    ragged=True (BASELINE configs[4]: partitions balanced by sum(nodes + edges) hold different graph counts): the ranks' row
+    counts are exchanged ONCE, here; every step then gathers rows padded to the largest count (a padded staging buffer per
+    in-flight slot, its pad rows zero) and `rows(buf)` trims the result.  force_collective=True issues the collective on a
+    one-rank group too (tests/test_gpu_rccl_single_rank.py: this class against RCCL on one MI355X)."""
+
+    def __init__(self, b_local: int, answers: int, device, what: str = "logits", depth: int = 2, group=None,
+                 ragged: bool = False, force_collective: bool = False):
         import torch.distributed as dist
         if what not in ("logits", "answers"):
             raise ValueError(f"GatherPipeline: what = {what!r}")
         self.what, self.depth, self.group = what, max(1, int(depth)), group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.b_local, self.answers = int(b_local), int(answers)
-        shape = (self.world * self.b_local, self.answers) if what == "logits" else (self.world * self.b_local,)
+        up = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if up else 1
+        self.active = self.world > 1 or (bool(force_collective) and up)
+        self.b_local, self.answers, self.ragged = int(b_local), int(answers), bool(ragged)
+        self.sizes = [self.b_local] * self.world
+        if self.ragged and self.active:
+            n = torch.tensor([self.b_local], dtype=torch.long, device=device)
+            got = [torch.zeros_like(n) for _ in range(self.world)]
+            dist.all_gather(got, n, group=group)
+            self.sizes = [int(v) for v in got]
+        elif self.active and self.world > 1:          # equal shards are the caller's promise: hold it to that, once
+            n = torch.tensor([self.b_local], dtype=torch.long, device=device)
+            lo, hi = n.clone(), n.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            if int(lo) != int(hi):
+                raise ValueError(f"GatherPipeline: shards of {int(lo)}..{int(hi)} rows need ragged=True")
+        self.b_max = max(self.sizes)
+        shape = (self.world * self.b_max, self.answers) if what == "logits" else (self.world * self.b_max,)
         dtype = torch.float32 if what == "logits" else torch.int64
-        self.buffers = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth + 1)] if self.world > 1 else []
+        self.buffers = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth + 1)] if self.active else []
+        self.stage = ([torch.zeros(shape[:0] + (self.b_max,) + shape[1:], dtype=dtype, device=device) for _ in range(self.depth + 1)]
+                      if self.active and self.b_local < self.b_max else [])
         self.pending = []          # (work, input kept alive), oldest first
 
     def drain(self, keep: int = 0) -> None:
@@ -118,16 +142,35 @@ class GatherPipeline:
 
     def submit(self, i: int, logits: Tensor) -> Tensor:
         """Queue step i's gather behind the producer of `logits`; returns the buffer it lands in (valid after drain())."""
-        if self.world == 1:
+        if not self.active:
             return logits
-        self.drain(self.depth - 1)     # the oldest gather's buffer is free again, its input may be released
+        if logits.size(0) != self.b_local:
+            raise ValueError(f"GatherPipeline.submit: {logits.size(0)} rows, built for {self.b_local}")
+        self.drain(self.depth - 1)     # the oldest gather's buffer (and staging slot) is free again, its input may be released
         src = logits if self.what == "logits" else logits.argmax(dim=1)
-        out, work = all_gather_logits(src, self.buffers[i % (self.depth + 1)], group=self.group, async_op=True)
+        if self.stage:
+            st = self.stage[i % (self.depth + 1)]
+            st[: self.b_local].copy_(src)          # on the producer's stream; rows beyond b_local stay zero
+            src = st
+        import torch.distributed as dist
+        out = self.buffers[i % (self.depth + 1)]
+        work = dist.all_gather_into_tensor(out, src.contiguous(), group=self.group, async_op=True)
         self.pending.append((work, src))
         return out
 
+    def rows(self, buf: Tensor) -> List[Tensor]:
+        """The ranks' rows of a gathered buffer (views; rank r's padding trimmed)."""
+        if not self.active:
+            return [buf]
+        return [buf[r * self.b_max: r * self.b_max + self.sizes[r]] for r in range(self.world)]
+
     def describe(self) -> dict:
-        per = self.b_local * (self.answers * 4 if self.what == "logits" else 8)
-        return {"collective": f"all_gather_into_tensor(logits[B_local,{self.answers}] f32)" if self.what == "logits"
-                else "all_gather_into_tensor(answers[B_local] i64)",
-                "bytes_per_rank": per, "bytes_received_per_rank": (self.world - 1) * per, "in_flight": self.depth}
+        row = self.answers * 4 if self.what == "logits" else 8
+        per = self.b_max * row
+        d = {"collective": f"all_gather_into_tensor(logits[B_local,{self.answers}] f32)" if self.what == "logits"
+             else "all_gather_into_tensor(answers[B_local] i64)",
+             "bytes_per_rank": per, "bytes_received_per_rank": (self.world - 1) * per, "in_flight": self.depth}
+        if self.ragged:
+            d.update(ragged=True, rows_per_rank=list(self.sizes), padded_rows=self.b_max,
+                     payload_bytes_per_rank=[n * row for n in self.sizes])
+        return d

@@ -109,7 +109,7 @@ sys.modules[__name__].__class__ = _OpsModule
 
 # Launches that leave this library's own dense kernels, and extra passes a missing hand-off costs; bench.py prints them
 # per step ("no GEMM of the inference path runs on hipBLASLt" is then a number, not a sentence).
-COUNTERS = {"torch_linear": 0, "torch_layer_norm": 0, "torch_attention": 0, "row_absmax": 0,
+COUNTERS = {"torch_linear": 0, "torch_layer_norm": 0, "torch_attention": 0, "row_absmax": 0, "linear_h3p": 0, "h3p_segmented": 0,
             "tile_nodes": 0, "oversize_nodes": 0}      # nodes the tile kernels took / nodes of graphs beyond a tile (mixed dispatch)
 
 
@@ -1431,18 +1431,18 @@ def mp_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool, feat_byte
     return feat_bytes * (3 * N * HC + E * HC) + 4 * E * H + 16 * E + (4 * E if masked else 0)
 
 
-def edge_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, K: int, masked: bool, K2: int = 0) -> int:
+def edge_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, K: int, masked: bool, K2: int = 0, feat_bytes: int = 4) -> int:
     """isg_gatv2_edge_logits' OWN minimum traffic: edge_attr rows (4*E*K), every x_l and x_r row once (2 * 4*N*HC), the
     logits (4*E*H), eid / src / dst (12*E), the edge mask if any (4*E).  The W planes (4*HC*K) stay in L2.  K2 > 0: the
     form that computes x_r itself reads every layer-input row once (4*N*K2) instead of x_r (4*N*HC)."""
-    xr = 4 * N * K2 if K2 else 4 * N * H * C
-    return 4 * E * K + 4 * N * H * C + xr + 4 * E * H + 12 * E + (4 * E if masked else 0)
+    xr = 4 * N * K2 if K2 else feat_bytes * N * H * C
+    return 4 * E * K + feat_bytes * N * H * C + xr + 4 * E * H + 12 * E + (4 * E if masked else 0)
 
 
-def mp_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool) -> int:
+def mp_logits_algorithmic_bytes(N: int, E: int, H: int, C: int, masked: bool, feat_bytes: int = 4) -> int:
     """isg_gatv2_mp_fwd_logits' OWN minimum traffic: x_l in and out back (2 * 4*N*HC), logits in and alpha out (8*E*H),
     the CSR (16*E as in bytes_mp), the edge mask if any (4*E)."""
-    return 8 * N * H * C + 8 * E * H + 16 * E + (4 * E if masked else 0)
+    return 2 * feat_bytes * N * H * C + 8 * E * H + 16 * E + (4 * E if masked else 0)
 
 
 def scatter_mean(msg: Tensor, plan: GraphPlan) -> Tensor:
@@ -2340,6 +2340,8 @@ def linear_h3p(x, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = Fa
     Kc = 2 * ksplit if seg else K                    # the k extent the kernel walks: both segments with their padding
     seg_args = (xp.inv_first.data_ptr(), ksplit) if seg else (0, 0)
     timer = H3P_TIMER
+    COUNTERS["linear_h3p"] += 1                      # launches of the engine / of them, those fed a segmented message-passing result
+    COUNTERS["h3p_segmented"] += 1 if seg else 0
     if timer is not None:
         ev0, ev1 = timer.bracket({"M": M, "N": N, "K": Kc, "planes_out": bool(planes_out)})
     if planes_out:

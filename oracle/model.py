@@ -413,7 +413,8 @@ def mgat_pool_classify(sd, x: Tensor, edge_index: Tensor, edge_attr: Tensor, bat
 def isubgvqa_forward(sd, node_embeddings: Tensor, edge_index: Tensor, edge_embeddings: Tensor,
                      batch: Tensor, questions: Tensor, qsts_att_mask: Tensor, x_bbox: Tensor,
                      added_sym_edge: Tensor, cfg: PathConfig,
-                     noises: Optional[Dict[int, Tensor]] = None, text_uniform: Optional[Tensor] = None):
+                     noises: Optional[Dict[int, Tensor]] = None, text_uniform: Optional[Tensor] = None,
+                     trace: Optional[list] = None):
     enc = question_encoder_forward(sd, "question_encoder", questions, qsts_att_mask, cfg.nhead_text)  # :228
     mask_text = None
     if text_uniform is not None:                                       # --text_sampling (:229-241), k = mgat_layers
@@ -427,5 +428,5 @@ def isubgvqa_forward(sd, node_embeddings: Tensor, edge_index: Tensor, edge_embed
     glf, instr = language_features(sd, qst_feats)
     x_enc, e_enc = scene_graph_encoder_forward(sd, "scene_graph_encoder", node_embeddings, edge_index,
                                                edge_embeddings, batch, x_bbox, added_sym_edge, cfg)  # :255
-    logits, mask, gate = mgat_pool_classify(sd, x_enc, edge_index, e_enc, batch, instr, glf, cfg, noises)
+    logits, mask, gate = mgat_pool_classify(sd, x_enc, edge_index, e_enc, batch, instr, glf, cfg, noises, trace)
     return logits, mask, gate, [], mask_text                                                         # :297

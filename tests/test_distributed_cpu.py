@@ -64,6 +64,20 @@ def _worker(rank, world, port, balance, q):
         pipe.drain()
         # buffers rotate over depth + 1 = 3: steps 2, 3, 4 are the ones still held
         piped = (pipe.describe(), [o.clone() for o in outs[2:]], outs[4].data_ptr() == outs[1].data_ptr())
+    else:
+        # BASELINE configs[4]'s collective as `bench.py --workload cfg5` builds it: balanced shards hold different graph counts, the
+        # pipeline exchanges the counts once and gathers rows padded to the largest shard; an equal-shard pipeline must refuse them
+        a5 = bench.parse(["--workload", "cfg5"])
+        assert a5.graphs == 2048 and a5.features == "fp16" and a5.gather == "logits"
+        try:
+            GatherPipeline(local.size(0), local.size(1), local.device, what=a5.gather, depth=a5.gather_depth)
+            refused = False
+        except ValueError:
+            refused = True
+        pipe = GatherPipeline(local.size(0), local.size(1), local.device, what=a5.gather, depth=a5.gather_depth, ragged=True)
+        outs = [pipe.submit(i, local + float(i)) for i in range(5)]
+        pipe.drain()
+        piped = (pipe.describe(), [torch.cat(pipe.rows(o)).clone() for o in outs[2:]], refused)
     if rank == 0:
         q.put((full, shard.num_graphs, ans, piped))
     dist.barrier()
@@ -98,6 +112,14 @@ def test_shard_compute_allgather_world2(balance):
         assert rotated
         for i, got in zip((2, 3, 4), held):
             assert torch.allclose(got, ref + float(i), atol=1e-5)
+    else:
+        desc, held, refused = piped
+        assert refused, "an equal-shard GatherPipeline accepted shards of different sizes"
+        sizes = desc["rows_per_rank"]
+        assert desc["ragged"] and sum(sizes) == cfg.num_graphs and sizes[0] == n0 and sizes[0] != sizes[1], desc
+        assert desc["padded_rows"] == max(sizes) and desc["bytes_per_rank"] == max(sizes) * full.size(1) * 4
+        for i, got in zip((2, 3, 4), held):
+            assert got.shape == ref.shape and torch.allclose(got, ref + float(i), atol=1e-5)
 
 
 def test_graph_ranges_balance_by_nodes_plus_edges():

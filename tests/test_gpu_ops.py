@@ -815,6 +815,97 @@ def test_edge_logits_pair_on_fp16_rows_matches_the_unfused_fp16_kernels(dev, mas
     assert da < 2e-3 and do <= 2.0 ** -9 * max(scale, 1.0)       # out: two half-precision ulps of its largest value, at most
 
 
+@pytest.mark.parametrize("mask", [None, "node", "edge"])
+@pytest.mark.parametrize("H,C,K", [(4, 128, 128), (4, 128, 300), (2, 96, 128)])
+def test_edge_logits_pair_on_fp16_rows_matches_an_fp64_evaluation_of_the_cpu_paths_fp16_mode(dev, mask, H, C, K):
+    """The fp16 pair against the ORACLE's fp16 mode (oracle/model.py::gatv2_conv_forward with fp16_features: x_l, x_r and
+    e_proj rounded to half, fp32 arithmetic, the output rounded to half), not against its un-fused sibling.  The logits are held
+    to an fp64 evaluation of att . leaky(x_l[src] + x_r[dst] + half(lin_edge(edge_attr))) with a bound that is exact about the one
+    thing the kernel may do differently: an element of e_proj whose fp64 value lies within an fp32 product's error of a half
+    rounding boundary may round either way, and moves its logit by |att_c| * slope * ulp_half(e_c).  alpha against the
+    oracle's softmax of those logits, the half output rows against oracle rows rounded to half."""
+    from isubgvqa_amd import ops
+    from oracle import model as OM
+    gen = torch.Generator().manual_seed(9 + H + C + K)
+    sizes = torch.randint(3, 40, (60,), generator=gen).tolist()
+    batch, ei = _rand_graphs(gen, sizes, extra_per_node=1.5, hub=(5, 40))
+    N, E, HC = batch.numel(), ei.size(1), H * C
+    x_lr = torch.randn(N, 2 * HC, generator=gen).half()
+    ea = torch.randn(E, K, generator=gen)
+    w = torch.randn(HC, K, generator=gen) / K ** 0.5
+    att, bias = torch.randn(1, H, C, generator=gen), torch.randn(HC, generator=gen)
+    nm = (torch.rand(N, generator=gen) < 0.6).float() if mask == "node" else None
+    em = (torch.rand(E, generator=gen) < 0.6).float() if mask == "edge" else None
+    emask = em if em is not None else (None if nm is None else nm[ei[0]] * nm[ei[1]])
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=len(sizes))
+    t = lambda v: None if v is None else v.to(dev)
+    x_lr_d = x_lr.to(dev)
+    x_l, x_r = x_lr_d[:, :HC], x_lr_d[:, HC:]
+    res = ops.gatv2_mp_edge_logits(x_l, x_r, t(ea), t(w), t(att), plan, H, bias=t(bias), node_mask=t(nm), edge_mask=t(em))
+    assert res is not None, "the fp16 pair has no kernel for this shape"
+    out_k, alpha_k = res[0].cpu(), res[1].cpu()
+    lg = ops.gatv2_edge_logits(x_l, x_r, t(ea), t(w), t(att), plan, H, node_mask=t(nm), edge_mask=t(em)).cpu().double()
+    eid, s_, d_ = plan.eid.cpu().long(), plan.src.cpu().long(), plan.dst.cpu().long()
+    # ---- fp64 evaluation in slot order
+    e64 = (ea.double() @ w.double().t())[eid]                              # [E, HC], exact to fp64
+    e16 = e64.half().double()                                               # round-to-nearest-even, as the kernel's cvt
+    mk = torch.ones(E, 1, dtype=torch.float64) if emask is None else emask.double()[eid].unsqueeze(1)
+    z = (x_lr[:, HC:].double()[d_] + x_lr[:, :HC].double()[s_] + e16) * mk
+    slope = torch.where(z > 0, 1.0, 0.2)
+    a64 = att.double().view(1, HC)
+    ref = (z * slope * mk * a64).view(E, H, C).sum(-1)
+    # elements that may round the other way: within two fp32 ulps of the K-term sum's magnitude (sum_k |ea_k w_k|) of a half rounding boundary
+    ulp16 = torch.maximum(2.0 ** (torch.floor(torch.log2(e64.abs().clamp_min(2.0 ** -14))) - 10), torch.tensor(2.0 ** -24, dtype=torch.float64))
+    lo = torch.minimum(e16, torch.where(e64 >= e16, e16 + ulp16, e16 - ulp16))
+    boundary = lo + 0.5 * ulp16                                             # the midpoint between e64's two half neighbours
+    t64 = (ea.double().abs() @ w.double().abs().t())[eid]                  # what the sum is made of: the products' error scales with it
+    amb = (e64 - boundary).abs() <= 2.0 ** -23 * t64 + 1e-30
+    flip = (amb.double() * ulp16 * a64.abs() * mk * mk).view(E, H, C).sum(-1)      # slope <= 1
+    terms = (z.abs() * a64.abs()).view(E, H, C).sum(-1)
+    excess = ((lg - ref).abs() - flip - 2e-6 * terms - 1e-7).max().item()
+    print(f"fp16 pair vs the CPU path's fp16 mode H={H} C={C} K={K} mask={mask}: logits max err {(lg - ref).abs().max().item():.2e}, "
+          f"ambiguous e_proj elements {int(amb.sum())} of {amb.numel()}, excess over the bound {excess:.2e}")
+    assert excess <= 0.0, "a logit differs from the fp16-mode evaluation by more than its ambiguous roundings explain"
+    # ---- alpha and the half output rows against the oracle itself (fp32 arithmetic on the half-rounded tensors)
+    e_orc = e64.half().float()
+    inv = torch.empty_like(eid); inv[eid] = torch.arange(E)
+    ref_out, ref_alpha = OM.gatv2_message_passing(x_lr[:, :HC].float().reshape(N, H, C), x_lr[:, HC:].float().reshape(N, H, C),
+                                                  e_orc[inv].view(E, H, C), att, ei, None if emask is None else emask.view(E, 1), 0.2)
+    ref_out = (ref_out.reshape(N, HC) + bias).half().float()
+    da = (alpha_k - ref_alpha).abs().max().item()
+    worst_flip = flip.max().item()
+    scale = ref_out.abs().max().item()
+    do = (out_k.float() - ref_out).abs().max().item()
+    print(f"    alpha vs oracle {da:.2e} (largest ambiguous-rounding logit shift {worst_flip:.2e}); out vs oracle {do:.2e} (|out| <= {scale:.1f})")
+    assert da <= 2.0 * worst_flip + 2e-5                       # |d softmax| <= |d logit| (twice: numerator and denominator)
+    assert do <= 2.0 ** -9 * max(scale, 1.0)                   # two half-precision ulps of the largest row value
+
+
+def test_edge_logits_panel_kernel_small_heads_first_then_many_heads(dev):
+    """the panel kernel's dynamic LDS grows with H (43 KB at H = 4, 67.6 KB at H = 16, C = 128 -- beyond the
+    64 KB a kernel gets without hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute used to be set once, to the FIRST
+    caller's size: H = 4 first, then H = 16 in the same process failed at launch.  Both orders in one process, against fp64."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(44)
+    batch, ei = _rand_graphs(gen, [9, 30, 17, 22], extra_per_node=2.0)
+    N, E, K = batch.numel(), ei.size(1), 64
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=4)
+    eid, s_, d_ = plan.eid.cpu().long(), plan.src.cpu().long(), plan.dst.cpu().long()
+    for H, C in [(4, 128), (16, 128), (2, 64), (32, 64), (16, 128)]:
+        xl, xr = torch.randn(N, H * C, generator=gen), torch.randn(N, H * C, generator=gen)
+        ea = torch.randn(E, K, generator=gen)
+        w = torch.randn(H * C, K, generator=gen) / K ** 0.5
+        att = torch.randn(1, H, C, generator=gen)
+        got = ops.gatv2_edge_logits(xl.to(dev), xr.to(dev), ea.to(dev), w.to(dev), att.to(dev), plan, H)
+        assert got is not None, f"the panel kernel refused H={H} C={C} K={K}"
+        z = xl.double()[s_] + xr.double()[d_] + (ea.double() @ w.double().t())[eid]
+        z = torch.where(z > 0, z, 0.2 * z).view(E, H, C)
+        ref = (z * att.double().view(1, H, C)).sum(-1)
+        scale = (z.abs() * att.double().abs().view(1, H, C)).sum(-1)
+        err = ((got.cpu().double() - ref).abs() / scale.clamp_min(1e-30)).max().item()
+        assert err < 2e-6, f"H={H} C={C}: logits off by {err:.2e} of their terms' magnitude"
+
+
 @pytest.mark.parametrize("C,K", [(300, 300), (128, 128), (128, 64)])
 @pytest.mark.parametrize("sizes,extra", [((2,), 0), ((1, 3), 1), ((7, 2, 5), 2), ((33,) * 9, 3)])
 def test_edge_logits_on_tiny_and_ragged_batches(dev, sizes, extra, C, K):

@@ -25,20 +25,33 @@ SCRIPT = textwrap.dedent("""
     assert dist.get_backend() == "nccl"
     g = torch.Generator(device=dev).manual_seed(0)
     logits = torch.randn(4096, 1842, device=dev, generator=g)              # one rank's answer logits (30 MB)
-    bufs = [torch.empty_like(logits) for _ in range(3)]
-    pending, sent = [], []
-    for i in range(4):                              # distributed.GatherPipeline's pattern: two gathers in flight, three buffers
-        while len(pending) > 1:
-            pending.pop(0)[0].wait()
-        w = dist.all_gather_into_tensor(bufs[i %% 3], logits, async_op=True)
-        pending.append((w, logits))                                         # the input stays referenced until the wait
+    # distributed.GatherPipeline ITSELF, with bench.py's parsed default arguments, on RCCL (force_collective: a one-rank group
+    # would otherwise skip the collective): two gathers in flight over three receive buffers
+    import bench
+    from isubgvqa_amd.distributed import GatherPipeline
+    args = bench.parse([])
+    pipe = GatherPipeline(logits.size(0), logits.size(1), dev, what=args.gather, depth=args.gather_depth, force_collective=True)
+    assert pipe.active and len(pipe.buffers) == 3 and pipe.describe()["in_flight"] == 2
+    outs, sent = [], []
+    for i in range(4):
+        outs.append(pipe.submit(i, logits))
+        assert len(pipe.pending) <= 2
         sent.append(logits)
         logits = logits + 1.0                                               # next step's producer runs beside the collective
-    while pending:
-        pending.pop(0)[0].wait()
+    pipe.drain()
     torch.cuda.synchronize()
-    assert torch.equal(bufs[0], sent[3]) and torch.equal(bufs[2], sent[2]) and torch.equal(bufs[1], sent[1]), \
+    assert outs[3].data_ptr() == outs[0].data_ptr()
+    assert torch.equal(outs[3], sent[3]) and torch.equal(outs[2], sent[2]) and torch.equal(outs[1], sent[1]), \
         "gathered logits differ from what was sent"
+    # the ragged form (bench.py --workload cfg5): sizes exchanged once at construction, rows() trims
+    a5 = bench.parse(["--workload", "cfg5"])
+    rp = GatherPipeline(1000, 1842, dev, what=a5.gather, depth=a5.gather_depth, ragged=True, force_collective=True)
+    assert rp.sizes == [1000] and rp.describe()["ragged"]
+    part = sent[0][:1000].contiguous()
+    got = rp.submit(0, part)
+    rp.drain()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(rp.rows(got)), part)
     # the opt-in light collective of bench.py (--gather answers): every rank's arg-max answers, i64, async like the logits
     ans = sent[3].argmax(dim=1)
     abuf = torch.empty_like(ans)

@@ -34,3 +34,5 @@ with tempfile.TemporaryDirectory(prefix="isg_var_") as tmp:
     lib = os.path.join(out, f"libisg_{name}.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", lib])
     print(lib)
+# a variant library is measured against the shipped one: it has to obey the same rule about packed fp32 operands
+sys.exit(subprocess.call([sys.executable, os.path.join(ROOT, "tools", "scan_pk_cross.py"), lib]))

@@ -4,7 +4,10 @@ LOW-half operand from the HIGH dword of a register pair (op_sel:[..1..]) intermi
 48-63 in isg_gatv2_tile_conv (tools/flake/: 48-417 wrong launches of 1600 in every variant that has such an operation, 0 of 1600 in
 the variants without -- same loop, same LDS reads, one v_mov_b32 more).  The library must not contain one.
 
-  python3 tools/scan_pk_cross.py                 every code object of the BUILT library (what tests/test_host_cpu.py runs)
+  python3 tools/scan_pk_cross.py                 every code object of the BUILT libraries: libisg_hip.so, libisg_hip_strict.so and
+                                                 whatever tools/build_variant.py left in tools/_build/ (tests/test_host_cpu.py runs
+                                                 the first two; a variant library is scanned by build_variant.py when it is made)
+  python3 tools/scan_pk_cross.py lib.so ...      the given libraries
   python3 tools/scan_pk_cross.py file.hip ...    compile the given sources to assembly and scan that (while editing a kernel)
 """
 import os
@@ -17,8 +20,11 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "intrinsic-subgraph-generation-for-vqa_amd", "csrc")
 LIB = os.path.join(CSRC, "libisg_hip.so")
+STRICT_LIB = os.path.join(CSRC, "libisg_hip_strict.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-PK = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32)\b(.*)")
+# every packed fp32 ARITHMETIC operation of gfx950 (v_pk_mov_b32 moves bits, it computes nothing: its op_sel is how the compiler
+# swaps halves and is not the form that failed)
+PK = re.compile(r"\b(v_pk_(?:fma|mul|add|max|min|maximum3|minimum3)_f32)\b(.*)")
 CROSS = re.compile(r"op_sel:\[[01,]*1")          # some source's LOW half comes from a high dword
 
 
@@ -76,17 +82,29 @@ def demangle(name):
         return name
 
 
+def built_libraries():
+    """The shipped pair and any variant library tools/build_variant.py left behind."""
+    var = os.path.join(ROOT, "tools", "_build")
+    extra = sorted(os.path.join(var, f) for f in os.listdir(var) if f.endswith(".so")) if os.path.isdir(var) else []
+    return [p for p in (LIB, STRICT_LIB) if os.path.exists(p)] + extra
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
+    args = sys.argv[1:]
+    if args and all(a.endswith(".hip") for a in args):
         total, hits = 0, []
-        for src in sys.argv[1:]:
+        for src in args:
             t, h = scan_source(src)
             total += t
             hits += h
-        where = ", ".join(os.path.basename(s) for s in sys.argv[1:])
+        where = ", ".join(os.path.basename(s) for s in args)
     else:
-        n, total, hits = scan_library()
-        where = f"{n} code objects of {os.path.relpath(LIB, ROOT)}"
+        n, total, hits = 0, 0, []
+        libs = args or built_libraries()
+        for lib in libs:
+            o, t, h = scan_library(lib)
+            n, total, hits = n + o, total + t, hits + [(f"{os.path.basename(lib)}: {k}", x) for k, x in h]
+        where = f"{n} code objects of {', '.join(os.path.relpath(l, ROOT) for l in libs)}"
     for kern, text in hits:
         print(f"{demangle(kern)}\n    {text}")
     print(f"{len(hits)} cross-selecting packed fp32 operation(s) among {total} in {where}")
