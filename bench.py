@@ -35,6 +35,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   sustained     >= 2.5 s of back-to-back configs[1] steps behind the timed burst: ms/step and its ratio to the burst's
   cfg5          BASELINE configs[4] on one GPU (skewed graphs, AIMLE, fp16 rows): ms/step, MP kernel GB/s on s = 2 bytes, the
                 imbalance of contiguous graph ranges over 8 ranks
+  eval_batch    the reference's evaluation batch (1 024 graphs) on the product path: eager vs its hipGraph option (capture=True)
+  summary       the legs' headline numbers, flat, at the front of the line
   mixed         the configs[1] batch with a few graphs beyond a graph tile (what real GQA batches are: the reference caps nothing):
                 ms/step with the tile kernels + the big graphs as a sub-batch (ops.run_split) and with the per-graph kernels for all
   fallbacks     launches per step that left this library's dense kernels (0 = none), extra row-maximum passes
@@ -490,6 +492,36 @@ def dense_err_vs_fp32(dev):
             ((got - ref).abs().max() / (base - ref).abs().max().clamp_min(1e-30)).item(), 3)
     out["max"] = max(out.values())
     return out
+
+
+def eval_batch_leg(dev, graphs: int = 1024, steps: int = 200):
+    """The reference's evaluation batch (datasets/build.py:59-62: 4 x --batch-size graphs; 1 024 at the configs[1] distribution) on the
+    PRODUCT path, eager against its own hipGraph option (`AnswerModel.forward(..., capture=True)` = ops.StepCapture): at this size
+    the step is launch-bound, which is what the option is for.  Noise from torch's generator in both (the captured
+    step draws it inside the graph)."""
+    import torch
+    from isubgvqa_amd import synthetic
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": graphs, "seed": 4242})
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).to(dev).eval()
+    res = {}
+    with torch.no_grad():
+        for name, kw in (("eager", {}), ("captured", {"capture": True})):
+            for _ in range(5):
+                model(wl, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = model(wl, **kw)[0]
+            torch.cuda.synchronize()
+            res[name] = (time.perf_counter() - t0) / steps
+        assert torch.isfinite(out).all()
+        model._step_capture.verify()
+    return {"workload": "the reference's evaluation batch: configs[1] distribution, in-model Gumbel noise from torch's generator",
+            "graphs": graphs, "nodes": int(wl.x.size(0)), "steps": steps,
+            "eager_ms_per_step": round(res["eager"] * 1e3, 4), "captured_ms_per_step": round(res["captured"] * 1e3, 4),
+            "captured_questions_per_s": round(graphs / res["captured"], 1),
+            "option": "AnswerModel.forward(..., capture=True) / ISubGVQA.forward(..., capture=True): ops.StepCapture, one hipGraph per batch shape"}
 
 
 def mixed_leg(dev, graphs: int = 4096, big: int = 8, steps: int = 10):
@@ -960,6 +992,11 @@ def main(argv=None):
             res["mixed"] = mixed_leg(dev)
             res["summary"].update(mixed_ms_per_step=res["mixed"]["ms_per_step"],
                                   mixed_host_issue_ms_per_step=res["mixed"]["host_issue_ms_per_step"])
+        if world == 1 and not cfg5 and not args.no_mixed:
+            progress("eval_batch leg (1024 graphs: eager vs the product path's hipGraph option)")
+            res["eval_batch"] = eval_batch_leg(dev)
+            res["summary"].update(eval_batch_1024_eager_ms=res["eval_batch"]["eager_ms_per_step"],
+                                  eval_batch_1024_captured_ms=res["eval_batch"]["captured_ms_per_step"])
         ops.check_plans()           # any understated GraphPlan hint of this run raises here
         if world == 1 and not cfg5 and not args.no_cpu_baseline:
             progress("cpu_baseline leg (oracle on the host cores)")

@@ -106,14 +106,50 @@ class ISubGVQA(torch.nn.Module):
         feats = ops.mlp(self.embedding, ops.cat_mul(embed, glf), want_rowmax=True)       # :288-291 (row maxima: for logit_fc)
         return ops.linear(feats, self.logit_fc.weight, self.logit_fc.bias), imle_mask, gate, node_logits_layers   # :292
 
+    def _captured(self, node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask, explainer, explainer_stage,
+                  scene_graphs, noises, seed, plan, text_uniform):
+        """forward() as a replayed hipGraph (ops.StepCapture), one capture per batch SHAPE -- the opt-in for evaluation loops whose
+        batches are launch-bound (run_token_coo.py:49-79 evaluates one question at a time; datasets/build.py:59-62 four times the
+        training batch).  Needs the collate's per-graph bounds on `scene_graphs` (max_nodes / max_edges: loader.SceneGraphBatch
+        carries them); sampler noise from `noises` or from torch's generator inside the graph; a `seed` is refused (it would be
+        frozen into the graph).  Returns the graph's static output tensors: valid until the next call with the same shapes."""
+        if seed is not None:
+            raise ValueError("capture=True: a seed is a kernel argument and would repeat in every replay; pass `noises` or neither")
+        if plan is not None or explainer or explainer_stage:
+            raise ValueError("capture=True: the plain inference forward only (no caller-built plan, no explainer)")
+        mn, me = getattr(scene_graphs, "max_nodes", None), getattr(scene_graphs, "max_edges", None)
+        if not mn or not me:
+            raise ValueError("capture=True needs scene_graphs.max_nodes / .max_edges (the collate's per-graph bounds): a captured "
+                             "step cannot read them back from the device")
+        import argparse
+        cap = self.__dict__.get("_step_capture")
+        if cap is None:
+            cap = self.__dict__["_step_capture"] = ops.StepCapture()
+        keys = sorted(noises) if noises else []
+        x_bbox, sym = scene_graphs.x_bbox, scene_graphs.added_sym_edge
+
+        def fn(ne, ei, ee, b, q, qm, bbox, s, tu, *nz):
+            sg = argparse.Namespace(x_bbox=bbox, added_sym_edge=s)
+            p = ops.GraphPlan.build(b, ei, num_graphs=q.size(0), max_nodes=int(mn), max_edges=int(me))
+            out = self.forward(ne, ei, ee, b, q, qm, return_masks=True, scene_graphs=sg, noises=dict(zip(keys, nz)) if keys else None,
+                               plan=p, text_uniform=tu)
+            return out, p
+
+        tensors = [node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask, x_bbox, sym, text_uniform] + \
+                  [noises[k] for k in keys]
+        return cap.run(fn, tensors, key_extra=("isubgvqa", int(mn), int(me), tuple(keys), self.training))
+
     def forward(self, node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask,
                 return_masks=False, explainer=False, explainer_stage=False, expl_bypass_x=False, scene_graphs=None,
                 noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
-                plan: Optional[ops.GraphPlan] = None, text_uniform: Optional[Tensor] = None):
+                plan: Optional[ops.GraphPlan] = None, text_uniform: Optional[Tensor] = None, capture: bool = False):
         if not return_masks:
             # the reference unpacks two values from GlobalAttention.forward, which returns a bare tensor when
             # return_mask=False (isubgvqa.py:280, att_pooling.py:75-77): return_masks=True is mandatory there
             raise ValueError("return_masks=True is required (isubgvqa.py:280 unpacks (embed, gate))")
+        if capture:
+            return self._captured(node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask, explainer,
+                                  explainer_stage, scene_graphs, noises, seed, plan, text_uniform)
         glf, instr_vectors = self.language_features(questions, qsts_att_mask, text_uniform,
                                                     None if seed is None else seed + 7919)
         mask_text = self.last_mask_text

@@ -122,7 +122,8 @@ class SceneGraphEncoder(torch.nn.Module):
         if split:   # inference: no [E, 900] concatenation (forward_split); the sign of :80 rides along as a vector
             sign = torch.ones(edge_attr.numel(), dtype=torch.float32, device=edge_attr.device)
             if sym is not None and sym.numel() > 0:
-                sign[sym] = -1.0                                                         # :80 (duplicates: flipped once)
+                sign.index_fill_(0, sym, -1.0)        # :80 (duplicates: flipped once); index_fill_, not sign[sym] = ...: the indexed
+                                                      # assignment synchronises on this stack and cannot sit in a captured step
             x_enc, e_enc = self.scene_graph_encoding_layer.forward_split(
                 x_embed_sum.contiguous(), edge_index, edge_attr.contiguous(), sign, self.sg_vocab_embedding, plan)
         else:

@@ -252,6 +252,9 @@ _PENDING_HINTS = []      # (event, pinned int32[2] = true [max nodes, max edges]
 _PENDING_SIZES = []      # (event, pinned int64[2 or 3] = graphs beyond a tile / their nodes / their edges counted on the device, the hint's counts)
 
 
+_CAPTURE_BOUNDS = []     # StepCapture: the pinned int32[2] a plan built inside the capture in progress hands its last kernel
+
+
 def check_plans(block: bool = True) -> None:
     """Raise IsgError if a GraphPlan was built with hints smaller than the batch's true per-graph bounds.
     block=False only looks at copies that have already completed."""
@@ -347,6 +350,13 @@ class GraphPlan:
     graph_ids: Optional[Tensor] = None            # int32 [B]: this plan's graphs are a CUT of a larger batch and these are their numbers
                                                   # there -- the samplers' in-kernel noise is keyed by them (ops._gid_ptr)
     holes: Optional["OversizeGraphs"] = None      # set by run_split: the tile kernels pass over these graphs and NOTHING fills their rows
+    _memo: Optional[dict] = None                  # answers that depend on the plan and the switches only (tile_mode, a layer's dispatch):
+                                                  # asked ~17 times per step by the layers, computed once (shared by run_split's copy)
+
+    def memo(self) -> dict:
+        if self._memo is None:
+            self._memo = {}
+        return self._memo
 
     def edge_planes(self, edge_attr: Tensor) -> Tuple[Tensor, Tensor]:
         """(planes int16 [E, 2, 128], inv_scale fp32 [E]) of the batch's edge features in CSR slot order (isg_edge_planes): the
@@ -443,11 +453,16 @@ class GraphPlan:
             return "none"
         if self.N < CFG.mixed_min_nodes:
             return "none"                   # decided before the device-to-host sync below: a small batch never pays for it
-        st = self._oversize_stats(node_cap, edge_cap)
-        if st is None or st["stats"][0] == 0:
-            return "tiles"                  # the hints overstated the batch
-        # (the LIST of such graphs -- ~30 launches -- is only built for a batch that then uses it)
-        return "mixed" if st["stats"][1] <= CFG.mixed_max_fraction * self.N else "none"
+        key = ("tile_mode", node_cap, ecap, CFG.mixed_max_fraction)
+        hit = self.memo().get(key)
+        if hit is None:
+            st = self._oversize_stats(node_cap, edge_cap)
+            if st is None or st["stats"][0] == 0:
+                hit = "tiles"               # the hints overstated the batch
+            else:   # (the LIST of such graphs -- ~30 launches -- is only built for a batch that then uses it)
+                hit = "mixed" if st["stats"][1] <= CFG.mixed_max_fraction * self.N else "none"
+            self._memo[key] = hit
+        return hit
 
     def _oversize_stats(self, node_cap: int, edge_cap: int) -> Optional[dict]:
         """How many graphs of the batch lie beyond a tile, with their node / edge totals and maxima: ONE device-to-host sync, paid
@@ -591,9 +606,11 @@ class GraphPlan:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             if CFG.plan_fused:
                 # hinted and eager: the plan's last kernel stores the bounds into pinned host memory itself (no copy in the stream)
-                if (max_nodes is not None and max_edges is not None and CFG.bounds_to_host
-                        and not torch.cuda.is_current_stream_capturing()):
-                    host_bounds = torch.empty(2, dtype=torch.int32, pin_memory=True)
+                if max_nodes is not None and max_edges is not None and CFG.bounds_to_host:
+                    if not torch.cuda.is_current_stream_capturing():
+                        host_bounds = torch.empty(2, dtype=torch.int32, pin_memory=True)
+                    elif _CAPTURE_BOUNDS:          # StepCapture: pinned memory allocated BEFORE the capture; every replay rewrites it
+                        host_bounds = _CAPTURE_BOUNDS[-1]
                 _lib.check(lib.isg_graph_plan_build(batch.data_ptr(), edge_index.data_ptr(), N, E, B, ptr.data_ptr(),
                                                     bounds.data_ptr(), 0 if host_bounds is None else host_bounds.data_ptr(),
                                                     plan.rowptr.data_ptr(), plan.eid.data_ptr(),
@@ -621,6 +638,7 @@ class GraphPlan:
             # (every replay rewrites them); the owner of the graph calls plan.verify_hints() after replays -- one sync, outside
             # the captured work -- and gets the same error an eager build would raise one step late.
             plan._bounds_dev = bounds
+            plan._bounds_host = host_bounds           # (StepCapture reads it between replays, without a sync)
             plan._hints = (int(max_nodes), None if edge_index is None else int(max_edges))
         else:                                       # hinted: verify later, without a sync (see check_plans)
             if _PENDING_HINTS or _PENDING_SIZES:
@@ -995,6 +1013,88 @@ def gatv2_mp_edge_logits(x_l: Tensor, x_r: Tensor, edge_attr: Tensor, w_edge: Te
     return out, alpha
 
 
+class StepCapture:
+    """Product-path hipGraph execution (opt-in: `AnswerModel.forward(..., capture=True)`, `ISubGVQA.forward(..., capture=True)`).
+    A forward over fixed-shape inputs is ~25-110 launches; below ~1000 graphs per step the step is launch-bound (1 024
+    graphs 0.641 ms eager vs 0.542 ms replayed, 256 graphs 0.652 vs 0.332).  `run(fn, tensors, key)` keeps one captured hipGraph
+    per KEY = (shape / dtype / device of every input, the caller's hints and options, the module's switches): the first call of a key
+    runs `fn` eagerly on private static copies of the inputs (kernel attributes, derived weights, allocator pools; the plan's hints
+    are checked), captures it once, and every call replays it after copying the caller's tensors into the static ones (a tensor
+    that already IS the static one is not copied).  `fn(*tensors) -> (outputs, plan)`: the GraphPlan must be built INSIDE fn from
+    host-side bounds (no device-to-host read is possible in a capture); its true bounds are written to pinned host memory by the
+    plan's own last kernel on every replay and compared with the hints at the next call -- a batch whose graphs exceed the hints
+    raises IsgError one call late, exactly like an eager hinted build (check_plans).  Outputs are the graph's static tensors: valid
+    until the next call with the same key.  Nothing here is a fallback: a forward that cannot be captured raises."""
+
+    def __init__(self, max_entries: int = 8):
+        import collections
+        self.entries = collections.OrderedDict()
+        self.max_entries = int(max_entries)
+        self.replays = 0
+        self.captures = 0
+
+    @staticmethod
+    def _sig(t):
+        return None if t is None else (tuple(t.shape), t.dtype, t.device.index)
+
+    def _check_bounds(self, ent) -> None:
+        plan, host = ent["plan"], ent["host"]
+        if plan is None or host is None or not ent["event"].query():
+            return                                      # the last replay has not finished: look again at the next call
+        n_true, e_true = int(host[0]), int(host[1])
+        hn, he = plan._hints
+        if n_true > hn or (he is not None and e_true > he):
+            raise _lib.IsgError(f"GraphPlan hints understate the batch: max_nodes={hn} / max_edges={he} given, but a graph of a "
+                                f"recent replay has {n_true} nodes / {e_true} edges; results of that replay are invalid")
+
+    def run(self, fn, tensors, key_extra=(), warm: int = 2):
+        if torch.is_grad_enabled():
+            raise RuntimeError("StepCapture: inference only (wrap the call in torch.no_grad() / inference_mode())")
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("StepCapture: already inside a capture")
+        key = (tuple(self._sig(t) for t in tensors), key_extra, CFG)
+        ent = self.entries.get(key)
+        if ent is None:
+            static = [None if t is None else t.clone() for t in tensors]
+            for _ in range(max(1, warm)):
+                fn(*static)
+            check_plans()                              # the eager runs' hints: a wrong one raises HERE, before anything is captured
+            torch.cuda.synchronize()
+            host = torch.zeros(2, dtype=torch.int32, pin_memory=True)
+            graph = torch.cuda.CUDAGraph()
+            _CAPTURE_BOUNDS.append(host)
+            try:
+                with torch.cuda.graph(graph):
+                    outs, plan = fn(*static)
+            finally:
+                _CAPTURE_BOUNDS.pop()
+            if plan is not None and getattr(plan, "_bounds_host", None) is None:
+                host = None                            # (a plan without an edge list / without both hints keeps its bounds on the device)
+            ent = {"graph": graph, "static": static, "outs": outs, "plan": plan, "host": host, "event": torch.cuda.Event()}
+            self.entries[key] = ent
+            self.captures += 1
+            while len(self.entries) > self.max_entries:
+                self.entries.popitem(last=False)
+        else:
+            self.entries.move_to_end(key)
+            self._check_bounds(ent)
+            for st, t in zip(ent["static"], tensors):
+                if t is not None and st.data_ptr() != t.data_ptr():
+                    st.copy_(t, non_blocking=True)
+        ent["graph"].replay()
+        ent["event"].record()
+        self.replays += 1
+        return ent["outs"]
+
+    def verify(self) -> None:
+        """Synchronise and check every entry's last replay (tests; the end of an evaluation loop)."""
+        torch.cuda.synchronize()
+        for ent in self.entries.values():
+            self._check_bounds(ent)
+            if ent["plan"] is not None and ent["host"] is None:
+                ent["plan"].verify_hints()
+
+
 ISG_EUNSUPPORTED = -2      # include/isg.h
 
 # message + softmax + aggregation with lin_edge inside as ONE launch on graph-aligned tiles (csrc/isg_layer_tile.hip): the
@@ -1117,9 +1217,20 @@ def run_split(plan: "GraphPlan", sub: "OversizeGraphs", core, x: Tensor, edge_in
         return core(xs, sub.edge_index, es, sub.batch, instr_s, glf_s, sub.plan, nz_s, seed, gate_s)
 
     def run_main():
-        holed = copy.copy(plan)        # the SAME tensors and caches (dictionaries are shared), its own `holes`: the caller's plan is
-        holed.holes = sub              # not written to, and a second run_split on it (another thread, a re-entrant core) sees none
-        return core(x, edge_index, edge_attr, batch, instr, glf, holed, noises, seed, None)
+        # the SAME tensors and caches, its own `holes`: the caller's plan is not written to, and a second run_split on it (another
+        # thread, a re-entrant core) sees none.  The lazily created cache containers are made on `plan` BEFORE the copy, so that
+        # what the main pass builds (tiles, edge planes, memo) lands where the caller's plan finds it again
+        if plan._tiles is None:
+            plan._tiles = {}
+        if plan._oversize is None:
+            plan._oversize = {}
+        plan.memo()
+        holed = copy.copy(plan)
+        holed.holes = sub
+        holed._memo = {}               # (a layer's dispatch depends on `holes`: the holed plan answers for itself)
+        res = core(x, edge_index, edge_attr, batch, instr, glf, holed, noises, seed, None)
+        plan._edge_planes = holed._edge_planes          # (a tuple, not a container: handed back)
+        return res
 
     if CFG.split_stream and x.is_cuda and not torch.cuda.is_current_stream_capturing():
         # The sub-batch is a chain of ~60 launches of one or a few workgroups each (0.65 ms of GPU time for ONE 100-node graph):

@@ -160,8 +160,10 @@ class AnswerModel(torch.nn.Module):
         self.logit_fc = torch.nn.Linear(512, num_answers)
 
     def forward(self, wl: Workload, noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
-                plan=None, use_hints: bool = True):
+                plan=None, use_hints: bool = True, capture: bool = False):
         from . import ops
+        if capture:
+            return self._captured(wl, noises, seed, plan)
         if plan is None:
             plan = ops.GraphPlan.build(wl.batch, wl.edge_index, num_graphs=wl.glf.size(0),
                                        max_nodes=(wl.max_nodes or None) if use_hints else None,
@@ -173,6 +175,34 @@ class AnswerModel(torch.nn.Module):
         # a few graphs beyond a graph tile: they run as a batch of their own, the rest stays on the tile kernels
         return ops.run_split(plan, sub, self._answer, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, noises, seed,
                              kinds="gnn")
+
+    def _captured(self, wl: Workload, noises, seed, plan):
+        """forward() as a replayed hipGraph (ops.StepCapture), one capture per batch SHAPE: for evaluation loops whose batches are
+        launch-bound (the reference evaluates 4 x --batch-size graphs per step, datasets/build.py:59-62).  The plan is built inside
+        the graph from the collate's bounds (wl.max_nodes / wl.max_edges, required); sampler noise comes from `noises` (copied into
+        the graph's static tensors) or, when none is given, from torch's generator inside the graph -- fresh on every replay, like
+        the reference's own draw; a kernel-argument `seed` would be frozen into the graph and is refused."""
+        from . import ops
+        if seed is not None:
+            raise ValueError("capture=True: a seed is a kernel argument and would repeat in every replay; pass `noises` or neither")
+        if plan is not None:
+            raise ValueError("capture=True builds its plan inside the captured step")
+        if not wl.max_nodes or not wl.max_edges:
+            raise ValueError("capture=True needs the batch's per-graph bounds (Workload.max_nodes / max_edges): a captured step cannot "
+                             "read them back from the device")
+        cap = self.__dict__.get("_step_capture")
+        if cap is None:
+            cap = self.__dict__["_step_capture"] = ops.StepCapture()
+        keys = sorted(noises) if noises else []
+        hints = (int(wl.max_nodes), int(wl.max_edges))
+
+        def fn(x, edge_index, edge_attr, batch, instr, glf, *nz):
+            p = ops.GraphPlan.build(batch, edge_index, num_graphs=glf.size(0), max_nodes=hints[0], max_edges=hints[1])
+            out = self._answer(x, edge_index, edge_attr, batch, instr, glf, p, dict(zip(keys, nz)) if keys else None, None, None)
+            return out, p
+
+        tensors = [wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf] + [noises[k] for k in keys]
+        return cap.run(fn, tensors, key_extra=("answer", hints, tuple(keys), self.training))
 
     def _answer(self, x, edge_index, edge_attr, batch, instr, glf, plan, noises, seed, gate_feats):
         from . import ops as _ops

@@ -128,7 +128,7 @@ def test_traffic_summaries_are_tied_to_kernel_kind_batch_shape_and_kernel_source
     assert bench.load_traffic(N, E, "layer_conv") is not None
 
 
-SAMPLE = "r05_bench_sample.json"        # a default-flag `python bench.py` line of this round, committed under profiles/ by name
+SAMPLE = "r06_bench_sample.json"        # a default-flag `python bench.py` line of this round, committed under profiles/ by name
 
 
 def test_bench_line_schema_on_the_committed_sample():

@@ -823,6 +823,96 @@ def test_a_step_captured_as_a_hipgraph_replays_to_the_eager_result(dev):
             plan3.verify_hints()
 
 
+def test_capture_option_of_the_product_forward_replays_to_the_eager_result(dev):
+    """`AnswerModel.forward(..., capture=True)` (ops.StepCapture): the product path's own hipGraph execution, keyed by batch shape.
+    With explicit noise the captured step equals the eager one bit for bit -- on the batch it was captured on AND on a second batch
+    of the same shapes handed in as other tensors (copied into the graph's static inputs); a second shape gets its own capture;
+    noise drawn inside the graph is fresh per replay; a seed is refused; an understated hint raises one call late."""
+    from isubgvqa_amd import _lib, ops, synthetic
+    cfg = synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": 300})
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).to(dev).eval()
+    layers = [i for i, t in enumerate(cfg.masks) if t != 1.0]
+    noise = {i: synthetic.gumbel_noise((cfg.num_graphs, wl.max_nodes), dev) for i in layers}
+    with torch.no_grad():
+        ref = model(wl, noises=noise)
+        out = model(wl, noises=noise, capture=True)
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+        cap = model._step_capture
+        assert (cap.captures, cap.replays) == (1, 1)
+        # the same shapes, other tensors and other values: one more replay, no new capture
+        gen = torch.Generator(device=dev).manual_seed(5)
+        wl2 = synthetic.Workload(torch.randn(wl.x.shape, device=dev, generator=gen), wl.edge_index.clone(),
+                                 torch.randn(wl.edge_attr.shape, device=dev, generator=gen), wl.batch.clone(),
+                                 torch.randn(wl.instr.shape, device=dev, generator=gen), torch.randn(wl.glf.shape, device=dev, generator=gen),
+                                 wl.num_graphs, wl.max_nodes, wl.max_edges)
+        noise2 = {i: synthetic.gumbel_noise((cfg.num_graphs, wl.max_nodes), dev) for i in layers}
+        ref2 = model(wl2, noises=noise2)
+        out2 = model(wl2, noises=noise2, capture=True)
+        assert (cap.captures, cap.replays) == (1, 2)
+        assert torch.equal(out2[0], ref2[0]) and torch.equal(out2[1], ref2[1])
+        assert not torch.equal(ref2[0], ref[0])
+        # noise from torch's generator inside the graph: another key, fresh per replay
+        a = model(wl, capture=True)[1].clone()
+        masks = {a.cpu().numpy().tobytes()}
+        for _ in range(4):
+            masks.add(model(wl, capture=True)[1].clone().cpu().numpy().tobytes())
+        assert cap.captures == 2 and len(masks) > 1, "the in-graph Gumbel noise repeated on every replay"
+        with pytest.raises(ValueError, match="seed"):
+            model(wl, seed=3, capture=True)
+        cap.verify()
+        # an understated hint: the eager warm-up of a new key raises before anything is captured
+        bad = synthetic.Workload(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.instr, wl.glf, wl.num_graphs,
+                                 max(2, wl.max_nodes // 2), wl.max_edges)
+        with pytest.raises(_lib.IsgError, match="understate"):
+            model(bad, capture=True)
+        # ... and a batch that grows beyond the hints of an existing capture raises at the next call / verify()
+        big = synthetic.make_workload(synthetic.WorkloadConfig(**{**synthetic.CFG2.__dict__, "num_graphs": 300, "nodes_mean": 30.0,
+                                                                  "nodes_std": 6.0, "seed": 77})).to(dev)
+        small_hint = synthetic.Workload(big.x, big.edge_index, big.edge_attr, big.batch, big.instr, big.glf, big.num_graphs,
+                                        big.max_nodes, big.max_edges)
+        model(small_hint, noises=noise_like(big, layers, dev), capture=True)
+        cap.verify()                                   # honest hints: fine
+        # same shapes, a graph larger than the captured hints: build such a batch by permuting nothing but the hints' owner
+        ent = list(cap.entries.values())[-1]
+        ent["plan"]._hints = (max(2, big.max_nodes // 2), big.max_edges)        # what a lying collate would have captured
+        with pytest.raises(_lib.IsgError, match="understate"):
+            cap.verify()
+        ent["plan"]._hints = (big.max_nodes, big.max_edges)
+
+
+def noise_like(wl, layers, dev):
+    from isubgvqa_amd import synthetic
+    return {i: synthetic.gumbel_noise((wl.num_graphs, wl.max_nodes), dev) for i in layers}
+
+
+def test_capture_option_of_the_full_model(dev):
+    """`ISubGVQA.forward(..., capture=True)`: the whole model (question encoder / decoder, scene-graph encoder, MGAT, pooling,
+    classifier) as one replayed hipGraph, bit-equal to the eager forward on the batch it was captured on and on a second batch of
+    the same shapes."""
+    from isubgvqa_amd import synthetic
+    from isubgvqa_amd.models import build_model
+    torch.manual_seed(0)
+    model = build_model(synthetic.full_model_args(text_vocab_size=2048), None).to(dev).eval()
+    with torch.no_grad():
+        outs = []
+        for seed in (3, 4):
+            wl = synthetic.make_full_workload(96, tokens=10, seed=3, text_vocab=2048).to(dev)      # same topology: same shapes
+            if seed == 4:
+                g = torch.Generator(device=dev).manual_seed(9)
+                wl.x = torch.randint(0, 2578, wl.x.shape, device=dev, generator=g)
+                wl.questions = torch.randint(0, 2048, wl.questions.shape, device=dev, generator=g)
+            sg = wl.scene_graphs()
+            ref = model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg)
+            got = model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg,
+                        capture=True)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+            outs.append(ref[0].clone())
+        assert not torch.equal(outs[0], outs[1])
+        assert (model._step_capture.captures, model._step_capture.replays) == (1, 2)
+        model._step_capture.verify()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Mixed dispatch: graphs beyond a 64-node / 256-slot tile go to the per-graph kernels, the rest stays on the tile kernels
 # ---------------------------------------------------------------------------------------------------------------------
