@@ -96,14 +96,14 @@ class MGAT(torch.nn.Module):
         # every layer projects the SAME edge features (mgat.py:144-148): one launch splits each 64-row panel of
         # edge_attr into its bf16 planes once and writes one dense [E, H*C] tensor per layer (isg_linear_panel_multi)
         e_projs = None
-        fdt = self.convs[0].feature_dtype
+        fdt = self.convs[0].rows_dtype(plan)
         fused = (edge_attr.dim() == 2 and not torch.is_grad_enabled()
                  and (fdt == torch.float32 or (fdt == torch.float16 and edge_attr.size(1) >= 128))       # MaskingGATv2Conv.dispatch
                  and ops.fused_logits_supported(plan, self.heads, self.convs[0].out_channels, edge_attr.size(1)))
         if (not fused and not torch.is_grad_enabled() and all(c.lin_edge is not None for c in self.convs)
                 and edge_attr.dim() == 2):
             e_projs = ops.linear_multi(edge_attr, [c.lin_edge.weight for c in self.convs],
-                                       out_dtype=self.convs[0].feature_dtype)
+                                       out_dtype=fdt)
         L = len(self.convs)
         wide = self.heads * self.convs[0].out_channels
         x_gated = x_planes = None     # gelu(h * ins_i[batch]) when the previous layer's fused tail has written it: fp32 rows, planes

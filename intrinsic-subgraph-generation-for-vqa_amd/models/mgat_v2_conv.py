@@ -76,6 +76,16 @@ class MaskingGATv2Conv(torch.nn.Module):
         if self.bias is not None:
             torch.nn.init.zeros_(self.bias)
 
+    def rows_dtype(self, plan) -> torch.dtype:
+        """The storage type of x_l / x_r / e_proj / out for THIS batch: feature_dtype -- unless it is half and a graph of the batch lies
+        beyond the per-graph kernel's 256-node / 1 024-slot tables (GK_NCAP_L / GK_ECAP_L, csrc/isg_mp_graph.hip), the only kernels
+        that read half rows: such a batch keeps fp32 rows (more precise than the half rows it was asked for, never less; within the
+        1e-3 the fp16 mode is held to) instead of raising ISG_EUNSUPPORTED from the message-passing launch."""
+        fdt = self.feature_dtype
+        if fdt == torch.float16 and plan is not None and (plan.nmax > ops.GK_NCAP_L or plan.emax > ops.GK_ECAP_L):
+            return torch.float32
+        return fdt
+
     def dispatch(self, plan, in_channels: int, edge_attr, e_proj=None) -> str:
         """Which kernels run this layer's message passing -- the ONE place that decides (forward, layer_conv_ready and
         needs_rows all ask here):
@@ -90,7 +100,7 @@ class MaskingGATv2Conv(torch.nn.Module):
         # forward, layer_conv_ready and needs_rows of this layer and MGAT's look-ahead ask ~6 times per layer and step: the answer
         # depends on the plan, the widths, the storage type and the switches only, and is kept on the plan (host time: 0.15 ms per step)
         memo = plan.memo()
-        key = ("dispatch", id(self), in_channels, edge_attr.size(1), self.feature_dtype, self.share_weights)
+        key = ("dispatch", id(self), in_channels, edge_attr.size(1), self.rows_dtype(plan), self.share_weights)
         hit = memo.get(key)
         if hit is not None and hit[0] is ops.CFG:
             return hit[1]
@@ -102,7 +112,7 @@ class MaskingGATv2Conv(torch.nn.Module):
         H, C = self.heads, self.out_channels
         if not ops.fused_logits_supported(plan, H, C, edge_attr.size(1)):
             return "unfused"
-        if self.feature_dtype != torch.float32:
+        if self.rows_dtype(plan) != torch.float32:
             # fp16 feature rows (BASELINE configs[4]): the pair exists on the rows kernel (K >= 128), the tile kernels do not
             return "pair" if self.feature_dtype == torch.float16 and edge_attr.size(1) >= 128 else "unfused"
         if not self.share_weights and ops.layer_conv_supported(plan, H, C, in_channels, edge_attr.size(1)):
@@ -153,7 +163,7 @@ class MaskingGATv2Conv(torch.nn.Module):
             x = x.float().contiguous()
             if self.use_instr and how == "layer_conv":
                 x, planes = ops.instr_gate_planes(x, instruction.contiguous(), batch, want_rows=need_rows)   # :156-157
-            elif self.use_instr and not torch.is_grad_enabled() and self.feature_dtype == torch.float32 and \
+            elif self.use_instr and not torch.is_grad_enabled() and self.rows_dtype(plan) == torch.float32 and \
                     ops.h3p_supported(x.size(0), (1 if self.share_weights else 2) * H * C, x.size(1)):
                 # the projection runs on the planes32 engine: the gate writes its operand (and fp32 rows only for a node gate)
                 masked = self.mask.masking_threshold != 1.0
@@ -172,7 +182,7 @@ class MaskingGATv2Conv(torch.nn.Module):
                 return out, mask, (edge_index, alpha)                                    # :237
             return out, mask                                                             # :241
 
-        fdt = self.feature_dtype
+        fdt = self.rows_dtype(plan)
         kw = dict(bias=self.bias, node_mask=mask, negative_slope=self.negative_slope)
         if how == "layer_conv":
             # lin_l | lin_r, lin_edge, logits, softmax and aggregation as ONE persistent launch on graph-aligned tiles

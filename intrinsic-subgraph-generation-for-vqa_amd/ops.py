@@ -833,6 +833,9 @@ def gatv2_mp(x_l: Tensor, x_r: Tensor, e_proj: Tensor, att: Tensor, plan: GraphP
 
 # lin_edge folded into the attention logits (csrc/isg_mp_logits.hip): e_proj [E, H*C] is never written or read
 # CFG.fuse_logits (ops.FUSE_LOGITS): 
+GK_NCAP_L, GK_ECAP_L = 256, 1024      # the per-graph message-passing kernel's largest tables (csrc/isg_mp_graph.hip)
+
+
 def fused_logits_supported(plan: "GraphPlan", heads: int, channels: int, edge_dim: int) -> bool:
     """Shape test of isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits (inference, fp32 rows, per-graph kernel)."""
     cp = (channels + 31) // 32 * 32       # round 5: heads padded to whole 32-channel tiles (the reference's C = 300 -> 320), K <= 304

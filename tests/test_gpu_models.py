@@ -219,6 +219,31 @@ def test_cfg5_skewed_graphs_aimle_fp16_features(dev):
     assert err < 1e-3
 
 
+def test_fp16_rows_with_a_graph_beyond_the_per_graph_tables(dev):
+    """fp16 feature rows (configs[4]'s storage) on a batch with ONE graph of 300 nodes -- beyond the 256-node / 1 024-slot tables of
+    the per-graph kernels, the only ones that read half rows.  Round 5 launched the rows kernel and then raised ISG_EUNSUPPORTED
+    from the message-passing launch; now the layer keeps fp32 rows for such a batch (`rows_dtype`: more precise than
+    asked, never less) and the result stays within the fp16 mode's 1e-3 of the CPU path's fp16 evaluation."""
+    from isubgvqa_amd import ops, synthetic
+    sizes = (20,) * 30 + (300,) + (20,) * 30
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler="aimle", feature_dtype="fp16", seed=12)
+    wl = synthetic.make_workload(cfg)
+    model = synthetic.build_answer_model(cfg)
+    plan = ops.GraphPlan.build(wl.batch.to(dev), wl.edge_index.to(dev), num_graphs=cfg.num_graphs)
+    assert plan.nmax == 300 > ops.GK_NCAP_L
+    conv = model.gat_seq.convs[0]
+    assert conv.feature_dtype == torch.float16 and conv.rows_dtype(plan) == torch.float32
+    keep = wl.batch < 30
+    small = ops.GraphPlan.build(wl.batch[keep].to(dev), wl.edge_index[:, keep[wl.edge_index[1]]].to(dev), num_graphs=30)
+    with torch.no_grad():
+        assert conv.rows_dtype(small) == torch.float16 and conv.dispatch(small, 128, wl.edge_attr.to(dev)) == "pair"
+    wl, (rl, rm, rg), (gl, gm, gg) = _run_both(cfg, dev)
+    bad = torch.zeros(cfg.num_graphs, dtype=torch.bool)
+    bad[wl.batch[(gm != rm).view(-1)]] = True
+    assert int(bad.sum()) <= 1
+    assert (gl[~bad] - rl[~bad]).abs().max() < 1e-3
+
+
 def test_simple_sampler_model_level(dev):
     """SURVEY §8f row 4 inside the model: ragged batch (most graphs have more zero pads than k, i.e. the circuit's
     padding accidents decide their marginals), masks bit-exact, logits within 1e-4."""

@@ -68,6 +68,13 @@ VARIANTS = {
     "opaque_w": pairs(after_loads='asm volatile("" : "+v"(w0)); asm volatile("" : "+v"(w1));'),   # no weight through a high dword
     "scalar": pairs(fma0=ASM_FMA.format(o="o", u="u0", w="w0"), fma1=ASM_FMA.format(o="o", u="u1", w="w1")),   # no packed fp32
     "between_nop": pairs(between='asm volatile("s_nop 7" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));'),   # issue distance between the pair's two writes
+    # round 6 ("the operand form" vs "a timing window the form happens to open"): `opaque_w` differs from the
+    # failing `pairs` by ONE v_mov_b32 in front of the first fma -- and by that instruction's issue slot.  These keep the slot and
+    # the cross-dword select both: the same v_mov_b32 at the same place (one, and two), its result unused by the fmas.  If they fail
+    # like `pairs`, the extra instruction's timing is not what cures `opaque_w`; the operand form is.
+    "cross_plus_mov": pairs(after_loads='{ float dm; asm volatile("v_mov_b32 %0, %1" : "=v"(dm) : "v"(w1)); asm volatile("" :: "v"(dm)); }'),
+    "cross_plus_2mov": pairs(after_loads='{ float dm, dn; asm volatile("v_mov_b32 %0, %1\\n\\tv_mov_b32 %2, %3" : "=v"(dm), "=v"(dn) : "v"(w1), "v"(w0)); '
+                                         'asm volatile("" :: "v"(dm), "v"(dn)); }'),
 }
 # the next tile's requests issued AFTER the aggregation instead of under it (no VMEM in flight across C2), around the failing form
 NO_INFLIGHT = "unroll2_no_inflight"
@@ -99,7 +106,7 @@ def build(name):
     finally:
         os.remove(src)
     objs = [os.path.join(CSRC, "_obj", f) for f in sorted(os.listdir(os.path.join(CSRC, "_obj")))
-            if f.endswith(".o") and f != "isg_layer_tile.o"]
+            if f.endswith(".o") and not f.endswith(".strict.o") and f != "isg_layer_tile.o"]
     lib = os.path.join(OUT, f"libisg_agg_{name}.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", obj, *objs, "-o", lib])
     os.remove(obj)
