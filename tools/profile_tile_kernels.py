@@ -28,5 +28,12 @@ with torch.no_grad():
                                       want_rowmax=True)
         h, xg, _ = ops.mgat_dense_tail(out, m.x_proj[0], ins, x, plan, bn.weight, bn.bias, bn.mean_scale, bn.eps, ins_next=ins_next)
         ops.readout_tile(h, net.graph_global_attention_pooling.node_nn, wl.glf, plan)
+    if "--tile-conv" in sys.argv:
+        # round 6: isg_gatv2_tile_conv (x_l / x_r projected before it) -- the SAME edge chunks, logit epilogue and aggregation as the
+        # layer kernel, as TWO independent four-wave workgroups per CU (74 KB of LDS each) instead of one eight-wave workgroup: the
+        # in-tree instance of "two independent pipelines per CU" 
+        x_l, x_r = ops.linear_fused(x, (conv.lin_l, conv.lin_r))
+        for rep in range(5):
+            ops.gatv2_tile_conv(x_l, x_r, wl.edge_attr, conv.lin_edge.weight, conv.att, plan, H, bias=conv.bias, want_rowmax=True)
 torch.cuda.synchronize()
 print("ok")
