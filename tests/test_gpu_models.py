@@ -566,7 +566,8 @@ def test_full_model_matches_the_reference_forward_golden(dev, ci, engine):
                   {"hip_vs_fp64": hip_loss, "reference_fp32_vs_fp64": ref_loss, "hip_vs_reference": x_err,
                    "bound": "hip_vs_fp64 <= 4 x reference_fp32_vs_fp64: the exact-split products carry 2 x 11 = 22 mantissa bits against fp32's 24"})
     # the exact-split Linears (two fp16 planes per operand, three products) carry 22 mantissa bits per product against fp32's 24:
-    # up to 4x an fp32 evaluation's loss on an intermediate; measured 1.2-2.6x on these cases (the engine dispatch the larger)
+    # up to 4x an fp32 evaluation's loss on an intermediate; measured 0.3-0.4x at the shipped thresholds (bf16x6: 24 bits) and
+    # 0.55x / 2.6x under the engine dispatch
     assert hip_loss <= 4.0 * ref_loss + 1e-6 and x_err <= 5.0 * ref_loss + 1e-6
     assert torch.equal(mask.cpu() > 0.5, case["mask"] > 0.5), "top-k node mask differs from the reference"
     assert err < LOGIT_TOL
