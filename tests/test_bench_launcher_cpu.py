@@ -179,3 +179,28 @@ def test_both_launch_modes_of_the_bench_count_their_fallbacks():
                                if isinstance(n, ast.Assign) for t in n.targets)
     assert assigns(branch.body), "the hipGraph branch never sets step_counters"
     assert assigns(branch.orelse), "the eager branch never sets step_counters"
+
+
+def test_cfg5_workload_lines_name_configs4_and_carry_the_partition():
+    """`bench.py --workload cfg5` (BASELINE configs[4] as the timed workload): the committed one-GPU line and the two-rank rehearsal
+    (gloo ranks sharing the one MI355X) pass the schema of a run with the extra legs off, name configs[4], and the N > 1 line carries
+    what the balanced partition gave every rank and the ragged collective's row counts."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = json.load(open(os.path.join(root, "profiles", "r06_a_cfg5_n1.json")))
+    two = json.load(open(os.path.join(root, "profiles", "r06_a_cfg5_2rank_gloo.json")))
+    for line in (one, two):
+        bench.validate_line(line, full=False)
+        assert "configs[4]" in line["config"]["workload"] and line["config"]["graphs_per_gpu"] == 2048
+        assert line["summary"]["configs1_ms_per_step"] is None and line["summary"]["roofline_frac"] == line["roofline"]["frac"]
+    assert one["n_gpus"] == 1 and one["config"]["global_batch"] == 2048
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 4096
+    pr, rc = two["per_rank"], two["rccl"]
+    assert sum(pr["graphs"]) == 4096 and pr["graphs"] == rc["rows_per_rank"] and rc["ragged"] and rc["padded_rows"] == max(pr["graphs"])
+    assert 1.0 <= pr["imbalance_max_over_mean"] < 1.01 and len(pr["nodes_plus_edges"]) == 2
+    args = bench.parse(["--workload", "cfg5"])
+    assert (args.graphs, args.features) == (2048, "fp16")
+    args = bench.parse([])
+    assert (args.graphs, args.features, args.workload) == (4096, "fp32", "cfg2")

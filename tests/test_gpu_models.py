@@ -917,6 +917,24 @@ def noise_like(wl, layers, dev):
     return {i: synthetic.gumbel_noise((wl.num_graphs, wl.max_nodes), dev) for i in layers}
 
 
+def test_capture_option_with_a_graph_beyond_a_tile(dev):
+    """A captured step cannot list the graphs beyond a tile (that takes a device-to-host read): `tile_mode()` answers "none" inside a
+    capture and the whole batch runs on the per-graph kernels -- slower than the mixed dispatch, never wrong: the same masks as the
+    eager (mixed) forward, logits within 2e-5 (the bound between the two dispatches, test_mixed_dispatch_off_gives_the_same_answers)."""
+    from isubgvqa_amd import synthetic
+    sizes = (20,) * 100 + (130,) + (20,) * 100
+    cfg = synthetic.WorkloadConfig(num_graphs=len(sizes), sizes=sizes, sampler="imle", seed=5)
+    wl = synthetic.make_workload(cfg).to(dev)
+    model = synthetic.build_answer_model(cfg).eval().to(dev)
+    with torch.no_grad():
+        l0, m0, g0 = _forced_mixed(lambda: model(wl))
+        l1, m1, g1 = model(wl, capture=True)
+        l2, m2, g2 = model(wl, capture=True)
+        model._step_capture.verify()
+    assert torch.equal(m0, m1) and torch.equal(m1, m2)
+    assert (l0 - l1).abs().max() < 2e-5 and torch.equal(l1, l2)
+
+
 def test_capture_option_of_the_full_model(dev):
     """`ISubGVQA.forward(..., capture=True)`: the whole model (question encoder / decoder, scene-graph encoder, MGAT, pooling,
     classifier) as one replayed hipGraph, bit-equal to the eager forward on the batch it was captured on and on a second batch of
