@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISG_ABI_VERSION 19
+#define ISG_ABI_VERSION 20
 
 #define ISG_OK 0
 #define ISG_EINVAL (-1)       /* null pointer / negative size / inconsistent sizes          */
@@ -509,6 +509,16 @@ int isg_split_bf16x3(const float *w, int64_t rows, int32_t K, uint16_t *planes, 
  * Requires 4 | K, 4 | lda, a 16-byte aligned. */
 int isg_linear_bf16x6(const float *a, const uint16_t *w_planes, const float *bias, float *d, int64_t M, int32_t N,
                       int32_t K, int32_t lda, int32_t ldd, int32_t act, void *stream);
+
+/* The same Linear for SMALL M (a handful of questions per forward: run_token_coo.py:49-79 evaluates one), where the tile kernels
+ * are bound by the latency of their serial k loop (20-36 us per launch whatever the size): the reduction is split over the eight
+ * waves of a workgroup, operands go from memory straight into TRUE fp32 MFMAs (v_mfma_f32_32x32x2_f32; no planes, no row scales,
+ * no weight preparation), the eight partial tiles are added in wave order -- a row's bits depend on K alone, not on the batch.
+ * a fp32 [M,K] (row stride lda); w fp32 [N,K] in torch's Linear layout (row stride ldw); bias fp32 [N] or NULL; d fp32 (row
+ * stride ldd); act 0 none, 1 exact GELU, 2 ReLU.  ISG_EUNSUPPORTED unless 4 | K, 4 | lda, 4 | ldw, a and w 16-byte aligned.
+ * csrc/isg_gemm_skinny.hip. */
+int isg_linear_skinny(const float *a, int32_t lda, const float *w, int32_t ldw, const float *bias, float *d, int32_t ldd, int64_t M,
+                      int32_t N, int32_t K, int32_t act, void *stream);
 
 /* isg_linear_bf16x6 reading A as fp16 (a_is_f16) and / or writing D as fp16 (d_is_f16, one rounding after bias and
  * activation); lda / ldd count elements of the respective type.  The products are still exact: an fp16 value splits

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libisg_hip.so")
 
 ISG_OK = 0
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # name -> (restype, argtypes); one entry per symbol declared in include/isg.h
 SIGNATURES = {
@@ -59,6 +59,8 @@ SIGNATURES = {
     "isg_node_to_edge_mask_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "isg_split_bf16x3": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "isg_linear_bf16x6": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                  c_int32, c_void_p]),
+    "isg_linear_skinny": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                   c_int32, c_void_p]),
     "isg_linear_bf16x6_f16": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                       c_int32, c_int32, c_int32, c_void_p]),

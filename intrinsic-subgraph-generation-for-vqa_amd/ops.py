@@ -69,6 +69,10 @@ class Switches:
     h3p_min_m: int = 8192
     h3p_store_policy: int = -1
     linear_multi_h3p: bool = True
+    skinny: bool = True
+    rows_kernel_min_edges: int = 8192
+    skinny_max_m: int = 1024
+    skinny_max_work: int = 1 << 30
 
 CFG = Switches()
 _SWITCH_FIELDS = {f.name.upper(): f.name for f in dataclasses.fields(Switches)}
@@ -109,7 +113,7 @@ sys.modules[__name__].__class__ = _OpsModule
 
 # Launches that leave this library's own dense kernels, and extra passes a missing hand-off costs; bench.py prints them
 # per step ("no GEMM of the inference path runs on hipBLASLt" is then a number, not a sentence).
-COUNTERS = {"torch_linear": 0, "torch_layer_norm": 0, "torch_attention": 0, "row_absmax": 0, "linear_h3p": 0, "h3p_segmented": 0,
+COUNTERS = {"torch_linear": 0, "torch_layer_norm": 0, "torch_attention": 0, "row_absmax": 0, "linear_h3p": 0, "h3p_segmented": 0, "linear_skinny": 0,
             "tile_nodes": 0, "oversize_nodes": 0}      # nodes the tile kernels took / nodes of graphs beyond a tile (mixed dispatch)
 
 
@@ -840,6 +844,11 @@ def fused_logits_supported(plan: "GraphPlan", heads: int, channels: int, edge_di
     """Shape test of isg_gatv2_edge_logits + isg_gatv2_mp_fwd_logits (inference, fp32 rows, per-graph kernel)."""
     cp = (channels + 31) // 32 * 32       # round 5: heads padded to whole 32-channel tiles (the reference's C = 300 -> 320), K <= 304
     wide = channels % 32 != 0 or edge_dim > 128
+    if wide and plan.E < CFG.rows_kernel_min_edges:
+        # the rows kernel streams all of lin_edge's tiles through its three-slot ring whatever the number of slots: ~94 us for 400
+        # edges as for 50 000 (40 tiles x one DMA round trip each).  A small batch projects its few edge rows (isg_linear_skinny, ~5 us)
+        # and runs the flat kernel on e_proj instead
+        return False
     return (CFG.fuse_logits and (CFG.fuse_logits_wide or not wide) and CFG.gemm_backend == "bf16x6" and CFG.gemm_f16x3 and
             CFG.mp_kernel == "graph" and channels % 4 == 0 and heads * cp <= 2048 and 0 < edge_dim <= 304 and edge_dim % 4 == 0 and
             plan.B > 0 and plan.nmax > 0 and plan.rowptr is not None and plan.E > 0)
@@ -2193,6 +2202,10 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         if M == 0:
             return x.new_empty(0, N)
         return _linear_torch(x, weight, bias, gelu, False)
+    if skinny_supported(M, N, K) and not f16_io and x.dtype == torch.float32:
+        y = linear_skinny(x, weight, bias, gelu=gelu, relu=relu)
+        if y is not None:
+            return y
     if not f16_io and h3p_supported(M, N, K) and x.stride(1) == 1 and (x.stride(0) & 3) == 0 and (x.data_ptr() & 15) == 0:
         # K >= 256 over many rows: the planes32 engine (csrc/isg_gemm_h3p.hip); the split of x stays attached to x
         return linear_h3p(x, weight, bias, gelu=gelu, relu=relu, cache_planes=cache_planes)
@@ -2363,6 +2376,38 @@ def _h3p_weight(weight: Tensor, bias: Optional[Tensor], cache: bool = True, seg_
         with torch.no_grad():
             return build()
     return derived_weight(f"h3p{seg_cols or ''}", (weight,) if bias is None else (weight, bias), build)
+
+
+# CFG.rows_kernel_min_edges (ops.ROWS_KERNEL_MIN_EDGES): below this many edges a wide layer (C = 300 / K = 300) projects its edge rows and runs un-fused
+# CFG.skinny (ops.SKINNY): Linears over at most CFG.skinny_max_m rows (and M N K <= CFG.skinny_max_work) on isg_linear_skinny (A/B switch)
+# CFG.skinny_max_m (ops.SKINNY_MAX_M): the latency-bound regime: a handful of questions per forward (csrc/isg_gemm_skinny.hip)
+# CFG.skinny_max_work (ops.SKINNY_MAX_WORK): true fp32 MFMAs run at 1/16 of the fp16 rate: beyond ~1e9 multiply-adds the exact-split tile kernels win
+def skinny_supported(M: int, N: int, K: int) -> bool:
+    return (CFG.skinny and CFG.gemm_backend == "bf16x6" and CFG.gemm_kernel == "auto" and 0 < M <= CFG.skinny_max_m and (K & 3) == 0
+            and M * N * K <= CFG.skinny_max_work)
+
+
+def linear_skinny(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False, relu: bool = False) -> Optional[Tensor]:
+    """act(x @ weight^T + bias) on isg_linear_skinny (small M: the reduction split over a workgroup's waves, true fp32 MFMAs, the
+    weight read as it is).  None when the operands' layout is not the kernel's (the caller takes the tile kernels)."""
+    w = weight.detach()
+    if (x.dim() != 2 or w.dim() != 2 or x.stride(1) != 1 or w.stride(1) != 1 or (x.stride(0) & 3) or (w.stride(0) & 3)
+            or (x.data_ptr() & 15) or (w.data_ptr() & 15) or w.dtype != torch.float32 or w.device != x.device):
+        return None
+    lib = _lib.load()
+    M, K = x.shape
+    N = w.size(0)
+    if w.size(1) != K:
+        raise ValueError(f"linear_skinny: x has {K} columns, weight {tuple(w.shape)}")
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    rc = lib.isg_linear_skinny(_chk_rows(x, "x"), x.stride(0), w.data_ptr(), w.stride(0),
+                               _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
+                               out.data_ptr(), N, M, N, K, 2 if relu else (1 if gelu else 0), _stream())
+    if rc == ISG_EUNSUPPORTED:
+        return None
+    _lib.check(rc, "isg_linear_skinny")
+    COUNTERS["linear_skinny"] += 1
+    return out
 
 
 # CFG.h3p (ops.H3P): Linears with K >= CFG.h3p_min_k over at least CFG.h3p_min_m rows on isg_linear_h3p (A/B switch)

@@ -328,7 +328,8 @@ def _dispatch(engine):
     goldens' sizes.  The context manager is what the shipped thresholds otherwise decide from the row count alone."""
     import contextlib
     from isubgvqa_amd import ops
-    return ops.configured(h3p_min_m=1) if engine else contextlib.nullcontext()
+    # (skinny=False, rows_kernel_min_edges=0: the small-batch kernels of round 6 would otherwise take these few rows first)
+    return ops.configured(h3p_min_m=1, skinny=False, rows_kernel_min_edges=0) if engine else contextlib.nullcontext()
 
 
 def _assert_engine_ran(engine, c):

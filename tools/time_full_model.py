@@ -48,3 +48,18 @@ with torch.no_grad():
     dt = (time.perf_counter() - t0) / steps
 print(f"full model, {graphs} graphs (N={wl.x.size(0)}, E={wl.edge_index.size(1)}, T={wl.questions.size(1)}): "
       f"{dt * 1e3:.2f} ms/step = {graphs / dt:,.0f} questions/s; h3p store policy {ops.h3p_store_policy()}")
+if '--capture' in sys.argv:       # the same batch through the product path's hipGraph option (ops.StepCapture)
+    def cstep():
+        return model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg,
+                     capture=True)[0]
+    with torch.no_grad():
+        for _ in range(3):
+            cout = cstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cout = cstep()
+        torch.cuda.synchronize()
+        dc = (time.perf_counter() - t0) / steps
+        model._step_capture.verify()
+    print(f"    capture=True: {dc * 1e3:.3f} ms/step = {graphs / dc:,.0f} questions/s; equal to the eager logits: {torch.equal(cout, out)}")
