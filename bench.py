@@ -36,6 +36,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   cfg5          BASELINE configs[4] on one GPU (skewed graphs, AIMLE, fp16 rows): ms/step, MP kernel GB/s on s = 2 bytes, the
                 imbalance of contiguous graph ranges over 8 ranks
   eval_batch    the reference's evaluation batch (1 024 graphs) on the product path: eager vs its hipGraph option (capture=True)
+  small_batch   the full model at 1 / 8 / 32 questions (run_token_coo.py's batch is one): eager and capture=True
   summary       the legs' headline numbers, flat, at the front of the line
   mixed         the configs[1] batch with a few graphs beyond a graph tile (what real GQA batches are: the reference caps nothing):
                 ms/step with the tile kernels + the big graphs as a sub-batch (ops.run_split) and with the per-graph kernels for all
@@ -524,6 +525,41 @@ def eval_batch_leg(dev, graphs: int = 1024, steps: int = 200):
             "option": "AnswerModel.forward(..., capture=True) / ISubGVQA.forward(..., capture=True): ops.StepCapture, one hipGraph per batch shape"}
 
 
+def small_batch_leg(dev, sizes=(1, 8, 32), steps: int = 100):
+    """The FULL model (C = 300, 4 MGAT layers, question encoder / decoder, scene-graph encoder) at the batch sizes of the reference's own
+    evaluation script (run_token_coo.py:49-79: one question per forward): ms per forward, eager and as a replayed hipGraph
+    (`ISubGVQA.forward(..., capture=True)`).  The latency-bound regime: round 6's isg_linear_skinny and the small-batch dispatch."""
+    import torch
+    from isubgvqa_amd import ops, synthetic
+    from isubgvqa_amd.models import build_model
+    torch.manual_seed(0)
+    model = build_model(synthetic.full_model_args(), None).to(dev).eval()
+    out = {"workload": "full ISubGVQA model (configs[2] stand-in) at 1 / 8 / 32 questions of 12 tokens", "steps": steps, "sizes": {}}
+    with torch.no_grad():
+        for g in sizes:
+            wl = synthetic.make_full_workload(g).to(dev)
+            sg = wl.scene_graphs()
+            res = {}
+            for name, kw in (("eager", {}), ("captured", {"capture": True})):
+                f = lambda: model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True,
+                                  scene_graphs=sg, **kw)[0]
+                for _ in range(5):
+                    f()
+                torch.cuda.synchronize()
+                ops.reset_counters()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    logits = f()
+                torch.cuda.synchronize()
+                res[name + "_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+                if name == "eager":
+                    res["skinny_linears_per_forward"] = round(ops.counters()["linear_skinny"] / steps, 1)
+            assert torch.isfinite(logits).all()
+            out["sizes"][str(g)] = res
+        model._step_capture.verify()
+    return out
+
+
 def mixed_leg(dev, graphs: int = 4096, big: int = 8, steps: int = 10):
     """The configs[1] batch with `big` of its graphs replaced by graphs of 100-189 nodes, after the timed region: the default
     dispatch (tile kernels for the graphs that fit a 64-node / 256-in-edge tile, the others as a batch of their own through the whole
@@ -997,6 +1033,12 @@ def main(argv=None):
             res["eval_batch"] = eval_batch_leg(dev)
             res["summary"].update(eval_batch_1024_eager_ms=res["eval_batch"]["eager_ms_per_step"],
                                   eval_batch_1024_captured_ms=res["eval_batch"]["captured_ms_per_step"])
+        if world == 1 and not cfg5 and not args.no_full_model:
+            progress("small_batch leg (full model at 1 / 8 / 32 questions: eager vs capture=True)")
+            res["small_batch"] = small_batch_leg(dev)
+            sb = res["small_batch"]["sizes"]
+            res["summary"].update(full_model_1_question_eager_ms=sb["1"]["eager_ms"], full_model_1_question_captured_ms=sb["1"]["captured_ms"],
+                                  full_model_8_questions_captured_ms=sb["8"]["captured_ms"])
         ops.check_plans()           # any understated GraphPlan hint of this run raises here
         if world == 1 and not cfg5 and not args.no_cpu_baseline:
             progress("cpu_baseline leg (oracle on the host cores)")

@@ -10,20 +10,21 @@
 // size, a K = 2048 reduction four launches of it (84 us), and the full model is ~75 of them back to back: 2.8 ms for ONE question
 // as for 256 (profiles/r06_k_full_model_b8_kernel_stats.csv).  Here the reduction is split over the EIGHT WAVES of a workgroup
 // (wave w owns k in [w ks, (w + 1) ks)), every wave reads its slices of A and W straight from memory into MFMA operands -- no LDS
-// staging, no barrier inside the k loop -- and the eight partial 32 x 32 tiles are added through LDS in wave order: one barrier per
-// workgroup.  The products are TRUE fp32 (v_mfma_f32_32x32x2_f32: 1/16 of the fp16 rate, irrelevant at these sizes): no row
+// staging, no barrier inside the k loop -- and the eight partial tiles are added through LDS in wave order: one barrier per
+// workgroup.  The products are TRUE fp32 (v_mfma_f32_16x16x4_f32: 1/16 of the fp16 rate, irrelevant at these sizes): no row
 // scales, no planes, no weight preparation.
-//   grid    (ceil(N / 32), ceil(M / 32)); block 512 = 8 waves; LDS 8 x 32 x 33 x 4 = 33,792 bytes
-//   wave    lane (r = lane & 31, hh = lane >> 5) loads A[m0 + r][k .. k + 3] and W[n0 + r][k .. k + 3] with k = kk + 4 hh as float4
-//           and issues four 32x32x2 MFMAs on their components: the pair of k values an MFMA reduces is (kk + j, kk + 4 + j)
-//   order   a row's sum is: per wave its k slice ascending (pairs as above), then waves 0..7 ascending -- a function of K alone, so the
+//   grid    (ceil(N / 16), ceil(M / 16)); block 512 = 8 waves; LDS 8 x 16 x 17 x 4 = 8,704 bytes.  16 x 16 output tiles, not 32 x 32:
+//           the fp32 MFMA rate of ONE CU is what a workgroup's chain costs (a 32 x 32 x 2048 tile is 8 us of it), and a small Linear has
+//           few tiles -- four times as many workgroups put four times as many CUs under the same reduction
+//   wave    lane (r = lane & 15, q = lane >> 4) loads A[m0 + r][k .. k + 3] and W[n0 + r][k .. k + 3] with k = kk + 4 q as float4 and
+//           issues four 16x16x4 MFMAs on their components: MFMA j of a step reduces k = kk + 4 q + j over q = 0..3
+//   order   a row's sum is: per wave its k slice ascending (as above), then waves 0..7 ascending -- a function of K alone, so the
 //           SAME row gives the SAME bits wherever it sits in the batch and whatever the batch's size (distributed.py's contract)
 #include "isg_common.hpp"
 
 namespace isg {
 
-constexpr int SK_WAVES = 8, SK_THREADS = 64 * SK_WAVES, SK_T = 32, SK_LD = SK_T + 1;
-typedef float sk_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SK_WAVES = 8, SK_THREADS = 64 * SK_WAVES, SK_T = 16, SK_LD = SK_T + 1;
 typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
 
 template <int ACT>
@@ -33,51 +34,48 @@ __global__ __launch_bounds__(SK_THREADS) void linear_skinny_kernel(const float *
   __shared__ float s_part[SK_WAVES][SK_T][SK_LD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hh = lane >> 5;
+  const int r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * SK_T, m0 = blockIdx.y * SK_T;
   // rows past the end repeat the last row (their results are never stored)
   const float *ap = A + (int64_t)min(m0 + r, M - 1) * lda;
   const float *wp = W + (int64_t)min(n0 + r, N - 1) * ldw;
-  const int ks = (K + 8 * SK_WAVES - 1) / (8 * SK_WAVES) * 8;            // a wave's slice: a whole number of 8-wide steps
+  const int ks = (K + 16 * SK_WAVES - 1) / (16 * SK_WAVES) * 16;         // a wave's slice: a whole number of 16-wide steps
   const int k_lo = wave * ks, k_hi = min(K, k_lo + ks);
-  sk_f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const sk_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  // four steps (32 columns of k) per round; the NEXT round's eight loads are in flight under this round's sixteen MFMAs (two
+  // four steps (64 columns of k) per round; the NEXT round's eight loads are in flight under this round's sixteen MFMAs (two
   // register images, the loop unrolled by two so that neither is ever copied)
   sk_f32x4 a0[4], b0[4], a1[4], b1[4];
 #define SK_LOAD(RA, RB, kk_)                                                                                       \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
-    const int k = (kk_) + 8 * u + 4 * hh;                               /* 4 | K: k < K means k + 3 < K */          \
+    const int k = (kk_) + 16 * u + 4 * q;                               /* 4 | K: k < K means k + 3 < K */          \
     const bool in = k < k_hi;                                                                                      \
     RA[u] = in ? *reinterpret_cast<const sk_f32x4 *>(ap + k) : zero;                                               \
     RB[u] = in ? *reinterpret_cast<const sk_f32x4 *>(wp + k) : zero;                                               \
   }
 #define SK_MFMA(RA, RB)                                                                                            \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(RA[u][j], RB[u][j], acc, 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(RA[u][j], RB[u][j], acc, 0, 0, 0); \
   }
   if (k_lo < k_hi) {
     SK_LOAD(a0, b0, k_lo)
 #pragma unroll 1
-    for (int kk = k_lo; kk < k_hi; kk += 64) {
-      SK_LOAD(a1, b1, kk + 32)            // (past the slice's end: zeros, and the MFMAs on them below add nothing)
+    for (int kk = k_lo; kk < k_hi; kk += 128) {
+      SK_LOAD(a1, b1, kk + 64)            // (past the slice's end: zeros, and the MFMAs on them below would add nothing)
       SK_MFMA(a0, b0)
-      if (kk + 32 >= k_hi) break;
-      SK_LOAD(a0, b0, kk + 64)
+      if (kk + 64 >= k_hi) break;
+      SK_LOAD(a0, b0, kk + 128)
       SK_MFMA(a1, b1)
     }
   }
 #undef SK_LOAD
 #undef SK_MFMA
-  // acc[i]: row (i & 3) + 8 (i >> 2) + 4 hh of the tile, column r
+  // acc[i]: row 4 q + i of the tile, column r
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s_part[wave][(i & 3) + 8 * (i >> 2) + 4 * hh][r] = acc[i];
+  for (int i = 0; i < 4; ++i) s_part[wave][4 * q + i][r] = acc[i];
   __syncthreads();
-#pragma unroll
-  for (int o = tid; o < SK_T * SK_T; o += SK_THREADS) {
-    const int row = o >> 5, col = o & 31;
+  if (tid < SK_T * SK_T) {
+    const int row = tid >> 4, col = tid & 15;
     float v = s_part[0][row][col];
 #pragma unroll
     for (int w = 1; w < SK_WAVES; ++w) v += s_part[w][row][col];

@@ -2390,19 +2390,30 @@ def skinny_supported(M: int, N: int, K: int) -> bool:
 def linear_skinny(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool = False, relu: bool = False) -> Optional[Tensor]:
     """act(x @ weight^T + bias) on isg_linear_skinny (small M: the reduction split over a workgroup's waves, true fp32 MFMAs, the
     weight read as it is).  None when the operands' layout is not the kernel's (the caller takes the tile kernels)."""
-    w = weight.detach()
-    if (x.dim() != 2 or w.dim() != 2 or x.stride(1) != 1 or w.stride(1) != 1 or (x.stride(0) & 3) or (w.stride(0) & 3)
-            or (x.data_ptr() & 15) or (w.data_ptr() & 15) or w.dtype != torch.float32 or w.device != x.device):
+    # (host time matters here -- a forward at this size is ~70 of these calls and the GPU needs ~10 us for each: every tensor
+    # property is read once, nothing is detached or viewed)
+    if x.dim() != 2 or weight.dim() != 2:
         return None
-    lib = _lib.load()
     M, K = x.shape
-    N = w.size(0)
-    if w.size(1) != K:
-        raise ValueError(f"linear_skinny: x has {K} columns, weight {tuple(w.shape)}")
+    N, Kw = weight.shape
+    lda, ldw, xp, wp = x.stride(0), weight.stride(0), x.data_ptr(), weight.data_ptr()
+    if (x.stride(1) != 1 or weight.stride(1) != 1 or ((lda | ldw) & 3) or ((xp | wp) & 15) or x.dtype != torch.float32
+            or weight.dtype != torch.float32 or weight.device != x.device):
+        return None
+    if not x.is_cuda:
+        raise _lib.IsgError(f"x must live on the GPU (got {x.device}); this path has no CPU fallback")
+    if Kw != K:
+        raise ValueError(f"linear_skinny: x has {K} columns, weight {tuple(weight.shape)}")
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        raise NotImplementedError("linear_skinny has no backward (autograd.linear is the differentiable Linear)")
+    bp = 0
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous() or bias.device != x.device:
+            raise ValueError(f"linear_skinny: bias must be a contiguous fp32 [{N}] tensor on {x.device}")
+        bp = bias.data_ptr()
+    lib = _lib.load()
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    rc = lib.isg_linear_skinny(_chk_rows(x, "x"), x.stride(0), w.data_ptr(), w.stride(0),
-                               _chk(None if bias is None else bias.detach(), "bias", torch.float32, (N,), optional=True),
-                               out.data_ptr(), N, M, N, K, 2 if relu else (1 if gelu else 0), _stream())
+    rc = lib.isg_linear_skinny(xp, lda, wp, ldw, bp, out.data_ptr(), N, M, N, K, 2 if relu else (1 if gelu else 0), _stream())
     if rc == ISG_EUNSUPPORTED:
         return None
     _lib.check(rc, "isg_linear_skinny")

@@ -1096,6 +1096,30 @@ def test_linear_skinny_matches_fp64_like_an_fp32_gemm(dev, M, N, K, act):
         assert (y2.double() - ref2).abs().max().item() <= 2.0 * e32 + 1e-5
 
 
+def test_small_batch_dispatch_skinny_linears_and_no_rows_kernel_below_its_break_even(dev):
+    """The shipped switches at a handful of questions: a wide layer (the reference's C = 300, 300 edge features) with fewer than
+    ops.CFG.rows_kernel_min_edges edges does NOT take the edge-logits pair (the rows kernel streams all 40 weight tiles through its
+    ring whatever the number of slots: ~94 us for 400 edges) -- it projects its edge rows (isg_linear_skinny) and runs the un-fused
+    kernel; a narrow layer (C = 128, K = 128: the panel / tile kernels) is not affected; above the break-even the pair is back."""
+    from isubgvqa_amd import ops
+    from isubgvqa_amd.models.mgat_v2_conv import MaskingGATv2Conv
+    gen = torch.Generator().manual_seed(2)
+    batch, ei = _rand_graphs(gen, [20] * 8, extra_per_node=1.5)
+    plan = ops.GraphPlan.build(batch.to(dev), ei.to(dev), num_graphs=8)
+    assert plan.E < ops.CFG.rows_kernel_min_edges
+    assert not ops.fused_logits_supported(plan, 4, 300, 300) and ops.fused_logits_supported(plan, 4, 128, 128)
+    with ops.configured(rows_kernel_min_edges=0):
+        assert ops.fused_logits_supported(plan, 4, 300, 300)
+    conv = MaskingGATv2Conv(300, 300, heads=4, edge_dim=300, add_self_loops=False, masking_threshold=1.0, use_instr=True, use_topk=True,
+                            sampler_type="imle", sample_k=5).to(dev).eval()
+    ea = torch.randn(ei.size(1), 300, generator=gen).to(dev)
+    with torch.no_grad():
+        assert conv.dispatch(plan, 300, ea) == "unfused"
+        big_b, big_ei = _rand_graphs(gen, [20] * 200, extra_per_node=1.5)
+        big = ops.GraphPlan.build(big_b.to(dev), big_ei.to(dev), num_graphs=200)
+        assert big.E >= ops.CFG.rows_kernel_min_edges and conv.dispatch(big, 300, torch.empty(big.E, 300, device=dev)) == "pair"
+
+
 def test_linear_skinny_rows_do_not_depend_on_the_batch(dev):
     """distributed.py's contract (a shard's result is the path run on the shard alone) needs the SAME row to give the SAME bits in
     any batch: isg_linear_skinny's summation order is a function of K alone -- a row alone, the row inside 97 others, shifted by 13."""
