@@ -2187,6 +2187,13 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
     if isinstance(x, Planes32):                    # the producer handed the rows over pre-split (a Linear's planes output)
         return linear_h3p(x, weight, bias, gelu=gelu, relu=relu, cache_planes=cache_planes)
     M, K = x.shape
+    if (M <= CFG.skinny_max_m and out_dtype == torch.float32 and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and skinny_supported(M, weight.size(0), K)):
+        # the latency-bound regime first: at these sizes the HOST's time per call is what the forward costs, and
+        # nothing below applies (inference, fp32 rows in and out)
+        y = linear_skinny(x, weight, bias, gelu=gelu, relu=relu)
+        if y is not None:
+            return y
     f16_io = x.dtype == torch.float16 or out_dtype == torch.float16
     if f16_io and (CFG.gemm_backend != "bf16x6" or (K & 3) != 0 or _rec(x, weight, bias)):
         raise _lib.IsgError("fp16 feature rows are an inference feature of the bf16x6 kernel (K % 4 == 0, no autograd)")
