@@ -527,8 +527,8 @@ def eval_batch_leg(dev, graphs: int = 1024, steps: int = 200):
 
 def small_batch_leg(dev, sizes=(1, 8, 32), steps: int = 100):
     """The FULL model (C = 300, 4 MGAT layers, question encoder / decoder, scene-graph encoder) at the batch sizes of the reference's own
-    evaluation script (run_token_coo.py:49-79: one question per forward): ms per forward, eager and as a replayed hipGraph
-    (`ISubGVQA.forward(..., capture=True)`).  The latency-bound regime: round 6's isg_linear_skinny and the small-batch dispatch."""
+    evaluation script (run_token_coo.py:49-79: one question per forward): ms per forward, eager, as a replayed hipGraph
+    (`ISubGVQA.forward(..., capture=True)`) and with the question side alone replayed (`capture="language"`).  The latency-bound regime: round 6's isg_linear_skinny and the small-batch dispatch."""
     import torch
     from isubgvqa_amd import ops, synthetic
     from isubgvqa_amd.models import build_model
@@ -540,7 +540,9 @@ def small_batch_leg(dev, sizes=(1, 8, 32), steps: int = 100):
             wl = synthetic.make_full_workload(g).to(dev)
             sg = wl.scene_graphs()
             res = {}
-            for name, kw in (("eager", {}), ("captured", {"capture": True})):
+            # "language": only the question side replayed (keyed by the questions' shape: what a loop over single questions whose
+            # scene graphs never repeat a shape can use), the graph side eager
+            for name, kw in (("eager", {}), ("captured", {"capture": True}), ("language_captured", {"capture": "language"})):
                 f = lambda: model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True,
                                   scene_graphs=sg, **kw)[0]
                 for _ in range(5):
@@ -1038,6 +1040,7 @@ def main(argv=None):
             res["small_batch"] = small_batch_leg(dev)
             sb = res["small_batch"]["sizes"]
             res["summary"].update(full_model_1_question_eager_ms=sb["1"]["eager_ms"], full_model_1_question_captured_ms=sb["1"]["captured_ms"],
+                                  full_model_1_question_language_captured_ms=sb["1"]["language_captured_ms"],
                                   full_model_8_questions_captured_ms=sb["8"]["captured_ms"])
         ops.check_plans()           # any understated GraphPlan hint of this run raises here
         if world == 1 and not cfg5 and not args.no_cpu_baseline:

@@ -139,20 +139,42 @@ class ISubGVQA(torch.nn.Module):
                   [noises[k] for k in keys]
         return cap.run(fn, tensors, key_extra=("isubgvqa", int(mn), int(me), tuple(keys), self.training))
 
+    def _captured_language(self, questions, qsts_att_mask, text_uniform, seed):
+        """language_features() -- question encoder, program decoder, the two reductions: ~65 of a forward's ~110 launches -- as a
+        replayed hipGraph keyed by the questions' SHAPE alone (`capture="language"`).  The whole-forward capture needs every batch
+        shape to repeat; an evaluation loop over single questions (run_token_coo.py:49-79) never repeats a scene graph's (N, E) but
+        has only a couple of dozen question lengths: the question side is replayed, the graph side issued eagerly behind it on the
+        same stream (which is what orders the reads of the graph's static outputs before the next replay writes them).  Below ~32
+        questions the forward is bound by the host's issue time: this removes more than half of it."""
+        if self.text_sampling and seed is not None:
+            raise ValueError("capture='language' with --text_sampling: a seed would be frozen into the graph; pass text_uniform or neither")
+        cap = self.__dict__.get("_language_capture")
+        if cap is None:
+            cap = self.__dict__["_language_capture"] = ops.StepCapture(max_entries=64)
+        return cap.run(lambda q, m, tu: (self.language_features(q, m, tu, None), None), [questions, qsts_att_mask, text_uniform],
+                       key_extra=("language", self.training))
+
     def forward(self, node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask,
                 return_masks=False, explainer=False, explainer_stage=False, expl_bypass_x=False, scene_graphs=None,
                 noises: Optional[Dict[int, Tensor]] = None, seed: Optional[int] = None,
-                plan: Optional[ops.GraphPlan] = None, text_uniform: Optional[Tensor] = None, capture: bool = False):
+                plan: Optional[ops.GraphPlan] = None, text_uniform: Optional[Tensor] = None, capture=False):
         if not return_masks:
             # the reference unpacks two values from GlobalAttention.forward, which returns a bare tensor when
             # return_mask=False (isubgvqa.py:280, att_pooling.py:75-77): return_masks=True is mandatory there
             raise ValueError("return_masks=True is required (isubgvqa.py:280 unpacks (embed, gate))")
-        if capture:
+        if capture is True:
             return self._captured(node_embeddings, edge_index, edge_embeddings, batch, questions, qsts_att_mask, explainer,
                                   explainer_stage, scene_graphs, noises, seed, plan, text_uniform)
-        glf, instr_vectors = self.language_features(questions, qsts_att_mask, text_uniform,
-                                                    None if seed is None else seed + 7919)
+        if capture == "language":
+            glf, instr_vectors = self._captured_language(questions, qsts_att_mask, text_uniform, seed)
+        elif capture:
+            raise ValueError(f"capture = {capture!r}: True (the whole forward), 'language' (the question side only) or False")
+        else:
+            glf, instr_vectors = self.language_features(questions, qsts_att_mask, text_uniform,
+                                                        None if seed is None else seed + 7919)
         mask_text = self.last_mask_text
+        if capture == "language" and mask_text is not None:
+            mask_text = mask_text.clone()                  # (a static tensor of the replayed graph: the caller gets its own)
         if explainer and explainer_stage > 0:                                            # :249-253
             node_embeddings, expl_bypass_x = expl_bypass_x, node_embeddings.clone()
         if plan is None:   # a loader.SceneGraphBatch carries the per-graph bounds: the plan is then built without a sync

@@ -963,6 +963,32 @@ def test_capture_option_of_the_full_model(dev):
         model._step_capture.verify()
 
 
+def test_capture_of_the_question_side_alone(dev):
+    """`ISubGVQA.forward(..., capture="language")`: the question encoder / decoder and the two reductions replayed from a hipGraph keyed
+    by the questions' shape, the graph side eager -- for loops whose scene graphs never repeat a shape (run_token_coo.py:49-79).  Three
+    batches of 4 questions x 9 tokens over DIFFERENT scene graphs (other N, E): one capture, three replays, every result bit-equal to
+    the eager forward; another question length: a second capture."""
+    from isubgvqa_amd import synthetic
+    from isubgvqa_amd.models import build_model
+    torch.manual_seed(0)
+    model = build_model(synthetic.full_model_args(text_vocab_size=2048), None).to(dev).eval()
+    shapes = set()
+    with torch.no_grad():
+        for seed, tokens in ((3, 9), (4, 9), (5, 9), (6, 13)):
+            wl = synthetic.make_full_workload(4, tokens=tokens, seed=seed, text_vocab=2048).to(dev)
+            shapes.add((wl.x.size(0), wl.edge_index.size(1)))
+            sg = wl.scene_graphs()
+            ref = model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg)
+            got = model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg,
+                        capture="language")
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+        cap = model._language_capture
+        assert len(shapes) >= 3, "the batches were meant to differ in their graphs' sizes"
+        assert (cap.captures, cap.replays) == (2, 4)
+        with pytest.raises(ValueError, match="capture"):
+            model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg, capture="all")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Mixed dispatch: graphs beyond a 64-node / 256-slot tile go to the per-graph kernels, the rest stays on the tile kernels
 # ---------------------------------------------------------------------------------------------------------------------

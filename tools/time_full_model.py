@@ -63,3 +63,18 @@ if '--capture' in sys.argv:       # the same batch through the product path's hi
         dc = (time.perf_counter() - t0) / steps
         model._step_capture.verify()
     print(f"    capture=True: {dc * 1e3:.3f} ms/step = {graphs / dc:,.0f} questions/s; equal to the eager logits: {torch.equal(cout, out)}")
+
+    def lstep():
+        return model(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg,
+                     capture="language")[0]
+    with torch.no_grad():
+        for _ in range(3):
+            lout = lstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lout = lstep()
+        torch.cuda.synchronize()
+        dl = (time.perf_counter() - t0) / steps
+    print(f"    capture='language' (question side replayed, graph side eager): {dl * 1e3:.3f} ms/step = {graphs / dl:,.0f} questions/s; "
+          f"equal: {torch.equal(lout, out)}")
