@@ -70,7 +70,7 @@ class Switches:
     h3p_store_policy: int = -1
     linear_multi_h3p: bool = True
     skinny: bool = True
-    rows_kernel_min_edges: int = 8192
+    rows_kernel_min_edges: int = 16384
     skinny_max_m: int = 1024
     skinny_max_work: int = 1 << 30
 

@@ -21,7 +21,7 @@ def dev():
 @pytest.fixture(autouse=True)
 def _kernels_under_test(request):
     """The tests of this file address individual kernels through ops.linear and the layers' dispatch at SMALL sizes.  Round 6's
-    small-batch dispatch (isg_linear_skinny for Linears over at most 1 024 rows; no rows kernel below 8 192 edges at the wide shapes)
+    small-batch dispatch (isg_linear_skinny for Linears over at most 1 024 rows; no rows kernel below 16 384 edges at the wide shapes)
     would take those sizes before the kernel a test is about: it is switched off here, except in the tests that are about it.  The
     model-level tests (tests/test_gpu_models.py) run with the shipped switches."""
     from isubgvqa_amd import ops
@@ -1115,8 +1115,8 @@ def test_small_batch_dispatch_skinny_linears_and_no_rows_kernel_below_its_break_
     ea = torch.randn(ei.size(1), 300, generator=gen).to(dev)
     with torch.no_grad():
         assert conv.dispatch(plan, 300, ea) == "unfused"
-        big_b, big_ei = _rand_graphs(gen, [20] * 200, extra_per_node=1.5)
-        big = ops.GraphPlan.build(big_b.to(dev), big_ei.to(dev), num_graphs=200)
+        big_b, big_ei = _rand_graphs(gen, [20] * 400, extra_per_node=1.5)
+        big = ops.GraphPlan.build(big_b.to(dev), big_ei.to(dev), num_graphs=400)
         assert big.E >= ops.CFG.rows_kernel_min_edges and conv.dispatch(big, 300, torch.empty(big.E, 300, device=dev)) == "pair"
 
 

@@ -28,7 +28,7 @@ def dev():
 @pytest.fixture(autouse=True)
 def _kernels_under_test(request):
     """The tests of this file address individual kernels through ops.linear and the layers' dispatch at SMALL sizes.  Round 6's
-    small-batch dispatch (isg_linear_skinny for Linears over at most 1 024 rows; no rows kernel below 8 192 edges at the wide shapes)
+    small-batch dispatch (isg_linear_skinny for Linears over at most 1 024 rows; no rows kernel below 16 384 edges at the wide shapes)
     would take those sizes before the kernel a test is about: it is switched off here, except in the tests that are about it.  The
     model-level tests (tests/test_gpu_models.py) run with the shipped switches."""
     from isubgvqa_amd import ops
