@@ -66,7 +66,7 @@ class Switches:
     h3p: bool = True
     h3p_min_k: int = 256
     h3p_chain: bool = True
-    h3p_min_m: int = 8192
+    h3p_min_m: int = 2048
     h3p_store_policy: int = -1
     linear_multi_h3p: bool = True
     skinny: bool = True
@@ -2431,7 +2431,7 @@ def linear_skinny(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu
 # CFG.h3p (ops.H3P): Linears with K >= CFG.h3p_min_k over at least CFG.h3p_min_m rows on isg_linear_h3p (A/B switch)
 # CFG.h3p_min_k (ops.H3P_MIN_K): CFG.ln_planes (ops.LN_PLANES): isg_add_layernorm writes its result as planes32 too where Linears on the engine read it (A/B switch)
 # CFG.h3p_chain (ops.H3P_CHAIN): linear1 -> linear2 of the Transformer layers through planes (no fp32 intermediate): A/B switch
-# CFG.h3p_min_m (ops.H3P_MIN_M): 
+# CFG.h3p_min_m (ops.H3P_MIN_M): 8192 until round 6; swept with the small-batch kernels in place (tools/time_full_model.py G --set=H3P_MIN_M=...): 2048 is 5-7 % faster at 160-700 graphs
 def h3p_supported(M: int, N: int, K: int) -> bool:
     return (CFG.h3p and CFG.gemm_backend == "bf16x6" and CFG.gemm_kernel == "auto" and CFG.gemm_f16x3 and K >= CFG.h3p_min_k and (K & 3) == 0 and
             (N & 3) == 0 and M >= CFG.h3p_min_m and M * ((K + 31) // 32) * 128 < (1 << 31) and N * ((K + 31) // 32) * 128 < (1 << 31)

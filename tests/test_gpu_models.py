@@ -324,7 +324,7 @@ ENGINE = pytest.mark.parametrize("engine", [False, True], ids=["shipped_threshol
 def _dispatch(engine):
     """engine=True: `ops.configured(h3p_min_m=1)` -- every K >= 256 Linear of the full model on isg_linear_h3p with its planes32
     producers / consumers (instr_gate_planes32, gather_add planes, add_layernorm planes, mha planes, the flat message-passing
-    kernel's segmented planes into x_proj.0): the dispatch bench.py's `full_model` leg times at >= 8192 rows, here at the
+    kernel's segmented planes into x_proj.0): the dispatch bench.py's `full_model` leg times at 49 152 question rows, here at the
     goldens' sizes.  The context manager is what the shipped thresholds otherwise decide from the row count alone."""
     import contextlib
     from isubgvqa_amd import ops
@@ -335,8 +335,8 @@ def _dispatch(engine):
 def _assert_engine_ran(engine, c):
     if engine:
         assert c["linear_h3p"] >= 20 and c["h3p_segmented"] >= 1 and c["torch_linear"] == 0, c
-    else:
-        assert c["linear_h3p"] == 0, c
+    else:       # (one engine launch is the scene-graph encoder's projected embedding TABLE: 2 578 rows whatever the batch)
+        assert c["linear_h3p"] <= 1 and c["h3p_segmented"] == 0, c
 
 
 def _full_args(**kw):
@@ -409,7 +409,7 @@ def test_full_isubgvqa_model_matches_oracle(dev, sampler, engine):
 
 def test_full_model_mid_size_at_the_shipped_thresholds_matches_the_oracle(dev):
     """BASELINE configs[2] stand-in at the dispatch bench.py's `full_model` leg times, with NO switch touched: 704 graphs x 12-token
-    questions = 8 448 question rows and ~14 k nodes / ~35 k edges, all >= ops.CFG.h3p_min_m = 8 192 -- every K >= 256 Linear on
+    questions = 8 448 question rows and ~14 k nodes / ~35 k edges, all >= ops.CFG.h3p_min_m (8 192 until round 6, 2 048 since) -- every K >= 256 Linear on
     isg_linear_h3p, the rows kernel (isg_gatv2_edge_logits) on > 60 workgroups, the flat message-passing kernel from logits handing
     x_proj.0 its segmented planes.  Logits within 1e-4 of the CPU path, I-MLE masks bit-exact -- a differing graph is admitted only
     where the CPU path's own k-th largest gate has another gate within 4 ulps (deterministic_scheme.py:36-43 keeps or drops it by the
@@ -422,7 +422,7 @@ def test_full_model_mid_size_at_the_shipped_thresholds_matches_the_oracle(dev):
     args = synthetic.full_model_args(text_vocab_size=4096)
     model = build_model(args, None).eval()
     wl = synthetic.make_full_workload(B, tokens=12, seed=17, text_vocab=4096)
-    assert wl.x.size(0) >= ops.CFG.h3p_min_m and B * 12 >= ops.CFG.h3p_min_m and ops.CFG.h3p_min_m == 8192
+    assert wl.x.size(0) >= 8192 >= ops.CFG.h3p_min_m and B * 12 >= 8192
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     ocfg = OM.PathConfig(heads=4, masking_thresholds=[1.0, 1.0, 1.0, 0.15], sampler_type="imle", sample_k=5)
     trace = []

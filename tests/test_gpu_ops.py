@@ -28,7 +28,7 @@ def _kernels_under_test(request):
     if "skinny" in request.node.name:
         yield
         return
-    with ops.configured(skinny=False, rows_kernel_min_edges=0):
+    with ops.configured(skinny=False, rows_kernel_min_edges=0, h3p_min_m=8192):      # (the engine's row threshold these tests were written under)
         yield
 
 
