@@ -67,6 +67,7 @@ class Switches:
     h3p_min_k: int = 256
     h3p_chain: bool = True
     h3p_min_m: int = 2048
+    h3p_min_m_unsplit: int = 8192
     h3p_store_policy: int = -1
     linear_multi_h3p: bool = True
     skinny: bool = True
@@ -2213,8 +2214,11 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu: bool 
         y = linear_skinny(x, weight, bias, gelu=gelu, relu=relu)
         if y is not None:
             return y
-    if not f16_io and h3p_supported(M, N, K) and x.stride(1) == 1 and (x.stride(0) & 3) == 0 and (x.data_ptr() & 15) == 0:
-        # K >= 256 over many rows: the planes32 engine (csrc/isg_gemm_h3p.hip); the split of x stays attached to x
+    if (not f16_io and h3p_supported(M, N, K) and (M >= CFG.h3p_min_m_unsplit or has_planes32(x)) and x.stride(1) == 1
+            and (x.stride(0) & 3) == 0 and (x.data_ptr() & 15) == 0):
+        # K >= 256 over many rows: the planes32 engine (csrc/isg_gemm_h3p.hip); the split of x stays attached to x.  Between
+        # CFG.h3p_min_m and CFG.h3p_min_m_unsplit rows only an input whose PRODUCER left its planes (isg_add_layernorm, the attention
+        # kernels, the gates): an isolated Linear there would pay a split pass of its own and loses to the tile kernels
         return linear_h3p(x, weight, bias, gelu=gelu, relu=relu, cache_planes=cache_planes)
     lib = _lib.load()
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
@@ -2326,6 +2330,12 @@ class Planes32(NamedTuple):
     seg_cols: int = 0
 
 
+def has_planes32(x: Tensor) -> bool:
+    """Did x's producer leave its planes32 (still valid for x's current version)?"""
+    hit = getattr(x, "_isg_planes32", None)
+    return hit is not None and hit[0] == (_ver(x), x.data_ptr(), tuple(x.shape))
+
+
 def split_planes32(x: Tensor) -> Planes32:
     """fp32 rows [M, K] -> planes32 (exact row maxima).  The planes stay attached to `x` (tied to its version counter, like
     the row maxima): a second Linear over the same rows (the decoder layers' cross-attention over the encoder memory) does
@@ -2431,6 +2441,7 @@ def linear_skinny(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gelu
 # CFG.h3p (ops.H3P): Linears with K >= CFG.h3p_min_k over at least CFG.h3p_min_m rows on isg_linear_h3p (A/B switch)
 # CFG.h3p_min_k (ops.H3P_MIN_K): CFG.ln_planes (ops.LN_PLANES): isg_add_layernorm writes its result as planes32 too where Linears on the engine read it (A/B switch)
 # CFG.h3p_chain (ops.H3P_CHAIN): linear1 -> linear2 of the Transformer layers through planes (no fp32 intermediate): A/B switch
+# CFG.h3p_min_m_unsplit (ops.H3P_MIN_M_UNSPLIT): ... but a Linear whose input carries no planes from its producer takes the engine from this many rows only
 # CFG.h3p_min_m (ops.H3P_MIN_M): 8192 until round 6; swept with the small-batch kernels in place (tools/time_full_model.py G --set=H3P_MIN_M=...): 2048 is 5-7 % faster at 160-700 graphs
 def h3p_supported(M: int, N: int, K: int) -> bool:
     return (CFG.h3p and CFG.gemm_backend == "bf16x6" and CFG.gemm_kernel == "auto" and CFG.gemm_f16x3 and K >= CFG.h3p_min_k and (K & 3) == 0 and
