@@ -218,6 +218,35 @@ def progress(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def cpu_baseline_single_question(seconds: float = 4.0, max_threads: int = 16):
+    """The CPU path's latency for ONE question through the FULL model (run_token_coo.py:49-79 evaluates one question per forward): the
+    oracle's isubgvqa_forward (kind 'port') on the same synthetic question / scene graph the `small_batch` leg times on the GPU,
+    median of the passes that fit `seconds`, at 1 thread and at `max_threads` (a 21-node graph does not scale with threads)."""
+    import torch
+    from isubgvqa_amd import synthetic
+    from isubgvqa_amd.models import build_model
+    from oracle import model as OM
+    torch.manual_seed(0)
+    model = build_model(synthetic.full_model_args(), None).eval()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    wl = synthetic.make_full_workload(1)
+    ocfg = OM.PathConfig(heads=4, masking_thresholds=[1.0, 1.0, 1.0, 0.15], sampler_type="imle", sample_k=5)
+    out = {"unit": "ms per question", "kind": "port", "what": "oracle.model.isubgvqa_forward, 1 question of 12 tokens, full model at C = 300"}
+    with torch.no_grad():
+        for threads in (1, min(usable_cpus(), max_threads)):
+            torch.set_num_threads(threads)
+            f = lambda: OM.isubgvqa_forward(sd, wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, wl.x_bbox,
+                                            wl.added_sym_edge, ocfg, None)
+            f()
+            times, t_end = [], time.perf_counter() + seconds / 2
+            while not times or (time.perf_counter() < t_end and len(times) < 200):
+                t0 = time.perf_counter()
+                f()
+                times.append(time.perf_counter() - t0)
+            out[f"threads_{threads}_ms"] = round(sorted(times)[len(times) // 2] * 1e3, 3)
+    return out
+
+
 def cpu_baseline_cfg1(seconds: float = 8.0, max_threads: int = 32):
     """SURVEY §8(d) / BASELINE configs[0] exactly: 256 graphs as 8 batches of 32 (<= 16 nodes, <= 32 edges), C = 300, 4 MGAT
     layers, masks [1, 1, 1, 0.15], Gumbel k = 5 with explicit noise, the oracle under no_grad on every CPU this process
@@ -1048,6 +1077,9 @@ def main(argv=None):
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_graphs, args.cpu_seconds, args.cpu_threads)
             res["cpu_baseline"]["cpu"] = cpu_model_string()
             res["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
+            res["cpu_baseline"]["single_question"] = cpu_baseline_single_question()
+            sq = res["cpu_baseline"]["single_question"]
+            res["summary"]["cpu_full_model_1_question_ms"] = min(v for k, v in sq.items() if k.endswith("_ms"))
         else:
             res["cpu_baseline"] = None
         validate_line(res, full=world == 1 and not cfg5 and not (args.no_cpu_baseline or args.no_full_model or args.no_cfg5 or args.no_mixed
