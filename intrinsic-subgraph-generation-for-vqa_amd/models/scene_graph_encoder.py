@@ -76,7 +76,10 @@ class _MetaLayer(torch.nn.Module):
         w_e = ops.derived_weight("sg_e", (nm[0].weight,), lambda: nm[0].weight[:, nf:].contiguous())
         row, col = edge_index[0].contiguous(), edge_index[1].contiguous()
         P = ops.linear(x, w_nodes, None)                                   # [N, 3C]: W_a x | W_b x | W_x x
-        table = ops.linear(embedding.weight, w_tok, None)                  # [V, C]: W_c emb
+        # [V, C]: W_c emb -- a function of the parameters alone: made once per (weights, switches), not once per forward (it was a
+        # 20 us launch of every forward: 2.5 % of a single question's GPU time)
+        table = ops.derived_weight(("sg_table", hash(ops.CFG)), (embedding.weight, em[0].weight),
+                                   lambda: ops.linear(embedding.weight.detach(), w_tok, None))
         E = row.numel()
         po = ops.GATHER_ADD_PLANES and ops.h3p_supported(E, em[2].weight.size(0), C)   # the Linear behind a gather-add runs on the planes32
         h = ops.gather_add(P[:, :C], row, P[:, C:2 * C], col, table, edge_tokens, edge_sign, bias=em[0].bias, gelu=True,
