@@ -89,8 +89,10 @@ class ISubGVQA(torch.nn.Module):
         qst_feats = self.program_decoder(memory=enc)                                     # :243
         # :244-246 -- a .view, not a permute: rows 4b..4b+3 of the flattened [n_ins*B, 512] (quirk Q4)
         flat = qst_feats.contiguous().view(qst_feats.size(1), int(qst_feats.size(0)), qst_feats.size(2)).flatten(1)
-        glf = self.qsts_reduction(flat)                                                  # :247
-        instr = self.instr_reduction(qst_feats)                                          # :265
+        # Linear + GELU on this library's kernels (ops.mlp; autograd-aware), not the torch modules' hipBLASLt + GELU launches
+        glf = ops.mlp(self.qsts_reduction, flat)                                         # :247
+        n_ins, B, D = qst_feats.shape
+        instr = ops.mlp(self.instr_reduction, qst_feats.reshape(n_ins * B, D)).view(n_ins, B, -1)      # :265
         return glf, instr
 
     def answer_graphs(self, x_encoded, edge_index, edge_attr_encoded, batch, instr_vectors, glf, plan,
