@@ -264,6 +264,113 @@ __global__ void plan_fill_kernel(const int64_t *__restrict__ dst, int E, int N, 
   if ((threadIdx.x & 63) == 0 && cnt > 0) atomicMax(emax, cnt);
 }
 
+
+// ---- the whole plan as ONE workgroup (small batches) ----------------------------------------------------------------------------
+// The six launches above are ~4.5 us each whatever the batch; for a handful of graphs (run_token_coo.py:49-79 evaluates one question
+// per forward) they are 27 us of a forward whose GPU time is 0.75 ms, and six of the ~60 launches the host issues on the graph side.
+// Below 2 048 nodes / 8 192 edges one workgroup of 1 024 threads walks the same six phases with a barrier between them (every
+// array stays where the six-launch form has it; a phase's writes to global memory are visible to the workgroup's other threads
+// behind __syncthreads()): identical outputs (the final order inside a segment is by edge id either way).
+constexpr int PS_THREADS = 1024, PS_MAX_N = 2048, PS_MAX_E = 8192;
+__global__ __launch_bounds__(PS_THREADS) void plan_small_kernel(const int64_t *__restrict__ batch, const int64_t *__restrict__ edge_index,
+                                                                int N, int E, int B, int *__restrict__ ptr, int *__restrict__ bounds,
+                                                                int *bounds_host, int *__restrict__ rowptr, int *__restrict__ eid,
+                                                                int *__restrict__ src, int *__restrict__ dst, int *__restrict__ eptr,
+                                                                int *__restrict__ deg, int *__restrict__ cursor, int *__restrict__ eid_tmp) {
+  __shared__ int s_scan[PS_THREADS];
+  __shared__ int s_max[2];
+  const int tid = threadIdx.x;
+  // (1) zero; graph boundaries from the sorted batch vector
+  for (int i = tid; i <= N; i += PS_THREADS) { deg[i] = 0; cursor[i] = 0; }
+  if (tid < 2) s_max[tid] = 0;
+  if (N == 0) {
+    for (int i = tid; i <= B; i += PS_THREADS) ptr[i] = 0;
+  } else {
+    for (int i = tid; i < N; i += PS_THREADS) {
+      int b = (int)batch[i];
+      const int prev = i > 0 ? (int)batch[i - 1] : -1;
+      if (b >= B) b = B - 1;
+      for (int g = prev + 1; g <= b; ++g) ptr[g] = i;
+      if (i == N - 1)
+        for (int g = b + 1; g <= B; ++g) ptr[g] = N;
+    }
+  }
+  __syncthreads();
+  // (2) in-degree histogram; the largest graph
+  const int64_t *dsts = edge_index + E;
+  for (int i = tid; i < E; i += PS_THREADS) {
+    const int d = (int)dsts[i];
+    if (d >= 0 && d < N) atomicAdd(&deg[d], 1);
+  }
+  {
+    int v = 0;
+    for (int g = tid; g < B; g += PS_THREADS) v = max(v, ptr[g + 1] - ptr[g]);
+    if (v > 0) atomicMax(&s_max[0], v);
+  }
+  __syncthreads();
+  // (3) + (4) exclusive scan of the degrees -> rowptr: a run of ceil(N / threads) nodes per thread, the runs' sums scanned in LDS
+  const int per = (N + PS_THREADS - 1) / PS_THREADS;
+  const int lo = min(tid * per, N), hi = min(lo + per, N);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += deg[i];
+  s_scan[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < PS_THREADS; off <<= 1) {
+    const int v = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  {
+    int run = s_scan[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+      rowptr[i] = run;
+      run += deg[i];
+    }
+    if (tid == PS_THREADS - 1) rowptr[N] = s_scan[tid];      // number of valid edges
+  }
+  __syncthreads();
+  // (5) atomic fill; per-graph slot ranges and the largest edge count
+  for (int i = tid; i < E; i += PS_THREADS) {
+    const int d = (int)dsts[i];
+    if (d >= 0 && d < N) {
+      const int slot = atomicAdd(&cursor[d], 1);
+      eid_tmp[rowptr[d] + slot] = i;
+    }
+  }
+  {
+    int cnt = 0;
+    for (int g = tid; g <= B; g += PS_THREADS) {
+      const int l = rowptr[ptr[g]];
+      eptr[g] = l;
+      if (g < B) cnt = max(cnt, rowptr[ptr[g + 1]] - l);
+    }
+    if (cnt > 0) atomicMax(&s_max[1], cnt);
+  }
+  __syncthreads();
+  // (6) rank by edge id inside each segment; the bounds
+  if (tid < 2) {
+    bounds[tid] = s_max[tid];
+    if (bounds_host) {
+      bounds_host[tid] = s_max[tid];
+      __threadfence_system();
+    }
+  }
+  const int total = rowptr[N];
+  for (int t = tid; t < total; t += PS_THREADS) {
+    const int e = eid_tmp[t];
+    const int d = (int)dsts[e];
+    const int rb = rowptr[d], re = rowptr[d + 1];
+    int rank = 0;
+    for (int u = rb; u < re; ++u) rank += (eid_tmp[u] < e) ? 1 : 0;
+    int sn = (int)edge_index[e];
+    sn = min(max(sn, 0), N - 1);
+    eid[rb + rank] = e;
+    src[rb + rank] = sn;
+    if (dst) dst[rb + rank] = d;
+  }
+}
+
 }  // namespace isg
 
 using namespace isg;
@@ -356,6 +463,12 @@ extern "C" int isg_graph_plan_build(const int64_t *batch, const int64_t *edge_in
   int *eid_tmp = cursor + (N + 1);        // E
   int *chunk_sums = eid_tmp + E;          // ceil(N / SCAN_CHUNK) + 1
   const int n = (int)N, e = (int)E, b = (int)B;
+  static const bool small_ok = [] { const char *f = getenv("ISG_PLAN_SMALL"); return !f || atoi(f) != 0; }();
+  if (small_ok && n <= PS_MAX_N && e <= PS_MAX_E && b <= PS_MAX_N && e > 0) {      // a handful of graphs: one workgroup, one launch
+    plan_small_kernel<<<1, PS_THREADS, 0, st>>>(batch, edge_index, n, e, b, ptr, bounds, bounds_host, rowptr, eid, src, dst, eptr, deg,
+                                               cursor, eid_tmp);
+    return check_launch();
+  }
   const int nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   const long long span1 = std::max<long long>(std::max<long long>(2ll * (n + 1), n), b + 1);
   plan_init_kernel<<<(unsigned)((span1 + 255) / 256), 256, 0, st>>>(batch, n, b, ptr, deg, 2 * (n + 1), bounds);

@@ -54,6 +54,33 @@ def _rand_graphs(gen, sizes, extra_per_node=2.0, hub=None):
 
 
 # --------------------------------------------------------------------------------------------- plan
+def test_plan_build_forms_agree(dev):
+    """isg_graph_plan_build has three forms of the same plan: ONE workgroup / one launch below 2 048 nodes and 8 192 edges (round 6:
+    csrc/isg_graph.hip::plan_small_kernel), six launches above, and the fourteen launches of the step-by-step entry points
+    (ops.configured(plan_fused=False)).  Every array must be equal: small and ragged batches (an empty graph in the middle, trailing
+    empty graphs, a hub, duplicate edges, edges with an endpoint out of range dropped) on the one-launch form, a batch beyond its
+    limits on the six-launch form."""
+    from isubgvqa_amd import ops
+    gen = torch.Generator().manual_seed(17)
+    cases = [[3, 1, 7, 0, 5, 64, 2, 0, 0], [1], [20] * 8, [2, 2, 2, 2], [40] * 45, [30] * 100]
+    for sizes in cases:
+        batch, ei = _rand_graphs(gen, sizes, extra_per_node=2.0, hub=(min(5, len(sizes) - 1), 30))
+        if len(sizes) == 9:          # malformed ids must be dropped / clamped the same way
+            ei = torch.cat([ei, torch.tensor([[0, batch.numel() + 5], [batch.numel() + 3, 1]])], dim=1)
+        b, e = batch.to(dev), ei.to(dev)
+        with ops.configured(plan_fused=True):
+            pf = ops.GraphPlan.build(b, e, num_graphs=len(sizes))
+        with ops.configured(plan_fused=False):
+            pu = ops.GraphPlan.build(b, e, num_graphs=len(sizes))
+        valid = int(pu.rowptr[-1].item())
+        assert (pf.nmax, pf.emax) == (pu.nmax, pu.emax), sizes
+        for name in ("ptr", "rowptr", "eptr"):
+            assert torch.equal(getattr(pf, name), getattr(pu, name)), (name, sizes)
+        for name in ("eid", "src", "dst"):
+            assert torch.equal(getattr(pf, name)[:valid], getattr(pu, name)[:valid]), (name, sizes)
+    assert batch.numel() > 2048 and ei.size(1) > 8192, "the last case was meant to lie beyond the one-launch form"
+
+
 def test_graph_plan_ptr_nmax_and_csr(dev):
     from isubgvqa_amd import ops
     gen = torch.Generator().manual_seed(0)
