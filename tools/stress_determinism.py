@@ -86,5 +86,17 @@ def full(it):
 
 
 total += run("full model (C = 300, 256 graphs)", full, max(iters // 6, 4))
+
+
+def full_small(it):       # round 6: the latency regime (isg_linear_skinny, the one-launch plan, un-fused wide layers), 1-12 questions
+    from isubgvqa_amd.models import build_model
+    torch.manual_seed(it)
+    m = build_model(synthetic.full_model_args(text_vocab_size=4096), None).to(dev).eval()
+    wl = synthetic.make_full_workload(1 + it % 12, tokens=6 + it % 9, seed=1900 + it, text_vocab=4096).to(dev)
+    sg = wl.scene_graphs()
+    return m, (lambda: m(wl.x, wl.edge_index, wl.edge_attr, wl.batch, wl.questions, wl.att_mask, return_masks=True, scene_graphs=sg)[:3])
+
+
+total += run("full model at 1-12 questions (small-batch kernels)", full_small, max(iters // 2, 8))
 print("TOTAL differences:", total)
 sys.exit(1 if total else 0)
